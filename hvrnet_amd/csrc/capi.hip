@@ -1,0 +1,300 @@
+// extern "C" surface of libhvr_hip.so (declarations + contracts: include/hvr_hip.h).
+// Argument validation lives here; kernels assume validated inputs.
+#include "../../include/hvr_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "common.h"
+#include "gemm_params.h"
+
+namespace hvr {
+hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
+hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
+hipError_t run_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+hipError_t run_cast(const void*, void*, long, int, int, hipStream_t);
+hipError_t run_permute(const void*, void*, int, int, int, int, int, int, hipStream_t);
+hipError_t run_det_decode(const float*, int, int, int, int, const float*, int, const float*, const float*, float, float,
+                          float, float, float*, float*, hipStream_t);
+hipError_t run_roi_align_fwd(const void*, const float*, void*, int, int, int, int, int, int, int, float, int, int, int,
+                             hipStream_t);
+hipError_t run_roi_align_bwd(const float*, const float*, float*, int, int, int, int, int, int, float, int, int, hipStream_t);
+size_t nms_workspace_bytes(int P, int n);
+hipError_t run_nms_batched(const float*, int, int, float, int, int, int, long long*, int*, void*, hipStream_t);
+hipError_t run_rpn_select(const void*, const void*, long, long, float*, const RpnParams&, int, hipStream_t);
+hipError_t run_rpn_gather(const float*, const long long*, const int*, int, int, int, int, float*, int*, hipStream_t);
+hipError_t run_multiclass_nms(const float*, const float*, int, int, float, float, int, float*, long long*, int*, void*,
+                              hipStream_t);
+size_t multiclass_nms_workspace_bytes(int R, int ncls);
+}  // namespace hvr
+
+using namespace hvr;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+static int check_launch(hipError_t e, const char* what) {
+  if (e == hipSuccess) return HVR_OK;
+  if (e == hipErrorInvalidValue) return fail(HVR_EUNSUPPORTED, "%s: shape outside the implemented envelope", what);
+  return fail(HVR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static inline int elem_size(int dtype) { return dtype == HVR_BF16 ? 2 : 4; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" {
+
+int hvr_abi_version(void) { return 1; }
+const char* hvr_last_error(void) { return g_err.c_str(); }
+
+static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
+                       long ldc, int dtype, int staging) {
+  std::memset(&p, 0, sizeof p);
+  if (dtype != HVR_F32 && dtype != HVR_BF16) return fail(HVR_EINVAL, "dtype %d is neither HVR_F32 nor HVR_BF16", dtype);
+  const int bke = 128 / elem_size(dtype);
+  if (!A || !B || !C) return fail(HVR_EINVAL, "null operand pointer");
+  if (M <= 0 || N <= 0 || K <= 0) return fail(HVR_EINVAL, "empty problem M=%d N=%d K=%d", M, N, K);
+  if (K % bke) return fail(HVR_EINVAL, "K=%d is not a multiple of the %d-element K-step", K, bke);
+  if (N % 4) return fail(HVR_EINVAL, "N=%d is not a multiple of 4", N);
+  if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return fail(HVR_EINVAL, "operands must be 16-byte aligned");
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.dtype = dtype;
+  p.staging = staging ? 1 : 0;
+  return HVR_OK;
+}
+
+int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
+  if (!d) return fail(HVR_EINVAL, "null descriptor");
+  GemmParams p;
+  int rc = fill_linear(p, d->A, d->B, d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->dtype, d->staging);
+  if (rc) return rc;
+  const int es = elem_size(d->dtype);
+  if ((d->lda * es) % 16 || (d->ldb * es) % 16) return fail(HVR_EINVAL, "lda/ldb rows must be 16-byte multiples");
+  if ((d->ldc * (d->out_f32 ? 4 : es)) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
+  p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
+  return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm");
+}
+
+int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
+  if (!d) return fail(HVR_EINVAL, "null descriptor");
+  const int OH = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const int OW = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  if (OH <= 0 || OW <= 0) return fail(HVR_EINVAL, "empty conv output %dx%d", OH, OW);
+  const int bke = 128 / elem_size(d->dtype);
+  if (d->Cin % bke) return fail(HVR_EINVAL, "Cin=%d is not a multiple of %d", d->Cin, bke);
+  GemmParams p;
+  const long M = (long)d->B * OH * OW;
+  if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
+  const int K = d->KH * d->KW * d->Cin;
+  int rc = fill_linear(p, d->x, d->w, d->y, (int)M, d->Cout, K, d->Cin, K, d->Cout, d->dtype, d->staging);
+  if (rc) return rc;
+  const bool pointwise = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+  if (!pointwise) {
+    if (!d->zero) return fail(HVR_EINVAL, "conv needs the zero page");
+    p.conv = 1; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = OH; p.OW = OW; p.KH = d->KH; p.KW = d->KW;
+    p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.zero = d->zero;
+  }
+  p.bias = d->bias; p.resid = d->resid; p.ldr = d->Cout; p.relu = d->relu; p.out_f32 = d->out_f32;
+  return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
+}
+
+int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream) {
+  if (!img || !cols || B <= 0) return fail(HVR_EINVAL, "bad stem arguments");
+  if (KP < 147 || KP % (128 / elem_size(dtype))) return fail(HVR_EINVAL, "KP=%d must be >= 147 and a K-step multiple", KP);
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  return check_launch(run_im2col_stem(img, cols, B, H, W, OH, OW, KP, dtype, (hipStream_t)stream), "hvr_im2col_stem");
+}
+
+int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !y || C % 4) return fail(HVR_EINVAL, "bad maxpool arguments (C %% 4 == 0 required)");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  return check_launch(run_maxpool3x3s2(x, y, B, H, W, C, OH, OW, dtype, (hipStream_t)stream), "hvr_maxpool3x3s2_nhwc");
+}
+
+// ---- relation ----
+static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
+
+size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
+  const long ldp = rel_ldp(Mk), nt = ldp / 128;
+  const size_t es = elem_size(dtype);
+  return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 3 * align256((size_t)Mq * nt * 4);
+}
+
+int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
+                     int64_t ldo, int Mq, int Mk, int D, float scale, int dtype, int staging, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!Q || !K || !V || !O || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (Mq <= 0 || Mk <= 0) return fail(HVR_EINVAL, "empty relation Mq=%d Mk=%d", Mq, Mk);
+  if (ws_bytes < hvr_relation_workspace_bytes(Mq, Mk, D, dtype))
+    return fail(HVR_EWORKSPACE, "relation workspace %zu < %zu", ws_bytes, hvr_relation_workspace_bytes(Mq, Mk, D, dtype));
+  const long ldp = rel_ldp(Mk);
+  const int nt = (int)(ldp / 128);
+  const size_t es = elem_size(dtype);
+  char* w = (char*)ws;
+  void* P = w;                w += align256((size_t)Mq * ldp * es);
+  void* Vt = w;               w += align256((size_t)D * ldp * es);
+  float* mstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
+  float* lstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
+  float* g = (float*)w;
+  hipStream_t s = (hipStream_t)stream;
+
+  int rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
+  if (rc) return rc;
+  GemmParams p;
+  rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
+  if (rc) return rc;
+  p.N = Mk;  // keys beyond Mk are masked inside the score epilogue
+  p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+  rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
+  if (rc) return rc;
+  rc = check_launch(run_relation_stats(mstat, lstat, g, Mq, nt, s), "relation: stats");
+  if (rc) return rc;
+  rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
+  if (rc) return rc;
+  p.g = g; p.ntile = nt;
+  return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
+}
+
+// ---- RoIAlign ----
+int hvr_roi_align_fwd(const void* feat, const float* rois, void* out, int B, int C, int H, int W, int K, int PH, int PW,
+                      float spatial_scale, int sample_num, int dtype, int layout, void* stream) {
+  if (K == 0) return HVR_OK;
+  if (!feat || !rois || !out) return fail(HVR_EINVAL, "null pointer");
+  if (K < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return fail(HVR_EINVAL, "bad roi_align shape");
+  if (layout != HVR_LAYOUT_NCHW && layout != HVR_LAYOUT_NHWC) return fail(HVR_EINVAL, "bad layout %d", layout);
+  return check_launch(run_roi_align_fwd(feat, rois, out, B, C, H, W, K, PH, PW, spatial_scale, sample_num, dtype, layout,
+                                        (hipStream_t)stream),
+                      "hvr_roi_align_fwd");
+}
+
+int hvr_roi_align_bwd(const float* grad_out, const float* rois, float* grad_feat, int B, int C, int H, int W, int K, int PH,
+                      int PW, float spatial_scale, int sample_num, int layout, void* stream) {
+  (void)B;
+  if (K == 0) return HVR_OK;
+  if (!grad_out || !rois || !grad_feat) return fail(HVR_EINVAL, "null pointer");
+  return check_launch(run_roi_align_bwd(grad_out, rois, grad_feat, C, H, W, K, PH, PW, spatial_scale, sample_num, layout,
+                                        (hipStream_t)stream),
+                      "hvr_roi_align_bwd");
+}
+
+// ---- NMS ----
+size_t hvr_nms_workspace_bytes(int n) { return nms_workspace_bytes(1, n) + 256; }
+
+int hvr_nms(const float* dets, int n, float thr, int ge_semantics, int64_t* keep, int32_t* n_keep, void* ws,
+            size_t ws_bytes, void* stream) {
+  if (!n_keep) return fail(HVR_EINVAL, "null n_keep");
+  if (n == 0) {
+    (void)hipMemsetAsync(n_keep, 0, sizeof(int32_t), (hipStream_t)stream);
+    return HVR_OK;
+  }
+  if (!dets || !keep || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (n < 0 || n > 8192) return fail(HVR_EUNSUPPORTED, "hvr_nms supports 0 <= n <= 8192, got %d", n);
+  if (ws_bytes < hvr_nms_workspace_bytes(n)) return fail(HVR_EWORKSPACE, "nms workspace too small");
+  return check_launch(run_nms_batched(dets, 1, n, thr, ge_semantics, 0, 0, (long long*)keep, n_keep, ws, (hipStream_t)stream),
+                      "hvr_nms");
+}
+
+// ---- RPN ----
+static inline int rpn_npre(int H, int W, int A, int nms_pre) {
+  const long n = (long)H * W * A;
+  return (nms_pre > 0 && n > nms_pre) ? nms_pre : (int)n;
+}
+
+size_t hvr_rpn_workspace_bytes(int T, int H, int W, int A, int nms_pre) {
+  const int npre = rpn_npre(H, W, A, nms_pre);
+  return align256((size_t)T * npre * 5 * 4) + align256((size_t)T * npre * 8) + align256((size_t)T * 4) +
+         nms_workspace_bytes(T, npre) + 256;
+}
+
+int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  if (!d || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (d->A > 32) return fail(HVR_EUNSUPPORTED, "at most 32 base anchors");
+  const long n_anchor = (long)d->H * d->W * d->A;
+  const int npre = rpn_npre(d->H, d->W, d->A, d->nms_pre);
+  if (npre > 8192) return fail(HVR_EUNSUPPORTED, "nms_pre (or anchor count) above 8192");
+  if (d->nms_post > 4096) return fail(HVR_EUNSUPPORTED, "nms_post above 4096");
+  if (ws_bytes < hvr_rpn_workspace_bytes(d->T, d->H, d->W, d->A, d->nms_pre)) return fail(HVR_EWORKSPACE, "rpn workspace too small");
+  RpnParams rp;
+  rp.T = d->T; rp.H = d->H; rp.W = d->W; rp.A = d->A; rp.npre = npre; rp.n_anchor = (int)n_anchor;
+  rp.stride = d->anchor_stride; rp.img_h = d->img_h; rp.img_w = d->img_w;
+  for (int i = 0; i < 4; ++i) { rp.m[i] = d->means[i]; rp.s[i] = d->stds[i]; }
+  rp.max_ratio = std::fabs(std::log(d->wh_ratio_clip));
+  for (int a = 0; a < d->A; ++a)
+    for (int i = 0; i < 4; ++i) rp.base[a][i] = d->base_anchors[a * 4 + i];
+  char* w = (char*)ws;
+  float* props = (float*)w;          w += align256((size_t)d->T * npre * 5 * 4);
+  long long* keep = (long long*)w;   w += align256((size_t)d->T * npre * 8);
+  int* n_keep = (int*)w;             w += align256((size_t)d->T * 4);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = check_launch(run_rpn_select(d->cls, d->reg, n_anchor, n_anchor * 4, props, rp, HVR_F32, s), "rpn: select");
+  if (rc) return rc;
+  const int presorted = n_anchor > npre ? 1 : 0;
+  // with score-sorted input the first nms_post survivors are known after nms_post keeps
+  rc = check_launch(run_nms_batched(props, d->T, npre, d->nms_thr, 1, presorted, presorted ? d->nms_post : 0, keep, n_keep, w, s),
+                    "rpn: nms");
+  if (rc) return rc;
+  return check_launch(run_rpn_gather(props, keep, n_keep, d->T, npre, d->nms_post, d->max_num, d->proposals, d->counts, s),
+                      "rpn: gather");
+}
+
+// ---- RCNN read-out ----
+int hvr_det_decode(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const float* rois, int R,
+                   const float* means, const float* stds, float wh_ratio_clip, float img_h, float img_w,
+                   float scale_factor, float* scores, float* boxes, void* stream) {
+  if (R == 0) return HVR_OK;
+  if (!logits || !rois || !scores || !boxes || !means || !stds) return fail(HVR_EINVAL, "null pointer");
+  return check_launch(run_det_decode(logits, ldl, cls_off, reg_off, ncls, rois, R, means, stds,
+                                     std::fabs(std::log(wh_ratio_clip)), img_h, img_w, scale_factor, scores, boxes,
+                                     (hipStream_t)stream),
+                      "hvr_det_decode");
+}
+
+size_t hvr_multiclass_nms_workspace_bytes(int R, int ncls) { return multiclass_nms_workspace_bytes(R, ncls); }
+
+int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls, float score_thr, float iou_thr, int max_num,
+                       float* dets, int64_t* labels, int32_t* n_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!n_out) return fail(HVR_EINVAL, "null n_out");
+  if (R == 0) {
+    (void)hipMemsetAsync(n_out, 0, sizeof(int32_t), (hipStream_t)stream);
+    return HVR_OK;
+  }
+  if (!boxes || !scores || !dets || !labels || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (R > 512) return fail(HVR_EUNSUPPORTED, "hvr_multiclass_nms supports R <= 512, got %d", R);
+  if (ws_bytes < hvr_multiclass_nms_workspace_bytes(R, ncls)) return fail(HVR_EWORKSPACE, "multiclass nms workspace too small");
+  return check_launch(run_multiclass_nms(boxes, scores, R, ncls, score_thr, iou_thr, max_num, dets, (long long*)labels, n_out,
+                                         ws, (hipStream_t)stream),
+                      "hvr_multiclass_nms");
+}
+
+// ---- plumbing ----
+int hvr_cast(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, void* stream) {
+  if (n == 0) return HVR_OK;
+  if (!in || !out) return fail(HVR_EINVAL, "null pointer");
+  return check_launch(run_cast(in, out, n, from_dtype, to_dtype, (hipStream_t)stream), "hvr_cast");
+}
+
+int hvr_permute_nchw_nhwc(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from_dtype, int to_dtype,
+                          void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || HW <= 0) return fail(HVR_EINVAL, "bad permute arguments");
+  return check_launch(run_permute(in, out, B, C, HW, to_nhwc, from_dtype, to_dtype, (hipStream_t)stream), "hvr_permute");
+}
+
+int hvr_transpose_pad(const void* in, void* out, int R, int C, int64_t ldx, int64_t ldt, int dtype, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0 || ldt < R) return fail(HVR_EINVAL, "bad transpose arguments");
+  return check_launch(run_transpose_pad(in, out, R, C, ldx, ldt, dtype, (hipStream_t)stream), "hvr_transpose_pad");
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Kernel-argument block of the MFMA tile engine (internal; the public ABI is include/hvr_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hvr {
+
+enum { EPI_LINEAR = 0, EPI_SCORES = 1, EPI_APPLY = 2 };
+
+// RPN proposal selection parameters (nms.hip)
+struct RpnParams {
+  int T, H, W, A, npre, n_anchor;
+  int stride;
+  float img_h, img_w;
+  float m[4], s[4];
+  float max_ratio;
+  float base[32][4];  // base anchors (<= 32)
+};
+
+struct GemmParams {
+  const void* A;  // [M][lda] or NHWC activation when conv != 0
+  const void* B;  // [N][ldb], K contiguous
+  void* C;        // [M][ldc]
+  int M, N, K;    // K is a multiple of 128 bytes / sizeof(elem)
+  long lda, ldb, ldc;
+  int dtype;    // DT_F32 / DT_BF16 (operands; accumulation is always f32)
+  int staging;  // 0 = register-staged global->LDS, 1 = direct global_load_lds
+  // implicit-GEMM gather on the A side
+  int conv, H, W, Cin, OH, OW, KH, KW, stride, pad, dil;
+  const void* zero;  // >= 16 readable zero bytes (padding taps)
+  // EPI_LINEAR
+  const float* bias;  // [N] or null
+  const void* resid;  // [M][ldr] (operand dtype) or null
+  long ldr;
+  int relu, out_f32;
+  // EPI_SCORES / EPI_APPLY
+  float scale;
+  float* mstat;    // [M][ntile] tile max (log2 units)
+  float* lstat;    // [M][ntile] tile sum
+  const float* g;  // [M][ntile] per-(row, 128-key block) weight
+  int ntile;
+};
+
+hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream);
+hipError_t run_relation_stats(const float* mstat, const float* lstat, float* g, int M, int ntile, hipStream_t stream);
+
+}  // namespace hvr

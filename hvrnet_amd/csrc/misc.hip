@@ -1,0 +1,242 @@
+// HBM-bound helper kernels around the MFMA tile engine: layout changes, casts, the
+// 7x7 stem's patch gather, 3x3/2 max pooling, the class softmax and box decode.
+// All are coalesced 16-byte-per-lane streaming kernels (no LDS reuse to exploit), except
+// the transpose which stages a 64x64 tile through LDS.
+#include "common.h"
+
+namespace hvr {
+
+// ---- out[C][ldt] = in[R][ldx]^T, zero-filled for columns R..ldt-1 (relation V^T) ----
+template <typename T>
+__global__ void transpose_pad_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int C, long ldx, long ldt) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    T v = T(0);
+    if (r < R && c < C) v = in[(long)r * ldx + c];
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < ldt) out[(long)c * ldt + r] = tile[tx][i];
+  }
+}
+
+// ---- stem patch gather (reference conv: mmdet/models/backbones/resnet.py:456-466) ----
+// img NCHW f32 [B][3][H][W] -> cols [B*OH*OW][KP], k = (ky*7+kx)*3 + c, zero for k >= 147
+template <typename T>
+__global__ void im2col_stem_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W, int OH,
+                                   int OW, int KP) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;
+  const int chunks = KP / EPC;
+  const long total = (long)B * OH * OW * chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % chunks);
+    const long m = idx / chunks;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((long)OW * OH));
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int k = ch * EPC + e;
+      float x = 0.f;
+      if (k < 147) {
+        const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+        const int iy = oy * 2 - 3 + ky, ix = ox * 2 - 3 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) x = img[(((long)b * 3 + c) * H + iy) * W + ix];
+      }
+      v[e] = x;
+    }
+    T* dst = cols + m * KP + ch * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) store4(dst + e, v + e);
+  }
+}
+
+// ---- 3x3 stride-2 pad-1 max pooling, NHWC (resnet.py:466 nn.MaxPool2d(3, 2, 1)) ----
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int OH,
+                                    int OW) {
+  const int c4 = C / 4;
+  const long total = (long)B * OH * OW * c4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(idx % c4);
+    const long px = idx / c4;
+    const int ox = (int)(px % OW), oy = (int)((px / OW) % OH), b = (int)(px / ((long)OW * OH));
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float v[4];
+        load4(in + (((long)b * H + iy) * W + ix) * C + cq * 4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+      }
+    }
+    store4(out + px * C + cq * 4, best);
+  }
+}
+
+// ---- element casts ----
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      float v[4];
+      load4(in + i, v);
+      store4(out + i, v);
+    } else {
+      for (long j = i; j < n; ++j) out[j] = f2bf(in[j]);
+    }
+  }
+}
+__global__ void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      float v[4];
+      load4(in + i, v);
+      store4(out + i, v);
+    } else {
+      for (long j = i; j < n; ++j) out[j] = bf2f(in[j]);
+    }
+  }
+}
+
+// ---- [B][C][HW] <-> [B][HW][C] (API-boundary layout changes only) ----
+template <typename TI, typename TO>
+__global__ void permute_bchw_kernel(const TI* __restrict__ in, TO* __restrict__ out, int C, int HW, int to_nhwc) {
+  // treats each image as a [C][HW] (to_nhwc) or [HW][C] matrix and transposes it through LDS
+  __shared__ float tile[64][65];
+  const int R = to_nhwc ? C : HW, Cn = to_nhwc ? HW : C;
+  const long img = (long)blockIdx.z * C * HW;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cn) ? ElemTraits<TI>::load(in + img + (long)r * Cn + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cn && r < R) ElemTraits<TO>::store(out + img + (long)c * R + r, tile[tx][i]);
+  }
+}
+
+// ---- class softmax + box decode for the key frame's rois ----
+// reference: mmdet/models/bbox_heads/bbox_head.py:141-158, mmdet/core/bbox/transforms.py:78-110.
+// logits [R][ldl] f32 (cls at col cls_off.., 4 deltas at col reg_off..), rois [R][5]
+// -> scores [R][ncls], boxes [R][4]
+__global__ void det_decode_kernel(const float* __restrict__ logits, int ldl, int cls_off, int reg_off, int ncls,
+                                  const float* __restrict__ rois, int R, float m0, float m1, float m2, float m3,
+                                  float s0, float s1, float s2, float s3, float max_ratio, float img_h, float img_w,
+                                  float scale_factor, float* __restrict__ scores, float* __restrict__ boxes) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* l = logits + (long)r * ldl;
+  float mx = -INFINITY;
+  for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, l[cls_off + c]);
+  float sum = 0.f;
+  for (int c = 0; c < ncls; ++c) sum += expf(l[cls_off + c] - mx);
+  for (int c = 0; c < ncls; ++c) scores[(long)r * ncls + c] = expf(l[cls_off + c] - mx) / sum;
+
+  const float* roi = rois + (long)r * 5;
+  const float dx = l[reg_off + 0] * s0 + m0, dy = l[reg_off + 1] * s1 + m1;
+  float dw = l[reg_off + 2] * s2 + m2, dh = l[reg_off + 3] * s3 + m3;
+  dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+  dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+  const float px = (roi[1] + roi[3]) * 0.5f, py = (roi[2] + roi[4]) * 0.5f;
+  const float pw = roi[3] - roi[1] + 1.0f, ph = roi[4] - roi[2] + 1.0f;
+  const float gw = pw * expf(dw), gh = ph * expf(dh);
+  const float gx = px + pw * dx, gy = py + ph * dy;
+  float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f;
+  float x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
+  if (img_w > 0.f) {
+    x1 = fminf(fmaxf(x1, 0.f), img_w - 1.f);
+    y1 = fminf(fmaxf(y1, 0.f), img_h - 1.f);
+    x2 = fminf(fmaxf(x2, 0.f), img_w - 1.f);
+    y2 = fminf(fmaxf(y2, 0.f), img_h - 1.f);
+  }
+  float* b = boxes + (long)r * 4;
+  // rescale=True divides by scale_factor (bbox_head.py:152-158); scale_factor <= 0 means rescale=False
+  if (scale_factor > 0.f) { x1 /= scale_factor; y1 /= scale_factor; x2 /= scale_factor; y2 /= scale_factor; }
+  b[0] = x1; b[1] = y1; b[2] = x2; b[3] = y2;
+}
+
+// ---------------- launchers ----------------
+static inline int grid_for(long work, int block, int cap = 256 * 16) {
+  long g = (work + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+hipError_t run_transpose_pad(const void* in, void* out, int R, int C, long ldx, long ldt, int dtype, hipStream_t s) {
+  dim3 grid((C + 63) / 64, (int)((ldt + 63) / 64));
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(transpose_pad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, R, C, ldx, ldt);
+  else
+    hipLaunchKernelGGL(transpose_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, R, C, ldx, ldt);
+  return hipGetLastError();
+}
+
+hipError_t run_im2col_stem(const float* img, void* cols, int B, int H, int W, int OH, int OW, int KP, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16) {
+    const long work = (long)B * OH * OW * (KP / 8);
+    hipLaunchKernelGGL(im2col_stem_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (bf16_t*)cols, B, H, W, OH, OW, KP);
+  } else {
+    const long work = (long)B * OH * OW * (KP / 4);
+    hipLaunchKernelGGL(im2col_stem_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (float*)cols, B, H, W, OH, OW, KP);
+  }
+  return hipGetLastError();
+}
+
+hipError_t run_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int dtype, hipStream_t s) {
+  const long work = (long)B * OH * OW * (C / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C, OH, OW);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C, OH, OW);
+  return hipGetLastError();
+}
+
+hipError_t run_cast(const void* in, void* out, long n, int from, int to, hipStream_t s) {
+  const int g = grid_for((n + 3) / 4, 256);
+  if (from == DT_F32 && to == DT_BF16)
+    hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(g), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
+  else if (from == DT_BF16 && to == DT_F32)
+    hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(g), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t run_permute(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from, int to, hipStream_t s) {
+  const int R = to_nhwc ? C : HW, Cn = to_nhwc ? HW : C;
+  dim3 grid((Cn + 63) / 64, (R + 63) / 64, B);
+  if (from == DT_F32 && to == DT_F32)
+    hipLaunchKernelGGL((permute_bchw_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, C, HW, to_nhwc);
+  else if (from == DT_F32 && to == DT_BF16)
+    hipLaunchKernelGGL((permute_bchw_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)in, (bf16_t*)out, C, HW, to_nhwc);
+  else if (from == DT_BF16 && to == DT_F32)
+    hipLaunchKernelGGL((permute_bchw_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)in, (float*)out, C, HW, to_nhwc);
+  else
+    hipLaunchKernelGGL((permute_bchw_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, C, HW, to_nhwc);
+  return hipGetLastError();
+}
+
+hipError_t run_det_decode(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const float* rois, int R,
+                          const float* means, const float* stds, float max_ratio, float img_h, float img_w,
+                          float scale_factor, float* scores, float* boxes, hipStream_t s) {
+  hipLaunchKernelGGL(det_decode_kernel, dim3((R + 63) / 64), dim3(64), 0, s, logits, ldl, cls_off, reg_off, ncls, rois, R,
+                     means[0], means[1], means[2], means[3], stds[0], stds[1], stds[2], stds[3], max_ratio, img_h, img_w,
+                     scale_factor, scores, boxes);
+  return hipGetLastError();
+}
+
+}  // namespace hvr

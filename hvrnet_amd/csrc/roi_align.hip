@@ -1,0 +1,210 @@
+// RoIAlign forward / backward, legacy "+1 pixel" (non-aligned) convention.
+// Replaces mmdet/ops/roi_align/src/roi_align_kernel.cu:16-141 (forward) and :143-282
+// (backward).  Same arithmetic per sample point; different parallelisation:
+//   * one workgroup per RoI, lanes along channels (NHWC: 16 B of channels per lane per
+//     bilinear tap -> coalesced gathers, coalesced [roi][bin][C] stores),
+//   * all frames of a window in ONE launch (the roi's batch index selects the frame),
+//     where the reference launches once per frame (detectors/hnmb_rcnn.py:596-598).
+// HBM-bound: bytes = feature map once + output once; taps hit L2.
+#include "common.h"
+
+namespace hvr {
+
+struct BilinearTap {
+  int y_low, x_low, y_high, x_high;
+  float w1, w2, w3, w4;  // all zero when the point is outside (-1, H) x (-1, W)
+  bool inside;
+};
+
+// roi_align_kernel.cu:16-61 (value) / :143-183 (gradient weights): identical index rule
+__device__ __forceinline__ BilinearTap make_tap(int height, int width, float y, float x) {
+  BilinearTap t;
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+    t.y_low = t.x_low = t.y_high = t.x_high = 0;
+    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+    t.inside = false;
+    return t;
+  }
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+  t.y_low = y_low; t.x_low = x_low; t.y_high = y_high; t.x_high = x_high;
+  t.w1 = hy * hx; t.w2 = hy * lx; t.w3 = ly * hx; t.w4 = ly * lx;
+  t.inside = true;
+  return t;
+}
+
+struct RoiGeom {
+  int batch;
+  float start_w, start_h, bin_w, bin_h;
+  int sn_h, sn_w;
+};
+
+// roi_align_kernel.cu:76-99
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float spatial_scale, int sample_num, int ph, int pw) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.start_w = roi[1] * spatial_scale;
+  g.start_h = roi[2] * spatial_scale;
+  const float end_w = (roi[3] + 1.f) * spatial_scale, end_h = (roi[4] + 1.f) * spatial_scale;
+  const float roi_w = fmaxf(end_w - g.start_w, 0.f), roi_h = fmaxf(end_h - g.start_h, 0.f);
+  g.bin_h = roi_h / ph;
+  g.bin_w = roi_w / pw;
+  g.sn_h = sample_num > 0 ? sample_num : (int)ceilf(roi_h / ph);
+  g.sn_w = sample_num > 0 ? sample_num : (int)ceilf(roi_w / pw);
+  return g;
+}
+
+// layout 1: features [B][H][W][C], output [K][PH][PW][C]; CV channels per lane
+template <typename T, int CV>
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                          T* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                          float spatial_scale, int sample_num) {
+  const int k = blockIdx.x;
+  const int lanes_c = C / CV;  // threads along channels
+  const int groups = blockDim.x / lanes_c;
+  const int cl = threadIdx.x % lanes_c, grp = threadIdx.x / lanes_c;
+  if (grp >= groups) return;
+  const RoiGeom g = roi_geom(rois + (long)k * 5, spatial_scale, sample_num, PH, PW);
+  const T* fb = feat + (long)g.batch * H * W * C + cl * CV;
+  for (int bin = grp; bin < PH * PW; bin += groups) {
+    const int ph = bin / PW, pw = bin - ph * PW;
+    float acc[CV];
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[e] = 0.f;
+    for (int iy = 0; iy < g.sn_h; ++iy) {
+      const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.sn_h;
+      for (int ix = 0; ix < g.sn_w; ++ix) {
+        const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.sn_w;
+        const BilinearTap t = make_tap(H, W, y, x);
+        if (!t.inside) continue;
+        float lt[CV], rt[CV], lb[CV], rb[CV];
+#pragma unroll
+        for (int e = 0; e < CV; e += 4) {
+          load4(fb + ((long)t.y_low * W + t.x_low) * C + e, lt + e);
+          load4(fb + ((long)t.y_low * W + t.x_high) * C + e, rt + e);
+          load4(fb + ((long)t.y_high * W + t.x_low) * C + e, lb + e);
+          load4(fb + ((long)t.y_high * W + t.x_high) * C + e, rb + e);
+        }
+#pragma unroll
+        for (int e = 0; e < CV; ++e) acc[e] += (t.w1 * lt[e] + t.w2 * rt[e] + t.w3 * lb[e] + t.w4 * rb[e]);
+      }
+    }
+    const float cnt = (float)(g.sn_h * g.sn_w);
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[e] /= cnt;
+    T* dst = out + ((long)k * PH * PW + bin) * C + cl * CV;
+#pragma unroll
+    for (int e = 0; e < CV; e += 4) store4(dst + e, acc + e);
+  }
+}
+
+// layout 0: features [B][C][H][W], output [K][C][PH][PW] -- the reference's own layout
+// (kept for drop-in callers that hand NCHW tensors; one thread per output element).
+template <typename T>
+__global__ void roi_align_fwd_nchw(const T* __restrict__ feat, const float* __restrict__ rois, T* __restrict__ out,
+                                   long total, int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < total; index += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(index % PW), ph = (int)((index / PW) % PH);
+    const int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    const RoiGeom g = roi_geom(rois + (long)n * 5, spatial_scale, sample_num, PH, PW);
+    const T* fb = feat + ((long)g.batch * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < g.sn_h; ++iy) {
+      const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.sn_h;
+      for (int ix = 0; ix < g.sn_w; ++ix) {
+        const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.sn_w;
+        const BilinearTap t = make_tap(H, W, y, x);
+        if (!t.inside) continue;
+        const float lt = ElemTraits<T>::load(fb + t.y_low * W + t.x_low), rt = ElemTraits<T>::load(fb + t.y_low * W + t.x_high);
+        const float lb = ElemTraits<T>::load(fb + t.y_high * W + t.x_low), rb = ElemTraits<T>::load(fb + t.y_high * W + t.x_high);
+        acc += (t.w1 * lt + t.w2 * rt + t.w3 * lb + t.w4 * rb);
+      }
+    }
+    acc /= (float)(g.sn_h * g.sn_w);
+    ElemTraits<T>::store(out + index, acc);
+  }
+}
+
+// backward (f32 only, like the reference: roi_align_kernel.cu:269-272 rejects double and
+// the training path runs f32): scatter grad * w / count with atomics.
+// layout 1: grad_out [K][PH][PW][C] -> grad_in [B][H][W][C]; layout 0: NCHW both.
+__global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
+                                     float* __restrict__ gin, long total, int C, int H, int W, int PH, int PW,
+                                     float spatial_scale, int sample_num, int nhwc) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < total; index += (long)gridDim.x * blockDim.x) {
+    int pw, ph, c, n;
+    if (nhwc) {
+      c = (int)(index % C); pw = (int)((index / C) % PW); ph = (int)((index / C / PW) % PH); n = (int)(index / C / PW / PH);
+    } else {
+      pw = (int)(index % PW); ph = (int)((index / PW) % PH); c = (int)((index / PW / PH) % C); n = (int)(index / PW / PH / C);
+    }
+    const RoiGeom g = roi_geom(rois + (long)n * 5, spatial_scale, sample_num, PH, PW);
+    const float go = gout[index];
+    const float count = (float)(g.sn_h * g.sn_w);
+    for (int iy = 0; iy < g.sn_h; ++iy) {
+      const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.sn_h;
+      for (int ix = 0; ix < g.sn_w; ++ix) {
+        const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.sn_w;
+        const BilinearTap t = make_tap(H, W, y, x);
+        if (!t.inside) continue;
+        const float g1 = go * t.w1 / count, g2 = go * t.w2 / count, g3 = go * t.w3 / count, g4 = go * t.w4 / count;
+        if (nhwc) {
+          float* base = gin + (long)g.batch * H * W * C + c;
+          atomicAdd(base + ((long)t.y_low * W + t.x_low) * C, g1);
+          atomicAdd(base + ((long)t.y_low * W + t.x_high) * C, g2);
+          atomicAdd(base + ((long)t.y_high * W + t.x_low) * C, g3);
+          atomicAdd(base + ((long)t.y_high * W + t.x_high) * C, g4);
+        } else {
+          float* base = gin + ((long)g.batch * C + c) * H * W;
+          atomicAdd(base + t.y_low * W + t.x_low, g1);
+          atomicAdd(base + t.y_low * W + t.x_high, g2);
+          atomicAdd(base + t.y_high * W + t.x_low, g3);
+          atomicAdd(base + t.y_high * W + t.x_high, g4);
+        }
+      }
+    }
+  }
+}
+
+hipError_t run_roi_align_fwd(const void* feat, const float* rois, void* out, int B, int C, int H, int W, int K, int PH,
+                             int PW, float scale, int sample_num, int dtype, int layout, hipStream_t s) {
+  (void)B;
+  if (K == 0) return hipSuccess;
+  if (layout == 1) {
+    if (dtype == DT_BF16) {
+      if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
+        hipLaunchKernelGGL((roi_align_fwd_nhwc<bf16_t, 8>), dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale, sample_num);
+      } else if (C % 4 == 0 && C / 4 <= 256) {
+        hipLaunchKernelGGL((roi_align_fwd_nhwc<bf16_t, 4>), dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale, sample_num);
+      } else {
+        return hipErrorInvalidValue;
+      }
+    } else {
+      if (C % 4 != 0 || C / 4 > 256) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((roi_align_fwd_nhwc<float, 4>), dim3(K), dim3(256), 0, s, (const float*)feat, rois, (float*)out, C, H, W, PH, PW, scale, sample_num);
+    }
+  } else {
+    const long total = (long)K * C * PH * PW;
+    const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL(roi_align_fwd_nchw<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, total, C, H, W, PH, PW, scale, sample_num);
+    else
+      hipLaunchKernelGGL(roi_align_fwd_nchw<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, (float*)out, total, C, H, W, PH, PW, scale, sample_num);
+  }
+  return hipGetLastError();
+}
+
+hipError_t run_roi_align_bwd(const float* gout, const float* rois, float* gin, int C, int H, int W, int K, int PH, int PW,
+                             float scale, int sample_num, int layout, hipStream_t s) {
+  if (K == 0) return hipSuccess;
+  const long total = (long)K * C * PH * PW;
+  const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(grid), dim3(256), 0, s, gout, rois, gin, total, C, H, W, PH, PW, scale, sample_num, layout);
+  return hipGetLastError();
+}
+
+}  // namespace hvr

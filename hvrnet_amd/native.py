@@ -1,0 +1,374 @@
+"""ctypes binding of ``libhvr_hip.so`` (C ABI: ``include/hvr_hip.h``).
+
+PyTorch is used only for device memory and streams: every wrapper here takes CUDA(ROCm)
+tensors, passes ``data_ptr()`` + sizes + the current stream to the C ABI and returns
+tensors it allocated with the torch allocator.  There is NO CPU fallback: a missing
+library or a CPU tensor raises (the reference's RoIAlign raises ``NotImplementedError`` on
+CPU input the same way, ``mmdet/ops/roi_align/roi_align.py:27-28``).
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhvr_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hvr_hip.h')
+
+HVR_F32, HVR_BF16 = 0, 1
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+# default operand staging of the MFMA tile engine (0 register-staged, 1 global->LDS DMA)
+STAGING = int(os.environ.get('HVR_STAGING', '1'))
+
+
+class HvrError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p),
+                ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('lda', ctypes.c_int64), ('ldb', ctypes.c_int64), ('ldc', ctypes.c_int64),
+                ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p), ('ldr', ctypes.c_int64),
+                ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
+                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+                ('Cin', ctypes.c_int32), ('Cout', ctypes.c_int32), ('KH', ctypes.c_int32),
+                ('KW', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
+                ('dil', ctypes.c_int32),
+                ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p),
+                ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
+                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32),
+                ('zero', ctypes.c_void_p)]
+
+
+class RpnDesc(ctypes.Structure):
+    _fields_ = [('cls', ctypes.c_void_p), ('reg', ctypes.c_void_p),
+                ('T', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+                ('A', ctypes.c_int32), ('anchor_stride', ctypes.c_int32),
+                ('base_anchors', ctypes.c_void_p), ('means', ctypes.c_void_p), ('stds', ctypes.c_void_p),
+                ('img_h', ctypes.c_float), ('img_w', ctypes.c_float), ('wh_ratio_clip', ctypes.c_float),
+                ('nms_pre', ctypes.c_int32), ('nms_post', ctypes.c_int32), ('max_num', ctypes.c_int32),
+                ('nms_thr', ctypes.c_float),
+                ('proposals', ctypes.c_void_p), ('counts', ctypes.c_void_p)]
+
+
+# every symbol include/hvr_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
+SYMBOLS = {
+    'hvr_abi_version': (_i, []),
+    'hvr_last_error': (ctypes.c_char_p, []),
+    'hvr_gemm': (_i, [ctypes.POINTER(GemmDesc), _vp]),
+    'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'hvr_relation_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'hvr_relation_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'hvr_nms_workspace_bytes': (_sz, [_i]),
+    'hvr_nms': (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    'hvr_rpn_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'hvr_rpn_proposals': (_i, [ctypes.POINTER(RpnDesc), _vp, _sz, _vp]),
+    'hvr_det_decode': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
+    'hvr_multiclass_nms_workspace_bytes': (_sz, [_i, _i]),
+    'hvr_multiclass_nms': (_i, [_vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'hvr_cast': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    'hvr_permute_nchw_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'hvr_transpose_pad': (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 into ``hvrnet_amd/libhvr_hip.so`` (in-tree)."""
+    script = os.path.join(_HERE, 'csrc', 'build.sh')
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+        for f in os.listdir(os.path.join(_HERE, 'csrc', 'build')) if os.path.isdir(os.path.join(_HERE, 'csrc', 'build')) else []:
+            os.remove(os.path.join(_HERE, 'csrc', 'build', f))
+    subprocess.run(['bash', script], check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises HvrError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HvrError('libhvr_hip.so is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(there is no CPU or PyTorch fallback for the HVR hot path)')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HvrError('%s failed (%d): %s' % (what, rc, lib().hvr_last_error().decode()))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return HVR_F32
+    if t.dtype == torch.bfloat16:
+        return HVR_BF16
+    raise HvrError('unsupported tensor dtype %s (float32 / bfloat16 only)' % t.dtype)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise NotImplementedError('hvr_hip ops run on the GPU only; got a %s tensor' % t.device)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def kstep(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+# ----------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, staging=None):
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + resid).  a / w / resid share one dtype."""
+    _need_cuda(a, w, bias, resid)
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
+    d = GemmDesc(A=a.data_ptr(), B=w.data_ptr(), C=out.data_ptr(), M=M, N=N, K=K,
+                 lda=a.stride(0), ldb=w.stride(0), ldc=out.stride(0),
+                 bias=bias.data_ptr() if bias is not None else None,
+                 resid=resid.data_ptr() if resid is not None else None,
+                 ldr=resid.stride(0) if resid is not None else 0,
+                 relu=int(relu), out_f32=int(out.dtype == torch.float32 and a.dtype != torch.float32),
+                 dtype=_dt(a), staging=STAGING if staging is None else staging)
+    _check(lib().hvr_gemm(ctypes.byref(d), _stream()), 'hvr_gemm')
+    return out
+
+
+def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None):
+    """x [B,H,W,Cin] (physical NHWC), w [Cout,KH,KW,Cin] -> [B,OH,OW,Cout]."""
+    _need_cuda(x, w, bias, resid)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    y = torch.empty((B, OH, OW, Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW,
+                 stride=stride, pad=pad, dil=dil,
+                 bias=bias.data_ptr() if bias is not None else None,
+                 resid=resid.data_ptr() if resid is not None else None,
+                 relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
+                 staging=STAGING if staging is None else staging,
+                 zero=zero_page(x.device).data_ptr())
+    _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
+    return y
+
+
+def im2col_stem(img, dtype, kp=192):
+    """img [B,3,H,W] f32 NCHW -> ([B*OH*OW, kp] patches, OH, OW)."""
+    _need_cuda(img)
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    B, _, H, W = img.shape
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    cols = torch.empty((B * OH * OW, kp), dtype=dtype, device=img.device)
+    _check(lib().hvr_im2col_stem(_ptr(img), _ptr(cols), B, H, W, kp, _dt(cols), _stream()), 'hvr_im2col_stem')
+    return cols, OH, OW
+
+
+def maxpool3x3s2_nhwc(x):
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+    _check(lib().hvr_maxpool3x3s2_nhwc(_ptr(x), _ptr(y), B, H, W, C, _dt(x), _stream()), 'hvr_maxpool3x3s2_nhwc')
+    return y
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    key = (tag, device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def relation_fwd(q, k, v, scale, staging=None):
+    """softmax(scale * q @ k^T, dim=1) @ v without materialising the f32 logits."""
+    _need_cuda(q, k, v)
+    Mq, D = q.shape
+    Mk = k.shape[0]
+    assert k.shape[1] == D and v.shape == (Mk, D) and q.dtype == k.dtype == v.dtype
+    o = torch.empty((Mq, D), dtype=q.dtype, device=q.device)
+    nbytes = lib().hvr_relation_workspace_bytes(Mq, Mk, D, _dt(q))
+    ws = _workspace(nbytes, q.device, 'relation')
+    _check(lib().hvr_relation_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
+                                  Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging,
+                                  _ptr(ws), ws.numel(), _stream()), 'hvr_relation_fwd')
+    return o
+
+
+def roi_align_fwd(feat, rois, out_h, out_w, spatial_scale, sample_num, layout):
+    """layout NCHW: feat [B,C,H,W] -> [K,C,oh,ow]; NHWC: feat [B,H,W,C] -> [K,oh,ow,C] (physical shapes)."""
+    _need_cuda(feat, rois)
+    rois = rois.contiguous().float()
+    K = rois.shape[0]
+    if layout == LAYOUT_NCHW:
+        B, C, H, W = feat.shape
+        out = torch.empty((K, C, out_h, out_w), dtype=feat.dtype, device=feat.device)
+    else:
+        B, H, W, C = feat.shape
+        out = torch.empty((K, out_h, out_w, C), dtype=feat.dtype, device=feat.device)
+    assert feat.is_contiguous()
+    _check(lib().hvr_roi_align_fwd(_ptr(feat), _ptr(rois), _ptr(out), B, C, H, W, K, out_h, out_w, float(spatial_scale),
+                                   int(sample_num), _dt(feat), layout, _stream()), 'hvr_roi_align_fwd')
+    return out
+
+
+def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sample_num, layout):
+    _need_cuda(grad_out, rois)
+    grad_out = grad_out.contiguous().float()
+    rois = rois.contiguous().float()
+    grad_in = torch.zeros(feat_shape, dtype=torch.float32, device=grad_out.device)
+    if layout == LAYOUT_NCHW:
+        B, C, H, W = feat_shape
+        K, _, PH, PW = grad_out.shape
+    else:
+        B, H, W, C = feat_shape
+        K, PH, PW, _ = grad_out.shape
+    _check(lib().hvr_roi_align_bwd(_ptr(grad_out), _ptr(rois), _ptr(grad_in), B, C, H, W, K, PH, PW, float(spatial_scale),
+                                   int(sample_num), layout, _stream()), 'hvr_roi_align_bwd')
+    return grad_in
+
+
+def nms(dets, iou_thr, ge_semantics=True):
+    """dets [n,5] f32 cuda -> int64 indices kept (ascending input order). One D2H of the count."""
+    _need_cuda(dets)
+    dets = dets.contiguous().float()
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long, device=dets.device)
+    keep = torch.empty(n, dtype=torch.long, device=dets.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dets.device)
+    ws = _workspace(lib().hvr_nms_workspace_bytes(n), dets.device, 'nms')
+    _check(lib().hvr_nms(_ptr(dets), n, float(iou_thr), int(ge_semantics), _ptr(keep), _ptr(cnt), _ptr(ws), ws.numel(),
+                         _stream()), 'hvr_nms')
+    return keep[:int(cnt.item())]
+
+
+def rpn_proposals(cls, reg, base_anchors, anchor_stride, means, stds, img_shape, nms_pre, nms_post, max_num, nms_thr,
+                  wh_ratio_clip=16 / 1000):
+    """cls [T,H,W,A] f32, reg [T,H,W,4A] f32 (physical NHWC) -> (proposals [T,max_num,5], counts [T] int32)."""
+    _need_cuda(cls, reg)
+    assert cls.dtype == torch.float32 and reg.dtype == torch.float32 and cls.is_contiguous() and reg.is_contiguous()
+    T, H, W, A = cls.shape
+    props = torch.zeros((T, max_num, 5), dtype=torch.float32, device=cls.device)
+    counts = torch.zeros(T, dtype=torch.int32, device=cls.device)
+    ba = (ctypes.c_float * (A * 4))(*[float(v) for v in base_anchors.reshape(-1).tolist()])
+    mm = (ctypes.c_float * 4)(*[float(v) for v in means])
+    ss = (ctypes.c_float * 4)(*[float(v) for v in stds])
+    d = RpnDesc(cls=cls.data_ptr(), reg=reg.data_ptr(), T=T, H=H, W=W, A=A, anchor_stride=int(anchor_stride),
+                base_anchors=ctypes.cast(ba, ctypes.c_void_p), means=ctypes.cast(mm, ctypes.c_void_p),
+                stds=ctypes.cast(ss, ctypes.c_void_p), img_h=float(img_shape[0]), img_w=float(img_shape[1]),
+                wh_ratio_clip=float(wh_ratio_clip), nms_pre=int(nms_pre), nms_post=int(nms_post), max_num=int(max_num),
+                nms_thr=float(nms_thr), proposals=props.data_ptr(), counts=counts.data_ptr())
+    ws = _workspace(lib().hvr_rpn_workspace_bytes(T, H, W, A, int(nms_pre)), cls.device, 'rpn')
+    _check(lib().hvr_rpn_proposals(ctypes.byref(d), _ptr(ws), ws.numel(), _stream()), 'hvr_rpn_proposals')
+    return props, counts
+
+
+def det_decode(logits, cls_off, reg_off, ncls, rois, means, stds, img_shape, scale_factor, wh_ratio_clip=16 / 1000):
+    """logits [R,ld] f32 -> (scores [R,ncls], boxes [R,4])."""
+    _need_cuda(logits, rois)
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    rois = rois.contiguous().float()
+    R = rois.shape[0]
+    scores = torch.empty((R, ncls), dtype=torch.float32, device=logits.device)
+    boxes = torch.empty((R, 4), dtype=torch.float32, device=logits.device)
+    mm = (ctypes.c_float * 4)(*[float(v) for v in means])
+    ss = (ctypes.c_float * 4)(*[float(v) for v in stds])
+    ih, iw = (float(img_shape[0]), float(img_shape[1])) if img_shape is not None else (0.0, 0.0)
+    _check(lib().hvr_det_decode(_ptr(logits), logits.stride(0), cls_off, reg_off, ncls, _ptr(rois), R,
+                                ctypes.cast(mm, ctypes.c_void_p), ctypes.cast(ss, ctypes.c_void_p), float(wh_ratio_clip),
+                                ih, iw, float(scale_factor), _ptr(scores), _ptr(boxes), _stream()), 'hvr_det_decode')
+    return scores, boxes
+
+
+def multiclass_nms(boxes, scores, score_thr, iou_thr, max_num):
+    """boxes [R,4], scores [R,ncls] f32 -> (dets [max_num,5], labels [max_num] int64, n int32[1]) device tensors."""
+    _need_cuda(boxes, scores)
+    R, ncls = scores.shape
+    dets = torch.zeros((max_num, 5), dtype=torch.float32, device=boxes.device)
+    labels = torch.zeros(max_num, dtype=torch.long, device=boxes.device)
+    n_out = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    ws = _workspace(lib().hvr_multiclass_nms_workspace_bytes(R, ncls), boxes.device, 'mcnms')
+    _check(lib().hvr_multiclass_nms(_ptr(boxes.contiguous()), _ptr(scores.contiguous()), R, ncls, float(score_thr),
+                                    float(iou_thr), int(max_num), _ptr(dets), _ptr(labels), _ptr(n_out), _ptr(ws),
+                                    ws.numel(), _stream()), 'hvr_multiclass_nms')
+    return dets, labels, n_out
+
+
+def cast(x, dtype):
+    _need_cuda(x)
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _check(lib().hvr_cast(_ptr(x), _ptr(out), x.numel(), _dt(x), _dt(out), _stream()), 'hvr_cast')
+    return out
+
+
+def nchw_to_nhwc(x, dtype=None):
+    """[B,C,H,W] contiguous -> physical [B,H,W,C] (optionally casting)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, C), dtype=dtype or x.dtype, device=x.device)
+    _check(lib().hvr_permute_nchw_nhwc(_ptr(x), _ptr(out), B, C, H * W, 1, _dt(x), _dt(out), _stream()), 'hvr_permute')
+    return out
+
+
+def nhwc_to_nchw(x, dtype=None):
+    """physical [B,H,W,C] contiguous -> [B,C,H,W] contiguous."""
+    _need_cuda(x)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty((B, C, H, W), dtype=dtype or x.dtype, device=x.device)
+    _check(lib().hvr_permute_nchw_nhwc(_ptr(x), _ptr(out), B, C, H * W, 0, _dt(x), _dt(out), _stream()), 'hvr_permute')
+    return out

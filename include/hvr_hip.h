@@ -1,0 +1,172 @@
+/*
+ * hvr_hip -- C ABI of the MI355X (gfx950) kernels behind the HVRNet video-detection
+ * forward path.  This is the drop-in boundary: every entry point below names the
+ * reference interface it replaces (paths relative to the youthHan/HVRNet tree).
+ *
+ * Conventions (mirroring the reference's caller-allocates pybind ABI,
+ * mmdet/ops/roi_align/src/roi_align_cuda.cpp:27-53, mmdet/ops/roi_align/roi_align.py:23):
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *     the library never allocates, frees or retains memory;
+ *   - work is enqueued on `stream` (hipStream_t passed as void*); nothing synchronises;
+ *   - return 0 on success, a negative HVR_E* code otherwise; hvr_last_error() gives the
+ *     message of the calling thread's last failure (the reference printf()s "wrong roi
+ *     size" and carries on, roi_align_cuda.cpp:39-42 -- this library never does that);
+ *   - dtype: HVR_F32 = 0, HVR_BF16 = 1 (element type of activations / weights; all
+ *     accumulation, softmax, box and score arithmetic is f32);
+ *   - re-entrant, no global mutable state besides one-time kernel attribute setup.
+ */
+#ifndef HVR_HIP_H_
+#define HVR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVR_OK 0
+#define HVR_EINVAL (-1)       /* bad argument (shape, alignment, null pointer) */
+#define HVR_EUNSUPPORTED (-2) /* valid request outside the implemented envelope */
+#define HVR_ELAUNCH (-3)      /* HIP reported a launch error */
+#define HVR_EWORKSPACE (-4)   /* workspace too small */
+
+#define HVR_F32 0
+#define HVR_BF16 1
+
+#define HVR_LAYOUT_NCHW 0 /* reference layout */
+#define HVR_LAYOUT_NHWC 1 /* native layout of this library */
+
+int hvr_abi_version(void);
+const char* hvr_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense contraction with fused epilogue:  C[M][N] = act(A[M][K] . B[N][K]^T + bias + R)
+ * Replaces the ATen calls behind nn.Linear / 1x1 Conv2d on the path:
+ *   selsa_bbox_head.py:156,159,185-186,220-221,237 ; hrnmp_bbox_head.py:283,286,345-346,827-906.
+ * K must be a multiple of 128 bytes / sizeof(elem); N a multiple of 4; rows 16-byte aligned.
+ * staging: 0 = register-staged loads, 1 = direct global->LDS DMA.
+ * ---------------------------------------------------------------------------------- */
+typedef struct hvr_gemm_desc {
+  const void* A; const void* B; void* C;
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc;   /* in elements */
+  const float* bias;       /* [N] f32 or NULL */
+  const void* resid;       /* [M][ldr] (operand dtype) or NULL */
+  int64_t ldr;
+  int32_t relu;            /* apply max(x, 0) last */
+  int32_t out_f32;         /* store C as f32 regardless of dtype */
+  int32_t dtype;
+  int32_t staging;
+} hvr_gemm_desc;
+int hvr_gemm(const hvr_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * NHWC convolution as implicit GEMM (frozen BatchNorm folded into w / bias by the caller)
+ * with fused bias + residual + ReLU.  Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU (+ the
+ * Bottleneck residual add): mmdet/models/backbones/resnet.py:220-266,
+ * mmdet/models/shared_heads/res_layer.py:67-74, mmdet/models/anchor_heads/rpn_head.py:30-35.
+ *   x [B][H][W][Cin], w [Cout][KH][KW][Cin], y [B][OH][OW][Cout]; Cin % (128/sizeof elem) == 0.
+ *   zero: >= 16 readable zero bytes on the device (source of padding taps).
+ * ---------------------------------------------------------------------------------- */
+typedef struct hvr_conv_desc {
+  const void* x; const void* w; void* y;
+  int32_t B, H, W, Cin, Cout, KH, KW, stride, pad, dil;
+  const float* bias;
+  const void* resid;       /* [B][OH][OW][Cout] or NULL */
+  int32_t relu, out_f32, dtype, staging;
+  const void* zero;
+} hvr_conv_desc;
+int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
+
+/* 7x7/2 stem: gathers img (NCHW f32, the reference's input layout, resnet.py:522-524) into
+ * patch rows [B*OH*OW][KP] with k = (ky*7+kx)*3 + c and zeros for k >= 147 (KP = 192). */
+int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream);
+/* nn.MaxPool2d(3, 2, 1) on NHWC (resnet.py:466,526) */
+int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Relation core:  O = softmax(scale * Q K^T, over keys) V      (single head, D up to any
+ * multiple of the K-step).  Replaces torch.bmm / scalar mul / nn.Softmax / torch.mm in
+ * selsa_bbox_head.py:166-182 and hrnmp_bbox_head.py:293-342 without materialising the
+ * f32 Mq x Mk logits.  Q [Mq][ldq], K [Mk][ldk], V [Mk][ldv], O [Mq][ldo], all `dtype`.
+ * ---------------------------------------------------------------------------------- */
+size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype);
+int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                     void* O, int64_t ldo, int Mq, int Mk, int D, float scale, int dtype, int staging,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * RoIAlign (legacy "+1" convention).  Replaces roi_align_cuda.forward / .backward:
+ *   mmdet/ops/roi_align/src/roi_align_cuda.cpp:27-80, roi_align_kernel.cu:63-141,187-282.
+ * rois [K][5] f32 = (batch_idx, x1, y1, x2, y2).  layout NCHW: feat [B][C][H][W] ->
+ * out [K][C][PH][PW]; layout NHWC: feat [B][H][W][C] -> out [K][PH][PW][C].
+ * Backward is f32 only (as the reference) and ACCUMULATES into grad_feat (caller zeroes).
+ * ---------------------------------------------------------------------------------- */
+int hvr_roi_align_fwd(const void* feat, const float* rois, void* out, int B, int C, int H, int W, int K,
+                      int PH, int PW, float spatial_scale, int sample_num, int dtype, int layout, void* stream);
+int hvr_roi_align_bwd(const float* grad_out, const float* rois, float* grad_feat, int B, int C, int H, int W,
+                      int K, int PH, int PW, float spatial_scale, int sample_num, int layout, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Greedy NMS.  Replaces nms_cpu.nms / nms_cuda.nms (mmdet/ops/nms/src/nms_cpu.cpp:5-71,
+ * nms_kernel.cu:24-136) with no host round trip.  dets [n][5] f32 (x1,y1,x2,y2,score);
+ * ge_semantics != 0 suppresses at IoU >= thr (the CPU reference), 0 at IoU > thr (the CUDA
+ * reference).  keep [n] int64 receives the surviving indices in ascending input order,
+ * *n_keep their count (both device memory).  n <= 8192.
+ * ---------------------------------------------------------------------------------- */
+size_t hvr_nms_workspace_bytes(int n);
+int hvr_nms(const float* dets, int n, float thr, int ge_semantics, int64_t* keep, int32_t* n_keep,
+            void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * RPN proposal generation for T frames in one call.  Replaces RPNHead.get_bboxes_single
+ * (mmdet/models/anchor_heads/rpn_head.py:55-104) + AnchorGenerator.grid_anchors
+ * (mmdet/core/anchor/anchor_generator.py:66-83) + delta2bbox (core/bbox/transforms.py:78-110):
+ * sigmoid, top nms_pre, decode + clip, NMS(thr, >=), first nms_post, top max_num by score.
+ *   cls [T][H][W][A] f32 logits, reg [T][H][W][A*4] f32 (NHWC conv outputs),
+ *   base_anchors host [A][4] f32, means/stds host [4] f32.
+ *   proposals [T][max_num][5] f32, counts [T] int32 (rows beyond counts[t] are untouched).
+ * ---------------------------------------------------------------------------------- */
+typedef struct hvr_rpn_desc {
+  const float* cls; const float* reg;
+  int32_t T, H, W, A, anchor_stride;
+  const float* base_anchors; const float* means; const float* stds;  /* host */
+  float img_h, img_w, wh_ratio_clip;
+  int32_t nms_pre, nms_post, max_num;
+  float nms_thr;
+  float* proposals; int32_t* counts;
+} hvr_rpn_desc;
+size_t hvr_rpn_workspace_bytes(int T, int H, int W, int A, int nms_pre);
+int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * RCNN detection read-out for one key frame.  Replaces BBoxHead.get_det_bboxes
+ * (mmdet/models/bbox_heads/bbox_head.py:132-169; hrnmp_bbox_head.py:1009-1052 per branch):
+ *   hvr_det_decode:     softmax over classes + delta2bbox + clip (+ / scale_factor)
+ *   hvr_multiclass_nms: mmdet/core/post_processing/bbox_nms.py:6-66 (class-agnostic boxes)
+ * logits [R][ldl] f32 with class logits at cls_off.. and 4 deltas at reg_off..;
+ * rois [R][5]; scores [R][ncls]; boxes [R][4]; dets [max_num][5]; labels [max_num] int64
+ * (0-based foreground class); *n_out device int32.  R <= 512.
+ * scale_factor <= 0 means rescale=False.  img_w <= 0 means no clipping.
+ * ---------------------------------------------------------------------------------- */
+int hvr_det_decode(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const float* rois, int R,
+                   const float* means, const float* stds, float wh_ratio_clip, float img_h, float img_w,
+                   float scale_factor, float* scores, float* boxes, void* stream);
+size_t hvr_multiclass_nms_workspace_bytes(int R, int ncls);
+int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls, float score_thr, float iou_thr,
+                       int max_num, float* dets, int64_t* labels, int32_t* n_out, void* ws, size_t ws_bytes,
+                       void* stream);
+
+/* ---- layout / dtype plumbing at the API boundary ---- */
+int hvr_cast(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, void* stream);
+/* to_nhwc != 0: [B][C][HW] -> [B][HW][C]; else the inverse */
+int hvr_permute_nchw_nhwc(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from_dtype,
+                          int to_dtype, void* stream);
+/* out[C][ldt] = in[R][ldx]^T, zero-filled for columns >= R */
+int hvr_transpose_pad(const void* in, void* out, int R, int C, int64_t ldx, int64_t ldt, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVR_HIP_H_ */

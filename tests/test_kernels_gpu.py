@@ -1,0 +1,169 @@
+"""Kernel-level numerics on the GPU: every HIP kernel against a plain PyTorch fp32 (CPU)
+statement of the same op on the same seeded inputs.  (The reference-anchored parity tests
+that go through the oracle live in test_parity_gpu.py.)
+
+Tolerances: bf16 operands are rounded before both sides see them, so the only error left is
+f32 accumulation order (+ bf16 rounding of stored outputs, 2^-9 relative).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hvrnet_amd import native  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _tol(dtype, out_dtype=None):
+    out_dtype = out_dtype or dtype
+    return dict(rtol=2e-2, atol=2e-2) if out_dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('staging', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 128), (300, 256, 1024), (4500 // 9, 64, 192), (77, 36, 64), (257, 1024, 576)])
+def test_gemm_matches_torch(M, N, K, dtype, staging):
+    a, w = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, 0.1)
+    bias = _rand((N,), torch.float32, 3)
+    resid = _rand((M, N), dtype, 4)
+    ref = torch.relu(a.float() @ w.float().t() + bias + resid.float())
+    out = native.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV), relu=True, staging=staging)
+    assert out.dtype == dtype
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+    # transposition-detecting plain product, f32 output
+    out2 = native.gemm(a.to(DEV), w.to(DEV), out_f32=True, staging=staging)
+    assert out2.dtype == torch.float32
+    torch.testing.assert_close(out2.cpu(), a.float() @ w.float().t(), rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize('staging', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('cfg', [
+    dict(Cin=64, Cout=64, k=3, stride=1, pad=1, dil=1, H=19, W=23),
+    dict(Cin=128, Cout=128, k=3, stride=1, pad=2, dil=2, H=17, W=21),   # res5-style dilation
+    dict(Cin=256, Cout=128, k=1, stride=2, pad=0, dil=1, H=20, W=31),   # caffe-style strided 1x1
+    dict(Cin=64, Cout=256, k=1, stride=1, pad=0, dil=1, H=9, W=14),
+])
+def test_conv_matches_torch(cfg, dtype, staging):
+    B = 2
+    x = _rand((B, cfg['Cin'], cfg['H'], cfg['W']), dtype, 5)
+    w = _rand((cfg['Cout'], cfg['Cin'], cfg['k'], cfg['k']), dtype, 6, 0.05)
+    bias = _rand((cfg['Cout'],), torch.float32, 7)
+    ref = F.conv2d(x.float(), w.float(), bias, stride=cfg['stride'], padding=cfg['pad'], dilation=cfg['dil'])
+    resid = _rand(ref.shape, dtype, 8)
+    ref = torch.relu(ref + resid.float())
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wn = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = native.conv2d_nhwc(xn, wn, bias.to(DEV), rn, relu=True, stride=cfg['stride'], pad=cfg['pad'], dil=cfg['dil'],
+                           staging=staging)
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, **_tol(dtype))
+
+
+def _relation_ref(q, k, v, scale):
+    p = torch.softmax(scale * (q.double() @ k.double().t()), dim=1)
+    return (p @ v.double()).float()
+
+
+@pytest.mark.parametrize('staging', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('Mq,Mk', [(96, 96), (300, 700), (37, 129)])
+def test_relation_matches_torch(Mq, Mk, dtype, staging):
+    D = 1024
+    q, k, v = _rand((Mq, D), dtype, 11, 1.5), _rand((Mk, D), dtype, 12, 1.5), _rand((Mk, D), dtype, 13)
+    ref = _relation_ref(q, k, v, 1.0 / 32)
+    out = native.relation_fwd(q.to(DEV), k.to(DEV), v.to(DEV), 1.0 / 32, staging=staging)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_relation_peaky_rows_and_tile_max_jumps(dtype):
+    """Forces the cross-tile rescale path: one key far above the rest, placed in a late 128-key tile."""
+    Mq, Mk, D = 64, 520, 1024
+    q, k, v = _rand((Mq, D), dtype, 21), _rand((Mk, D), dtype, 22), _rand((Mk, D), dtype, 23)
+    k[400] = (q[5].float() * 3).to(dtype)     # logit ~ 3*|q|^2/32 ~ 96 above the rest for row 5
+    k[3] = (q[9].float() * 2).to(dtype)       # early-tile spike for row 9
+    ref = _relation_ref(q, k, v, 1.0 / 32)
+    out = native.relation_fwd(q.to(DEV), k.to(DEV), v.to(DEV), 1.0 / 32)
+    assert torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+
+
+def test_maxpool_and_stem_patches():
+    x = _rand((2, 64, 21, 30), torch.float32, 31)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    y = native.maxpool3x3s2_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    torch.testing.assert_close(y.cpu().permute(0, 3, 1, 2), ref, rtol=0, atol=0)
+    img = _rand((2, 3, 37, 45), torch.float32, 32)
+    w = _rand((64, 3, 7, 7), torch.float32, 33, 0.1)
+    ref = F.conv2d(img, w, None, stride=2, padding=3)
+    cols, OH, OW = native.im2col_stem(img.to(DEV), torch.float32)
+    wp = torch.zeros(64, 192)
+    wp[:, :147] = w.permute(0, 2, 3, 1).reshape(64, 147)
+    out = native.gemm(cols, wp.to(DEV)).cpu().view(2, OH, OW, 64).permute(0, 3, 1, 2)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_layout_and_cast_round_trip():
+    x = _rand((2, 24, 5, 7), torch.float32, 41).to(DEV)
+    n = native.nchw_to_nhwc(x)
+    assert torch.equal(n.cpu(), x.cpu().permute(0, 2, 3, 1))
+    assert torch.equal(native.nhwc_to_nchw(n).cpu(), x.cpu())
+    b = native.cast(x, torch.bfloat16)
+    assert torch.equal(b.cpu(), x.cpu().to(torch.bfloat16))
+    assert torch.equal(native.cast(b, torch.float32).cpu(), x.cpu().to(torch.bfloat16).float())
+
+
+def _greedy_nms(dets, thr, ge=True):
+    import numpy as np
+    d = dets.numpy().astype(np.float32)
+    n = len(d)
+    order = sorted(range(n), key=lambda i: (-float(d[i, 4]), i))
+    one = np.float32(1)
+    area = (d[:, 2] - d[:, 0] + one) * (d[:, 3] - d[:, 1] + one)
+    dead = np.zeros(n, bool)
+    for a, i in enumerate(order):
+        if dead[i]:
+            continue
+        rest = np.array(order[a + 1:], dtype=np.int64)
+        if rest.size == 0:
+            break
+        w = np.maximum(np.float32(0), np.minimum(d[i, 2], d[rest, 2]) - np.maximum(d[i, 0], d[rest, 0]) + one)
+        h = np.maximum(np.float32(0), np.minimum(d[i, 3], d[rest, 3]) - np.maximum(d[i, 1], d[rest, 1]) + one)
+        inter = w * h
+        ovr = inter / (area[i] + area[rest] - inter)
+        hit = (ovr >= np.float32(thr)) if ge else (ovr > np.float32(thr))
+        dead[rest[hit]] = True
+    return [i for i in range(n) if not dead[i]]
+
+
+def _boxes(n, seed, span=200.0):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand((n, 2), generator=g) * span
+    wh = torch.rand((n, 2), generator=g) * 60 + 4
+    sc = torch.rand((n, 1), generator=g)
+    return torch.cat([xy, xy + wh, sc], 1)
+
+
+@pytest.mark.parametrize('n,thr', [(1, 0.5), (7, 0.7), (64, 0.3), (65, 0.7), (300, 0.3), (700, 0.5)])
+def test_nms_matches_greedy(n, thr):
+    dets = _boxes(n, 50 + n)
+    keep = native.nms(dets.to(DEV), thr).cpu().tolist()
+    assert keep == _greedy_nms(dets, thr)
+
+
+def test_nms_docstring_case_and_empty():
+    dets = torch.tensor([[49.1, 32.4, 51.0, 35.9, 0.9], [49.3, 32.9, 51.0, 35.3, 0.9], [49.2, 31.8, 51.0, 35.4, 0.5],
+                         [35.1, 11.5, 39.1, 15.7, 0.5], [35.6, 11.8, 39.3, 14.2, 0.5], [35.3, 11.5, 39.9, 14.5, 0.4],
+                         [35.2, 11.7, 39.7, 15.7, 0.3]])
+    assert native.nms(dets.to(DEV), 0.7).cpu().tolist() == [0, 3, 4]
+    assert native.nms(torch.zeros((0, 5), device=DEV), 0.5).numel() == 0

@@ -1,0 +1,96 @@
+"""Per-kernel timings of the hot-path shapes (HIP events on the launch stream).
+
+    python tools/kernel_bench.py [--dtype bf16|f32] [--iters 20]
+
+Prints one line per (kernel, shape): ms, achieved TFLOP/s or GB/s.  Used to pick tile
+shapes / staging and to fill DESIGN.md's roofline table; bench.py is the contract bench.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hvrnet_amd import native  # noqa: E402
+
+
+def timed(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--frames', type=int, default=15)
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dev = 'cuda:0'
+    T = args.frames
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, device=dev) * scale).to(dt)
+
+    print('# dtype=%s frames=%d' % (args.dtype, T))
+    # ---- plain GEMMs of the head ----
+    for name, M, N, K in [('fc_new_1', 4500, 1024, 12544), ('qk_proj', 4500, 2048, 1024), ('out_proj', 4500, 1024, 1024),
+                          ('fc_key', 300, 1024, 1024), ('square4k', 4096, 4096, 4096)]:
+        a, w = rnd(M, K), rnd(N, K, scale=0.05)
+        for st in (0, 1):
+            ms = timed(lambda: native.gemm(a, w, staging=st), args.iters)
+            print('gemm %-10s M=%d N=%d K=%d staging=%d  %.3f ms  %.1f TF/s' % (name, M, N, K, st, ms, 2.0 * M * N * K / ms / 1e9))
+    # ---- relation core ----
+    for Mq, Mk in [(4500, 4500), (300, 4500)]:
+        q, k, v = rnd(Mq, 1024), rnd(Mk, 1024), rnd(Mk, 1024)
+        for st in (0, 1):
+            ms = timed(lambda: native.relation_fwd(q, k, v, 1 / 32, staging=st), args.iters)
+            print('relation Mq=%d Mk=%d staging=%d  %.3f ms  %.1f TF/s' % (Mq, Mk, st, ms, 4.0 * Mq * Mk * 1024 / ms / 1e9))
+    # ---- backbone conv classes (T frames) ----
+    convs = [
+        ('l1.conv2 3x3 64', 152, 252, 64, 64, 3, 1, 1, 1),
+        ('l1.conv3 1x1 64->256', 152, 252, 64, 256, 1, 1, 0, 1),
+        ('l1.conv1 1x1 256->64', 152, 252, 256, 64, 1, 1, 0, 1),
+        ('l2.conv2 3x3 128', 76, 126, 128, 128, 3, 1, 1, 1),
+        ('l2.conv3 1x1 128->512', 76, 126, 128, 512, 1, 1, 0, 1),
+        ('l3.conv1 1x1 1024->256', 38, 63, 1024, 256, 1, 1, 0, 1),
+        ('l3.conv2 3x3 256', 38, 63, 256, 256, 3, 1, 1, 1),
+        ('l3.conv3 1x1 256->1024', 38, 63, 256, 1024, 1, 1, 0, 1),
+        ('l3.0.conv1 1x1/2 512->256', 76, 126, 512, 256, 1, 2, 0, 1),
+        ('r5.conv2 3x3 d2 512', 38, 63, 512, 512, 3, 1, 2, 2),
+        ('r5.conv3 1x1 512->2048', 38, 63, 512, 2048, 1, 1, 0, 1),
+        ('r5.conv1 1x1 2048->512', 38, 63, 2048, 512, 1, 1, 0, 1),
+        ('rpn 3x3 1024->512', 38, 63, 1024, 512, 3, 1, 1, 1),
+    ]
+    for name, H, W, Cin, Cout, k, s, p, d in convs:
+        x, w = rnd(T, H, W, Cin), rnd(Cout, k, k, Cin, scale=0.05)
+        b = torch.zeros(Cout, device=dev)
+        OH = (H + 2 * p - d * (k - 1) - 1) // s + 1
+        OW = (W + 2 * p - d * (k - 1) - 1) // s + 1
+        fl = 2.0 * T * OH * OW * Cout * k * k * Cin
+        by = (x.numel() + T * OH * OW * Cout + w.numel()) * x.element_size()
+        for st in (0, 1):
+            ms = timed(lambda: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=st), args.iters)
+            print('conv %-28s staging=%d  %.3f ms  %.1f TF/s  %.0f GB/s(min-traffic)' % (name, st, ms, fl / ms / 1e9, by / ms / 1e6))
+    # ---- RoIAlign, all frames in one launch ----
+    feat = rnd(T, 38, 63, 256)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xy = torch.rand((T * 300, 2), generator=g) * torch.tensor([800.0, 450.0])
+    wh = torch.rand((T * 300, 2), generator=g) * 200 + 16
+    rois = torch.cat([torch.arange(T).repeat_interleave(300)[:, None].float(), xy, xy + wh], 1).to(dev)
+    ms = timed(lambda: native.roi_align_fwd(feat, rois, 7, 7, 1 / 16, 2, native.LAYOUT_NHWC), args.iters)
+    by = (feat.numel() + T * 300 * 49 * 256) * feat.element_size() + rois.numel() * 4
+    print('roi_align nhwc K=%d  %.3f ms  %.0f GB/s(algorithmic)' % (T * 300, ms, by / ms / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,312 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference and oracle/_ref
+
+The reference cannot be imported as a package (missing generated files, mmcv,
+CUDA-only ops, modules that do not exist), so its hot-path modules are loaded file by file
+under stub parent packages; a ~30-line fake `mmcv` supplies the helpers they import.  Nothing
+of the reference is copied: this script only *executes* it where it lies and stores inputs /
+outputs (data) as fixtures.  Known reference defects patched here, and only here:
+  D1  HRNMPBBoxHead.__init__ unpacks 6 values from _add_selsa_with_fc which returns 4
+      (hrnmp_bbox_head.py:100-103 vs :189)  -> wrapper appends (None, None).
+RoIAlign has no CPU/reference path (roi_align.py:27-28): where a pipeline needs it, the
+oracle's restatement is used and the fixture says so (`roi_align: "oracle"`).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------ stub loader
+def _pkg(name, path=None):
+    m = types.ModuleType(name)
+    m.__path__ = [path] if path else []
+    sys.modules[name] = m
+    parent, _, child = name.rpartition('.')
+    if parent:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    parent, _, child = name.rpartition('.')
+    if parent in sys.modules:
+        setattr(sys.modules[parent], child, m)
+    spec.loader.exec_module(m)
+    return m
+
+
+def install_reference():
+    import torch.nn as nn
+    # fake mmcv
+    mmcv = _pkg('mmcv')
+    mmcv.is_str = lambda x: isinstance(x, str)
+    mmcv.bbox_flip = None
+    cnn = _pkg('mmcv.cnn')
+
+    def constant_init(module, val, bias=0):
+        nn.init.constant_(module.weight, val)
+        if getattr(module, 'bias', None) is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def kaiming_init(module, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+        nn.init.kaiming_normal_(module.weight, mode=mode, nonlinearity=nonlinearity)
+        if getattr(module, 'bias', None) is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def normal_init(module, mean=0, std=1, bias=0):
+        nn.init.normal_(module.weight, mean, std)
+        if getattr(module, 'bias', None) is not None:
+            nn.init.constant_(module.bias, bias)
+
+    cnn.constant_init, cnn.kaiming_init, cnn.normal_init = constant_init, kaiming_init, normal_init
+    cnn.xavier_init = lambda *a, **k: None
+    runner = _pkg('mmcv.runner')
+    runner.load_checkpoint = lambda *a, **k: None
+    runner.OptimizerHook = object
+    runner.get_dist_info = lambda: (0, 1)
+
+    pml = _pkg('pytorch_metric_learning')
+    losses = _pkg('pytorch_metric_learning.losses')
+    losses.TripletNonLocalLoss = type('TripletNonLocalLoss', (), {'__init__': lambda self, *a, **k: None})
+    pml.losses = losses
+
+    _pkg('mmdet', os.path.join(REF, 'mmdet'))
+    utils = _pkg('mmdet.utils')
+    reg = _load('mmdet.utils.registry', 'mmdet/utils/registry.py')
+    utils.Registry, utils.build_from_cfg = reg.Registry, reg.build_from_cfg
+
+    # mmdet.ops: only nms is real (the reference's nms_cpu.cpp compiled unmodified)
+    from oracle import build_ref
+    build_ref.build()
+    nms_cpu = build_ref.load_ref()
+    assert nms_cpu is not None, 'oracle/_ref was not built'
+    ops = _pkg('mmdet.ops')
+    ops_nms = _pkg('mmdet.ops.nms')
+    wrapper = types.ModuleType('mmdet.ops.nms.nms_wrapper')
+
+    def nms(dets, iou_thr, device_id=None):  # nms_wrapper.py:8-61, CPU tensor branch
+        if dets.shape[0] == 0:
+            inds = dets.new_zeros(0, dtype=torch.long)
+        else:
+            inds = nms_cpu.nms(dets, iou_thr)
+        return dets[inds, :], inds
+
+    wrapper.nms = nms
+    sys.modules['mmdet.ops.nms.nms_wrapper'] = wrapper
+    ops_nms.nms_wrapper = wrapper
+    ops.nms = nms
+    for dummy in ('ContextBlock', 'DeformConv', 'ModulatedDeformConv', 'RoIAlign', 'RoIPool'):
+        setattr(ops, dummy, type(dummy, (nn.Module,), {}))
+
+    core = _pkg('mmdet.core')
+    _pkg('mmdet.core.anchor')
+    _pkg('mmdet.core.bbox')
+    _pkg('mmdet.core.fp16')
+    _pkg('mmdet.core.utils')
+    _pkg('mmdet.core.post_processing')
+    ag = _load('mmdet.core.anchor.anchor_generator', 'mmdet/core/anchor/anchor_generator.py')
+    tr = _load('mmdet.core.bbox.transforms', 'mmdet/core/bbox/transforms.py')
+    _load('mmdet.core.fp16.utils', 'mmdet/core/fp16/utils.py')
+    dec = _load('mmdet.core.fp16.decorators', 'mmdet/core/fp16/decorators.py')
+    misc = _load('mmdet.core.utils.misc', 'mmdet/core/utils/misc.py')
+    core.AnchorGenerator = ag.AnchorGenerator
+    for n in ('delta2bbox', 'bbox2delta', 'bbox2roi', 'bbox2result', 'bbox_mapping', 'bbox_flip'):
+        setattr(core, n, getattr(tr, n))
+    core.auto_fp16, core.force_fp32 = dec.auto_fp16, dec.force_fp32
+    core.multi_apply = misc.multi_apply
+    core.anchor_target = core.bbox_target = None
+    core.merge_aug_bboxes = core.merge_aug_masks = core.merge_aug_proposals = None
+    bn = _load('mmdet.core.post_processing.bbox_nms', 'mmdet/core/post_processing/bbox_nms.py')
+    core.multiclass_nms = bn.multiclass_nms
+
+    models = _pkg('mmdet.models', os.path.join(REF, 'mmdet/models'))
+    _load('mmdet.models.registry', 'mmdet/models/registry.py')
+    _load('mmdet.models.builder', 'mmdet/models/builder.py')
+    plugins = _pkg('mmdet.models.plugins')
+    plugins.GeneralizedAttention = type('GeneralizedAttention', (nn.Module,), {})
+    mu = _pkg('mmdet.models.utils', os.path.join(REF, 'mmdet/models/utils'))
+    _load('mmdet.models.utils.conv_ws', 'mmdet/models/utils/conv_ws.py')
+    nm = _load('mmdet.models.utils.norm', 'mmdet/models/utils/norm.py')
+    cm = _load('mmdet.models.utils.conv_module', 'mmdet/models/utils/conv_module.py')
+    mu.ConvModule, mu.build_conv_layer, mu.build_norm_layer = cm.ConvModule, cm.build_conv_layer, nm.build_norm_layer
+    ml = _pkg('mmdet.models.losses', os.path.join(REF, 'mmdet/models/losses'))
+    _load('mmdet.models.losses.utils', 'mmdet/models/losses/utils.py')
+    acc = _load('mmdet.models.losses.accuracy', 'mmdet/models/losses/accuracy.py')
+    _load('mmdet.models.losses.cross_entropy_loss', 'mmdet/models/losses/cross_entropy_loss.py')
+    _load('mmdet.models.losses.smooth_l1_loss', 'mmdet/models/losses/smooth_l1_loss.py')
+    ml.accuracy = acc.accuracy
+    bb = _pkg('mmdet.models.backbones')
+    rn = _load('mmdet.models.backbones.resnet', 'mmdet/models/backbones/resnet.py')
+    bb.ResNet, bb.make_res_layer = rn.ResNet, rn.make_res_layer
+    _pkg('mmdet.models.shared_heads')
+    rl = _load('mmdet.models.shared_heads.res_layer', 'mmdet/models/shared_heads/res_layer.py')
+    _pkg('mmdet.models.anchor_heads')
+    _load('mmdet.models.anchor_heads.anchor_head', 'mmdet/models/anchor_heads/anchor_head.py')
+    rp = _load('mmdet.models.anchor_heads.rpn_head', 'mmdet/models/anchor_heads/rpn_head.py')
+    _pkg('mmdet.models.bbox_heads')
+    bh = _load('mmdet.models.bbox_heads.bbox_head', 'mmdet/models/bbox_heads/bbox_head.py')
+    sh = _load('mmdet.models.bbox_heads.selsa_bbox_head', 'mmdet/models/bbox_heads/selsa_bbox_head.py')
+    hh = _load('mmdet.models.bbox_heads.hrnmp_bbox_head', 'mmdet/models/bbox_heads/hrnmp_bbox_head.py')
+    # defect D1
+    orig = hh.HRNMPBBoxHead._add_selsa_with_fc
+    hh.HRNMPBBoxHead._add_selsa_with_fc = lambda self, *a, **k: tuple(orig(self, *a, **k)) + (None, None)
+    return types.SimpleNamespace(AnchorGenerator=ag.AnchorGenerator, tr=tr, nms=nms, nms_cpu=nms_cpu, multiclass_nms=bn.multiclass_nms,
+                                 ResNet=rn.ResNet, ResLayer=rl.ResLayer, RPNHead=rp.RPNHead, BBoxHead=bh.BBoxHead,
+                                 SelsaBBoxHead=sh.SelsaBBoxHead, HRNMPBBoxHead=hh.HRNMPBBoxHead)
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+    def copy(self):
+        return AttrDict(dict.copy(self))
+
+
+def _sub_state(sd, prefix):
+    return {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + '.')}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+
+
+def main():
+    import warnings
+    warnings.filterwarnings('ignore')
+    torch.set_num_threads(8)
+    ref = install_reference()
+    from hvrnet_amd import synthetic as S
+    from oracle import hvr_oracle as O
+    from tests.golden import cases as C
+
+    # ---- G1 anchors (anchor_generator.py) ----
+    agen = ref.AnchorGenerator(16, [4, 8, 16, 32], [0.5, 1.0, 2.0])
+    grid = agen.grid_anchors((38, 63), 16, device='cpu')
+    doc = ref.AnchorGenerator(9, [1.], [1.]).grid_anchors((2, 2), device='cpu')
+    save('g1_anchors', base=agen.base_anchors, grid_first=grid[:24], grid_last=grid[-24:], grid_count=grid.shape[0],
+         grid_sum=grid.double().sum(0), doctest=doc)
+
+    # ---- G2 delta2bbox ----
+    rois, deltas = C.delta2bbox_case()
+    out_rpn = ref.tr.delta2bbox(rois, deltas, [0., 0., 0., 0.], [1., 1., 1., 1.], (600, 1000))
+    out_rcnn = ref.tr.delta2bbox(rois, deltas, [0., 0., 0., 0.], [0.1, 0.1, 0.2, 0.2], (600, 1000))
+    out_noclip = ref.tr.delta2bbox(rois, deltas, [0., 0., 0., 0.], [0.1, 0.1, 0.2, 0.2], None)
+    d_rois = torch.Tensor([[0., 0., 1., 1.], [0., 0., 1., 1.], [0., 0., 1., 1.], [5., 5., 5., 5.]])
+    d_deltas = torch.Tensor([[0., 0., 0., 0.], [1., 1., 1., 1.], [0., 0., 2., -1.], [0.7, -1.9, -0.5, 0.3]])
+    save('g2_delta2bbox', rois=rois, deltas=deltas, out_rpn=out_rpn, out_rcnn=out_rcnn, out_noclip=out_noclip,
+         doc_rois=d_rois, doc_deltas=d_deltas, doc_out=ref.tr.delta2bbox(d_rois, d_deltas, max_shape=(32, 32)))
+
+    # ---- G3 nms_cpu.cpp (reference, compiled unmodified) ----
+    g3 = {}
+    for name, dets, thr in C.nms_cases():
+        g3[name + '_keep'] = ref.nms_cpu.nms(dets, thr)
+        g3[name + '_thr'] = thr
+        if dets.shape[0] <= 300:
+            g3[name + '_dets'] = dets
+    save('g3_nms', **g3)
+
+    # ---- G5 relation stage (selsa_bbox_head.py:108-200, hrnmp_bbox_head.py:216-355) ----
+    sd_hvr = S.synth_state_dict('hvr')
+    sd_selsa = S.synth_state_dict('selsa')
+    common = dict(with_avg_pool=False, in_channels=256, fc_feat_dim=1024, roi_feat_size=7, num_classes=31,
+                  target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2], reg_class_agnostic=True,
+                  loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                  loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+    selsa = ref.SelsaBBoxHead(sampler_num=32, t_dim=3, **common).eval()
+    selsa.load_state_dict(_sub_state(sd_selsa, 'bbox_head'), strict=True)
+    hvr = ref.HRNMPBBoxHead(sampler_num=32, t_dim=3, imgs_per_video=3, **common).eval()
+    hvr.load_state_dict(_sub_state(sd_hvr, 'bbox_head'), strict=True)
+    x = C.relation_input()
+    cur = dict(start=32, length=32)
+    with torch.no_grad():
+        y_all, _ = selsa.forward_single_selsa(x, 1, 96, index=1, cur_range=cur)
+        y_key, _ = hvr.forward_single_selsa(x, 1, 96, index=4, cur_range_s=[cur], idx_output_cur_only=True)
+        y_trunc, _ = selsa.forward_single_selsa(x, 1, 64, index=2, cur_range=cur)  # nongt_dim < M truncates the keys
+    save('g5_relation', y_all=y_all, y_key=y_key, y_trunc=y_trunc)
+
+    # ---- G6 / G7 heads at config-1 shapes (T=3, N=32) ----
+    feats = C.roi_feat_input()
+    with torch.no_grad():
+        cls_s, reg_s, _ = selsa(feats, cur_range=cur, key_dim=1)
+        cls_h, reg_h = hvr.forward_test(feats, [cur], key_dim=1)
+    save('g6_selsa_head', cls=cls_s, reg=reg_s)
+    save('g7_hvr_head', cls_branch=cls_h[0], cls=cls_h[1], reg_branch=reg_h[0], reg=reg_h[1])
+
+    # ---- G8 get_det_bboxes + multiclass_nms (bbox_head.py:132-169, bbox_nms.py) ----
+    rois8, cls8, reg8 = C.det_case()
+    rcnn_cfg = AttrDict(score_thr=0.001, nms=AttrDict(type='nms', iou_thr=0.3), max_per_img=300)
+    with torch.no_grad():
+        db, dl = selsa.get_det_bboxes(rois8, cls8, reg8, (600, 1000, 3), 1.0, rescale=True, cfg=rcnn_cfg)
+        rcnn_small = AttrDict(score_thr=0.001, nms=AttrDict(type='nms', iou_thr=0.3), max_per_img=100)
+        db2, dl2 = selsa.get_det_bboxes(rois8, cls8, reg8, (600, 1000, 3), 2.0, rescale=True, cfg=rcnn_small)
+        bb, sc = selsa.get_det_bboxes(rois8, cls8, reg8, (600, 1000, 3), 1.0, rescale=False, cfg=None)
+    save('g8_det', det_bboxes=db, det_labels=dl, det_bboxes_top100=db2, det_labels_top100=dl2, bboxes=bb, scores=sc)
+
+    # ---- G9 backbone / res5 / RPN at reduced size, full R101 weights ----
+    norm_cfg = dict(type='BN', requires_grad=False)
+    backbone = ref.ResNet(depth=101, num_stages=3, strides=(1, 2, 2), dilations=(1, 1, 1), out_indices=(2,), frozen_stages=1,
+                          style='caffe', norm_eval=True, norm_cfg=norm_cfg)
+    backbone.eval()  # the reference's train() override returns None (resnet.py:535-542)
+    backbone.load_state_dict(_sub_state(sd_hvr, 'backbone'), strict=True)
+    shared = ref.ResLayer(depth=101, stage=3, stride=1, dilation=2, style='caffe', norm_eval=True, norm_cfg=norm_cfg,
+                          external_conv=True)
+    shared.eval()
+    shared.load_state_dict(_sub_state(sd_hvr, 'shared_head'), strict=True)
+    rpn = ref.RPNHead(in_channels=1024, feat_channels=512, anchor_scales=[4, 8, 16, 32], anchor_ratios=[0.5, 1.0, 2.0],
+                      anchor_strides=[16], target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0],
+                      loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                      loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0)).eval()
+    rpn.load_state_dict(_sub_state(sd_hvr, 'rpn_head'), strict=True)
+    small = C.small_image()
+    with torch.no_grad():
+        c4 = backbone(small)[0]
+        c5 = shared(c4)
+        rc, rr = rpn([c4])
+    save('g9_backbone_small', c4=c4, c5=c5, rpn_cls=rc[0], rpn_reg=rr[0])
+
+    # ---- G10 config 1 end to end: 3 frames of 600x1000, 32 proposals, key frame 1 ----
+    T, key = 3, 1
+    imgs = [S.synth_frame(i) for i in range(T)]
+    metas = [S.synth_meta() for _ in range(T)]
+    rpn_cfg = AttrDict(nms_across_levels=False, nms_pre=6000, nms_post=32, max_num=32, nms_thr=0.7, min_bbox_size=0)
+    with torch.no_grad():
+        c4s = [backbone(im)[0] for im in imgs]
+        xcat = torch.cat(c4s, 0)
+        c5 = shared(xcat)
+        rcls, rreg = rpn([xcat])
+        props = rpn.get_bboxes(rcls, rreg, metas, rpn_cfg)
+        rois_all = [ref.tr.bbox2roi([p]) for p in props]
+        start = int(sum(r.shape[0] for r in rois_all[:key]))
+        cur_range = dict(start=start, length=rois_all[key].shape[0])
+        roi_feats = torch.cat([O.roi_align(c5[i:i + 1], rois_all[i], 7, 1.0 / 16, 2) for i in range(T)], 0)  # oracle (no ref path)
+        out = dict(proposals=torch.stack(props), c4_checksum=xcat.double().sum(), c5_checksum=c5.double().sum(),
+                   c4_slice=xcat[:, :8, 10:14, 20:24].contiguous(), c5_slice=c5[:, :8, 10:14, 20:24].contiguous())
+        cls_s, reg_s, _ = selsa(roi_feats, cur_range=cur_range, key_dim=key)
+        # the SELSA fixture reuses the HVR backbone/RPN weights (identical by construction of the seeded generator)
+        db, dl = selsa.get_det_bboxes(rois_all[key], cls_s, reg_s, metas[0]['img_shape'], 1.0, rescale=True, cfg=rcnn_cfg)
+        out.update(selsa_cls=cls_s, selsa_reg=reg_s, selsa_det_bboxes=db, selsa_det_labels=dl)
+        cls_h, reg_h = hvr.forward_test(roi_feats, [cur_range], key_dim=key)
+        dbs, dls = hvr.get_det_bboxes(rois_all[key], cls_h, reg_h, metas[0]['img_shape'], 1.0, rescale=True, cfg=rcnn_cfg)
+        for b in range(2):
+            out['hvr_cls_%d' % b], out['hvr_reg_%d' % b] = cls_h[b], reg_h[b]
+            out['hvr_det_bboxes_%d' % b], out['hvr_det_labels_%d' % b] = dbs[b], dls[b]
+    save('g10_config1', **out)
+
+
+if __name__ == '__main__':
+    main()

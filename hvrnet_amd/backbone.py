@@ -1,0 +1,282 @@
+"""ResNet-C4 backbone and the res5 shared head, executed by the gfx950 implicit-GEMM kernels.
+
+Host-side mirror of mmdet/models/backbones/resnet.py (Bottleneck 86-266, make_res_layer 269-329,
+ResNet 332-543) and mmdet/models/shared_heads/res_layer.py (ResLayer 13-81): same class names,
+constructor kwargs, sub-module names and parameter shapes, so `build_from_cfg` and reference
+checkpoints work unchanged.  The nn.Conv2d / nn.BatchNorm2d children only HOLD parameters; the
+forward pass runs on packed device buffers:
+  * activations are physical NHWC (exposed as logical NCHW `channels_last` tensors),
+  * frozen BatchNorm (eval mode, eps 1e-5: mmdet/models/utils/norm.py:43) is folded into the
+    conv weight / an f32 bias at pack time,
+  * bias + residual add + ReLU run in the GEMM epilogue (one launch per conv, no BN/ReLU/add
+    kernels; the reference issues ~4 launches per conv).
+Inference only: BN layers are always treated as frozen (both configs set norm_eval=True,
+requires_grad=False).  There is no CPU path (native.py raises on CPU tensors).
+"""
+import torch
+import torch.nn as nn
+
+from . import native
+from .registry import BACKBONES, SHARED_HEADS
+
+ARCH_SETTINGS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+STEM_KP = 192  # 7*7*3 = 147 patch elements padded to a K-step multiple
+
+
+def as_nhwc(x, dtype):
+    """Logical [B,C,H,W] tensor -> physical [B,H,W,C] contiguous tensor of `dtype` (no copy when it already is)."""
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v if x.dtype == dtype else native.cast(v, dtype)
+    return native.nchw_to_nhwc(x.contiguous(), dtype)
+
+
+def as_logical(y):
+    """Physical [B,H,W,C] -> logical [B,C,H,W] (channels_last strides, no copy)."""
+    return y.permute(0, 3, 1, 2)
+
+
+def fold_conv_bn(conv, bn, dtype):
+    """(w [Cout,KH,KW,Cin] in `dtype`, bias [Cout] f32) with eval-mode BN folded in."""
+    w = conv.weight.detach().float()
+    if bn is not None:
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        bias = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        w = w * scale[:, None, None, None]
+    else:
+        bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None and conv.bias is not None:
+        bias = bias + conv.bias.detach().float() * scale
+    return w.permute(0, 2, 3, 1).contiguous().to(dtype), bias.contiguous()
+
+
+class PackedMixin(object):
+    """Lazily packed device weights, rebuilt when the dtype/device changes or a state dict is loaded."""
+
+    def _init_packed(self):
+        self._packed = None
+        self._packed_key = None
+        self.compute_dtype = torch.bfloat16
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_packed())
+
+    def _drop_packed(self):
+        self._packed = None
+
+    def packed(self, device):
+        key = (self.compute_dtype, str(device))
+        if self._packed is None or self._packed_key != key:
+            with torch.no_grad():
+                self._packed = self._pack(self.compute_dtype)
+            self._packed_key = key
+        return self._packed
+
+
+def set_compute_dtype(module, dtype):
+    """bf16 (fast path) or f32 (exact-f32 MFMA path) for every packed module below `module`."""
+    assert dtype in (torch.bfloat16, torch.float32)
+    for m in module.modules():
+        if isinstance(m, PackedMixin):
+            m.compute_dtype = dtype
+            m._drop_packed()
+    return module
+
+
+class Bottleneck(nn.Module, PackedMixin):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', norm_cfg=None):
+        super(Bottleneck, self).__init__()
+        assert style in ['pytorch', 'caffe']
+        self.inplanes, self.planes, self.stride, self.dilation, self.style = inplanes, planes, stride, dilation, style
+        # caffe: stride on the first 1x1 (resnet.py:127-132)
+        self.conv1_stride, self.conv2_stride = (1, stride) if style == 'pytorch' else (stride, 1)
+        eps = (norm_cfg or {}).get('eps', 1e-5)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=self.conv1_stride, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes, eps=eps)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=self.conv2_stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes, eps=eps)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4, eps=eps)
+        self.downsample = downsample
+        self._init_packed()
+
+    def _pack(self, dtype):
+        p = dict(c1=fold_conv_bn(self.conv1, self.bn1, dtype), c2=fold_conv_bn(self.conv2, self.bn2, dtype),
+                 c3=fold_conv_bn(self.conv3, self.bn3, dtype))
+        if self.downsample is not None:
+            p['ds'] = fold_conv_bn(self.downsample[0], self.downsample[1], dtype)
+        return p
+
+    def forward_nhwc(self, x):
+        p = self.packed(x.device)
+        out = native.conv2d_nhwc(x, p['c1'][0], p['c1'][1], relu=True, stride=self.conv1_stride)
+        out = native.conv2d_nhwc(out, p['c2'][0], p['c2'][1], relu=True, stride=self.conv2_stride, pad=self.dilation,
+                                 dil=self.dilation)
+        identity = x
+        if self.downsample is not None:
+            identity = native.conv2d_nhwc(x, p['ds'][0], p['ds'][1], relu=False, stride=self.stride)
+        return native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=identity, relu=True)
+
+    def forward(self, x):
+        return as_logical(self.forward_nhwc(as_nhwc(x, self.compute_dtype)))
+
+
+def make_res_layer(block, inplanes, planes, blocks, stride=1, dilation=1, style='pytorch', norm_cfg=None, **_unused):
+    downsample = None
+    eps = (norm_cfg or {}).get('eps', 1e-5)
+    if stride != 1 or inplanes != planes * block.expansion:
+        downsample = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                                   nn.BatchNorm2d(planes * block.expansion, eps=eps))
+    layers = [block(inplanes, planes, stride, dilation, downsample, style=style, norm_cfg=norm_cfg)]
+    inplanes = planes * block.expansion
+    for _ in range(1, blocks):
+        layers.append(block(inplanes, planes, 1, dilation, style=style, norm_cfg=norm_cfg))
+    return nn.Sequential(*layers)
+
+
+def _freeze(module):
+    module.eval()
+    for p in module.parameters():
+        p.requires_grad = False
+
+
+@BACKBONES.register_module
+class ResNet(nn.Module, PackedMixin):
+    """Same kwargs as the reference ResNet (resnet.py:372-395); dcn / gcb / gen_attention must be None
+    (both hot-path configs leave them unset)."""
+    arch_settings = {d: (Bottleneck, s) for d, s in ARCH_SETTINGS.items()}
+
+    def __init__(self, depth, in_channels=3, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1),
+                 out_indices=(0, 1, 2, 3), style='pytorch', frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), gcb=None, stage_with_gcb=(False, False, False, False),
+                 gen_attention=None, stage_with_gen_attention=((), (), (), ()), with_cp=False, zero_init_residual=True):
+        super(ResNet, self).__init__()
+        if depth not in self.arch_settings:
+            raise KeyError('invalid depth {} for resnet'.format(depth))
+        if dcn is not None or gcb is not None or gen_attention is not None or conv_cfg is not None:
+            raise NotImplementedError('dcn / gcb / gen_attention / conv_cfg are outside the HVR hot path')
+        if norm_cfg.get('type', 'BN') != 'BN':
+            raise NotImplementedError('only frozen BatchNorm is supported')
+        assert 1 <= num_stages <= 4 and len(strides) == len(dilations) == num_stages and max(out_indices) < num_stages
+        assert in_channels == 3
+        self.depth, self.num_stages, self.strides, self.dilations = depth, num_stages, strides, dilations
+        self.out_indices, self.style, self.frozen_stages, self.norm_eval = out_indices, style, frozen_stages, norm_eval
+        self.zero_init_residual = zero_init_residual
+        block, stage_blocks = self.arch_settings[depth]
+        self.stage_blocks = stage_blocks[:num_stages]
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64, eps=norm_cfg.get('eps', 1e-5))
+        self.res_layers = []
+        inplanes = 64
+        for i, nb in enumerate(self.stage_blocks):
+            planes = 64 * 2 ** i
+            name = 'layer{}'.format(i + 1)
+            self.add_module(name, make_res_layer(block, inplanes, planes, nb, stride=strides[i], dilation=dilations[i],
+                                                 style=style, norm_cfg=norm_cfg))
+            inplanes = planes * block.expansion
+            self.res_layers.append(name)
+        self.feat_dim = block.expansion * 64 * 2 ** (len(self.stage_blocks) - 1)
+        _freeze(self)
+        self._init_packed()
+
+    def init_weights(self, pretrained=None):
+        """resnet.py:496-520 (pretrained checkpoints are loaded by the caller via load_state_dict)."""
+        if pretrained is not None:
+            raise NotImplementedError('load checkpoints with load_state_dict (keys match the reference)')
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+        set_compute_dtype(self, self.compute_dtype)
+
+    def _pack(self, dtype):
+        w, b = fold_conv_bn(self.conv1, self.bn1, torch.float32)  # [64,7,7,3]
+        wp = torch.zeros((64, STEM_KP), dtype=torch.float32, device=w.device)
+        wp[:, :147] = w.reshape(64, 147)
+        return dict(stem=(wp.to(dtype), b))
+
+    def forward(self, x):
+        """x [B,3,H,W] f32 -> tuple of logical-NCHW feature maps (resnet.py:522-533)."""
+        if not x.is_cuda:
+            raise NotImplementedError('ResNet runs on the GPU only (no CPU fallback)')
+        p = self.packed(x.device)
+        dt = self.compute_dtype
+        cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
+        y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
+        y = native.maxpool3x3s2_nhwc(y)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk in getattr(self, name):
+                y = blk.forward_nhwc(y)
+            if i in self.out_indices:
+                outs.append(as_logical(y))
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super(ResNet, self).train(False)  # frozen: inference-only build
+        return self
+
+
+@SHARED_HEADS.register_module
+class ResLayer(nn.Module, PackedMixin):
+    """res5 applied to the whole stride-16 map + the 1x1 2048->256 `new_layer_1` (res_layer.py:16-52,67-74)."""
+
+    def __init__(self, depth, stage=3, stride=2, dilation=1, style='pytorch', norm_cfg=dict(type='BN', requires_grad=True),
+                 norm_eval=True, with_cp=False, external_conv=False, dcn=None):
+        super(ResLayer, self).__init__()
+        if dcn is not None:
+            raise NotImplementedError('dcn is outside the HVR hot path')
+        self.norm_eval, self.norm_cfg, self.stage, self.external_conv = norm_eval, norm_cfg, stage, external_conv
+        self.fp16_enabled = False
+        stage_block = ARCH_SETTINGS[depth][stage]
+        planes = 64 * 2 ** stage
+        inplanes = 64 * 2 ** (stage - 1) * Bottleneck.expansion
+        self.add_module('layer{}'.format(stage + 1),
+                        make_res_layer(Bottleneck, inplanes, planes, stage_block, stride=stride, dilation=dilation, style=style,
+                                       norm_cfg=norm_cfg))
+        if external_conv:
+            # ConvModule(2048, 256, 1): conv + bias + ReLU, parameters under new_layer_1.conv.*
+            self.new_layer_1 = nn.Module()
+            self.new_layer_1.conv = nn.Conv2d(2048, 256, 1)
+        _freeze(self)
+        self._init_packed()
+
+    def init_weights(self, pretrained=None):
+        if pretrained is not None:
+            raise NotImplementedError('load checkpoints with load_state_dict (keys match the reference)')
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        set_compute_dtype(self, self.compute_dtype)
+
+    def _pack(self, dtype):
+        if not self.external_conv:
+            return {}
+        return dict(ext=fold_conv_bn(self.new_layer_1.conv, None, dtype))
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise NotImplementedError('ResLayer runs on the GPU only (no CPU fallback)')
+        y = as_nhwc(x, self.compute_dtype)
+        for blk in getattr(self, 'layer{}'.format(self.stage + 1)):
+            y = blk.forward_nhwc(y)
+        if self.external_conv:
+            w, b = self.packed(x.device)['ext']
+            y = native.conv2d_nhwc(y, w, b, relu=True)
+        return as_logical(y)
+
+    def train(self, mode=True):
+        super(ResLayer, self).train(False)
+        return self

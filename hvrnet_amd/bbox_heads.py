@@ -1,0 +1,280 @@
+"""SELSA / HVR proposal-relation heads on the MFMA tile engine.
+
+Mirrors of
+  BBoxHead        mmdet/models/bbox_heads/bbox_head.py:13-169
+  SelsaBBoxHead   mmdet/models/bbox_heads/selsa_bbox_head.py:11-261
+  HRNMPBBoxHead   mmdet/models/bbox_heads/hrnmp_bbox_head.py:57-214 (ctor), 800-909 (forward_test),
+                  1009-1052 (get_det_bboxes)
+with the same class names, constructor kwargs, parameter names/shapes (`fc_new_k`,
+`selsa_k.{q_data_fc_k,k_data_fc_k,linear_out_k}`, `fc_cls[_2]`, `fc_reg[_2]`) and call signatures.
+
+One relation stage (selsa_bbox_head.py:108-200) is 4 launches here instead of ~12 ATen ops:
+  [Q|K] = X [Wq;Wk]^T + b            one GEMM, N = 2048
+  O     = softmax(Q K^T / 32) X      hvr_relation_fwd (scores -> stats -> apply; logits never in HBM)
+  H     = relu(Xq + O Wz^T + bz)     GEMM with bias + residual + ReLU epilogue
+The intended behaviour is implemented where the reference dump is broken.
+Inference only; the training forward of HRNMPBBoxHead (hard-proposal mining + an un-vendored
+triplet loss) is not part of this round.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+
+from . import native
+from .backbone import PackedMixin
+from .registry import HEADS
+
+
+def _pad_rows(w, b, mult=4):
+    n = w.shape[0]
+    npad = (n + mult - 1) // mult * mult
+    if npad == n:
+        return w.contiguous(), b.contiguous()
+    wp = torch.zeros((npad, w.shape[1]), dtype=w.dtype, device=w.device)
+    bp = torch.zeros(npad, dtype=b.dtype, device=b.device)
+    wp[:n], bp[:n] = w, b
+    return wp, bp
+
+
+@HEADS.register_module
+class BBoxHead(nn.Module, PackedMixin):
+    """Simplest RoI head; here it carries what the relation heads inherit (ctor bookkeeping, read-out)."""
+
+    def __init__(self, with_avg_pool=False, with_cls=True, with_reg=True, roi_feat_size=7, in_channels=256, num_classes=81,
+                 target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2], reg_class_agnostic=False,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)):
+        super(BBoxHead, self).__init__()
+        assert with_cls and with_reg
+        if with_avg_pool:
+            raise NotImplementedError('with_avg_pool is outside the HVR hot path')
+        self.with_avg_pool, self.with_cls, self.with_reg = with_avg_pool, with_cls, with_reg
+        self.roi_feat_size = _pair(roi_feat_size)
+        self.roi_feat_area = self.roi_feat_size[0] * self.roi_feat_size[1]
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.target_means, self.target_stds = target_means, target_stds
+        self.reg_class_agnostic = reg_class_agnostic
+        if not reg_class_agnostic:
+            raise NotImplementedError('class-specific regression is outside the HVR hot path')
+        self.fp16_enabled = False
+        self.loss_cls_cfg, self.loss_bbox_cfg = loss_cls, loss_bbox
+        self.fc_cls = nn.Linear(in_channels * self.roi_feat_area, num_classes)
+        self.fc_reg = nn.Linear(in_channels * self.roi_feat_area, 4)
+        self._init_packed()
+
+    def init_weights(self):
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01)
+        nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001)
+        nn.init.constant_(self.fc_reg.bias, 0)
+        self._drop_packed()
+
+    # ---- read-out shared by all heads -------------------------------------------------------
+    def _decode(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale):
+        """(scores [R,ncls], boxes [R,4]): softmax + delta2bbox + clip (+ /scale_factor), bbox_head.py:141-158."""
+        if isinstance(cls_score, list):
+            cls_score = sum(cls_score) / float(len(cls_score))
+        if not isinstance(scale_factor, (int, float)):
+            raise NotImplementedError('per-axis scale_factor arrays are outside the HVR hot path')
+        logits = torch.cat([cls_score.float(), bbox_pred.float()], dim=1).contiguous()
+        ncls = cls_score.shape[1]
+        return native.det_decode(logits, 0, ncls, ncls, rois, self.target_means, self.target_stds, img_shape,
+                                 float(scale_factor) if rescale else 0.0)
+
+    def _nms(self, boxes, scores, cfg):
+        dets, labels, n = native.multiclass_nms(boxes, scores, cfg.score_thr, cfg.nms['iou_thr'], cfg.max_per_img)
+        k = int(n.item())  # the only host read of the read-out
+        return dets[:k], labels[:k]
+
+    def get_det_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        scores, bboxes = self._decode(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale)
+        if cfg is None:
+            return bboxes, scores
+        if cfg.nms.get('type', 'nms') != 'nms':
+            raise NotImplementedError('only greedy nms is on the HVR hot path')
+        return self._nms(bboxes, scores, cfg)
+
+
+class _RelationHead(BBoxHead):
+    """fc_new_k + relation stages shared by the SELSA and HVR heads."""
+    NUM_STAGES = 0
+
+    def __init__(self, sampler_num, t_dim, fc_feat_dim=1024, non_cur_space=False, dim=(1024, 1024, 1024),
+                 output_cur_only=False, conv_z=None, conv_g=None, *args, **kwargs):
+        super(_RelationHead, self).__init__(*args, **kwargs)
+        n = self.NUM_STAGES
+        conv_z = [True] * n if conv_z is None else conv_z
+        conv_g = [False] * n if conv_g is None else conv_g
+        if non_cur_space or any(conv_g[:n]) or not all(conv_z[:n]) or tuple(dim) != (fc_feat_dim,) * 3:
+            raise NotImplementedError('non_cur_space / conv_g / conv_z=False / dim != fc_feat_dim are outside the hot path')
+        self.feat_dim = self.in_channels * self.roi_feat_area
+        self.sampler_num, self.t_dim, self.fc_feat_dim = sampler_num, t_dim, fc_feat_dim
+        self.non_cur_space, self.dim, self.conv_z, self.conv_g = non_cur_space, dim, conv_z, conv_g
+        self.nongt_dim = sampler_num * t_dim
+        # computes only what reaches an output (identical results); off = every row the reference computes
+        self.dead_row_elimination = False
+        for k in range(1, n + 1):
+            setattr(self, 'fc_new_%d' % k, nn.Linear(self.feat_dim if k == 1 else dim[2], fc_feat_dim))
+            setattr(self, 'selsa_%d' % k, nn.ModuleDict({
+                'q_data_fc_%d' % k: nn.Linear(fc_feat_dim, dim[0]),
+                'k_data_fc_%d' % k: nn.Linear(fc_feat_dim, dim[1]),
+                'aff_softmax_%d' % k: nn.Softmax(dim=2),
+                'linear_out_%d' % k: nn.Conv2d(dim[2], dim[2], 1)}))
+        self.fc_cls = nn.Linear(dim[2], self.num_classes)
+        self.fc_reg = nn.Linear(dim[2], 4)
+
+    def init_weights(self):
+        super(_RelationHead, self).init_weights()
+        for k in range(1, self.NUM_STAGES + 1):
+            for m in [getattr(self, 'fc_new_%d' % k)] + list(getattr(self, 'selsa_%d' % k).values()):
+                if isinstance(m, nn.Linear):  # linear_out_k keeps the default Conv2d init (selsa_bbox_head.py:96-100)
+                    nn.init.normal_(m.weight, 0.0, 0.01)
+                    nn.init.constant_(m.bias, 0)
+        for name in ('fc_cls', 'fc_reg', 'fc_cls_2', 'fc_reg_2'):
+            if hasattr(self, name):
+                nn.init.normal_(getattr(self, name).weight, 0, 0.01)
+                nn.init.constant_(getattr(self, name).bias, 0)
+        self._drop_packed()
+
+    # ---- packing ---------------------------------------------------------------------------
+    def _readout_pack(self, cls, reg, dtype):
+        w = torch.cat([cls.weight.detach().float(), reg.weight.detach().float()], 0)
+        b = torch.cat([cls.bias.detach().float(), reg.bias.detach().float()], 0)
+        w, b = _pad_rows(w, b)
+        return w.to(dtype), b
+
+    def _pack(self, dtype):
+        p = {}
+        for k in range(1, self.NUM_STAGES + 1):
+            fc = getattr(self, 'fc_new_%d' % k)
+            sel = getattr(self, 'selsa_%d' % k)
+            q, kk, z = sel['q_data_fc_%d' % k], sel['k_data_fc_%d' % k], sel['linear_out_%d' % k]
+            w = fc.weight.detach().float()
+            if k == 1:
+                C, (ph, pw) = self.in_channels, self.roi_feat_size
+                p['fc1_chw'] = w.to(dtype).contiguous()  # RoI features flattened (c, ph, pw): the reference order
+                p['fc1_hwc'] = w.view(-1, C, ph, pw).permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+            else:
+                p['fc%d' % k] = w.to(dtype).contiguous()
+            p['fcb%d' % k] = fc.bias.detach().float().contiguous()
+            p['wqk%d' % k] = torch.cat([q.weight.detach().float(), kk.weight.detach().float()], 0).to(dtype).contiguous()
+            p['bqk%d' % k] = torch.cat([q.bias.detach().float(), kk.bias.detach().float()], 0).contiguous()
+            p['wz%d' % k] = z.weight.detach().float().view(z.weight.shape[0], -1).to(dtype).contiguous()
+            p['bz%d' % k] = z.bias.detach().float().contiguous()
+        p['out1'] = self._readout_pack(self.fc_cls, self.fc_reg, dtype)
+        if hasattr(self, 'fc_cls_2'):
+            p['out2'] = self._readout_pack(self.fc_cls_2, self.fc_reg_2, dtype)
+        return p
+
+    # ---- device pipeline ---------------------------------------------------------------------
+    def _fc1(self, p, bbox_feat):
+        """fc_new_1 on RoI features, accepting NCHW-contiguous or channels_last ([K,7,7,C] physical) input."""
+        if not bbox_feat.is_cuda:
+            raise NotImplementedError('relation heads run on the GPU only (no CPU fallback)')
+        if bbox_feat.dim() == 4 and not bbox_feat.is_contiguous() and bbox_feat.permute(0, 2, 3, 1).is_contiguous():
+            x, w = bbox_feat.permute(0, 2, 3, 1).reshape(bbox_feat.size(0), -1), p['fc1_hwc']
+        else:
+            x, w = bbox_feat.contiguous().view(bbox_feat.size(0), -1), p['fc1_chw']
+        return native.gemm(native.cast(x, self.compute_dtype), w, p['fcb1'])
+
+    def _stage(self, p, k, x, q_range=None):
+        """relu(Xq + relation_k(X)): rows `q_range` as queries (all rows when None), keys = X[:nongt_dim]."""
+        D = self.fc_feat_dim
+        kv = x if self.nongt_dim >= x.shape[0] else x[:self.nongt_dim]
+        wqk, bqk = p['wqk%d' % k], p['bqk%d' % k]
+        if q_range is None and kv is x:
+            qk = native.gemm(x, wqk, bqk)
+            q, kk, xq = qk[:, :D], qk[:, D:], x
+        else:
+            xq = x if q_range is None else x[q_range[0]:q_range[0] + q_range[1]]
+            q = native.gemm(xq, wqk[:D], bqk[:D])
+            kk = native.gemm(kv, wqk[D:], bqk[D:])
+        o = native.relation_fwd(q, kk, kv, 1.0 / math.sqrt(float(self.dim[1])))
+        return native.gemm(o, p['wz%d' % k], p['bz%d' % k], resid=xq, relu=True)
+
+    def _readout(self, p, name, h):
+        o = native.gemm(h, p[name][0], p[name][1], out_f32=True)
+        nc = self.num_classes
+        return o[:, :nc], o[:, nc:nc + 4]
+
+
+@HEADS.register_module
+class SelsaBBoxHead(_RelationHead):
+    NUM_STAGES = 2
+
+    def forward(self, bbox_feat, cur_range=None, key_dim=0, all_res=False):
+        """-> (cls_score, bbox_pred, None), selsa_bbox_head.py:203-261 (output_cur_only=False)."""
+        assert cur_range is not None, 'Feature num range along axis need specified'
+        self.key_dim = key_dim
+        self.nongt_dim = self.sampler_num * self.t_dim
+        s, l = int(cur_range['start']), int(cur_range['length'])
+        p = self.packed(bbox_feat.device)
+        f1 = self._fc1(p, bbox_feat)
+        h1 = self._stage(p, 1, f1)
+        f2 = native.gemm(h1, p['fc2'], p['fcb2'])
+        if all_res:
+            h2 = self._stage(p, 2, f2)
+        elif self.dead_row_elimination:
+            h2 = self._stage(p, 2, f2, (s, l))
+        else:
+            h2 = self._stage(p, 2, f2)[s:s + l]
+        cls, reg = self._readout(p, 'out1', h2)
+        return cls, reg, None
+
+
+@HEADS.register_module
+class HRNMPBBoxHead(_RelationHead):
+    NUM_STAGES = 4
+
+    def __init__(self, sampler_num, t_dim, imgs_per_video, *args, **kwargs):
+        super(HRNMPBBoxHead, self).__init__(sampler_num, t_dim, *args, **kwargs)
+        self.imgs_per_video = imgs_per_video
+        self.output_cur_only = False
+        self.fc_cls_2 = nn.Linear(self.dim[2], self.num_classes)
+        self.fc_reg_2 = nn.Linear(self.dim[2], 4)
+
+    def forward_test(self, bbox_feat_s, cur_range_s=None, key_dim=0, all_res=False):
+        """-> ([cls_branch, cls], [reg_branch, reg]), hrnmp_bbox_head.py:800-909."""
+        assert cur_range_s is not None, 'Feature num range along axis need specified'
+        self.key_dim = key_dim
+        self.nongt_dim = self.sampler_num * self.t_dim
+        assert self.nongt_dim >= bbox_feat_s.shape[0]  # hrnmp_bbox_head.py:249
+        cur = cur_range_s[0]
+        s, l = int(cur['start']), int(cur['length'])
+        p = self.packed(bbox_feat_s.device)
+        f1 = self._fc1(p, bbox_feat_s)
+        h1 = self._stage(p, 1, f1)
+        f2 = native.gemm(h1, p['fc2'], p['fcb2'])
+        if self.dead_row_elimination:
+            h2_key = self._stage(p, 2, f2, (s, l))
+        else:
+            h2_key = self._stage(p, 2, f2)[s:s + l]
+        cls_b, reg_b = self._readout(p, 'out1', h2_key)
+        x3 = f1.clone()            # non-key rows fall back to the stage-1 pre-attention features (:865-868)
+        x3[s:s + l] = h2_key
+        f3 = native.gemm(x3, p['fc3'], p['fcb3'])
+        h3 = self._stage(p, 3, f3)
+        f4 = native.gemm(h3, p['fc4'], p['fcb4'])
+        h4 = self._stage(p, 4, f4, (s, l))
+        cls, reg = self._readout(p, 'out2', h4)
+        return [cls_b, cls], [reg_b, reg]
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('HRNMPBBoxHead training forward (mining + TripletNonLocalLoss, whose source is not in '
+                                  'the reference tree) is not implemented; use forward_test')
+
+    def get_det_bboxes(self, rois, cls_scores, bbox_preds, img_shape, scale_factor, rescale=False, cfg=None):
+        """Per-branch read-out -> (list of det_bboxes, list of det_labels), hrnmp_bbox_head.py:1009-1052."""
+        boxes_c, scores_c = [], []
+        for cls_score, bbox_pred in zip(cls_scores, bbox_preds):
+            scores, bboxes = self._decode(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale)
+            if cfg is None or not hasattr(cfg, 'nms'):
+                boxes_c.append(bboxes)
+                scores_c.append(scores)
+            else:
+                d, lab = self._nms(bboxes, scores, cfg)
+                boxes_c.append(d)
+                scores_c.append(lab)
+        return boxes_c, scores_c

@@ -7,7 +7,7 @@
 //   * RPN proposal selection           <- mmdet/models/anchor_heads/rpn_head.py:55-104
 //   * multi-class NMS of the RCNN head <- mmdet/core/post_processing/bbox_nms.py:6-66
 //
-// Integer / index work: bit-exact against the oracle.  Tie rule (unspecified in the
+// Integer / index work: bit-exact against the CPU reference semantics.  Tie rule (unspecified in the
 // reference, which relies on torch.sort/topk): higher score first, then lower index.
 #include "common.h"
 #include "gemm_params.h"

@@ -1,0 +1,220 @@
+"""Video detectors: orchestration of one window, same public surface as the reference.
+
+  BaseDetector.forward dispatch        mmdet/models/detectors/base.py:106-132
+  TwoStageDetector ctor / extract_feat mmdet/models/detectors/two_stage.py:20-97
+  SelsaRCNN                            mmdet/models/detectors/selsa_rcnn.py:13-83, 281-338
+  HNMBRCNN                             mmdet/models/detectors/hnmb_rcnn.py:19-48, 195-222, 571-613
+
+What differs from the reference is HOW a window executes, not what it computes:
+  * RPN proposals for all T frames come from one device pipeline (one host read of T counts, where
+    the reference synchronises inside every per-frame NMS),
+  * RoIAlign runs once over all frames (batch index = frame) instead of T launches on split maps
+    (hnmb_rcnn.py:596-598),
+  * the read-out (softmax, decode, 30-class NMS) stays on the device; one host read of the count.
+The reference dump's defects are implemented as intended: SelsaRCNN takes
+`[:2]` of the head's 3-tuple (selsa_rcnn.py:306), `collections.Sequence` -> `collections.abc`.
+Inference only.
+"""
+import collections.abc
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import registry
+from .box_ops import bbox2result, bbox2roi
+from .registry import DETECTORS
+
+
+class BaseDetector(nn.Module):
+
+    def __init__(self):
+        super(BaseDetector, self).__init__()
+        self.fp16_enabled = False
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    @property
+    def with_shared_head(self):
+        return hasattr(self, 'shared_head') and self.shared_head is not None
+
+    @property
+    def with_bbox(self):
+        return hasattr(self, 'bbox_head') and self.bbox_head is not None
+
+    @property
+    def with_mask(self):
+        return False
+
+    def forward(self, img, img_meta, return_loss=True, backbone_feat=False, forward_feat=False, **kwargs):
+        """base.py:106-132: backbone_feat -> C4 features; forward_feat -> one window; else train / test."""
+        if backbone_feat:
+            if isinstance(img, list):
+                assert len(img) == len(img_meta), 'img and img_meta should have same number!'
+                return [self.extract_feat(im_) for im_ in img]
+            return self.extract_feat(img)
+        if forward_feat:
+            if isinstance(img_meta[0], list) and len(img_meta[0]) != 0:
+                raise NotImplementedError('multi-scale test-time augmentation (forward_feat_aug) is outside the hot path')
+            return self.forward_feat(img_meta=img_meta, **kwargs)
+        if return_loss:
+            raise NotImplementedError('the training step is not part of this round (SURVEY.md 8f.2)')
+        return self.forward_test(img, img_meta, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError('{} must be a list, but got {}'.format(name, type(var)))
+        if len(imgs) != 1:
+            raise NotImplementedError('test-time augmentation is outside the hot path')
+        assert imgs[0].size(0) == 1
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+
+class TwoStageDetector(BaseDetector):
+
+    def __init__(self, backbone, neck=None, shared_head=None, rpn_head=None, bbox_roi_extractor=None, bbox_head=None,
+                 mask_roi_extractor=None, mask_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super(TwoStageDetector, self).__init__()
+        if neck is not None or mask_head is not None or mask_roi_extractor is not None:
+            raise NotImplementedError('necks / mask heads are outside the HVR hot path')
+        self.backbone = registry.build_backbone(backbone)
+        if shared_head is not None:
+            self.shared_head = registry.build_shared_head(shared_head)
+        if rpn_head is not None:
+            self.rpn_head = registry.build_head(rpn_head)
+        self.feat_from_shared_head = False
+        if bbox_head is not None:
+            bbox_roi_extractor = dict(bbox_roi_extractor)
+            self.feat_from_shared_head = bbox_roi_extractor.pop('feat_from_shared_head', False)  # two_stage.py:46
+            self.bbox_roi_extractor = registry.build_roi_extractor(bbox_roi_extractor)
+            self.bbox_head = registry.build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_rpn(self):
+        return hasattr(self, 'rpn_head') and self.rpn_head is not None
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_shared_head:
+            self.shared_head.init_weights(pretrained=pretrained)
+        if self.with_rpn:
+            self.rpn_head.init_weights()
+        if self.with_bbox:
+            self.bbox_roi_extractor.init_weights()
+            self.bbox_head.init_weights()
+
+    def extract_feat(self, img):
+        return self.backbone(img)
+
+    def simple_test_rpn(self, x, img_meta, rpn_test_cfg):
+        """test_mixins.py:9-13."""
+        rpn_outs = self.rpn_head(x)
+        return self.rpn_head.get_bboxes(*(rpn_outs + (img_meta, rpn_test_cfg)))
+
+
+class _WindowDetector(TwoStageDetector):
+    """forward_feat / simple_test_bboxes shared by SelsaRCNN and HNMBRCNN."""
+
+    def get_roi_feat(self, x, rois):
+        if not self.feat_from_shared_head:
+            raise NotImplementedError('per-RoI shared head (feat_from_shared_head=False) is outside the hot path')
+        return self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+
+    @staticmethod
+    def _cat_frames(x):
+        """torch.cat(deque, 0) that keeps the physical NHWC layout (hnmb_rcnn.py:200)."""
+        if isinstance(x, torch.Tensor):
+            return x
+        assert isinstance(x, collections.abc.Sequence) and isinstance(x[0], torch.Tensor)
+        if all(not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous() for t in x):
+            return torch.cat([t.permute(0, 2, 3, 1) for t in x], dim=0).permute(0, 3, 1, 2)
+        return torch.cat(tuple(x), dim=0)
+
+    def window_tensors(self, x, img_meta, proposals=None, rescale=False):
+        """Runs one window up to the head outputs; returns a dict of device tensors (used by forward_feat and tests)."""
+        xc = self._cat_frames(x)
+        assert xc.shape[0] == len(img_meta)
+        feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
+        if proposals is None:
+            rpn_outs = self.rpn_head([xc])
+            props, counts = self.rpn_head.get_bboxes_batched(rpn_outs[0], rpn_outs[1], img_meta, self.test_cfg.rpn)
+            counts_h = counts.tolist()  # host read #1: T integers
+            T, mx = props.shape[0], props.shape[1]
+            frame = torch.arange(T, device=props.device, dtype=props.dtype).view(T, 1, 1).expand(T, mx, 1)
+            rois = torch.cat([frame, props[..., :4]], dim=-1)
+            if all(c == mx for c in counts_h):
+                rois = rois.reshape(T * mx, 5)
+            else:
+                rois = torch.cat([rois[i, :c] for i, c in enumerate(counts_h)], dim=0)
+            proposal_list = [props[i, :c] for i, c in enumerate(counts_h)]
+        else:
+            proposal_list = list(proposals)
+            counts_h = [p.shape[0] for p in proposal_list]
+            rois = bbox2roi([p for p in proposal_list])  # batch index = frame index
+        key = self.key_dim
+        start = int(np.sum(counts_h[:key]))
+        cur_range = dict(start=start, length=int(counts_h[key]))
+        roi_feats = self.get_roi_feat(feats, rois.contiguous())
+        key_rois = rois[start:start + cur_range['length']].clone()
+        key_rois[:, 0] = 0  # the reference's rois carry batch index 0 (hnmb_rcnn.py:582-584)
+        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range, key_rois=key_rois)
+
+    def simple_test_bboxes(self, x, img_meta, proposals, rcnn_test_cfg, rescale=False):
+        raise NotImplementedError
+
+    def simple_test(self, img, img_meta, proposals=None, rescale=False):
+        raise NotImplementedError('single-image testing bypasses the relation head; use the window path (forward_feat)')
+
+
+@DETECTORS.register_module
+class SelsaRCNN(_WindowDetector):
+
+    def __init__(self, backbone, rpn_head, bbox_roi_extractor, bbox_head, train_cfg, test_cfg, neck=None, shared_head=None,
+                 pretrained=None, loss_frames=1):
+        super(SelsaRCNN, self).__init__(backbone=backbone, neck=neck, shared_head=shared_head, rpn_head=rpn_head,
+                                        bbox_roi_extractor=bbox_roi_extractor, bbox_head=bbox_head, train_cfg=train_cfg,
+                                        test_cfg=test_cfg, pretrained=pretrained)
+        if self.train_cfg is not None:
+            self.key_dim = int(self.train_cfg.rcnn.key_dim)
+        else:  # selsa_rcnn.py:39-42
+            self.key_dim = int(self.test_cfg.relation_setup.frame_interval)
+            self.bbox_head.t_dim = int(test_cfg.bbox_head.t_dim)
+            self.bbox_head.sampler_num = int(test_cfg.bbox_head.sampler_num)
+
+    def forward_feat(self, x=None, img_meta=None, proposals=None, rescale=False):
+        w = self.window_tensors(x, img_meta, proposals, rescale)
+        cls_score, bbox_pred = self.bbox_head(w['roi_feats'], w['cur_range'], key_dim=self.key_dim, all_res=False)[:2]
+        det_bboxes, det_labels = self.bbox_head.get_det_bboxes(w['key_rois'], cls_score, bbox_pred, img_meta[0]['img_shape'],
+                                                               img_meta[0]['scale_factor'], rescale=rescale,
+                                                               cfg=self.test_cfg.rcnn)
+        return bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+
+
+@DETECTORS.register_module
+class HNMBRCNN(_WindowDetector):
+
+    def __init__(self, backbone, rpn_head, bbox_roi_extractor, bbox_head, train_cfg, test_cfg, neck=None, shared_head=None,
+                 pretrained=None, loss_frames=1):
+        super(HNMBRCNN, self).__init__(backbone=backbone, neck=neck, shared_head=shared_head, rpn_head=rpn_head,
+                                       bbox_roi_extractor=bbox_roi_extractor, bbox_head=bbox_head, train_cfg=train_cfg,
+                                       test_cfg=test_cfg, pretrained=pretrained)
+        if self.train_cfg is not None:
+            self.key_dim = int(self.train_cfg.rcnn.key_dim)
+        else:  # hnmb_rcnn.py:44-48
+            self.key_dim = int(self.test_cfg.bbox_head.key_dim)
+            self.bbox_head.t_dim = int(test_cfg.bbox_head.t_dim)
+            self.bbox_head.sampler_num = int(test_cfg.bbox_head.sampler_num)
+
+    def forward_feat(self, x=None, img_meta=None, proposals=None, rescale=False):
+        """-> [branch results, final results], each a list of 30 per-class [k,5] arrays (hnmb_rcnn.py:214-218)."""
+        w = self.window_tensors(x, img_meta, proposals, rescale)
+        cls_score, bbox_pred = self.bbox_head.forward_test(w['roi_feats'], [w['cur_range']], key_dim=self.key_dim, all_res=False)
+        det_bboxes_c, det_labels_c = self.bbox_head.get_det_bboxes(w['key_rois'], cls_score, bbox_pred,
+                                                                   img_meta[0]['img_shape'], img_meta[0]['scale_factor'],
+                                                                   rescale=rescale, cfg=self.test_cfg.rcnn)
+        return [bbox2result(b, l, self.bbox_head.num_classes) for b, l in zip(det_bboxes_c, det_labels_c)]

@@ -142,6 +142,63 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ---- optional per-call timing with HIP events on the launch stream (used by bench.py) ----
+_prof = None
+
+
+class _Span(object):
+    __slots__ = ('tag', 'work', 'start')
+
+    def __init__(self, tag, work):
+        self.tag, self.work = tag, work
+
+    def __enter__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.start.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(torch.cuda.current_stream())
+        _prof['spans'].append((self.tag, self.work, self.start, end))
+
+
+class _NoSpan(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
+def _span(tag, work=0.0):
+    if _prof is None or (tag not in _prof['tags'] and '*' not in _prof['tags']):
+        return _NOSPAN
+    return _Span(tag, work)
+
+
+def profile_begin(tags=('*',)):
+    """Start recording (tag, algorithmic work, HIP-event pair) for the C-ABI calls whose tag is in `tags`."""
+    global _prof
+    _prof = dict(tags=set(tags), spans=[])
+
+
+def profile_end():
+    """-> {tag: dict(calls, ms, work)}; synchronises once."""
+    global _prof
+    spans, _prof = _prof['spans'], None
+    torch.cuda.synchronize()
+    out = {}
+    for tag, work, s, e in spans:
+        d = out.setdefault(tag, dict(calls=0, ms=0.0, work=0.0))
+        d['calls'] += 1
+        d['ms'] += s.elapsed_time(e)
+        d['work'] += work
+    return out
+
+
 _zero_pages = {}
 
 
@@ -174,7 +231,8 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
                  ldr=resid.stride(0) if resid is not None else 0,
                  relu=int(relu), out_f32=int(out.dtype == torch.float32 and a.dtype != torch.float32),
                  dtype=_dt(a), staging=STAGING if staging is None else staging)
-    _check(lib().hvr_gemm(ctypes.byref(d), _stream()), 'hvr_gemm')
+    with _span('gemm', 2.0 * M * N * K):
+        _check(lib().hvr_gemm(ctypes.byref(d), _stream()), 'hvr_gemm')
     return out
 
 
@@ -193,7 +251,8 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
                  staging=STAGING if staging is None else staging,
                  zero=zero_page(x.device).data_ptr())
-    _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
+    with _span('conv', 2.0 * B * OH * OW * Cout * KH * KW * Cin):
+        _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
     return y
 
 
@@ -238,9 +297,10 @@ def relation_fwd(q, k, v, scale, staging=None):
     o = torch.empty((Mq, D), dtype=q.dtype, device=q.device)
     nbytes = lib().hvr_relation_workspace_bytes(Mq, Mk, D, _dt(q))
     ws = _workspace(nbytes, q.device, 'relation')
-    _check(lib().hvr_relation_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
-                                  Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging,
-                                  _ptr(ws), ws.numel(), _stream()), 'hvr_relation_fwd')
+    with _span('relation_full' if Mq == Mk else 'relation_key', 4.0 * Mq * Mk * D):
+        _check(lib().hvr_relation_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
+                                      Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging,
+                                      _ptr(ws), ws.numel(), _stream()), 'hvr_relation_fwd')
     return o
 
 
@@ -256,8 +316,9 @@ def roi_align_fwd(feat, rois, out_h, out_w, spatial_scale, sample_num, layout):
         B, H, W, C = feat.shape
         out = torch.empty((K, out_h, out_w, C), dtype=feat.dtype, device=feat.device)
     assert feat.is_contiguous()
-    _check(lib().hvr_roi_align_fwd(_ptr(feat), _ptr(rois), _ptr(out), B, C, H, W, K, out_h, out_w, float(spatial_scale),
-                                   int(sample_num), _dt(feat), layout, _stream()), 'hvr_roi_align_fwd')
+    with _span('roi_align', float((feat.numel() + out.numel()) * feat.element_size() + rois.numel() * 4)):
+        _check(lib().hvr_roi_align_fwd(_ptr(feat), _ptr(rois), _ptr(out), B, C, H, W, K, out_h, out_w, float(spatial_scale),
+                                       int(sample_num), _dt(feat), layout, _stream()), 'hvr_roi_align_fwd')
     return out
 
 
@@ -309,7 +370,8 @@ def rpn_proposals(cls, reg, base_anchors, anchor_stride, means, stds, img_shape,
                 wh_ratio_clip=float(wh_ratio_clip), nms_pre=int(nms_pre), nms_post=int(nms_post), max_num=int(max_num),
                 nms_thr=float(nms_thr), proposals=props.data_ptr(), counts=counts.data_ptr())
     ws = _workspace(lib().hvr_rpn_workspace_bytes(T, H, W, A, int(nms_pre)), cls.device, 'rpn')
-    _check(lib().hvr_rpn_proposals(ctypes.byref(d), _ptr(ws), ws.numel(), _stream()), 'hvr_rpn_proposals')
+    with _span('rpn_proposals', float(cls.numel() * 4 + reg.numel() * 4)):
+        _check(lib().hvr_rpn_proposals(ctypes.byref(d), _ptr(ws), ws.numel(), _stream()), 'hvr_rpn_proposals')
     return props, counts
 
 

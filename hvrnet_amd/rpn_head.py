@@ -1,0 +1,95 @@
+"""RPN head: 3x3 conv + ReLU, 1x1 objectness / delta convs and the fused proposal kernel.
+
+Mirror of mmdet/models/anchor_heads/rpn_head.py:12-104 (+ AnchorHead ctor / get_bboxes,
+anchor_head.py:33-81,208-278).  `forward` keeps the reference's per-level list interface;
+`get_bboxes` runs sigmoid -> top-6000 -> delta2bbox -> NMS(0.7) -> first 300 -> top-k for ALL
+frames of the window in one device pipeline (the reference loops over frames and synchronises
+with the host inside every NMS, nms_kernel.cu:104-108).
+"""
+import torch
+import torch.nn as nn
+
+from . import native
+from .backbone import PackedMixin, as_logical, as_nhwc, fold_conv_bn
+from .box_ops import AnchorGenerator
+from .registry import HEADS
+
+
+@HEADS.register_module
+class RPNHead(nn.Module, PackedMixin):
+
+    def __init__(self, in_channels, feat_channels=256, anchor_scales=[8, 16, 32], anchor_ratios=[0.5, 1.0, 2.0],
+                 anchor_strides=[4, 8, 16, 32, 64], anchor_base_sizes=None, target_means=(.0, .0, .0, .0),
+                 target_stds=(1.0, 1.0, 1.0, 1.0),
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0)):
+        super(RPNHead, self).__init__()
+        self.in_channels, self.num_classes, self.feat_channels = in_channels, 2, feat_channels
+        self.anchor_scales, self.anchor_ratios, self.anchor_strides = anchor_scales, anchor_ratios, anchor_strides
+        self.anchor_base_sizes = list(anchor_strides) if anchor_base_sizes is None else anchor_base_sizes
+        self.target_means, self.target_stds = target_means, target_stds
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        if not self.use_sigmoid_cls:
+            raise NotImplementedError('softmax RPN scores are outside the HVR hot path (configs use sigmoid)')
+        self.cls_out_channels = self.num_classes - 1
+        self.loss_cls_cfg, self.loss_bbox_cfg = loss_cls, loss_bbox
+        self.fp16_enabled = False
+        self.anchor_generators = [AnchorGenerator(b, anchor_scales, anchor_ratios) for b in self.anchor_base_sizes]
+        self.num_anchors = len(self.anchor_ratios) * len(self.anchor_scales)
+        self.rpn_conv = nn.Conv2d(self.in_channels, self.feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(self.feat_channels, self.num_anchors * self.cls_out_channels, 1)
+        self.rpn_reg = nn.Conv2d(self.feat_channels, self.num_anchors * 4, 1)
+        self._init_packed()
+
+    def init_weights(self):
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+        self._drop_packed()
+
+    def _pack(self, dtype):
+        A = self.num_anchors
+        wc, bc = fold_conv_bn(self.rpn_cls, None, dtype)
+        wr, br = fold_conv_bn(self.rpn_reg, None, dtype)
+        # objectness and deltas share one GEMM: rows [0, A) scores, [A, 5A) deltas, padded to a multiple of 4
+        n = 5 * A
+        npad = (n + 3) // 4 * 4
+        w = torch.zeros((npad, 1, 1, self.feat_channels), dtype=dtype, device=wc.device)
+        b = torch.zeros(npad, dtype=torch.float32, device=wc.device)
+        w[:A], w[A:n], b[:A], b[A:n] = wc, wr, bc, br
+        return dict(conv=fold_conv_bn(self.rpn_conv, None, dtype), heads=(w, b))
+
+    def forward_single(self, x):
+        """x logical [T,C,H,W] -> (cls [T,A,H,W], reg [T,4A,H,W]) f32, physically NHWC."""
+        if not x.is_cuda:
+            raise NotImplementedError('RPNHead runs on the GPU only (no CPU fallback)')
+        p = self.packed(x.device)
+        A = self.num_anchors
+        y = native.conv2d_nhwc(as_nhwc(x, self.compute_dtype), p['conv'][0], p['conv'][1], relu=True, pad=1)
+        o = native.conv2d_nhwc(y, p['heads'][0], p['heads'][1], relu=False, out_f32=True)  # [T,H,W,5A(+pad)] f32
+        return as_logical(o[..., :A]), as_logical(o[..., A:5 * A])
+
+    def forward(self, feats):
+        outs = [self.forward_single(f) for f in feats]
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+    def get_bboxes_batched(self, cls_scores, bbox_preds, img_metas, cfg):
+        """(proposals [T,max_num,5], counts [T] int32) on the device, no host synchronisation."""
+        if len(cls_scores) != 1:
+            raise NotImplementedError('single-level RPN only (anchor_strides=[16])')
+        if cfg.get('nms_across_levels', False) or cfg.get('min_bbox_size', 0) > 0:
+            raise NotImplementedError('nms_across_levels / min_bbox_size > 0 are outside the HVR hot path')
+        cls, reg = cls_scores[0], bbox_preds[0]
+        shape0 = tuple(img_metas[0]['img_shape'][:2])
+        if any(tuple(m['img_shape'][:2]) != shape0 for m in img_metas):
+            raise NotImplementedError('frames of one window share img_shape (one video)')
+        cls_n = cls.permute(0, 2, 3, 1).float().contiguous()
+        reg_n = reg.permute(0, 2, 3, 1).float().contiguous()
+        gen = self.anchor_generators[0]
+        return native.rpn_proposals(cls_n, reg_n, gen.base_anchors, self.anchor_strides[0], self.target_means,
+                                    self.target_stds, shape0, cfg['nms_pre'], cfg['nms_post'], cfg['max_num'], cfg['nms_thr'])
+
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale=False):
+        """list of [n_i, 5] proposals per frame (anchor_head.py:208-278); one host read of the counts."""
+        props, counts = self.get_bboxes_batched(cls_scores, bbox_preds, img_metas, cfg)
+        return [props[i, :c] for i, c in enumerate(counts.tolist())]

@@ -1,0 +1,82 @@
+"""Sliding-window video inference loop (host logic).
+
+Shape of the reference's `multi_selsa_gpu_test` (tools/test.py:143-306) without its dataset / pickle
+plumbing: per incoming frame run the backbone once (`model(backbone_feat=True)`), keep the last T
+C4 maps in a deque, and once the deque is full emit one key-frame detection per step with
+`model(x=deque, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)`.
+  first frame of a video  (flag 0): deque padded with copies until it holds (T+1)/2 entries (:201-212)
+  middle frames           (flag 2): append; emit when the deque holds T entries            (:214-250)
+  last frame              (flag 1): pad to T-1, then append + emit min(seg_len, (T+1)/2) times (:257-300)
+The emitted detection belongs to the deque's centre entry (index (T-1)/2, :238-242).
+"""
+from collections import deque
+
+FIRST, LAST, MIDDLE = 0, 1, 2
+
+
+def frame_flags(num_frames):
+    """key_frame_flag sequence of one video segment (imagenet_vid_sequence.py semantics: 0 first, 1 last, 2 else)."""
+    if num_frames == 1:
+        return [FIRST]
+    return [FIRST] + [MIDDLE] * (num_frames - 2) + [LAST]
+
+
+class VideoWindowRunner(object):
+    """Feeds frames of ONE video through `model`; yields (frame_offset, result) per emitted key frame."""
+
+    def __init__(self, model, window, rescale=True):
+        assert window % 2 == 1, 'window = 2 * frame_interval + 1'
+        self.model, self.T, self.rescale = model, window, rescale
+        self.center = (window - 1) // 2
+        self._reset()
+
+    def _reset(self):
+        self.feats = deque(maxlen=self.T)
+        self.offsets = deque(maxlen=self.T)
+        self.metas = deque(maxlen=self.T)
+
+    def _push(self, feat, offset, meta):
+        self.feats.append(feat)
+        self.offsets.append(offset)
+        self.metas.append(meta)
+
+    def _emit(self):
+        result = self.model(x=self.feats, img=None, img_meta=list(self.metas), forward_feat=True, return_loss=False,
+                            rescale=self.rescale)
+        return self.offsets[self.center], result
+
+    def step(self, img, img_meta, flag, frame_offset, seg_len=None):
+        """One loader iteration; returns the list of (frame_offset, result) emitted by it."""
+        out = []
+        feat = self.model(img=img, img_meta=[img_meta], backbone_feat=True)[0]
+        if flag == FIRST:
+            self._reset()
+            while len(self.feats) < (self.T + 1) // 2:
+                self._push(feat, frame_offset, img_meta)
+        elif flag == MIDDLE:
+            self._push(feat, frame_offset, img_meta)
+            if len(self.feats) == self.T:
+                out.append(self._emit())
+        elif flag == LAST:
+            while len(self.feats) < self.T - 1:
+                self._push(feat, frame_offset, img_meta)
+            n_end = (self.T + 1) // 2 if seg_len is None else min(seg_len, (self.T + 1) // 2)
+            for _ in range(n_end):
+                self._push(feat, frame_offset, img_meta)
+                out.append(self._emit())
+        else:
+            raise ValueError('bad key_frame_flag %r' % (flag,))
+        return out
+
+    def run_video(self, frames, metas):
+        """frames: iterable of [1,3,H,W] tensors of one video. Returns {frame_offset: result}."""
+        frames = list(frames)
+        flags = frame_flags(len(frames))
+        results = {}
+        for i, (img, meta, flag) in enumerate(zip(frames, metas, flags)):
+            for off, res in self.step(img, meta, flag, i, seg_len=len(frames)):
+                results[off] = res
+        if len(frames) == 1:  # a one-frame segment is both first and last
+            for off, res in self.step(frames[0], metas[0], LAST, 0, seg_len=1):
+                results[off] = res
+        return results

@@ -1,0 +1,154 @@
+"""CPU-side checks (-m "not gpu"): the plugin surface, config loading, checkpoint key layout,
+BatchNorm folding, the window loop, the C-ABI export table, and the rule that the product never
+touches the oracle."""
+import ast
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import hvrnet_amd
+from hvrnet_amd import backbone, native, registry, synthetic, window
+from hvrnet_amd.config import Config, ConfigDict, hvr_config, selsa_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CFG = '/root/reference/configs'
+
+
+def _build(cfg):
+    return registry.build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+
+
+def test_registry_names_match_the_reference_configs():
+    for reg, names in [(registry.DETECTORS, ['SelsaRCNN', 'HNMBRCNN']), (registry.BACKBONES, ['ResNet']),
+                       (registry.SHARED_HEADS, ['ResLayer']), (registry.ROI_EXTRACTORS, ['SingleRoIExtractor']),
+                       (registry.HEADS, ['RPNHead', 'SelsaBBoxHead', 'HRNMPBBoxHead', 'BBoxHead'])]:
+        for n in names:
+            assert reg.get(n) is not None, (reg.name, n)
+    with pytest.raises(KeyError):
+        registry.build_from_cfg(dict(type='NoSuchThing'), registry.HEADS)
+    with pytest.raises(KeyError):
+        registry.HEADS.register_module(hvrnet_amd.RPNHead)  # duplicate registration is an error, as in the reference
+
+
+@pytest.mark.parametrize('head', ['selsa', 'hvr'])
+def test_builtin_config_builds_and_state_dict_keys_are_the_checkpoint_contract(head):
+    cfg = selsa_config() if head == 'selsa' else hvr_config()
+    model = _build(cfg)
+    sd = synthetic.synth_state_dict(head)
+    mine = model.state_dict()
+    assert set(mine.keys()) == set(sd.keys())
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd, strict=True)
+    assert model.key_dim == 7 and model.bbox_head.t_dim == 15 and model.bbox_head.sampler_num == 300
+    assert model.feat_from_shared_head is True
+    assert tuple(model.state_dict()['bbox_head.selsa_1.linear_out_1.weight'].shape) == (1024, 1024, 1, 1)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference tree not present')
+@pytest.mark.parametrize('name,builtin', [('faster_rcnn_r101_selsa_c5.py', selsa_config), ('faster_rcnn_r101_hrnmp_c5.py', hvr_config)])
+def test_reference_config_files_load_unchanged(name, builtin):
+    cfg = Config.fromfile(os.path.join(REF_CFG, name))
+    assert cfg.test_cfg.rpn.nms_pre == 6000 and cfg.test_cfg.rcnn.nms.iou_thr == 0.3
+    mine = builtin(frame_interval=10).model.to_dict()
+    theirs = cfg.model.to_dict()
+    assert theirs == mine
+    assert cfg.test_cfg.to_dict() == builtin(frame_interval=10).test_cfg.to_dict()
+    model = _build(Config(dict(model=cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)))
+    assert model.bbox_head.t_dim == 21  # the shipped files: frame_interval = 10
+    assert type(model).__name__ == cfg.model.type
+
+
+def test_configdict_access_patterns_used_by_the_path():
+    c = ConfigDict(score_thr=0.001, nms=dict(type='nms', iou_thr=0.3), max_per_img=300)
+    assert hasattr(c, 'nms') and not hasattr(c, 'nope') and c.nms.iou_thr == 0.3 and c.get('x', 5) == 5
+    d = c.nms.copy()
+    d.pop('type')
+    assert 'type' in c.nms
+
+
+def test_fold_conv_bn_equals_conv_then_eval_bn():
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(8, 16, 3, padding=1, bias=False)
+    bn = torch.nn.BatchNorm2d(16).eval()
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 8, 9, 11)
+    w, b = backbone.fold_conv_bn(conv, bn, torch.float32)
+    assert w.shape == (16, 3, 3, 8)
+    y = torch.nn.functional.conv2d(x, w.permute(0, 3, 1, 2), b, padding=1)
+    torch.testing.assert_close(y, bn(conv(x)), rtol=1e-5, atol=1e-5)
+
+
+def test_gpu_only_modules_fail_loudly_on_cpu():
+    model = _build(hvr_config())
+    with pytest.raises(NotImplementedError):
+        model.backbone(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError):
+        hvrnet_amd.ops.RoIAlign(7, 1 / 16, 2)(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5))
+    with pytest.raises(NotImplementedError):
+        hvrnet_amd.ops.nms(torch.rand(4, 5), 0.5)
+    with pytest.raises(NotImplementedError):
+        model(None, None, return_loss=True)
+
+
+class _FakeModel(object):
+    def __init__(self):
+        self.windows = []
+
+    def __call__(self, img=None, img_meta=None, backbone_feat=False, forward_feat=False, x=None, **kw):
+        if backbone_feat:
+            return (img,)
+        self.windows.append(list(x))
+        return list(x)
+
+
+@pytest.mark.parametrize('n_frames,T', [(40, 15), (9, 15), (1, 5), (6, 5)])
+def test_window_loop_matches_reference_shape(n_frames, T):
+    """Every frame gets exactly one detection; windows are the frame's +-T//2 neighbours with edge replication."""
+    m = _FakeModel()
+    res = window.VideoWindowRunner(m, T).run_video(list(range(n_frames)), [dict(i=i) for i in range(n_frames)])
+    assert sorted(res.keys()) == list(range(n_frames))
+    half = T // 2
+    for f, win in res.items():
+        assert len(win) == T
+        want = [min(max(f + d, 0), n_frames - 1) for d in range(-half, half + 1)]
+        assert win == want, (f, win)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(native.HEADER_PATH).read()
+    declared = set(re.findall(r'\b(hvr_[a-z0-9_]+)\s*\(', header))
+    declared -= {'hvr_gemm_desc', 'hvr_conv_desc', 'hvr_rpn_desc'}
+    assert declared == set(native.SYMBOLS.keys()), declared ^ set(native.SYMBOLS.keys())
+    if not os.path.exists(native.LIB_PATH):
+        native.build()
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert native.lib().hvr_abi_version() == 1
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'hvrnet_amd')):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith('.py'):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or '']
+                    bad += [(path, m) for m in mods if m.split('.')[0] == 'oracle']
+            elif f.endswith(('.hip', '.h', '.cpp', '.sh')):
+                if 'oracle' in open(path).read():
+                    bad.append((path, 'mentions oracle'))
+    assert not bad, bad

@@ -1,0 +1,342 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors, on the GPU box.  The oracle is the checker only; nothing here reads /root/reference.
+
+Tolerances (north_star: class indices exact, boxes / scores within 1e-3 of the CPU reference):
+  * index / integer results (NMS keep sets, labels, proposal order): exact;
+  * f32 compute mode (exact-f32 MFMA): 1e-3 absolute on boxes / scores / logits end to end;
+  * bf16 compute mode: operands are rounded to bf16 (2^-9), so the stated tolerance is relative to the
+    tensor's scale and is written at each assert.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hvrnet_amd  # noqa: E402
+from hvrnet_amd import native, ops, synthetic as S  # noqa: E402
+from hvrnet_amd.box_ops import AnchorGenerator, multiclass_nms  # noqa: E402
+from hvrnet_amd.config import ConfigDict, hvr_config, selsa_config  # noqa: E402
+from tests.golden import cases as C  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def O():
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, 'oracle', 'libhvr_oracle.so')):
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle')], check=True)
+    from oracle import hvr_oracle
+    return hvr_oracle
+
+
+def gold(name):
+    return np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(torch.as_tensor(np.asarray(a.detach().float().cpu() if isinstance(a, torch.Tensor) else a)).float(),
+                               torch.as_tensor(np.asarray(b.detach().float().cpu() if isinstance(b, torch.Tensor) else b)).float(),
+                               rtol=rtol, atol=atol)
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(np.asarray(b)).float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+# ------------------------------------------------------------------------------- RoIAlign
+def _roi_cases(B, H, W, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand((n, 2), generator=g) * torch.tensor([W * 16.0, H * 16.0])
+    wh = torch.rand((n, 2), generator=g) * torch.tensor([W * 8.0, H * 8.0]) + 1
+    rois = torch.cat([torch.randint(0, B, (n, 1), generator=g).float(), xy, xy + wh], 1)
+    rois[0, 1:] = torch.tensor([0., 0., W * 16.0 - 1, H * 16.0 - 1])        # full image
+    rois[1, 1:] = torch.tensor([50., 60., 50., 60.])                          # single pixel
+    rois[2, 1:] = torch.tensor([120., 90., 40., 30.])                         # malformed (x2 < x1)
+    rois[3, 1:] = torch.tensor([-200., -150., 80., 60.])                      # sticks out top-left
+    rois[4, 1:] = torch.tensor([W * 16.0 - 40, H * 16.0 - 30, W * 16.0 + 300, H * 16.0 + 200])  # out bottom-right
+    rois[5, 1:] = torch.tensor([W * 16.0 + 50, H * 16.0 + 50, W * 16.0 + 90, H * 16.0 + 90])    # fully outside
+    return rois
+
+
+@pytest.mark.parametrize('H,W,C', [(15, 15, 8), (38, 63, 256)])
+def test_roi_align_forward_matches_oracle(O, H, W, C):
+    B = 3
+    feat = torch.randn((B, C, H, W), generator=torch.Generator().manual_seed(7))
+    rois = _roi_cases(B, H, W, 64, 8)
+    want = O.roi_align(feat, rois, 7, 1 / 16, 2)
+    got_nchw = ops.roi_align(feat.to(DEV), rois.to(DEV), 7, 1 / 16, 2)
+    close(got_nchw, want, 1e-5, 1e-5)
+    feat_cl = feat.to(DEV).contiguous(memory_format=torch.channels_last)
+    got_nhwc = ops.roi_align(feat_cl, rois.to(DEV), 7, 1 / 16, 2)
+    assert got_nhwc.shape == want.shape and got_nhwc.permute(0, 2, 3, 1).is_contiguous()
+    close(got_nhwc, want, 1e-5, 1e-5)
+    # bf16 storage: same arithmetic on the rounded input, output rounded once
+    fb = feat.to(torch.bfloat16)
+    want_b = O.roi_align(fb.float(), rois, 7, 1 / 16, 2)
+    got_b = ops.roi_align(fb.to(DEV).contiguous(memory_format=torch.channels_last), rois.to(DEV), 7, 1 / 16, 2)
+    close(got_b, want_b, 2 ** -8, 2 ** -8)
+    # sample_num = 0 (adaptive) and a non-square output, as in the reference's gradcheck recipe
+    want0 = O.roi_align(feat, rois[:20], (3, 5), 1 / 16, 0)
+    close(ops.roi_align(feat.to(DEV), rois[:20].to(DEV), (3, 5), 1 / 16, 0), want0, 1e-5, 1e-5)
+
+
+def test_roi_align_backward_and_errors(O):
+    feat = torch.randn((2, 6, 15, 15), generator=torch.Generator().manual_seed(9))
+    rois = _roi_cases(2, 15, 15, 20, 10)
+    go = torch.randn((20, 6, 3, 3), generator=torch.Generator().manual_seed(11))
+    want = O.roi_align_backward(go, rois, feat.shape, 1 / 16, 2)
+    f = feat.to(DEV).requires_grad_(True)
+    ops.roi_align(f, rois.to(DEV), 3, 1 / 16, 2).backward(go.to(DEV))
+    close(f.grad, want, 1e-4, 1e-5)
+    f2 = feat.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ops.roi_align(f2, rois.to(DEV), 3, 1 / 16, 2).backward(go.to(DEV))
+    close(f2.grad, want, 1e-4, 1e-5)
+    with pytest.raises(NotImplementedError):
+        ops.roi_align(feat, rois, 3, 1 / 16, 2)                      # CPU input, roi_align.py:27-28
+    with pytest.raises(ValueError):
+        ops.roi_align(feat.to(DEV), rois[:, :4].to(DEV), 3, 1 / 16, 2)  # "wrong roi size" is an error here
+    assert ops.roi_align(feat.to(DEV), torch.zeros((0, 5), device=DEV), 3, 1 / 16, 2).shape == (0, 6, 3, 3)
+
+
+# ------------------------------------------------------------------------------- NMS
+def test_nms_matches_reference_golden_vectors():
+    g = gold('g3_nms')
+    for name, dets, thr in C.nms_cases():
+        d, inds = ops.nms(dets.to(DEV), thr)
+        assert inds.cpu().tolist() == g[name + '_keep'].tolist(), name
+        assert torch.equal(d.cpu(), dets[inds.cpu()])
+    # idempotence at full size: survivors of NMS survive NMS
+    dets = C.boxes(6000, 77, span=(990.0, 590.0))
+    d, inds = ops.nms(dets.to(DEV), 0.7)
+    _, again = ops.nms(d, 0.7)
+    assert again.cpu().tolist() == list(range(d.shape[0]))
+    # numpy in, numpy out (nms_wrapper.py:38-60)
+    dn, kn = ops.nms(dets[:50].numpy(), 0.5, device_id=0)
+    assert isinstance(dn, np.ndarray) and kn.dtype == np.int64
+
+
+# ------------------------------------------------------------------------------- RPN
+@pytest.mark.parametrize('H,W', [(38, 63), (10, 12)])
+def test_rpn_proposals_match_oracle(O, H, W):
+    """(38,63): 28 728 anchors > nms_pre -> top-k path; (10,12): 1 440 anchors -> no top-k, index-order NMS output."""
+    T, A = 3, 12
+    g = torch.Generator().manual_seed(21)
+    cls = torch.randn((T, A, H, W), generator=g) * 1.5
+    reg = torch.randn((T, 4 * A, H, W), generator=g) * 0.3
+    gen = AnchorGenerator(16, [4, 8, 16, 32], [0.5, 1.0, 2.0])
+    base = O.gen_base_anchors(16, [4, 8, 16, 32], [0.5, 1.0, 2.0])
+    assert torch.equal(gen.base_anchors, base)
+    anchors = O.grid_anchors(base, (H, W), 16)
+    cfg = dict(O.RPN_TEST_CFG)
+    props, counts = native.rpn_proposals(cls.permute(0, 2, 3, 1).contiguous().to(DEV), reg.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                         gen.base_anchors, 16, (0., 0., 0., 0.), (1., 1., 1., 1.), (600, 1000), cfg['nms_pre'],
+                                         cfg['nms_post'], cfg['max_num'], cfg['nms_thr'])
+    for t in range(T):
+        want = O.rpn_get_bboxes_single(cls[t], reg[t], anchors, (600, 1000, 3), cfg)
+        n = int(counts[t].item())
+        assert n == want.shape[0]
+        close(props[t, :n], want, 1e-5, 2e-3)
+
+
+# ------------------------------------------------------------------------------- read-out
+def test_det_readout_matches_reference_golden():
+    g = gold('g8_det')
+    rois, cls, reg = C.det_case()
+    head = hvrnet_amd.SelsaBBoxHead(sampler_num=300, t_dim=15, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    bb, sc = head.get_det_bboxes(rois.to(DEV), cls.to(DEV), reg.to(DEV), (600, 1000, 3), 1.0, rescale=False, cfg=None)
+    close(bb, g['bboxes'], 1e-5, 2e-3)
+    close(sc, g['scores'], 1e-4, 1e-6)
+    cfg = ConfigDict(score_thr=0.001, nms=dict(type='nms', iou_thr=0.3), max_per_img=300)
+    db, dl = head.get_det_bboxes(rois.to(DEV), cls.to(DEV), reg.to(DEV), (600, 1000, 3), 1.0, rescale=True, cfg=cfg)
+    assert dl.cpu().tolist() == g['det_labels'].tolist()
+    close(db, g['det_bboxes'], 1e-4, 2e-3)
+    cfg100 = ConfigDict(score_thr=0.001, nms=dict(type='nms', iou_thr=0.3), max_per_img=100)
+    db, dl = head.get_det_bboxes(rois.to(DEV), cls.to(DEV), reg.to(DEV), (600, 1000, 3), 2.0, rescale=True, cfg=cfg100)
+    assert dl.cpu().tolist() == g['det_labels_top100'].tolist()
+    close(db, g['det_bboxes_top100'], 1e-4, 2e-3)
+    # mmdet.core.multiclass_nms signature on exact (golden) inputs: index-exact
+    db, dl = multiclass_nms(torch.as_tensor(g['bboxes']).to(DEV), torch.as_tensor(g['scores']).to(DEV), 0.001,
+                            dict(type='nms', iou_thr=0.3), 300)
+    assert dl.cpu().tolist() == g['det_labels'].tolist()
+    close(db, g['det_bboxes'], 0, 1e-6)
+
+
+# ------------------------------------------------------------------------------- relation + heads
+def _head(kind, dtype, sampler_num=32, t_dim=3):
+    cfg = (selsa_config if kind == 'selsa' else hvr_config)(frame_interval=1, nms_post=sampler_num)
+    h = hvrnet_amd.registry.build_head(cfg.model.bbox_head)
+    sd = {k[len('bbox_head.'):]: v for k, v in S.synth_state_dict(kind).items() if k.startswith('bbox_head.')}
+    h.load_state_dict(sd, strict=True)
+    h.sampler_num, h.t_dim = sampler_num, t_dim
+    hvrnet_amd.set_compute_dtype(h, dtype)
+    return h.to(DEV).eval()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+def test_relation_stage_matches_reference_golden(dtype, tol):
+    """G5: one stage from the reference's forward_single_selsa (all queries / key-only / truncated keys).
+    tol is relative to the output's max magnitude."""
+    g = gold('g5_relation')
+    x = C.relation_input().to(DEV)
+    hs, hh = _head('selsa', dtype), _head('hvr', dtype)
+    xs = native.cast(x, dtype)
+
+    def stage(head, k, q_range=None):
+        p = head.packed(x.device)
+        h = head._stage(p, k, xs, q_range)  # relu(xq + Y)
+        return h
+
+    # undo the fused residual + ReLU with inputs whose Y dominates: compare relu(x + Y_ref) instead
+    xq = C.relation_input()
+    want_all = torch.relu(xq + torch.as_tensor(g['y_all']))
+    assert rel_err(stage(hs, 1), want_all) < tol
+    want_key = torch.relu(xq[32:64] + torch.as_tensor(g['y_key']))
+    assert rel_err(stage(hh, 4, (32, 32)), want_key) < tol
+    hs.nongt_dim = 64
+    want_tr = torch.relu(xq + torch.as_tensor(g['y_trunc']))
+    assert rel_err(stage(hs, 2), want_tr) < tol
+
+
+@pytest.mark.parametrize('dtype,atol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_heads_match_reference_golden(dtype, atol):
+    """G6/G7 at config-1 shapes (T=3, N=32). f32: north_star's 1e-3.  bf16: logits have scale ~5, so 6e-2 is ~1%."""
+    feats = C.roi_feat_input()
+    cur = dict(start=32, length=32)
+    g6, g7 = gold('g6_selsa_head'), gold('g7_hvr_head')
+    for layout in ('nchw', 'nhwc'):
+        f = feats.to(DEV)
+        if layout == 'nhwc':
+            f = f.contiguous(memory_format=torch.channels_last)
+        cls, reg, _ = _head('selsa', dtype)(f, cur, key_dim=1)
+        close(cls, g6['cls'], 0, atol)
+        close(reg, g6['reg'], 0, atol)
+        cls_l, reg_l = _head('hvr', dtype).forward_test(f, [cur], key_dim=1)
+        close(cls_l[0], g7['cls_branch'], 0, atol)
+        close(cls_l[1], g7['cls'], 0, atol)
+        close(reg_l[0], g7['reg_branch'], 0, atol)
+        close(reg_l[1], g7['reg'], 0, atol)
+    # dead-row elimination computes the same outputs
+    h = _head('hvr', dtype)
+    h.dead_row_elimination = True
+    cls_d, reg_d = h.forward_test(feats.to(DEV), [cur], key_dim=1)
+    close(cls_d[1], g7['cls'], 0, atol)
+
+
+# ------------------------------------------------------------------------------- backbone
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+def test_backbone_res5_rpn_small_match_reference_golden(dtype, tol):
+    """G9: full R101 weights on a 64x96 image. tol relative to each tensor's max magnitude."""
+    g = gold('g9_backbone_small')
+    model = hvrnet_amd.build_model(hvr_config(), S.synth_state_dict('hvr'), dtype, DEV)
+    img = C.small_image().to(DEV)
+    c4 = model.backbone(img)[0]
+    assert c4.shape == (1, 1024, 4, 6)
+    assert rel_err(c4, g['c4']) < tol
+    c5 = model.shared_head(c4)
+    assert rel_err(c5, g['c5']) < tol
+    rc, rr = model.rpn_head([c4])
+    assert rel_err(rc[0], g['rpn_cls']) < tol and rel_err(rr[0], g['rpn_reg']) < tol
+
+
+# ------------------------------------------------------------------------------- config 1 end to end
+def _per_class(res):
+    return [np.asarray(r) for r in res]
+
+
+def test_config1_end_to_end_f32_matches_reference_golden():
+    """configs[0] through the whole GPU path in f32: class indices exact, boxes / scores within 1e-3."""
+    g = gold('g10_config1')
+    T = 3
+    imgs = [S.synth_frame(i).to(DEV) for i in range(T)]
+    metas = [S.synth_meta() for _ in range(T)]
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=1, nms_post=32), S.synth_state_dict('hvr'), torch.float32, DEV)
+    c4 = [model(img=im, img_meta=[m], backbone_feat=True)[0] for im, m in zip(imgs, metas)]
+    xcat = torch.cat([c.permute(0, 2, 3, 1) for c in c4], 0).permute(0, 3, 1, 2)
+    close(xcat[:, :8, 10:14, 20:24], g['c4_slice'], 1e-4, 2e-3)
+    w = model.window_tensors(c4, metas)
+    close(w['c5'][:, :8, 10:14, 20:24], g['c5_slice'], 1e-4, 1e-3)
+    close(torch.stack(w['proposals']), g['proposals'], 1e-4, 2e-2)
+    cls_l, reg_l = model.bbox_head.forward_test(w['roi_feats'], [w['cur_range']], key_dim=model.key_dim)
+    for b in range(2):
+        close(cls_l[b], g['hvr_cls_%d' % b], 0, 1e-3)
+        close(reg_l[b], g['hvr_reg_%d' % b], 0, 1e-3)
+    results = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+    assert len(results) == 2
+    for b in range(2):
+        labels = np.concatenate([np.full(len(r), i) for i, r in enumerate(results[b])])
+        boxes = np.concatenate(_per_class(results[b]), 0)
+        want_l, want_b = g['hvr_det_labels_%d' % b], g['hvr_det_bboxes_%d' % b]
+        order = np.argsort(want_l, kind='stable')  # bbox2result groups by class, keeping in-class order
+        assert labels.tolist() == want_l[order].tolist()
+        close(boxes, want_b[order], 0, 1e-3)
+    # SELSA detector on the same frames
+    ms = hvrnet_amd.build_model(selsa_config(frame_interval=1, nms_post=32), S.synth_state_dict('selsa'), torch.float32, DEV)
+    res = ms(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+    labels = np.concatenate([np.full(len(r), i) for i, r in enumerate(res)])
+    want_l, want_b = g['selsa_det_labels'], g['selsa_det_bboxes']
+    order = np.argsort(want_l, kind='stable')
+    assert labels.tolist() == want_l[order].tolist()
+    close(np.concatenate(_per_class(res), 0), want_b[order], 0, 1e-3)
+
+
+def test_config1_end_to_end_bf16_tracks_reference():
+    """bf16 fast path on configs[0]: every key-frame detection of the reference is reproduced (same class,
+    IoU > 0.9, score within 0.05) for >= 95% of the reference detections with score > 0.05."""
+    g = gold('g10_config1')
+    T = 3
+    imgs = [S.synth_frame(i).to(DEV) for i in range(T)]
+    metas = [S.synth_meta() for _ in range(T)]
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=1, nms_post=32), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    c4 = [model(img=im, img_meta=[m], backbone_feat=True)[0] for im, m in zip(imgs, metas)]
+    results = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+    want_l, want_b = g['hvr_det_labels_1'], g['hvr_det_bboxes_1']
+    hit = tot = 0
+    for lab, box in zip(want_l, want_b):
+        if box[4] < 0.05:
+            continue
+        tot += 1
+        cand = results[1][int(lab)]
+        if len(cand) == 0:
+            continue
+        x1 = np.maximum(cand[:, 0], box[0]); y1 = np.maximum(cand[:, 1], box[1])
+        x2 = np.minimum(cand[:, 2], box[2]); y2 = np.minimum(cand[:, 3], box[3])
+        inter = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
+        iou = inter / ((cand[:, 2] - cand[:, 0] + 1) * (cand[:, 3] - cand[:, 1] + 1) + (box[2] - box[0] + 1) * (box[3] - box[1] + 1) - inter)
+        j = int(np.argmax(iou))
+        hit += bool(iou[j] > 0.9 and abs(cand[j, 4] - box[4]) < 0.05)
+    assert tot > 0 and hit >= 0.95 * tot, (hit, tot)
+
+
+# ------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_T15_N300():
+    """BASELINE sizes (M = 4500, D = 1024): size-independent properties of the relation kernel."""
+    M, D = 4500, 1024
+    g = torch.Generator().manual_seed(31)
+    q = (torch.randn((M, D), generator=g) * 1.2).to(torch.bfloat16).to(DEV)
+    k = (torch.randn((M, D), generator=g) * 1.2).to(torch.bfloat16).to(DEV)
+    v = torch.randn((M, D), generator=g).to(torch.bfloat16).to(DEV)
+    o = native.relation_fwd(q, k, v, 1 / 32)
+    # (1) rows of softmax sum to one: constant V comes back unchanged
+    ones = torch.full((M, D), 0.75, dtype=torch.bfloat16, device=DEV)
+    oc = native.relation_fwd(q, k, ones, 1 / 32)
+    assert (oc.float() - 0.75).abs().max().item() < 4e-3
+    # (2) permuting keys/values together does not change the result (beyond f32 summation order)
+    perm = torch.randperm(M, generator=g).to(DEV)
+    op = native.relation_fwd(q, k[perm].contiguous(), v[perm].contiguous(), 1 / 32)
+    assert (op.float() - o.float()).abs().max().item() < 2e-2
+    # (3) query rows are independent: the key-frame slice equals the full result's slice
+    ok = native.relation_fwd(q[2100:2400], k, v, 1 / 32)
+    assert torch.equal(ok, o[2100:2400])
+    # (4) convex combination: outputs stay inside the value range
+    assert o.float().max().item() <= v.float().max().item() + 1e-2 and o.float().min().item() >= v.float().min().item() - 1e-2
+    # (5) spot rows against an f64 statement of the same rows
+    rows = [0, 1234, 4499]
+    ref = torch.softmax((q[rows].double() @ k.double().t()) / 32, 1) @ v.double()
+    assert (o[rows].double() - ref).abs().max().item() < 1.5e-2

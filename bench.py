@@ -44,13 +44,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPUs this process may actually use: min(affinity, cgroup quota). The GPU box shows 256 logical CPUs under a
+    16-CPU cgroup quota; oversubscribing it makes the CPU path ~200x slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (IOError, OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(head, T, n_prop, sd):
     """CPU oracle ("port": PyTorch-CPU restatement, oracle/hvr_oracle.py) on a bounded sample of one clip-mode window:
     3 of the T frames through backbone/res5/RPN/proposals/RoIAlign (scaled by T/3) + the full-size relation head
     (M = T * n_prop rows) + read-out, all host cores."""
     from hvrnet_amd import synthetic as S
     from oracle import hvr_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     ns = min(3, T)
     imgs = [S.synth_frame(i) for i in range(ns)]

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -85,6 +86,7 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   if ((d->lda * es) % 16 || (d->ldb * es) % 16) return fail(HVR_EINVAL, "lda/ldb rows must be 16-byte multiples");
   if ((d->ldc * (d->out_f32 ? 4 : es)) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
+  p.tile_hint = d->tile_hint;
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm");
 }
 
@@ -108,6 +110,7 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
     p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.zero = d->zero;
   }
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->Cout; p.relu = d->relu; p.out_f32 = d->out_f32;
+  p.tile_hint = d->tile_hint;
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
 }
 
@@ -125,6 +128,10 @@ int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, in
 }
 
 // ---- relation ----
+static int env_tile(const char* name) {  // tuning override, read once
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : 0;
+}
 static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
 
 size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
@@ -158,6 +165,8 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   if (rc) return rc;
   p.N = Mk;  // keys beyond Mk are masked inside the score epilogue
   p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+  static const int tile_scores = env_tile("HVR_TILE_SCORES"), tile_apply = env_tile("HVR_TILE_APPLY");
+  p.tile_hint = tile_scores;
   rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
   if (rc) return rc;
   rc = check_launch(run_relation_stats(mstat, lstat, g, Mq, nt, s), "relation: stats");
@@ -165,6 +174,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
   if (rc) return rc;
   p.g = g; p.ntile = nt;
+  p.tile_hint = tile_apply;
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
 }
 
@@ -229,6 +239,9 @@ int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* st
   if (ws_bytes < hvr_rpn_workspace_bytes(d->T, d->H, d->W, d->A, d->nms_pre)) return fail(HVR_EWORKSPACE, "rpn workspace too small");
   RpnParams rp;
   rp.T = d->T; rp.H = d->H; rp.W = d->W; rp.A = d->A; rp.npre = npre; rp.n_anchor = (int)n_anchor;
+  rp.cls_pitch = d->cls_pitch > 0 ? d->cls_pitch : d->A;
+  rp.reg_pitch = d->reg_pitch > 0 ? d->reg_pitch : 4 * d->A;
+  if (rp.cls_pitch < d->A || rp.reg_pitch < 4 * d->A || (rp.reg_pitch & 3)) return fail(HVR_EINVAL, "bad rpn pixel pitch");
   rp.stride = d->anchor_stride; rp.img_h = d->img_h; rp.img_w = d->img_w;
   for (int i = 0; i < 4; ++i) { rp.m[i] = d->means[i]; rp.s[i] = d->stds[i]; }
   rp.max_ratio = std::fabs(std::log(d->wh_ratio_clip));
@@ -239,7 +252,7 @@ int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* st
   long long* keep = (long long*)w;   w += align256((size_t)d->T * npre * 8);
   int* n_keep = (int*)w;             w += align256((size_t)d->T * 4);
   hipStream_t s = (hipStream_t)stream;
-  int rc = check_launch(run_rpn_select(d->cls, d->reg, n_anchor, n_anchor * 4, props, rp, HVR_F32, s), "rpn: select");
+  int rc = check_launch(run_rpn_select(d->cls, d->reg, (long)d->H * d->W * rp.cls_pitch, (long)d->H * d->W * rp.reg_pitch, props, rp, HVR_F32, s), "rpn: select");
   if (rc) return rc;
   const int presorted = n_anchor > npre ? 1 : 0;
   // with score-sorted input the first nms_post survivors are known after nms_post keeps

@@ -23,9 +23,11 @@ template <typename T> struct Mma;
 
 template <> struct Mma<bf16_t> {
   // one 16-byte chunk per lane = 8 consecutive k
+  template <bool ZERO>
   static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
-                                                  __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    // ZERO: start a fresh accumulation (C operand is the inline constant 0, no register clear)
+    const f32x4 c = ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
   }
   static constexpr int kChunkSteps = 2;  // chunk reads per 128-byte K-step (2 x 4 lane groups)
 };
@@ -34,8 +36,10 @@ template <> struct Mma<float> {
   // one 16-byte chunk per lane = 4 consecutive k; the 4 lane groups cover 16 k per
   // read, element i of every lane forms MFMA i (any k permutation is fine as long as
   // both operands use the same one).
+  template <bool ZERO>
   static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+    const f32x4 c = ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), c, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
@@ -165,8 +169,6 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   if constexpr (EPI == EPI_APPLY) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-#pragma unroll
-      for (int j = 0; j < FN; ++j) pacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       int m = m0 + (wm * FM + i) * 16 + (lane & 15);
       grow[i] = (m < p.M ? m : p.M - 1) * p.ntile;
       gcur[i] = p.g[grow[i]];
@@ -182,18 +184,19 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   commit_stage(smem);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // `first` / `last`: position of this K-step inside a 128-key statistics block (EPI_APPLY only;
+  // compile-time constants after unrolling, so the zero-C MFMA and the block combine fold away elsewhere)
+  auto do_step = [&](int kt, bool first, bool last) {
     char* cur = smem + (kt & 1) * STAGE_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
     const bool more = kt + 1 < nk;
     if (more) issue_loads(kt + 1, nxt);
     if constexpr (EPI == EPI_APPLY) {
-      if ((kt % STEPS_PER_BLOCK) == 0 && kt + STEPS_PER_BLOCK < nk) {
+      if (first && kt + STEPS_PER_BLOCK < nk) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) gnext[i] = p.g[grow[i] + kt / STEPS_PER_BLOCK + 1];
       }
     }
-
     const char* a_base = cur + (wm * FM * 16 + frag_row) * 128;
     const char* b_base = cur + BM * 128 + (wn * FN * 16 + frag_row) * 128;
 #pragma unroll
@@ -208,57 +211,116 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          if constexpr (EPI == EPI_APPLY) Mma<T>::run(wb[j], xa[i], pacc[i][j]);
-          else Mma<T>::run(wb[j], xa[i], acc[i][j]);
+          if constexpr (EPI == EPI_APPLY) {
+            if (first && kk == 0) Mma<T>::template run<true>(wb[j], xa[i], pacc[i][j]);
+            else Mma<T>::template run<false>(wb[j], xa[i], pacc[i][j]);
+          } else {
+            Mma<T>::template run<false>(wb[j], xa[i], acc[i][j]);
+          }
         }
     }
-
     if constexpr (EPI == EPI_APPLY) {
-      if ((kt % STEPS_PER_BLOCK) == STEPS_PER_BLOCK - 1) {
+      if (last) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
+          for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
-            pacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
           gcur[i] = gnext[i];
         }
       }
     }
-
     if (more) commit_stage(nxt);
     __syncthreads();
+  };
+  if constexpr (EPI == EPI_APPLY) {
+    for (int kb = 0; kb < nk; kb += STEPS_PER_BLOCK) {
+#pragma unroll
+      for (int st = 0; st < STEPS_PER_BLOCK; ++st) do_step(kb + st, st == 0, st == STEPS_PER_BLOCK - 1);
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) do_step(kt, false, false);
   }
 
   // ---------------- epilogues ----------------
   // lane holds, for fragment (i, j): m = .. + (lane & 15), n = .. + (lane >> 4) * 4 + r
   if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
+    // Stage the f32 tile through LDS (one wave-row block of FM*16 rows per pass) so that every global
+    // access of the epilogue is a full 16-byte-per-lane row segment: residual loads and output stores
+    // are whole lines instead of the 8-byte pieces of the MFMA fragment layout.
+    constexpr int ROWS = FM * 16, LDW = BN + 4, CH = BN / 8;
+    float* ebuf = reinterpret_cast<float*>(smem);
+    const int out_es = p.out_f32 ? 4 : (int)sizeof(T);
+    const bool wide_c = ((p.ldc * out_es) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.N & 7) == 0;
+    const bool wide_r = p.resid && ((p.ldr * (long)sizeof(T)) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
+#pragma unroll 1
+    for (int pass = 0; pass < WM; ++pass) {
+      if (wm == pass) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m = m0 + (wm * FM + i) * 16 + frag_row;
-      if (m >= p.M) continue;
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + (wn * FN + j) * 16 + frag_grp * 4;
-        if (n >= p.N) continue;  // N is a multiple of 4 (checked on the host)
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (p.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
+          for (int j = 0; j < FN; ++j) {
+            const int col = (wn * FN + j) * 16 + frag_grp * 4;
+            f32x4 v = acc[i][j];
+            if (p.bias && n0 + col < p.N) {
+              const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
+              v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            *reinterpret_cast<f32x4*>(ebuf + (i * 16 + frag_row) * LDW + col) = v;
+          }
+      }
+      __syncthreads();
+      for (int c = tid; c < ROWS * CH; c += NT) {
+        const int r = c / CH, cc = c - r * CH;
+        const int m = m0 + pass * ROWS + r, n = n0 + cc * 8;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        const float4 lo = *reinterpret_cast<const float4*>(ebuf + r * LDW + cc * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ebuf + r * LDW + cc * 8 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        const bool full = n + 8 <= p.N;  // N % 4 == 0: a chunk is either 8 or 4 valid columns
         if (p.resid) {
-          float rv[4];
-          load4(reinterpret_cast<const T*>(p.resid) + (long)m * p.ldr + n, rv);
-          v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+          const T* rp = reinterpret_cast<const T*>(p.resid) + (long)m * p.ldr + n;
+          float rv[8];
+          if (full && wide_r) {
+            if constexpr (sizeof(T) == 2) {
+              const uint4 t = *reinterpret_cast<const uint4*>(rp);
+              rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
+              rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
+              rv[4] = __uint_as_float(t.z << 16); rv[5] = __uint_as_float(t.z & 0xffff0000u);
+              rv[6] = __uint_as_float(t.w << 16); rv[7] = __uint_as_float(t.w & 0xffff0000u);
+            } else {
+              load4(rp, rv);
+              load4(rp + 4, rv + 4);
+            }
+          } else {
+            load4(rp, rv);
+            if (full) load4(rp + 4, rv + 4);
+            else rv[4] = rv[5] = rv[6] = rv[7] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
         }
         if (p.relu) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.out_f32) store4(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
-        else store4(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+        if (p.out_f32 || sizeof(T) == 4) {
+          float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+          store4(cp, v);
+          if (full) store4(cp + 4, v + 4);
+        } else {
+          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+          if (full && wide_c) {
+            *reinterpret_cast<uint4*>(cp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+          } else {
+            store4(cp, v);
+            if (full) store4(cp + 4, v + 4);
+          }
+        }
       }
+      __syncthreads();
     }
   } else {  // EPI_SCORES: per (row, 128-key tile) max / sum and P~ = exp(s - tilemax)
     static_assert(EPI != EPI_SCORES || BN == 128, "score tiles are 128 keys wide");
@@ -354,7 +416,9 @@ __global__ void relation_stats_kernel(const float* __restrict__ mstat, const flo
 template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS>
 static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t stage = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t epi = (size_t)FM * 16 * (BN + 4) * 4;  // LDS-staged epilogue buffer
+  constexpr size_t lds = stage > epi ? stage : epi;
   static bool attr_set = false;
   auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS>;
   if (!attr_set) {
@@ -366,15 +430,71 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Tile menu (BM x BN, waves).  Only the bf16 + global_load_lds path carries the whole menu; the
+// register-staged and f32 paths (tests, parity mode) keep the two base shapes.
+//   0: 128x128 (2x2 waves)   2 workgroups / CU      1: 128x64  (4x1)   3 / CU
+//   2: 144x256 (3x2)         1 / CU                 3: 144x128 (3x2)   2 / CU
+//   4: 256x128 (4x2)         1 / CU
+const TileShape kTileShapes[kNumTileShapes] = {
+    {128, 128, 2, 1.00f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.85f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f}};
+
+int choose_tile(const GemmParams& p, int epi) {
+  if (p.tile_hint > 0 && p.tile_hint <= kNumTileShapes) {
+    const int t = p.tile_hint - 1;
+    if (epi == EPI_SCORES && kTileShapes[t].bn != 128) return 0;
+    if (epi == EPI_APPLY && t == 2) return 3;
+    return t;
+  }
+  const bool full_menu = p.dtype == DT_BF16 && p.staging == 1;
+  if (!full_menu) return (epi == EPI_LINEAR && p.N <= 64) ? 1 : 0;
+  // Cost model (fitted to tools/kernel_bench.py sweeps on MI355X, profiles/r01_tile_sweep.txt):
+  // the chip runs `slots = 256 CUs x wg_per_cu` workgroups at a time; one full round of a shape costs
+  // area x wg_per_cu / eff; a trailing partial round that leaves CUs with fewer co-resident workgroups
+  // is cheaper, but not proportionally (a lone workgroup cannot saturate a CU).
+  static const double kPartial[4][4] = {{0, 0, 0, 0}, {0, 1.0, 0, 0}, {0, 0.67, 1.0, 0}, {0, 0.5, 0.8, 1.0}};
+  const int ksteps = p.K / (p.dtype == DT_BF16 ? 64 : 32);
+  int best = 0;
+  double best_cost = 1e300;
+  for (int t = 0; t < kNumTileShapes; ++t) {
+    const TileShape& s = kTileShapes[t];
+    if (epi == EPI_SCORES && s.bn != 128) continue;
+    if (epi == EPI_APPLY && t == 2) continue;  // two accumulator sets do not fit 144x256
+    if (p.N <= 64 && s.bn > 64 && t != 0) continue;
+    const long tiles = (long)((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
+    const long slots = 256L * s.wg_per_cu;
+    const long full = tiles / slots, rem = tiles % slots;
+    const double rounds = (double)full + (rem ? kPartial[s.wg_per_cu][(rem + 255) / 256] : 0.0);
+    // short K loops expose the prologue/epilogue of shapes that run one workgroup per CU
+    const double eff = s.eff * ((s.wg_per_cu == 1 && ksteps <= 8) ? 0.7 : 1.0);
+    const double cost = rounds * s.bm * s.bn * s.wg_per_cu / eff;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = t; }
+  }
+  return best;
+}
+
+template <typename T, int EPI, bool GLDS>
+static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t stream) {
+  if constexpr (GLDS && sizeof(T) == 2) {
+    switch (tile) {
+      case 1: if constexpr (EPI != EPI_SCORES) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS>(p, stream); break;
+      case 2: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS>(p, stream); break;
+      case 3: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS>(p, stream);
+      case 4: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS>(p, stream);
+      default: break;
+    }
+    return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);
+  } else {
+    if (tile == 1) {
+      if constexpr (EPI != EPI_SCORES) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS>(p, stream);
+    }
+    return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);
+  }
+}
+
 template <typename T, int EPI>
 static hipError_t dispatch_shape(const GemmParams& p, hipStream_t stream) {
-  const bool glds = p.staging == 1;
-  if (EPI == EPI_LINEAR && p.N <= 64) {
-    return glds ? launch_tile<T, 4, 1, 2, 4, EPI_LINEAR, true>(p, stream)
-                : launch_tile<T, 4, 1, 2, 4, EPI_LINEAR, false>(p, stream);
-  }
-  return glds ? launch_tile<T, 2, 2, 4, 4, EPI, true>(p, stream)
-              : launch_tile<T, 2, 2, 4, 4, EPI, false>(p, stream);
+  const int tile = choose_tile(p, EPI);
+  return p.staging == 1 ? dispatch_tile<T, EPI, true>(p, tile, stream) : dispatch_tile<T, EPI, false>(p, tile, stream);
 }
 
 hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream) {

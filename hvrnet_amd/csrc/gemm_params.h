@@ -9,6 +9,7 @@ enum { EPI_LINEAR = 0, EPI_SCORES = 1, EPI_APPLY = 2 };
 // RPN proposal selection parameters (nms.hip)
 struct RpnParams {
   int T, H, W, A, npre, n_anchor;
+  int cls_pitch, reg_pitch;  // channels per pixel of the maps holding objectness / deltas
   int stride;
   float img_h, img_w;
   float m[4], s[4];
@@ -24,6 +25,7 @@ struct GemmParams {
   long lda, ldb, ldc;
   int dtype;    // DT_F32 / DT_BF16 (operands; accumulation is always f32)
   int staging;  // 0 = register-staged global->LDS, 1 = direct global_load_lds
+  int tile_hint;  // 0 = choose by cost model, k > 0 = force tile shape k-1 (tuning / tests)
   // implicit-GEMM gather on the A side
   int conv, H, W, Cin, OH, OW, KH, KW, stride, pad, dil;
   const void* zero;  // >= 16 readable zero bytes (padding taps)
@@ -39,6 +41,11 @@ struct GemmParams {
   const float* g;  // [M][ntile] per-(row, 128-key block) weight
   int ntile;
 };
+
+struct TileShape { int bm, bn, wg_per_cu; float eff; };
+constexpr int kNumTileShapes = 5;
+extern const TileShape kTileShapes[kNumTileShapes];
+int choose_tile(const GemmParams& p, int epi);
 
 hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream);
 hipError_t run_relation_stats(const float* mstat, const float* lstat, float* g, int M, int ntile, hipStream_t stream);

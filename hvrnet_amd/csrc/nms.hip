@@ -202,7 +202,13 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
   __shared__ uint32_t sh_prefix, sh_remaining;
   __shared__ int sh_count;
 
-  auto score_of = [&](int i) { return 1.f / (1.f + expf(-ElemTraits<T>::load(c + i))); };  // torch.sigmoid
+  // anchor i = cell * A + a lives at pixel `cell`, channel a of a [H*W][cls_pitch] map (pitch >= A lets the
+  // objectness and delta maps be channel slices of one fused conv output)
+  const int A = rp.A, cpitch = rp.cls_pitch, rpitch = rp.reg_pitch;
+  auto score_of = [&](int i) {
+    const int cell = i / A, a = i - cell * A;
+    return 1.f / (1.f + expf(-ElemTraits<T>::load(c + (long)cell * cpitch + a)));  // torch.sigmoid
+  };
 
   if (n > k) {
     // radix select (MSB first) of the k-th largest (key, then smallest index) element
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
     const float ax1 = rp.base[a][0] + x * rp.stride, ay1 = rp.base[a][1] + y * rp.stride;
     const float ax2 = rp.base[a][2] + x * rp.stride, ay2 = rp.base[a][3] + y * rp.stride;
     float d[4];
-    load4(r + (long)i * 4, d);
+    load4(r + (long)cell * rpitch + a * 4, d);
     const float dx = d[0] * rp.s[0] + rp.m[0], dy = d[1] * rp.s[1] + rp.m[1];
     float dw = d[2] * rp.s[2] + rp.m[2], dh = d[3] * rp.s[3] + rp.m[3];
     dw = fminf(fmaxf(dw, -rp.max_ratio), rp.max_ratio);

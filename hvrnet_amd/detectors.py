@@ -125,6 +125,13 @@ class _WindowDetector(TwoStageDetector):
             raise NotImplementedError('per-RoI shared head (feat_from_shared_head=False) is outside the hot path')
         return self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
 
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault('_side_streams', {})
+        key = str(device)
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
+
     @staticmethod
     def _cat_frames(x):
         """torch.cat(deque, 0) that keeps the physical NHWC layout (hnmb_rcnn.py:200)."""
@@ -139,10 +146,22 @@ class _WindowDetector(TwoStageDetector):
         """Runs one window up to the head outputs; returns a dict of device tensors (used by forward_feat and tests)."""
         xc = self._cat_frames(x)
         assert xc.shape[0] == len(img_meta)
-        feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
         if proposals is None:
-            rpn_outs = self.rpn_head([xc])
-            props, counts = self.rpn_head.get_bboxes_batched(rpn_outs[0], rpn_outs[1], img_meta, self.test_cfg.rpn)
+            # The RPN branch (3x3 conv, heads, select / NMS: a few latency-bound workgroups) and res5 both
+            # depend only on C4: run the RPN on a second HIP stream underneath res5.
+            main, side = torch.cuda.current_stream(xc.device), self._side_stream(xc.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                rpn_outs = self.rpn_head([xc])
+                props, counts = self.rpn_head.get_bboxes_batched(rpn_outs[0], rpn_outs[1], img_meta, self.test_cfg.rpn)
+                done = torch.cuda.Event()
+                done.record(side)
+            feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
+            main.wait_event(done)
+            props.record_stream(main)
+            counts.record_stream(main)
             counts_h = counts.tolist()  # host read #1: T integers
             T, mx = props.shape[0], props.shape[1]
             frame = torch.arange(T, device=props.device, dtype=props.dtype).view(T, 1, 1).expand(T, mx, 1)
@@ -153,6 +172,7 @@ class _WindowDetector(TwoStageDetector):
                 rois = torch.cat([rois[i, :c] for i, c in enumerate(counts_h)], dim=0)
             proposal_list = [props[i, :c] for i, c in enumerate(counts_h)]
         else:
+            feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
             proposal_list = list(proposals)
             counts_h = [p.shape[0] for p in proposal_list]
             rois = bbox2roi([p for p in proposal_list])  # batch index = frame index

@@ -22,6 +22,8 @@ LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
 # default operand staging of the MFMA tile engine (0 register-staged, 1 global->LDS DMA)
 STAGING = int(os.environ.get('HVR_STAGING', '1'))
+# 0 = the library's cost model picks the tile shape; k > 0 forces shape k-1 (tools/kernel_bench.py sweeps)
+TILE_HINT = int(os.environ.get('HVR_TILE', '0'))
 
 
 class HvrError(RuntimeError):
@@ -34,7 +36,7 @@ class GemmDesc(ctypes.Structure):
                 ('lda', ctypes.c_int64), ('ldb', ctypes.c_int64), ('ldc', ctypes.c_int64),
                 ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p), ('ldr', ctypes.c_int64),
                 ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
-                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32)]
+                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -45,7 +47,7 @@ class ConvDesc(ctypes.Structure):
                 ('dil', ctypes.c_int32),
                 ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p),
                 ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
-                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32),
+                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32),
                 ('zero', ctypes.c_void_p)]
 
 
@@ -57,7 +59,8 @@ class RpnDesc(ctypes.Structure):
                 ('img_h', ctypes.c_float), ('img_w', ctypes.c_float), ('wh_ratio_clip', ctypes.c_float),
                 ('nms_pre', ctypes.c_int32), ('nms_post', ctypes.c_int32), ('max_num', ctypes.c_int32),
                 ('nms_thr', ctypes.c_float),
-                ('proposals', ctypes.c_void_p), ('counts', ctypes.c_void_p)]
+                ('proposals', ctypes.c_void_p), ('counts', ctypes.c_void_p),
+                ('cls_pitch', ctypes.c_int32), ('reg_pitch', ctypes.c_int32)]
 
 
 # every symbol include/hvr_hip.h declares: name -> (restype, argtypes)
@@ -215,7 +218,7 @@ def kstep(dtype):
 
 
 # ----------------------------------------------------------------------------------------
-def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, staging=None):
+def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, staging=None, tile=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + resid).  a / w / resid share one dtype."""
     _need_cuda(a, w, bias, resid)
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
@@ -230,13 +233,14 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
                  resid=resid.data_ptr() if resid is not None else None,
                  ldr=resid.stride(0) if resid is not None else 0,
                  relu=int(relu), out_f32=int(out.dtype == torch.float32 and a.dtype != torch.float32),
-                 dtype=_dt(a), staging=STAGING if staging is None else staging)
+                 dtype=_dt(a), staging=STAGING if staging is None else staging,
+                 tile_hint=TILE_HINT if tile is None else tile)
     with _span('gemm', 2.0 * M * N * K):
         _check(lib().hvr_gemm(ctypes.byref(d), _stream()), 'hvr_gemm')
     return out
 
 
-def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None):
+def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None, tile=None):
     """x [B,H,W,Cin] (physical NHWC), w [Cout,KH,KW,Cin] -> [B,OH,OW,Cout]."""
     _need_cuda(x, w, bias, resid)
     B, H, W, Cin = x.shape
@@ -249,7 +253,7 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  bias=bias.data_ptr() if bias is not None else None,
                  resid=resid.data_ptr() if resid is not None else None,
                  relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
-                 staging=STAGING if staging is None else staging,
+                 staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile,
                  zero=zero_page(x.device).data_ptr())
     with _span('conv', 2.0 * B * OH * OW * Cout * KH * KW * Cin):
         _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
@@ -355,10 +359,13 @@ def nms(dets, iou_thr, ge_semantics=True):
 
 def rpn_proposals(cls, reg, base_anchors, anchor_stride, means, stds, img_shape, nms_pre, nms_post, max_num, nms_thr,
                   wh_ratio_clip=16 / 1000):
-    """cls [T,H,W,A] f32, reg [T,H,W,4A] f32 (physical NHWC) -> (proposals [T,max_num,5], counts [T] int32)."""
+    """cls [T,H,W,A] f32, reg [T,H,W,4A] f32 (physical NHWC; may be channel slices of one wider contiguous
+    [T,H,W,P] tensor) -> (proposals [T,max_num,5], counts [T] int32)."""
     _need_cuda(cls, reg)
-    assert cls.dtype == torch.float32 and reg.dtype == torch.float32 and cls.is_contiguous() and reg.is_contiguous()
+    assert cls.dtype == torch.float32 and reg.dtype == torch.float32
     T, H, W, A = cls.shape
+    for t, ch in ((cls, A), (reg, 4 * A)):
+        assert t.stride(3) == 1 and t.stride(1) == W * t.stride(2) and t.stride(0) == H * W * t.stride(2) and t.stride(2) >= ch
     props = torch.zeros((T, max_num, 5), dtype=torch.float32, device=cls.device)
     counts = torch.zeros(T, dtype=torch.int32, device=cls.device)
     ba = (ctypes.c_float * (A * 4))(*[float(v) for v in base_anchors.reshape(-1).tolist()])
@@ -368,7 +375,8 @@ def rpn_proposals(cls, reg, base_anchors, anchor_stride, means, stds, img_shape,
                 base_anchors=ctypes.cast(ba, ctypes.c_void_p), means=ctypes.cast(mm, ctypes.c_void_p),
                 stds=ctypes.cast(ss, ctypes.c_void_p), img_h=float(img_shape[0]), img_w=float(img_shape[1]),
                 wh_ratio_clip=float(wh_ratio_clip), nms_pre=int(nms_pre), nms_post=int(nms_post), max_num=int(max_num),
-                nms_thr=float(nms_thr), proposals=props.data_ptr(), counts=counts.data_ptr())
+                nms_thr=float(nms_thr), proposals=props.data_ptr(), counts=counts.data_ptr(),
+                cls_pitch=cls.stride(2), reg_pitch=reg.stride(2))
     ws = _workspace(lib().hvr_rpn_workspace_bytes(T, H, W, A, int(nms_pre)), cls.device, 'rpn')
     with _span('rpn_proposals', float(cls.numel() * 4 + reg.numel() * 4)):
         _check(lib().hvr_rpn_proposals(ctypes.byref(d), _ptr(ws), ws.numel(), _stream()), 'hvr_rpn_proposals')

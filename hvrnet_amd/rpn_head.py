@@ -83,8 +83,9 @@ class RPNHead(nn.Module, PackedMixin):
         shape0 = tuple(img_metas[0]['img_shape'][:2])
         if any(tuple(m['img_shape'][:2]) != shape0 for m in img_metas):
             raise NotImplementedError('frames of one window share img_shape (one video)')
-        cls_n = cls.permute(0, 2, 3, 1).float().contiguous()
-        reg_n = reg.permute(0, 2, 3, 1).float().contiguous()
+        cls_n, reg_n = cls.permute(0, 2, 3, 1), reg.permute(0, 2, 3, 1)  # physical NHWC views, no copy
+        if cls_n.dtype != torch.float32 or cls_n.stride(3) != 1 or reg_n.stride(3) != 1:
+            cls_n, reg_n = cls_n.float().contiguous(), reg_n.float().contiguous()
         gen = self.anchor_generators[0]
         return native.rpn_proposals(cls_n, reg_n, gen.base_anchors, self.anchor_strides[0], self.target_means,
                                     self.target_stds, shape0, cfg['nms_pre'], cfg['nms_post'], cfg['max_num'], cfg['nms_thr'])

@@ -58,6 +58,7 @@ typedef struct hvr_gemm_desc {
   int32_t out_f32;         /* store C as f32 regardless of dtype */
   int32_t dtype;
   int32_t staging;
+  int32_t tile_hint;       /* 0 = library picks the tile shape; k > 0 forces shape k-1 (tuning) */
 } hvr_gemm_desc;
 int hvr_gemm(const hvr_gemm_desc* d, void* stream);
 
@@ -74,7 +75,7 @@ typedef struct hvr_conv_desc {
   int32_t B, H, W, Cin, Cout, KH, KW, stride, pad, dil;
   const float* bias;
   const void* resid;       /* [B][OH][OW][Cout] or NULL */
-  int32_t relu, out_f32, dtype, staging;
+  int32_t relu, out_f32, dtype, staging, tile_hint;
   const void* zero;
 } hvr_conv_desc;
 int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
@@ -136,6 +137,8 @@ typedef struct hvr_rpn_desc {
   int32_t nms_pre, nms_post, max_num;
   float nms_thr;
   float* proposals; int32_t* counts;
+  int32_t cls_pitch, reg_pitch;  /* channels per pixel of the cls / reg maps (0 = A / 4A); lets both be
+                                    channel slices of one fused [T][H][W][5A(+pad)] conv output */
 } hvr_rpn_desc;
 size_t hvr_rpn_workspace_bytes(int T, int H, int W, int A, int nms_pre);
 int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* stream);

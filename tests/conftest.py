@@ -8,8 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def usable_cpus():
+    """min(affinity, cgroup CPU quota): the GPU box exposes 256 logical CPUs under a 16-CPU quota, and a
+    256-thread torch pool under that quota is ~200x slower than a 16-thread one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (IOError, OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import torch
+    torch.set_num_threads(usable_cpus())
 
 
 def pytest_collection_modifyitems(config, items):

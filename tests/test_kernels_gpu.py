@@ -167,3 +167,29 @@ def test_nms_docstring_case_and_empty():
                          [35.2, 11.7, 39.7, 15.7, 0.3]])
     assert native.nms(dets.to(DEV), 0.7).cpu().tolist() == [0, 3, 4]
     assert native.nms(torch.zeros((0, 5), device=DEV), 0.5).numel() == 0
+
+
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (145, 36, 64)])
+def test_every_tile_shape_gives_the_same_gemm(M, N, K, tile):
+    """The tile menu (128x128, 128x64, 144x256, 144x128, 256x128) is a speed choice only."""
+    dtype = torch.bfloat16
+    a, w = _rand((M, K), dtype, 61), _rand((N, K), dtype, 62, 0.1)
+    bias, resid = _rand((N,), torch.float32, 63), _rand((M, N), dtype, 64)
+    ref = torch.relu(a.float() @ w.float().t() + bias + resid.float())
+    out = native.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV), relu=True, staging=1, tile=tile)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+    out32 = native.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), out_f32=True, staging=1, tile=tile)
+    torch.testing.assert_close(out32.cpu(), a.float() @ w.float().t() + bias, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize('tile', [1, 3, 4, 5])
+def test_every_tile_shape_gives_the_same_conv(tile):
+    dtype = torch.bfloat16
+    x = _rand((2, 128, 17, 21), dtype, 71)
+    w = _rand((256, 128, 3, 3), dtype, 72, 0.05)
+    bias = _rand((256,), torch.float32, 73)
+    ref = torch.relu(F.conv2d(x.float(), w.float(), bias, padding=2, dilation=2))
+    y = native.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), bias.to(DEV),
+                           relu=True, pad=2, dil=2, staging=1, tile=tile)
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, **_tol(dtype))

@@ -46,15 +46,14 @@ def main():
     for name, M, N, K in [('fc_new_1', 4500, 1024, 12544), ('qk_proj', 4500, 2048, 1024), ('out_proj', 4500, 1024, 1024),
                           ('fc_key', 300, 1024, 1024), ('square4k', 4096, 4096, 4096)]:
         a, w = rnd(M, K), rnd(N, K, scale=0.05)
-        for st in (0, 1):
-            ms = timed(lambda: native.gemm(a, w, staging=st), args.iters)
-            print('gemm %-10s M=%d N=%d K=%d staging=%d  %.3f ms  %.1f TF/s' % (name, M, N, K, st, ms, 2.0 * M * N * K / ms / 1e9))
+        for tile in (0, 1, 3, 4, 5):
+            ms = timed(lambda: native.gemm(a, w, staging=1, tile=tile), args.iters)
+            print('gemm %-10s M=%d N=%d K=%d tile=%d  %.3f ms  %.1f TF/s' % (name, M, N, K, tile, ms, 2.0 * M * N * K / ms / 1e9))
     # ---- relation core ----
     for Mq, Mk in [(4500, 4500), (300, 4500)]:
         q, k, v = rnd(Mq, 1024), rnd(Mk, 1024), rnd(Mk, 1024)
-        for st in (0, 1):
-            ms = timed(lambda: native.relation_fwd(q, k, v, 1 / 32, staging=st), args.iters)
-            print('relation Mq=%d Mk=%d staging=%d  %.3f ms  %.1f TF/s' % (Mq, Mk, st, ms, 4.0 * Mq * Mk * 1024 / ms / 1e9))
+        ms = timed(lambda: native.relation_fwd(q, k, v, 1 / 32, staging=1), args.iters)
+        print('relation Mq=%d Mk=%d  %.3f ms  %.1f TF/s' % (Mq, Mk, ms, 4.0 * Mq * Mk * 1024 / ms / 1e9))
     # ---- backbone conv classes (T frames) ----
     convs = [
         ('l1.conv2 3x3 64', 152, 252, 64, 64, 3, 1, 1, 1),
@@ -78,9 +77,11 @@ def main():
         OW = (W + 2 * p - d * (k - 1) - 1) // s + 1
         fl = 2.0 * T * OH * OW * Cout * k * k * Cin
         by = (x.numel() + T * OH * OW * Cout + w.numel()) * x.element_size()
-        for st in (0, 1):
-            ms = timed(lambda: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=st), args.iters)
-            print('conv %-28s staging=%d  %.3f ms  %.1f TF/s  %.0f GB/s(min-traffic)' % (name, st, ms, fl / ms / 1e9, by / ms / 1e6))
+        for tile in (0, 1, 2, 3, 4, 5):
+            if tile == 2 and Cout > 64:
+                continue
+            ms = timed(lambda: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=1, tile=tile), args.iters)
+            print('conv %-28s tile=%d  %.3f ms  %.1f TF/s  %.0f GB/s(min-traffic)' % (name, tile, ms, fl / ms / 1e9, by / ms / 1e6))
     # ---- RoIAlign, all frames in one launch ----
     feat = rnd(T, 38, 63, 256)
     g = torch.Generator(device='cpu').manual_seed(0)

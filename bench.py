@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--proposals', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
     return ap.parse_args()
 
 
@@ -164,6 +165,12 @@ def main():
     native.profile_begin(tags=('*',))
     step()
     classes = native.profile_end()
+    if args.breakdown and rank == 0:
+        native.profile_begin(tags=('*',), detail=True)
+        step()
+        for tag, d in sorted(native.profile_end().items(), key=lambda kv: -kv[1]['ms']):
+            rate = d['work'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+            sys.stderr.write('%-44s calls %3d  %8.3f ms  %8.1f T(FLOP|B)/s\n' % (tag, d['calls'], d['ms'], rate))
 
     if rank == 0:
         branch = res[-1] if args.head == 'hvr' else res
@@ -180,7 +187,7 @@ def main():
         kc = {}
         for tag, d in classes.items():
             e = dict(calls=d['calls'], ms=round(d['ms'], 4))
-            if tag in ('gemm', 'conv', 'relation_full', 'relation_key') and d['ms'] > 0:
+            if tag in ('gemm', 'conv', 'stem', 'relation_full', 'relation_key') and d['ms'] > 0:
                 e['tflops'] = round(d['work'] / (d['ms'] * 1e-3) / 1e12, 2)
                 e['frac_mfma_peak'] = round(e['tflops'] / peak, 4)
             elif d['ms'] > 0:

@@ -177,6 +177,7 @@ class ResNet(nn.Module, PackedMixin):
             inplanes = planes * block.expansion
             self.res_layers.append(name)
         self.feat_dim = block.expansion * 64 * 2 ** (len(self.stage_blocks) - 1)
+        self.fused_stem = True  # bf16 only: conv1 + bn1 + relu + maxpool in one kernel
         _freeze(self)
         self._init_packed()
 
@@ -200,7 +201,10 @@ class ResNet(nn.Module, PackedMixin):
         w, b = fold_conv_bn(self.conv1, self.bn1, torch.float32)  # [64,7,7,3]
         wp = torch.zeros((64, STEM_KP), dtype=torch.float32, device=w.device)
         wp[:, :147] = w.reshape(64, 147)
-        return dict(stem=(wp.to(dtype), b))
+        # fused bf16 stem: [n][ky][kx*4 + c], zero weight for the pad channel (c = 3) and the pad tap (kx = 7)
+        wf = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w.device)
+        wf[:, :, :7, :3] = w
+        return dict(stem=(wp.to(dtype), b), fused=wf.view(64, 7, 32).to(torch.bfloat16).contiguous())
 
     def forward(self, x):
         """x [B,3,H,W] f32 -> tuple of logical-NCHW feature maps (resnet.py:522-533)."""
@@ -208,9 +212,12 @@ class ResNet(nn.Module, PackedMixin):
             raise NotImplementedError('ResNet runs on the GPU only (no CPU fallback)')
         p = self.packed(x.device)
         dt = self.compute_dtype
-        cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
-        y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
-        y = native.maxpool3x3s2_nhwc(y)
+        if dt == torch.bfloat16 and self.fused_stem:
+            y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
+        else:  # generic route (f32 parity mode): patch matrix + GEMM + pooling
+            cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
+            y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
+            y = native.maxpool3x3s2_nhwc(y)
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):

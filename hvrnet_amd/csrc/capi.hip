@@ -30,6 +30,7 @@ hipError_t run_rpn_gather(const float*, const long long*, const int*, int, int, 
 hipError_t run_multiclass_nms(const float*, const float*, int, int, float, float, int, float*, long long*, int*, void*,
                               hipStream_t);
 size_t multiclass_nms_workspace_bytes(int R, int ncls);
+hipError_t run_stem_fused(const float*, const void*, const float*, void*, int, int, int, hipStream_t);
 }  // namespace hvr
 
 using namespace hvr;
@@ -119,6 +120,12 @@ int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, i
   if (KP < 147 || KP % (128 / elem_size(dtype))) return fail(HVR_EINVAL, "KP=%d must be >= 147 and a K-step multiple", KP);
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
   return check_launch(run_im2col_stem(img, cols, B, H, W, OH, OW, KP, dtype, (hipStream_t)stream), "hvr_im2col_stem");
+}
+
+int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream) {
+  if (!img || !wpk || !bias || !out || B <= 0 || H < 7 || W < 7) return fail(HVR_EINVAL, "bad fused-stem arguments");
+  if (!aligned16(wpk) || !aligned16(out) || !aligned16(bias)) return fail(HVR_EINVAL, "fused stem operands must be 16-byte aligned");
+  return check_launch(run_stem_fused(img, wpk, bias, out, B, H, W, (hipStream_t)stream), "hvr_stem_fused");
 }
 
 int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {

@@ -47,7 +47,9 @@ template <> struct Mma<float> {
   static constexpr int kChunkSteps = 2;
 };
 
-template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS>
+// RESPRE: the residual tile is fetched into registers in one burst at the top of the epilogue (in the store-phase
+// mapping) instead of one dependent load per store-phase iteration.
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false>
 __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16, NT = WM * WN * 64;
   constexpr int EPC = ElemTraits<T>::kPerChunk;  // elements per 16-byte chunk
@@ -243,6 +245,24 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) do_step(kt, false, false);
   }
 
+  // ---------------- residual fetch (RESPRE): all of the tile's residual loads are issued here, at the top of the
+  // epilogue (no LDS DMA is in flight any more, so the barriers below do not drain them): one overlapped round
+  // trip instead of one per store-phase iteration ----------------
+  constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH) / NT;
+  static_assert(!RESPRE || ((E_ROWS * E_CH) % NT == 0 && sizeof(T) == 2), "RESPRE needs an even store-phase split");
+  uint4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
+  if constexpr (RESPRE) {
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass)
+#pragma unroll
+      for (int it = 0; it < E_ITERS; ++it) {
+        const int c = it * NT + tid, r = c / E_CH, cc = c - r * E_CH;
+        const int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
+        rres[pass][it] = make_uint4(0u, 0u, 0u, 0u);
+        if (m < p.M && n < p.N) rres[pass][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
+      }
+  }
+
   // ---------------- epilogues ----------------
   // lane holds, for fragment (i, j): m = .. + (lane & 15), n = .. + (lane >> 4) * 4 + r
   if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     const int out_es = p.out_f32 ? 4 : (int)sizeof(T);
     const bool wide_c = ((p.ldc * out_es) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.N & 7) == 0;
     const bool wide_r = p.resid && ((p.ldr * (long)sizeof(T)) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
-#pragma unroll 1
+#pragma unroll
     for (int pass = 0; pass < WM; ++pass) {
       if (wm == pass) {
 #pragma unroll
@@ -271,7 +291,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           }
       }
       __syncthreads();
-      for (int c = tid; c < ROWS * CH; c += NT) {
+#pragma unroll
+      for (int it = 0; it < (ROWS * CH + NT - 1) / NT; ++it) {
+        const int c = it * NT + tid;
+        if (c >= ROWS * CH) continue;
         const int r = c / CH, cc = c - r * CH;
         const int m = m0 + pass * ROWS + r, n = n0 + cc * 8;
         if (m >= p.M || n >= p.N) continue;
@@ -280,7 +303,13 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         const float4 hi = *reinterpret_cast<const float4*>(ebuf + r * LDW + cc * 8 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
         const bool full = n + 8 <= p.N;  // N % 4 == 0: a chunk is either 8 or 4 valid columns
-        if (p.resid) {
+        if constexpr (RESPRE) {
+          const uint4 t = rres[pass][it];
+          v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
+          v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
+          v[4] += __uint_as_float(t.z << 16); v[5] += __uint_as_float(t.z & 0xffff0000u);
+          v[6] += __uint_as_float(t.w << 16); v[7] += __uint_as_float(t.w & 0xffff0000u);
+        } else if (p.resid) {
           const T* rp = reinterpret_cast<const T*>(p.resid) + (long)m * p.ldr + n;
           float rv[8];
           if (full && wide_r) {
@@ -413,14 +442,14 @@ __global__ void relation_stats_kernel(const float* __restrict__ mstat, const flo
 }
 
 // ---------------- host-side dispatch ----------------
-template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS>
-static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false>
+static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
   constexpr size_t stage = 2 * (size_t)(BM + BN) * 128;
   constexpr size_t epi = (size_t)FM * 16 * (BN + 4) * 4;  // LDS-staged epilogue buffer
   constexpr size_t lds = stage > epi ? stage : epi;
   static bool attr_set = false;
-  auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS>;
+  auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS, RESPRE>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -428,6 +457,15 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
+}
+
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS>
+static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
+  if constexpr (EPI == EPI_LINEAR && GLDS && sizeof(T) == 2) {
+    const bool pre = p.resid && (p.N & 7) == 0 && ((p.ldr * 2) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
+    if (pre) return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, true>(p, stream);
+  }
+  return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, false>(p, stream);
 }
 
 // Tile menu (BM x BN, waves).  Only the bf16 + global_load_lds path carries the whole menu; the

@@ -72,6 +72,7 @@ SYMBOLS = {
     'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'hvr_stem_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'hvr_relation_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_relation_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
@@ -177,15 +178,15 @@ _NOSPAN = _NoSpan()
 
 
 def _span(tag, work=0.0):
-    if _prof is None or (tag not in _prof['tags'] and '*' not in _prof['tags']):
+    if _prof is None or (tag.split(' ')[0] not in _prof['tags'] and '*' not in _prof['tags']):
         return _NOSPAN
     return _Span(tag, work)
 
 
-def profile_begin(tags=('*',)):
+def profile_begin(tags=('*',), detail=False):
     """Start recording (tag, algorithmic work, HIP-event pair) for the C-ABI calls whose tag is in `tags`."""
     global _prof
-    _prof = dict(tags=set(tags), spans=[])
+    _prof = dict(tags=set(tags), spans=[], detail=detail)
 
 
 def profile_end():
@@ -235,7 +236,7 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
                  relu=int(relu), out_f32=int(out.dtype == torch.float32 and a.dtype != torch.float32),
                  dtype=_dt(a), staging=STAGING if staging is None else staging,
                  tile_hint=TILE_HINT if tile is None else tile)
-    with _span('gemm', 2.0 * M * N * K):
+    with _span('gemm' if not (_prof and _prof['detail']) else 'gemm M%d N%d K%d' % (M, N, K), 2.0 * M * N * K):
         _check(lib().hvr_gemm(ctypes.byref(d), _stream()), 'hvr_gemm')
     return out
 
@@ -255,7 +256,8 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
                  staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile,
                  zero=zero_page(x.device).data_ptr())
-    with _span('conv', 2.0 * B * OH * OW * Cout * KH * KW * Cin):
+    with _span('conv' if not (_prof and _prof['detail']) else 'conv %dx%d %d->%d k%d s%d d%d%s' % (H, W, Cin, Cout, KH, stride, dil, '+res' if resid is not None else ''),
+               2.0 * B * OH * OW * Cout * KH * KW * Cin):
         _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
     return y
 
@@ -269,6 +271,19 @@ def im2col_stem(img, dtype, kp=192):
     cols = torch.empty((B * OH * OW, kp), dtype=dtype, device=img.device)
     _check(lib().hvr_im2col_stem(_ptr(img), _ptr(cols), B, H, W, kp, _dt(cols), _stream()), 'hvr_im2col_stem')
     return cols, OH, OW
+
+
+def stem_fused(img, wpk, bias):
+    """img [B,3,H,W] f32 NCHW -> conv7x7/2 + bias + ReLU + maxpool3x3/2 as physical NHWC bf16 [B,PH,PW,64]."""
+    _need_cuda(img, wpk, bias)
+    assert img.dtype == torch.float32 and img.is_contiguous() and wpk.dtype == torch.bfloat16 and wpk.shape == (64, 7, 32)
+    B, _, H, W = img.shape
+    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
+    out = torch.empty((B, PH, PW, 64), dtype=torch.bfloat16, device=img.device)
+    with _span('stem', 2.0 * B * CH * CW * 64 * 147):
+        _check(lib().hvr_stem_fused(_ptr(img), _ptr(wpk), _ptr(bias), _ptr(out), B, H, W, _stream()), 'hvr_stem_fused')
+    return out
 
 
 def maxpool3x3s2_nhwc(x):

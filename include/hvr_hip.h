@@ -83,6 +83,10 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
 /* 7x7/2 stem: gathers img (NCHW f32, the reference's input layout, resnet.py:522-524) into
  * patch rows [B*OH*OW][KP] with k = (ky*7+kx)*3 + c and zeros for k >= 147 (KP = 192). */
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream);
+/* Fused bf16 stem: conv1 7x7/2 (BN folded) + ReLU + MaxPool2d(3,2,1) (resnet.py:456-466,522-526) in one kernel.
+ * img NCHW f32 [B][3][H][W]; wpk bf16 [64][7][32] with wpk[n][ky][kx*4+c] = w[n][c][ky][kx] (zeros for c = 3 or
+ * kx = 7); bias f32 [64]; out bf16 NHWC [B][PH][PW][64], PH = ((H-1)/2+1 - 1)/2 + 1. */
+int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on NHWC (resnet.py:466,526) */
 int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 

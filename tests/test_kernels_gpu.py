@@ -193,3 +193,17 @@ def test_every_tile_shape_gives_the_same_conv(tile):
     y = native.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), bias.to(DEV),
                            relu=True, pad=2, dil=2, staging=1, tile=tile)
     torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize('H,W', [(37, 45), (64, 96), (608, 1008)])
+def test_fused_stem_matches_conv_relu_pool(H, W):
+    """conv7x7/2 + bias + ReLU + maxpool3x3/2 in one kernel == the three torch ops on bf16-rounded operands."""
+    img = _rand((2, 3, H, W), torch.float32, 81, 50.0)
+    w = _rand((64, 3, 7, 7), torch.float32, 82, 0.05).to(torch.bfloat16)
+    bias = _rand((64,), torch.float32, 83)
+    ref = F.max_pool2d(torch.relu(F.conv2d(img.to(torch.bfloat16).float(), w.float(), bias, stride=2, padding=3)), 3, 2, 1)
+    wf = torch.zeros((64, 7, 8, 4))
+    wf[:, :, :7, :3] = w.float().permute(0, 2, 3, 1)
+    y = native.stem_fused(img.to(DEV), wf.view(64, 7, 32).to(torch.bfloat16).to(DEV), bias.to(DEV))
+    assert y.shape == (2, ref.shape[2], ref.shape[3], 64)
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)

@@ -19,6 +19,17 @@
 
 namespace hvr {
 
+constexpr bool kAsmLdsReads = true;  // see tile_kernel::do_step
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ uint4 lds_read128(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
 template <typename T> struct Mma;
 
 template <> struct Mma<bf16_t> {
@@ -199,6 +210,43 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         for (int i = 0; i < FM; ++i) gnext[i] = p.g[grow[i] + kt / STEPS_PER_BLOCK + 1];
       }
     }
+    if constexpr (GLDS && kAsmLdsReads && !(WM == 3 && FN == 4)) {
+      // Fragment reads through inline asm: the compiler does not see them as LDS accesses, so it does not park an
+      // s_waitcnt vmcnt(0) in front of them for the LDS-DMA just issued into the OTHER stage -- the next K-step's
+      // loads stay in flight under this step's MFMAs (it tracks pending LDS-DMA per LDS object and there is one).
+      // LDS returns data in order, so `lgkmcnt(FM + FN)` after all 2 x (FM + FN) reads means "kk = 0 has landed".
+      // (The 6-wave 144x128 shape is register-bound and has only 24 MFMAs per wave-step to cover the rigid
+      // read / wait structure: measured slower, so it keeps compiler-scheduled reads.)
+      const uint32_t a_addr = lds_addr(cur) + (wm * FM * 16 + frag_row) * 128;
+      const uint32_t b_addr = lds_addr(cur) + BM * 128 + (wn * FN * 16 + frag_row) * 128;
+      uint4 xa[2][FM], wb[2][FN];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) xa[kk][i] = lds_read128(a_addr + i * 16 * 128 + chunk);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wb[kk][j] = lds_read128(b_addr + j * 16 * 128 + chunk);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        __builtin_amdgcn_sched_barrier(0);  // pin: MFMAs of kk = 0 stay above the second wait
+        if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);  // and no MFMA is hoisted above the wait it depends on
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            if constexpr (EPI == EPI_APPLY) {
+              if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
+              else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
+            } else {
+              Mma<T>::template run<false>(wb[kk][j], xa[kk][i], acc[i][j]);
+            }
+          }
+      }
+    } else {
     const char* a_base = cur + (wm * FM * 16 + frag_row) * 128;
     const char* b_base = cur + BM * 128 + (wn * FN * 16 + frag_row) * 128;
 #pragma unroll
@@ -220,6 +268,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
             Mma<T>::template run<false>(wb[j], xa[i], acc[i][j]);
           }
         }
+    }
     }
     if constexpr (EPI == EPI_APPLY) {
       if (last) {
@@ -474,7 +523,7 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
 //   2: 144x256 (3x2)         1 / CU                 3: 144x128 (3x2)   2 / CU
 //   4: 256x128 (4x2)         1 / CU
 const TileShape kTileShapes[kNumTileShapes] = {
-    {128, 128, 2, 1.00f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.85f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f}};
+    {128, 128, 2, 1.25f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.90f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f}};
 
 int choose_tile(const GemmParams& p, int epi) {
   if (p.tile_hint > 0 && p.tile_hint <= kNumTileShapes) {
@@ -489,7 +538,7 @@ int choose_tile(const GemmParams& p, int epi) {
   // the chip runs `slots = 256 CUs x wg_per_cu` workgroups at a time; one full round of a shape costs
   // area x wg_per_cu / eff; a trailing partial round that leaves CUs with fewer co-resident workgroups
   // is cheaper, but not proportionally (a lone workgroup cannot saturate a CU).
-  static const double kPartial[4][4] = {{0, 0, 0, 0}, {0, 1.0, 0, 0}, {0, 0.67, 1.0, 0}, {0, 0.5, 0.8, 1.0}};
+  static const double kPartial[4][4] = {{0, 0, 0, 0}, {0, 1.0, 0, 0}, {0, 0.8, 1.0, 0}, {0, 0.5, 0.8, 1.0}};
   const int ksteps = p.K / (p.dtype == DT_BF16 ? 64 : 32);
   int best = 0;
   double best_cost = 1e300;
@@ -503,7 +552,8 @@ int choose_tile(const GemmParams& p, int epi) {
     const long full = tiles / slots, rem = tiles % slots;
     const double rounds = (double)full + (rem ? kPartial[s.wg_per_cu][(rem + 255) / 256] : 0.0);
     // short K loops expose the prologue/epilogue of shapes that run one workgroup per CU
-    const double eff = s.eff * ((s.wg_per_cu == 1 && ksteps <= 8) ? 0.7 : 1.0);
+    // 144x256 (inline-asm fragment reads, one workgroup per CU) only pays off on long K loops
+    const double eff = (t == 2 && ksteps >= 64) ? 1.33 : s.eff * ((s.wg_per_cu == 1 && ksteps <= 8) ? 0.7 : 1.0);
     const double cost = rounds * s.bm * s.bn * s.wg_per_cu / eff;
     if (cost < best_cost * 0.999) { best_cost = cost; best = t; }
   }

@@ -1,0 +1,90 @@
+"""The N > 1 inference path on CPU: two real processes over gloo (the GPU box uses the same code over RCCL).
+Ranks take whole videos (no data-path collective); rank 0 ends up with every frame's result in global order."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from hvrnet_amd import sharding, window  # noqa: E402
+
+
+def test_partition_follows_the_reference_greedy_fill():
+    # ceil(40 / 2) = 20: rank 0 takes videos while the running frame count stays <= 20
+    assert sharding.partition_videos([8, 7, 5, 9, 11], 2) == [[0, 1, 2], [3, 4]]
+    # the last rank absorbs the remainder even past the average (imagenet_vid_sequence.py:138-141)
+    assert sharding.partition_videos([10, 10, 10, 10, 1], 2) == [[0, 1], [2, 3, 4]]
+    assert sharding.partition_videos([3, 3, 3], 1) == [[0, 1, 2]]
+    parts = sharding.partition_videos([5] * 17, 8)
+    assert sorted(v for p in parts for v in p) == list(range(17)) and all(parts)
+
+
+class _EchoModel(object):
+    """Stands in for the detector: backbone_feat returns the frame id, forward_feat returns the window."""
+
+    def __call__(self, img=None, img_meta=None, backbone_feat=False, forward_feat=False, x=None, **kw):
+        return (img,) if backbone_feat else list(x)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, lengths, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        def run_video(vid):
+            frames = [vid * 1000 + i for i in range(lengths[vid])]
+            res = window.VideoWindowRunner(_EchoModel(), 5).run_video(frames, [dict() for _ in frames])
+            return [res[i] for i in range(lengths[vid])]
+
+        out = sharding.run_sharded(lengths, run_video, rank, world)
+        # the barrier + max-over-ranks timing pattern of bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        q.put((rank, out, float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_over_gloo_cover_every_frame_once():
+    lengths = [6, 9, 4, 7, 5]
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        rank, out, tmax = q.get(timeout=240)
+        got[rank] = (out, tmax)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1][0] is None and got[0][1] == got[1][1] == 2.0
+    out = got[0][0]
+    assert len(out) == sum(lengths)
+    k = 0
+    for vid, n in enumerate(lengths):
+        for f in range(n):
+            centre = out[k][2]  # window of 5: centre entry is the frame the detection belongs to
+            assert centre == vid * 1000 + f
+            assert all(vid * 1000 <= w < vid * 1000 + n for w in out[k])  # windows never mix videos
+            k += 1

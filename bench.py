@@ -178,10 +178,14 @@ def main():
         full = rel.get('relation_full', dict(calls=0, ms=0.0, work=0.0))
         peak = MFMA_PEAK_TF[args.dtype]
         roofline = None
+        traffic = None  # HBM-side bytes per launch come from the committed PMC passes (bench.py cannot collect PMC itself)
+        tpath = os.path.join(ROOT, 'profiles', 'r01_relation_traffic.json')
+        if os.path.exists(tpath) and T * n_prop == 4500 and args.dtype == 'bf16':
+            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         if full['calls']:
             ach = full['work'] / (full['ms'] * 1e-3) / 1e12
             roofline = dict(kernel='relation core (V^T + scores + stats + apply), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
-                            achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                            achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
                             launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
                             flops_per_launch=full['work'] / full['calls'])
         kc = {}

@@ -174,6 +174,9 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
   static const int tile_scores = env_tile("HVR_TILE_SCORES"), tile_apply = env_tile("HVR_TILE_APPLY");
   p.tile_hint = tile_scores;
+  static const int gm_scores = std::getenv("HVR_GM_SCORES") ? std::atoi(std::getenv("HVR_GM_SCORES")) : 8;
+  static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
+  p.group_m = gm_scores;
   rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
   if (rc) return rc;
   rc = check_launch(run_relation_stats(mstat, lstat, g, Mq, nt, s), "relation: stats");
@@ -182,6 +185,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   if (rc) return rc;
   p.g = g; p.ntile = nt;
   p.tile_hint = tile_apply;
+  p.group_m = gm_apply;
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
 }
 

@@ -77,7 +77,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int pid_m = tile / tiles_n, pid_n = tile % tiles_n;  // n fastest: the A panel is reused across the N tiles
+  if (p.group_m > 1) {
+    // grouped order for problems whose B operand is as large as A (relation scores / apply): `group_m` row tiles
+    // share each B panel while their A panels stay L2-resident, instead of streaming all of B once per row tile
+    const int per_group = p.group_m * tiles_n, gid = tile / per_group, first = gid * p.group_m;
+    const int gsz = tiles_m - first < p.group_m ? tiles_m - first : p.group_m;
+    const int in_group = tile - gid * per_group;
+    pid_m = first + in_group % gsz;
+    pid_n = in_group / gsz;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
 
   // ---------------- loader setup: one 16-byte chunk per (thread, slot) ----------------
   const char* a_ptr[A_SLOTS];
@@ -210,13 +220,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         for (int i = 0; i < FM; ++i) gnext[i] = p.g[grow[i] + kt / STEPS_PER_BLOCK + 1];
       }
     }
-    if constexpr (GLDS && kAsmLdsReads && !(WM == 3 && FN == 4)) {
+    if constexpr (GLDS && kAsmLdsReads && (!(WM == 3 && FN == 4) || EPI == EPI_APPLY)) {
       // Fragment reads through inline asm: the compiler does not see them as LDS accesses, so it does not park an
       // s_waitcnt vmcnt(0) in front of them for the LDS-DMA just issued into the OTHER stage -- the next K-step's
       // loads stay in flight under this step's MFMAs (it tracks pending LDS-DMA per LDS object and there is one).
       // LDS returns data in order, so `lgkmcnt(FM + FN)` after all 2 x (FM + FN) reads means "kk = 0 has landed".
       // (The 6-wave 144x128 shape is register-bound and has only 24 MFMAs per wave-step to cover the rigid
-      // read / wait structure: measured slower, so it keeps compiler-scheduled reads.)
+      // read / wait structure: measured slower on the short-K convs, so it keeps compiler-scheduled reads -- except
+      // in the relation apply pass, whose K = 4608 loop runs one workgroup per CU and needs the in-wave overlap.)
       const uint32_t a_addr = lds_addr(cur) + (wm * FM * 16 + frag_row) * 128;
       const uint32_t b_addr = lds_addr(cur) + BM * 128 + (wn * FN * 16 + frag_row) * 128;
       uint4 xa[2][FM], wb[2][FN];

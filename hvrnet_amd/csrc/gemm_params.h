@@ -40,6 +40,7 @@ struct GemmParams {
   float* lstat;    // [M][ntile] tile sum
   const float* g;  // [M][ntile] per-(row, 128-key block) weight
   int ntile;
+  int group_m;  // > 1: tile order walks `group_m` row tiles per B panel (see tile_kernel)
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };

@@ -78,8 +78,6 @@ def main():
         fl = 2.0 * T * OH * OW * Cout * k * k * Cin
         by = (x.numel() + T * OH * OW * Cout + w.numel()) * x.element_size()
         for tile in (0, 1, 2, 3, 4, 5):
-            if tile == 2 and Cout > 64:
-                continue
             ms = timed(lambda: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=1, tile=tile), args.iters)
             print('conv %-28s tile=%d  %.3f ms  %.1f TF/s  %.0f GB/s(min-traffic)' % (name, tile, ms, fl / ms / 1e9, by / ms / 1e6))
     # ---- RoIAlign, all frames in one launch ----

@@ -161,6 +161,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the reference's own steady-state loop (tools/test.py:214-250): ONE new frame through the backbone per output
+    # frame, the other T-1 C4 maps come from the deque; reported next to the clip-mode headline, never as `value`
+    with torch.no_grad():
+        c4_all = model(img=frames, img_meta=metas, backbone_feat=True)[0]
+        window = [c4_all[i:i + 1] for i in range(T)]
+    n_loop = max(3, min(args.steps, 10))
+    sync()
+    t1 = time.perf_counter()
+    for i in range(n_loop):
+        with torch.no_grad():
+            new = model(img=frames[i % T:i % T + 1], img_meta=[metas[0]], backbone_feat=True)[0]
+            window = window[1:] + [new]
+            model(x=window, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+    sync()
+    ref_loop_fps = n_loop / (time.perf_counter() - t1)
+
     # per-class breakdown from one extra, fully instrumented window (outside the timed region)
     native.profile_begin(tags=('*',))
     step()
@@ -207,7 +223,9 @@ def main():
                                frames_per_window=T, proposals_per_frame=n_prop, input='3x600x1000 padded to 608x1008',
                                mode='clip (all T frames through backbone+res5+RPN+RoIAlign+head every step)',
                                parallelism='dp%d independent clips, no collectives' % world, key_frame_detections=n_det),
-                   roofline=roofline, kernel_classes=kc)
+                   roofline=roofline, kernel_classes=kc,
+                   ref_loop=dict(frames_per_s_per_gpu=round(ref_loop_fps, 2), steps=n_loop,
+                                 what='tools/test.py steady state: 1 new backbone frame + res5/RPN/RoIAlign/head on all T per output frame'))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.head, T, n_prop, sd)
         print(json.dumps(out))

@@ -144,7 +144,7 @@ static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
 size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
   const long ldp = rel_ldp(Mk), nt = ldp / 128;
   const size_t es = elem_size(dtype);
-  return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 3 * align256((size_t)Mq * nt * 4);
+  return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 2 * align256((size_t)Mq * nt * 4);
 }
 
 int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
@@ -161,8 +161,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   void* P = w;                w += align256((size_t)Mq * ldp * es);
   void* Vt = w;               w += align256((size_t)D * ldp * es);
   float* mstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
-  float* lstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
-  float* g = (float*)w;
+  float* lstat = (float*)w;
   hipStream_t s = (hipStream_t)stream;
 
   int rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
@@ -179,11 +178,9 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   p.group_m = gm_scores;
   rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
   if (rc) return rc;
-  rc = check_launch(run_relation_stats(mstat, lstat, g, Mq, nt, s), "relation: stats");
-  if (rc) return rc;
   rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
   if (rc) return rc;
-  p.g = g; p.ntile = nt;
+  p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
   p.tile_hint = tile_apply;
   p.group_m = gm_apply;
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");

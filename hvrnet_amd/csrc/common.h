@@ -1,6 +1,7 @@
 // Shared device helpers for the hvr_hip kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 
 namespace hvr {
@@ -14,17 +15,14 @@ enum { DT_F32 = 0, DT_BF16 = 1 };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, same rounding as torch's float->bfloat16 cast
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// round-to-nearest-even, same rounding as torch's float->bfloat16 cast (v_cvt_pk_bf16_f32 on gfx950)
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const hw_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -65,6 +63,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 }  // namespace hvr

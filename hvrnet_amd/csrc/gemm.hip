@@ -29,6 +29,27 @@ __device__ __forceinline__ uint4 lds_read128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+template <int OFF> __device__ __forceinline__ uint4 lds_read128_off(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// A global load the compiler does not track: the caller guarantees (by counting vmcnt) that it has landed before the
+// value is consumed, and marks that point with `landed()`.
+__device__ __forceinline__ float load_f32_untracked(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void landed(float& v) { asm volatile("" : "+v"(v)); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// loads one K-step costs the wave that issues the fewest (the last one: slots are dealt to waves in order)
+constexpr int min_wave_loads(int rows, int nt) {
+  int n = 0;
+  for (int i = 0; i * nt < rows * 8; ++i) n += (i * nt + (nt - 64) < rows * 8) ? 1 : 0;
+  return n;
+}
 
 template <typename T> struct Mma;
 
@@ -60,13 +81,22 @@ template <> struct Mma<float> {
 
 // RESPRE: the residual tile is fetched into registers in one burst at the top of the epilogue (in the store-phase
 // mapping) instead of one dependent load per store-phase iteration.
-template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false>
+//
+// NS: LDS stages.  NS = 2 is the classic double buffer (the next K-step's loads are issued at the top of a step and
+// drained at its bottom).  NS = 3 / 4 keep NS - 1 K-steps of LDS-DMA in flight: the waits are counted by hand
+// (`s_waitcnt vmcnt(n)` with n = the loads of the steps that may stay outstanding), which needs the inline-asm
+// fragment reads -- the compiler would otherwise drain every DMA in front of the first LDS read it can see.
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16, NT = WM * WN * 64;
   constexpr int EPC = ElemTraits<T>::kPerChunk;  // elements per 16-byte chunk
   constexpr int BKE = 8 * EPC;                   // elements per K-step (128 bytes)
   constexpr int A_SLOTS = (BM * 8 + NT - 1) / NT, B_SLOTS = (BN * 8 + NT - 1) / NT;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr bool ASM_READS = GLDS && kAsmLdsReads && (NS > 2 || !(WM == 3 && FN == 4) || EPI == EPI_APPLY);
+  static_assert(NS == 2 || (ASM_READS && NS <= 4), "deep pipelines need the hand-counted waits");
+  constexpr int MINL = min_wave_loads(BM, NT) + min_wave_loads(BN, NT);
+  constexpr bool kConvOk = EPI == EPI_LINEAR;  // the relation passes never gather: drop the conv state there
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -98,7 +128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    if (p.conv) {
+    if (kConvOk && p.conv) {
       const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
       a_iy[i] = oy * p.stride - p.pad;
       a_ix[i] = ox * p.stride - p.pad;
@@ -122,7 +152,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   auto issue_loads = [&](int kt, char* stage) {
     long a_koff;
     int dy = 0, dx = 0;
-    if (p.conv) {
+    if (kConvOk && p.conv) {
       const int k = kt * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       dy = ky * p.dil;
@@ -135,7 +165,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     for (int i = 0; i < A_SLOTS; ++i) {
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
         const char* src = a_ptr[i] + a_koff;
-        if (p.conv) {
+        if (kConvOk && p.conv) {
           const bool ok = (unsigned)(a_iy[i] + dy) < (unsigned)p.H && (unsigned)(a_ix[i] + dx) < (unsigned)p.W;
           src = ok ? src : (const char*)p.zero;
         }
@@ -184,125 +214,324 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // EPI_APPLY keeps a second accumulator set: `acc` is the running total, `pacc` the
-  // current 128-key block's un-scaled partial product.
-  f32x4 pacc[EPI == EPI_APPLY ? FM : 1][EPI == EPI_APPLY ? FN : 1];
-  float gcur[EPI == EPI_APPLY ? FM : 1], gnext[EPI == EPI_APPLY ? FM : 1];
+  // current 128-key block's un-scaled partial product.  The next block's weights g are fetched at the very top of
+  // a block, ahead of that block's LDS-DMA, by loads the compiler does not track (a tracked load makes it drain the
+  // whole DMA queue in front of the first use): the hand-counted vmcnt wait of the block's last K-step covers them.
+  constexpr int GN = EPI == EPI_APPLY ? FM : 1;
+  f32x4 pacc[GN][EPI == EPI_APPLY ? FN : 1];
+  float gcur[GN], gnext[GN];
+  float mstar[GN], invl[GN];  // per-row softmax reference (log2 units) and 1 / normaliser
   constexpr int STEPS_PER_BLOCK = 128 / BKE;  // K-steps per 128-key statistics block
-  int grow[EPI == EPI_APPLY ? FM : 1];
+  const int nk = p.K / BKE;
+  const int nblk = nk / STEPS_PER_BLOCK;
+  int grow[GN];
   if constexpr (EPI == EPI_APPLY) {
+    // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*):
+    // the four lanes that share a row split the key tiles, then merge their (max, sum) pairs.
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       int m = m0 + (wm * FM + i) * 16 + (lane & 15);
       grow[i] = (m < p.M ? m : p.M - 1) * p.ntile;
-      gcur[i] = p.g[grow[i]];
+      float mx = -INFINITY, l = 0.f;
+      for (int t = lane >> 4; t < p.ntile; t += 4) {
+        const float mt = p.mstat[grow[i] + t], lt = p.lstat[grow[i] + t];
+        const float mn = fmaxf(mx, mt);
+        l = l * exp2f(mx - mn) + lt * exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
+        mx = mn;
+      }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float mo = __shfl_xor(mx, o), lo = __shfl_xor(l, o);
+        const float mn = fmaxf(mx, mo);  // a lane without tiles carries (-inf, 0); some lane has a finite max
+        l = (mx == mn ? l : l * exp2f(mx - mn)) + (mo == mn ? lo : lo * exp2f(mo - mn));
+        mx = mn;
+      }
+      mstar[i] = mx;
+      invl[i] = 1.f / l;
+      gcur[i] = exp2f(p.mstat[grow[i]] - mx) * invl[i];
+      landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
       gnext[i] = 0.f;
     }
   }
 
-  const int nk = p.K / BKE;
   const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
+  // per-lane part of the fragment read addresses (kk = 1 is the same address with bit 6 flipped)
+  const uint32_t a_lane = lds_addr(smem) + (wm * FM * 16 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+  const uint32_t b_lane = lds_addr(smem) + BM * 128 + (wn * FN * 16 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
 
-  // ---------------- main loop: double-buffered LDS, one barrier per K-step ----------------
-  issue_loads(0, smem);
-  commit_stage(smem);
-  __syncthreads();
+  // ---------------- main loop ----------------
+  if constexpr (NS == 2) {
+    // Double buffer, one barrier per K-step: the next step's loads are issued at the top of a step and drained at
+    // its bottom (the compiler waits for them in front of the barrier).
+    issue_loads(0, smem);
+    commit_stage(smem);
+    __syncthreads();
 
-  // `first` / `last`: position of this K-step inside a 128-key statistics block (EPI_APPLY only;
-  // compile-time constants after unrolling, so the zero-C MFMA and the block combine fold away elsewhere)
-  auto do_step = [&](int kt, bool first, bool last) {
-    char* cur = smem + (kt & 1) * STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    const bool more = kt + 1 < nk;
-    if (more) issue_loads(kt + 1, nxt);
-    if constexpr (EPI == EPI_APPLY) {
-      if (first && kt + STEPS_PER_BLOCK < nk) {
+    // `first` / `last`: position of this K-step inside a 128-key statistics block (EPI_APPLY only;
+    // compile-time constants after unrolling, so the zero-C MFMA and the block combine fold away elsewhere)
+    auto do_step = [&](int kt, bool first, bool last) {
+      char* cur = smem + (kt & 1) * STAGE_BYTES;
+      char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      const bool more = kt + 1 < nk;
+      if constexpr (EPI == EPI_APPLY) {
+        if (first) {
+          if (kt + STEPS_PER_BLOCK < nk) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) gnext[i] = p.g[grow[i] + kt / STEPS_PER_BLOCK + 1];
-      }
-    }
-    if constexpr (GLDS && kAsmLdsReads && (!(WM == 3 && FN == 4) || EPI == EPI_APPLY)) {
-      // Fragment reads through inline asm: the compiler does not see them as LDS accesses, so it does not park an
-      // s_waitcnt vmcnt(0) in front of them for the LDS-DMA just issued into the OTHER stage -- the next K-step's
-      // loads stay in flight under this step's MFMAs (it tracks pending LDS-DMA per LDS object and there is one).
-      // LDS returns data in order, so `lgkmcnt(FM + FN)` after all 2 x (FM + FN) reads means "kk = 0 has landed".
-      // (The 6-wave 144x128 shape is register-bound and has only 24 MFMAs per wave-step to cover the rigid
-      // read / wait structure: measured slower on the short-K convs, so it keeps compiler-scheduled reads -- except
-      // in the relation apply pass, whose K = 4608 loop runs one workgroup per CU and needs the in-wave overlap.)
-      const uint32_t a_addr = lds_addr(cur) + (wm * FM * 16 + frag_row) * 128;
-      const uint32_t b_addr = lds_addr(cur) + BM * 128 + (wn * FN * 16 + frag_row) * 128;
-      uint4 xa[2][FM], wb[2][FN];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) xa[kk][i] = lds_read128(a_addr + i * 16 * 128 + chunk);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) wb[kk][j] = lds_read128(b_addr + j * 16 * 128 + chunk);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        __builtin_amdgcn_sched_barrier(0);  // pin: MFMAs of kk = 0 stay above the second wait
-        if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);  // and no MFMA is hoisted above the wait it depends on
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            if constexpr (EPI == EPI_APPLY) {
-              if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
-              else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
-            } else {
-              Mma<T>::template run<false>(wb[kk][j], xa[kk][i], acc[i][j]);
-            }
+            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + grow[i] + kt / STEPS_PER_BLOCK + 1);
           }
+          __builtin_amdgcn_sched_barrier(0);  // the g loads stay ahead of this step's DMA in the vmcnt queue
+        }
       }
-    } else {
-    const char* a_base = cur + (wm * FM * 16 + frag_row) * 128;
-    const char* b_base = cur + BM * 128 + (wn * FN * 16 + frag_row) * 128;
+      if (more) issue_loads(kt + 1, nxt);
+      if constexpr (ASM_READS) {
+        // Fragment reads through inline asm: the compiler does not see them as LDS accesses, so it does not park an
+        // s_waitcnt vmcnt(0) in front of them for the LDS-DMA just issued into the OTHER stage -- the next K-step's
+        // loads stay in flight under this step's MFMAs (it tracks pending LDS-DMA per LDS object and there is one).
+        // LDS returns data in order, so `lgkmcnt(FM + FN)` after all 2 x (FM + FN) reads means "kk = 0 has landed".
+        // (The 6-wave 144x128 shape is register-bound and has only 24 MFMAs per wave-step to cover the rigid
+        // read / wait structure: measured slower on the short-K convs, so it keeps compiler-scheduled reads there --
+        // except in the relation apply pass.)
+        const uint32_t soff = (uint32_t)(cur - smem);
+        const uint32_t a0 = a_lane + soff, b0 = b_lane + soff, a1 = a0 ^ 64u, b1 = b0 ^ 64u;
+        uint4 xa[2][FM], wb[2][FN];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
-      uint4 xa[FM], wb[FN];
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint32_t ab = kk ? a1 : a0, bb = kk ? b1 : b0;
+          static_for<FM>([&](auto I) { xa[kk][decltype(I)::value] = lds_read128_off<decltype(I)::value * 2048>(ab); });
+          static_for<FN>([&](auto J) { wb[kk][decltype(J)::value] = lds_read128_off<decltype(J)::value * 2048>(bb); });
+        }
 #pragma unroll
-      for (int i = 0; i < FM; ++i) xa[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * 128 + chunk);
+        for (int kk = 0; kk < 2; ++kk) {
+          __builtin_amdgcn_sched_barrier(0);  // pin: MFMAs of kk = 0 stay above the second wait
+          if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);  // and no MFMA is hoisted above the wait it depends on
 #pragma unroll
-      for (int j = 0; j < FN; ++j) wb[j] = *reinterpret_cast<const uint4*>(b_base + j * 16 * 128 + chunk);
+          for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j) {
+              if constexpr (EPI == EPI_APPLY) {
+                if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
+                else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
+              } else {
+                Mma<T>::template run<false>(wb[kk][j], xa[kk][i], acc[i][j]);
+              }
+            }
+        }
+      } else {
+        const char* a_base = cur + (wm * FM * 16 + frag_row) * 128;
+        const char* b_base = cur + BM * 128 + (wn * FN * 16 + frag_row) * 128;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          if constexpr (EPI == EPI_APPLY) {
-            if (first && kk == 0) Mma<T>::template run<true>(wb[j], xa[i], pacc[i][j]);
-            else Mma<T>::template run<false>(wb[j], xa[i], pacc[i][j]);
-          } else {
-            Mma<T>::template run<false>(wb[j], xa[i], acc[i][j]);
+        for (int kk = 0; kk < 2; ++kk) {
+          const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
+          uint4 xa[FM], wb[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) xa[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * 128 + chunk);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wb[j] = *reinterpret_cast<const uint4*>(b_base + j * 16 * 128 + chunk);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              if constexpr (EPI == EPI_APPLY) {
+                if (first && kk == 0) Mma<T>::template run<true>(wb[j], xa[i], pacc[i][j]);
+                else Mma<T>::template run<false>(wb[j], xa[i], pacc[i][j]);
+              } else {
+                Mma<T>::template run<false>(wb[j], xa[i], acc[i][j]);
+              }
+            }
+        }
+      }
+      if constexpr (EPI == EPI_APPLY) {
+        if (last) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
+            landed(gnext[i]);
+            gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - mstar[i]) * invl[i];
           }
         }
-    }
-    }
+      }
+      if (more) commit_stage(nxt);
+      __syncthreads();
+    };
     if constexpr (EPI == EPI_APPLY) {
-      if (last) {
+      for (int kb = 0; kb < nk; kb += STEPS_PER_BLOCK) {
+#pragma unroll
+        for (int st = 0; st < STEPS_PER_BLOCK; ++st) do_step(kb + st, st == 0, st == STEPS_PER_BLOCK - 1);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) do_step(kt, false, false);
+    }
+  } else {
+    // NS-slot LDS ring with a hand-placed instruction stream.  A K-step is two halves (kk = 0 / 1, 32 bf16 of K each);
+    // each half issues its FM x FN MFMAs with one "filler" after every MFMA: first the fragment reads of the NEXT
+    // half (into the other fragment register set), then this step's share of the LDS-DMA for K-step kt + NS - 1
+    // (A slots in half 0, B slots in half 1).  The per-CU load path (64 B/clk) and the LDS therefore run UNDER the
+    // MFMAs instead of in a burst in front of them, and a half never waits for data requested less than a half ago.
+    //   half 0:  lgkmcnt(0)                      -> frags(kt, 0) landed
+    //   half 1:  lgkmcnt(0)                      -> frags(kt, 1) landed: this wave is done reading slot kt % NS
+    //            vmcnt(n), s_barrier             -> K-step kt + 1 is in LDS for everyone; slot kt % NS is free
+    // The waits are counted by hand (vmcnt counts this wave's loads in issue order; n = the loads that may stay in
+    // flight, i.e. those of the K-steps after kt + 1, taken for the wave that issues the fewest).
+    static_assert(EPI != EPI_APPLY || STEPS_PER_BLOCK == 2, "the pipelined apply loop assumes 2 K-steps per block");
+    constexpr int MIN_A = min_wave_loads(BM, NT);
+    constexpr int NR = FM + FN, NM = FM * FN;
+    uint4 fa[2][FM], fb[2][FN];  // fragment sets: [0] = kk 0, [1] = kk 1
+    long a_koff = 0;
+    int dy = 0, dx = 0;  // conv: filter tap of the K-step being loaded
+
+    auto tap_of = [&](int kt) {
+      if (kConvOk && p.conv) {
+        const int k = kt * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        dy = ky * p.dil;
+        dx = kx * p.dil;
+        a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)sizeof(T);
+      } else {
+        a_koff = (long)kt * 128;
+      }
+    };
+    auto dma_a = [&](auto I, char* stage) {
+      constexpr int i = decltype(I)::value;
+      if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
+        const char* src = a_ptr[i] + a_koff;
+        if (kConvOk && p.conv) {
+          const bool ok = (unsigned)(a_iy[i] + dy) < (unsigned)p.H && (unsigned)(a_ix[i] + dx) < (unsigned)p.W;
+          src = ok ? src : (const char*)p.zero;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + (i * NT + wave * 64) * 16), 16, 0, 0);
+      }
+    };
+    auto dma_b = [&](auto I, int kt, char* stage) {
+      constexpr int i = decltype(I)::value;
+      if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
+        const char* src = b_ptr[i] + (long)kt * 128;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0,
+                                         0);
+      }
+    };
+    // fragment read r of half kk from the slot at byte offset soff
+    auto read_frag = [&](auto R, auto KK, uint32_t soff) {
+      constexpr int r = decltype(R)::value, kk = decltype(KK)::value;
+      if constexpr (r < FM) fa[kk][r] = lds_read128_off<r * 2048>((a_lane + soff) ^ (kk ? 64u : 0u));
+      else fb[kk][r - FM] = lds_read128_off<(r - FM) * 2048>((b_lane + soff) ^ (kk ? 64u : 0u));
+    };
+
+    // prologue: NS - 1 K-steps in flight, K-step 0 landed, its first half's fragments requested
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) issue_loads(s, smem + s * STAGE_BYTES);
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * MINL>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    static_for<NR>([&](auto R) { read_frag(R, std::integral_constant<int, 0>{}, 0u); });
+
+    int cs = 0;  // ring slot of the K-step being computed
+    // LOAD: this step issues the DMA of K-step kt + NS - 1.  NEXT: a K-step kt + 1 exists (its first fragments are
+    // requested in half 1).  FIRST / LAST: position inside a 128-key block (EPI_APPLY).
+    auto pipe_step = [&](int kt, auto LOAD, auto NEXT, auto FIRST, auto LAST) {
+      constexpr bool load = decltype(LOAD)::value, next = decltype(NEXT)::value;
+      constexpr bool first = decltype(FIRST)::value, last = decltype(LAST)::value;
+      const uint32_t soff = (uint32_t)cs * STAGE_BYTES;
+      const int ns = cs + 1 == NS ? 0 : cs + 1;
+      char* lstage = smem + (cs == 0 ? NS - 1 : cs - 1) * STAGE_BYTES;  // freed by the previous step's barrier
+      if constexpr (EPI == EPI_APPLY && first) {
+        if (kt + STEPS_PER_BLOCK < nk) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + grow[i] + kt / STEPS_PER_BLOCK + 1);
+        }
+      }
+      if constexpr (load) tap_of(kt + NS - 1);
+      static_for<2>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        constexpr int ND = load ? (kk == 0 ? A_SLOTS : B_SLOTS) : 0;
+        constexpr bool reads = kk == 0 || next;  // half 1 requests the next step's first fragments
+        constexpr int NF = (reads ? NR : 0) + ND;
+        constexpr int PER = (NF + NM - 1) / NM;  // fillers after each MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (kk == 1) {
+          // loads that may stay in flight: the K-steps after kt + 1 (full groups), plus the A half of the group
+          // this step is issuing; an apply block's g loads sit exactly that far back, hence one fewer there
+          constexpr int G = (EPI == EPI_APPLY && NS == 4) ? 1 : 0;
+          if constexpr (load) {
+            wait_vmcnt<(NS - 3) * MINL + MIN_A - G>();
+          } else {
+            if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G>();
+            else wait_vmcnt<0>();
+          }
+          __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NM>([&](auto Q) {
+          constexpr int q = decltype(Q)::value, i = q / FN, j = q % FN;
+          if constexpr (EPI == EPI_APPLY) {
+            if constexpr (first && kk == 0) Mma<T>::template run<true>(fb[kk][j], fa[kk][i], pacc[i][j]);
+            else Mma<T>::template run<false>(fb[kk][j], fa[kk][i], pacc[i][j]);
+          } else {
+            Mma<T>::template run<false>(fb[kk][j], fa[kk][i], acc[i][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<PER>([&](auto U) {
+            constexpr int f = q * PER + decltype(U)::value;
+            constexpr int fr = reads ? f : f + NR;  // filler index in the (reads, DMA) order
+            if constexpr (f < NF) {
+              if constexpr (fr < NR) {
+                if constexpr (kk == 0) read_frag(std::integral_constant<int, fr>{}, std::integral_constant<int, 1>{}, soff);
+                else read_frag(std::integral_constant<int, fr>{}, std::integral_constant<int, 0>{}, (uint32_t)ns * STAGE_BYTES);
+              } else {
+                if constexpr (kk == 0) dma_a(std::integral_constant<int, fr - NR>{}, lstage);
+                else dma_b(std::integral_constant<int, fr - NR>{}, kt + NS - 1, lstage);
+              }
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      if constexpr (EPI == EPI_APPLY && last) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
           for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
-          gcur[i] = gnext[i];
+          landed(gnext[i]);
+          gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - mstar[i]) * invl[i];
         }
       }
+      cs = ns;
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    if constexpr (EPI == EPI_APPLY) {
+      // nk is even (128-key blocks); a block's two steps share their LOAD / NEXT flags except at the very end
+      int kt = 0;
+      for (; kt + NS < nk; kt += 2) {  // both steps load (kt + 1 + NS - 1 < nk)
+        pipe_step(kt, Y, Y, Y, N);
+        pipe_step(kt + 1, Y, Y, N, Y);
+      }
+      for (; kt < nk; kt += 2) {
+        if (kt + NS - 1 < nk) pipe_step(kt, Y, Y, Y, N);
+        else pipe_step(kt, N, Y, Y, N);
+        if (kt + 2 < nk) {
+          if (kt + NS < nk) pipe_step(kt + 1, Y, Y, N, Y);
+          else pipe_step(kt + 1, N, Y, N, Y);
+        } else {
+          pipe_step(kt + 1, N, N, N, Y);
+        }
+      }
+    } else {
+      int kt = 0;
+      for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, Y, Y, N, N);
+      for (; kt + 1 < nk; ++kt) pipe_step(kt, N, Y, N, N);
+      if (kt < nk) pipe_step(kt, N, N, N, N);
     }
-    if (more) commit_stage(nxt);
-    __syncthreads();
-  };
-  if constexpr (EPI == EPI_APPLY) {
-    for (int kb = 0; kb < nk; kb += STEPS_PER_BLOCK) {
-#pragma unroll
-      for (int st = 0; st < STEPS_PER_BLOCK; ++st) do_step(kb + st, st == 0, st == STEPS_PER_BLOCK - 1);
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) do_step(kt, false, false);
   }
 
   // ---------------- residual fetch (RESPRE): all of the tile's residual loads are issued here, at the top of the
@@ -413,8 +642,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     }
   } else {  // EPI_SCORES: per (row, 128-key tile) max / sum and P~ = exp(s - tilemax)
     static_assert(EPI != EPI_SCORES || BN == 128, "score tiles are 128 keys wide");
-    float* red = reinterpret_cast<float*>(smem);  // [WN][BM] scratch, main loop is done
+    // LDS scratch (the main loop is done): the P~ tile, staged so that it leaves in whole 16-byte row segments,
+    // and [WN][BM] floats for the max / sum exchange between the column waves
+    constexpr int PITCH = BN * (int)sizeof(T) + 8;  // bytes per staged row; 66 dwords: the 8-byte writes of a lane
+                                                    // group (16 rows) land on 32 distinct banks
+    char* pbuf = smem;
+    float* red = reinterpret_cast<float*>(smem + BM * PITCH);
     const float sl2 = p.scale * 1.4426950408889634f;  // logits in log2 units
+    const bool ragged = n0 + BN > p.N;                // only the last key tile masks columns
     float tmax[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -424,7 +659,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         const int n = n0 + (wn * FN + j) * 16 + frag_grp * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float s = (n + r < p.N) ? acc[i][j][r] * sl2 : -INFINITY;
+          float s = acc[i][j][r] * sl2;
+          if (ragged) s = (n + r < p.N) ? s : -INFINITY;
           acc[i][j][r] = s;
           mx = fmaxf(mx, s);
         }
@@ -441,31 +677,47 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       for (int w = 0; w < WN; ++w) tmax[i] = fmaxf(tmax[i], red[w * BM + (wm * FM + i) * 16 + frag_row]);
     }
     __syncthreads();
-    float tsum[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int m = m0 + (wm * FM + i) * 16 + frag_row;
+      const int row = (wm * FM + i) * 16 + frag_row;
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int n = n0 + (wn * FN + j) * 16 + frag_grp * 4;
-        float v[4];
+        const int col = (wn * FN + j) * 16 + frag_grp * 4;
+        float e[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = exp2f(acc[i][j][r] - tmax[i]);  // masked keys: exp2(-inf) = 0
-          // the row sum is taken over the values PV will actually multiply
-          if constexpr (ElemTraits<T>::kCode == DT_BF16) e = bf2f(f2bf(e));
-          v[r] = e;
-          sum += e;
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(acc[i][j][r] - tmax[i]);  // masked keys: exp2(-inf) = 0
+        if constexpr (sizeof(T) == 2) {
+          // the row sum is taken over the rounded values the apply pass will actually multiply
+          const uint32_t lo = pack2bf(e[0], e[1]), hi = pack2bf(e[2], e[3]);
+          sum += (__uint_as_float(lo << 16) + __uint_as_float(lo & 0xffff0000u)) +
+                 (__uint_as_float(hi << 16) + __uint_as_float(hi & 0xffff0000u));
+          *reinterpret_cast<uint2*>(pbuf + row * PITCH + col * 2) = make_uint2(lo, hi);
+        } else {
+          sum += (e[0] + e[1]) + (e[2] + e[3]);
+          *reinterpret_cast<float2*>(pbuf + row * PITCH + col * 4) = make_float2(e[0], e[1]);
+          *reinterpret_cast<float2*>(pbuf + row * PITCH + col * 4 + 8) = make_float2(e[2], e[3]);
         }
-        if (m < p.M && n < p.ldc) store4(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
       }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      tsum[i] = sum;
-      if (frag_grp == 0) red[wn * BM + (wm * FM + i) * 16 + frag_row] = sum;
+      if (frag_grp == 0) red[wn * BM + row] = sum;
     }
     __syncthreads();
+    {  // P~ leaves in 16-byte row segments (ldc is a multiple of 128 keys: every column of the tile exists)
+      constexpr int CH = BN * (int)sizeof(T) / 16;  // chunks per row
+#pragma unroll
+      for (int it = 0; it < (BM * CH + NT - 1) / NT; ++it) {
+        const int c = it * NT + tid;
+        if ((BM * CH) % NT != 0 && c >= BM * CH) continue;
+        const int r = c / CH, cc = c - r * CH, m = m0 + r;
+        const uint2 lo = *reinterpret_cast<const uint2*>(pbuf + r * PITCH + cc * 16);
+        const uint2 hi = *reinterpret_cast<const uint2*>(pbuf + r * PITCH + cc * 16 + 8);
+        if (m < p.M)
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + ((long)m * p.ldc + n0) * (long)sizeof(T) + cc * 16) =
+              make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
     if (wn == 0 && frag_grp == 0) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
@@ -483,33 +735,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   }
 }
 
-// Per-row combine of the tile statistics: g[m][t] = 2^(m_t - m*) / L with
-// L = sum_t l_t 2^(m_t - m*).  One wave per row.
-__global__ void relation_stats_kernel(const float* __restrict__ mstat, const float* __restrict__ lstat,
-                                      float* __restrict__ g, int M, int ntile) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  float mx = -INFINITY;
-  for (int t = lane; t < ntile; t += 64) mx = fmaxf(mx, mstat[(long)row * ntile + t]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  float L = 0.f;
-  for (int t = lane; t < ntile; t += 64) L += lstat[(long)row * ntile + t] * exp2f(mstat[(long)row * ntile + t] - mx);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o);
-  const float inv = 1.f / L;
-  for (int t = lane; t < ntile; t += 64) g[(long)row * ntile + t] = exp2f(mstat[(long)row * ntile + t] - mx) * inv;
-}
-
 // ---------------- host-side dispatch ----------------
-template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false>
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false, int NS = 2>
 static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
-  constexpr size_t stage = 2 * (size_t)(BM + BN) * 128;
-  constexpr size_t epi = (size_t)FM * 16 * (BN + 4) * 4;  // LDS-staged epilogue buffer
+  constexpr size_t stage = NS * (size_t)(BM + BN) * 128;
+  constexpr size_t epi = EPI == EPI_SCORES ? (size_t)BM * (BN * sizeof(T) + 8) + (size_t)WN * BM * 4  // P~ tile + exchange
+                                           : (size_t)FM * 16 * (BN + 4) * 4;                      // one wave-row block, f32
   constexpr size_t lds = stage > epi ? stage : epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS, RESPRE>;
+  auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS, RESPRE, NS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -519,13 +755,13 @@ static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS>
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, int NS = 2>
 static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
   if constexpr (EPI == EPI_LINEAR && GLDS && sizeof(T) == 2) {
     const bool pre = p.resid && (p.N & 7) == 0 && ((p.ldr * 2) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
-    if (pre) return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, true>(p, stream);
+    if (pre) return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, true, NS>(p, stream);
   }
-  return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, false>(p, stream);
+  return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, false, NS>(p, stream);
 }
 
 // Tile menu (BM x BN, waves).  Only the bf16 + global_load_lds path carries the whole menu; the
@@ -533,14 +769,19 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
 //   0: 128x128 (2x2 waves)   2 workgroups / CU      1: 128x64  (4x1)   3 / CU
 //   2: 144x256 (3x2)         1 / CU                 3: 144x128 (3x2)   2 / CU
 //   4: 256x128 (4x2)         1 / CU
+// Deep-pipeline variants (NS LDS stages, NS - 1 K-steps of DMA in flight):
+//   5: 256x128 NS=3  1 / CU    6: 144x256 NS=3  1 / CU    7: 144x128 NS=4  1 / CU
+//   8: 128x128 NS=4  1 / CU    9: 128x64  NS=3  2 / CU
 const TileShape kTileShapes[kNumTileShapes] = {
-    {128, 128, 2, 1.25f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.90f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f}};
+    {128, 128, 2, 1.25f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.90f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f},
+    {256, 128, 1, 1.00f}, {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}, {128, 128, 1, 1.00f}, {128, 64, 2, 1.00f}};
 
 int choose_tile(const GemmParams& p, int epi) {
   if (p.tile_hint > 0 && p.tile_hint <= kNumTileShapes) {
     const int t = p.tile_hint - 1;
     if (epi == EPI_SCORES && kTileShapes[t].bn != 128) return 0;
-    if (epi == EPI_APPLY && t == 2) return 3;
+    if (epi == EPI_APPLY && (t == 2 || t == 6)) return 3;
+    if (epi != EPI_LINEAR && t == 9) return 0;
     return t;
   }
   const bool full_menu = p.dtype == DT_BF16 && p.staging == 1;
@@ -553,18 +794,25 @@ int choose_tile(const GemmParams& p, int epi) {
   const int ksteps = p.K / (p.dtype == DT_BF16 ? 64 : 32);
   int best = 0;
   double best_cost = 1e300;
-  for (int t = 0; t < kNumTileShapes; ++t) {
+  // candidates: the base shapes plus the two pipelined variants that win on this path's long-K problems
+  // (5 / 8 / 9 stay reachable through tile_hint for tuning)
+  static const int kCandidates[] = {0, 1, 2, 3, 4, 6, 7};
+  for (int t : kCandidates) {
     const TileShape& s = kTileShapes[t];
-    if (epi == EPI_SCORES && s.bn != 128) continue;
-    if (epi == EPI_APPLY && t == 2) continue;  // two accumulator sets do not fit 144x256
+    if (epi == EPI_SCORES && (s.bn != 128 || t >= kNumBaseShapes)) continue;
+    if (epi == EPI_APPLY && (t == 2 || t == 6)) continue;  // two accumulator sets do not fit 144x256
     if (p.N <= 64 && s.bn > 64 && t != 0) continue;
     const long tiles = (long)((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
     const long slots = 256L * s.wg_per_cu;
     const long full = tiles / slots, rem = tiles % slots;
     const double rounds = (double)full + (rem ? kPartial[s.wg_per_cu][(rem + 255) / 256] : 0.0);
-    // short K loops expose the prologue/epilogue of shapes that run one workgroup per CU
-    // 144x256 (inline-asm fragment reads, one workgroup per CU) only pays off on long K loops
-    const double eff = (t == 2 && ksteps >= 64) ? 1.33 : s.eff * ((s.wg_per_cu == 1 && ksteps <= 8) ? 0.7 : 1.0);
+    // short K loops expose the prologue/epilogue of shapes that run one workgroup per CU;
+    // 144x256 only pays off on long K loops, and with the 3-slot pipeline from ~24 K-steps on;
+    // 144x128 with the 4-slot pipeline (one workgroup per CU) is the long-K shape for M x N that fit one round
+    double eff = s.eff * ((s.wg_per_cu == 1 && ksteps <= 8) ? 0.7 : 1.0);
+    if (t == 2) eff = ksteps >= 64 ? 1.33 : s.eff;
+    if (t == 6) eff = ksteps >= 24 ? 1.40 : 0.85;
+    if (t == 7) eff = ksteps >= 64 ? 1.15 : (epi == EPI_APPLY && ksteps >= 8 ? 1.05 : 0.70);
     const double cost = rounds * s.bm * s.bn * s.wg_per_cu / eff;
     if (cost < best_cost * 0.999) { best_cost = cost; best = t; }
   }
@@ -579,6 +827,11 @@ static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t strea
       case 2: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS>(p, stream); break;
       case 3: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS>(p, stream);
       case 4: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS>(p, stream);
+      case 5: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS, 3>(p, stream);
+      case 6: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
+      case 7: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream);
+      case 8: return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream);
+      case 9: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS, 3>(p, stream); break;
       default: break;
     }
     return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);
@@ -605,13 +858,6 @@ hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream) {
   if (epi == EPI_LINEAR) return dispatch_shape<float, EPI_LINEAR>(p, stream);
   if (epi == EPI_SCORES) return dispatch_shape<float, EPI_SCORES>(p, stream);
   return dispatch_shape<float, EPI_APPLY>(p, stream);
-}
-
-hipError_t run_relation_stats(const float* mstat, const float* lstat, float* g, int M, int ntile, hipStream_t stream) {
-  const int rows_per_block = 4;
-  hipLaunchKernelGGL(relation_stats_kernel, dim3((M + rows_per_block - 1) / rows_per_block), dim3(rows_per_block * 64), 0,
-                     stream, mstat, lstat, g, M, ntile);
-  return hipGetLastError();
 }
 
 }  // namespace hvr

@@ -38,17 +38,16 @@ struct GemmParams {
   float scale;
   float* mstat;    // [M][ntile] tile max (log2 units)
   float* lstat;    // [M][ntile] tile sum
-  const float* g;  // [M][ntile] per-(row, 128-key block) weight
   int ntile;
   int group_m;  // > 1: tile order walks `group_m` row tiles per B panel (see tile_kernel)
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };
-constexpr int kNumTileShapes = 5;
+constexpr int kNumTileShapes = 10;
+constexpr int kNumBaseShapes = 5;  // shapes 5.. are deep-pipeline (3 / 4 LDS stage) variants of the base shapes
 extern const TileShape kTileShapes[kNumTileShapes];
 int choose_tile(const GemmParams& p, int epi);
 
 hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream);
-hipError_t run_relation_stats(const float* mstat, const float* lstat, float* g, int M, int ntile, hipStream_t stream);
 
 }  // namespace hvr

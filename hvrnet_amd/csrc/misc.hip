@@ -176,9 +176,44 @@ static inline int grid_for(long work, int block, int cap = 256 * 16) {
   return (int)g;
 }
 
+// bf16 fast path: 16-byte global accesses on both sides (a 64 x 64 tile = 512 chunks in, 512 chunks out)
+__global__ __launch_bounds__(256) void transpose_pad_bf16x8_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C,
+                                                                    long ldx, long ldt) {
+  constexpr int PITCH = 64 * 2 + 16;  // bytes per staged row
+  __shared__ __attribute__((aligned(16))) char tile[64 * PITCH];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, i = s >> 3, q = s & 7;  // row i, chunk q of the input tile
+    const int r = r0 + i, c = c0 + q * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R && c < C) v = *reinterpret_cast<const uint4*>(in + (long)r * ldx + c);  // C % 8 == 0
+    *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, q = s >> 6, i = s & 63;  // output row c0 + i, its chunk q (rows r0 + 8q .. + 7)
+    const int c = c0 + i, r = r0 + q * 8;
+    if (c >= C || r >= ldt) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e) * PITCH + i * 2);
+      const uint32_t hi = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+      w[e] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(out + (long)c * ldt + r) = make_uint4(w[0], w[1], w[2], w[3]);  // ldt % 8 == 0
+  }
+}
+
 hipError_t run_transpose_pad(const void* in, void* out, int R, int C, long ldx, long ldt, int dtype, hipStream_t s) {
   dim3 grid((C + 63) / 64, (int)((ldt + 63) / 64));
-  if (dtype == DT_BF16)
+  const bool wide = dtype == DT_BF16 && C % 8 == 0 && ldx % 8 == 0 && ldt % 8 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (wide)
+    hipLaunchKernelGGL(transpose_pad_bf16x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, R, C, ldx, ldt);
+  else if (dtype == DT_BF16)
     hipLaunchKernelGGL(transpose_pad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, R, C, ldx, ldt);
   else
     hipLaunchKernelGGL(transpose_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, R, C, ldx, ldt);

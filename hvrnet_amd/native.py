@@ -439,6 +439,16 @@ def cast(x, dtype):
     return out
 
 
+def transpose_pad(x, ldt):
+    """[R, C] -> [C, ldt] with columns R.. zero (the relation's V^T operand)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    R, C = x.shape
+    out = torch.empty((C, ldt), dtype=x.dtype, device=x.device)
+    _check(lib().hvr_transpose_pad(_ptr(x), _ptr(out), R, C, C, ldt, _dt(x), _stream()), 'hvr_transpose_pad')
+    return out
+
+
 def nchw_to_nhwc(x, dtype=None):
     """[B,C,H,W] contiguous -> physical [B,H,W,C] (optionally casting)."""
     _need_cuda(x)

@@ -169,10 +169,24 @@ def test_nms_docstring_case_and_empty():
     assert native.nms(torch.zeros((0, 5), device=DEV), 0.5).numel() == 0
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5])
-@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (145, 36, 64)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('R,C', [(300, 1024), (129, 64), (37, 72), (4500, 1024)])
+def test_transpose_pad_is_exact(R, C, dtype):
+    """V -> V^T with the key axis zero-padded to a multiple of 128 (the apply pass multiplies the pad by P~ = 0)."""
+    x = _rand((R, C), dtype, 81)
+    ldt = (R + 127) // 128 * 128
+    out = native.transpose_pad(x.to(DEV), ldt).cpu()
+    assert out.shape == (C, ldt)
+    assert torch.equal(out[:, :R], x.t())
+    assert not out[:, R:].any()
+
+
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (145, 36, 64), (700, 264, 192), (513, 128, 1280)])
 def test_every_tile_shape_gives_the_same_gemm(M, N, K, tile):
-    """The tile menu (128x128, 128x64, 144x256, 144x128, 256x128) is a speed choice only."""
+    """The tile menu (128x128, 128x64, 144x256, 144x128, 256x128 and their 3 / 4-stage pipelined variants) is a
+    speed choice only.  K = 64 ... 1280 covers 1, 2, 3, 5 and 20 K-steps: shorter than, equal to and longer than
+    the LDS ring of the pipelined variants."""
     dtype = torch.bfloat16
     a, w = _rand((M, K), dtype, 61), _rand((N, K), dtype, 62, 0.1)
     bias, resid = _rand((N,), torch.float32, 63), _rand((M, N), dtype, 64)
@@ -183,7 +197,7 @@ def test_every_tile_shape_gives_the_same_gemm(M, N, K, tile):
     torch.testing.assert_close(out32.cpu(), a.float() @ w.float().t() + bias, rtol=2e-4, atol=2e-3)
 
 
-@pytest.mark.parametrize('tile', [1, 3, 4, 5])
+@pytest.mark.parametrize('tile', [1, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_every_tile_shape_gives_the_same_conv(tile):
     dtype = torch.bfloat16
     x = _rand((2, 128, 17, 21), dtype, 71)

@@ -14,6 +14,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hvrnet_amd import native  # noqa: E402
 
+if os.environ.get('HVR_BENCH_LIB'):  # A/B a privately built library (tuning experiments only)
+    native.LIB_PATH = os.path.abspath(os.environ['HVR_BENCH_LIB'])
+
 
 def timed(fn, iters, warmup=3):
     for _ in range(warmup):
@@ -33,27 +36,42 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--frames', type=int, default=15)
+    ap.add_argument('--only', default='all', help='gemm | relation | conv | all')
+    ap.add_argument('--tiles', default='0,1,2,3,4,5,6,7,8,9,10', help='tile hints to sweep (0 = cost model)')
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     dev = 'cuda:0'
     T = args.frames
+    tiles = [int(t) for t in args.tiles.split(',')]
+    want = lambda k: args.only in ('all', k)
 
     def rnd(*shape, scale=1.0):
         return (torch.randn(*shape, device=dev) * scale).to(dt)
 
-    print('# dtype=%s frames=%d' % (args.dtype, T))
+    print('# dtype=%s frames=%d   columns: tile hint -> ms (0 = cost model)' % (args.dtype, T))
+
+    def sweep(label, fn, flops):
+        cells = []
+        for tile in tiles:
+            ms = timed(lambda: fn(tile), args.iters)
+            cells.append('%d:%.3f' % (tile, ms))
+        best = min(float(c.split(':')[1]) for c in cells)
+        print('%-34s %s   best %.1f TF/s' % (label, ' '.join(cells), flops / best / 1e9), flush=True)
+
     # ---- plain GEMMs of the head ----
-    for name, M, N, K in [('fc_new_1', 4500, 1024, 12544), ('qk_proj', 4500, 2048, 1024), ('out_proj', 4500, 1024, 1024),
-                          ('fc_key', 300, 1024, 1024), ('square4k', 4096, 4096, 4096)]:
-        a, w = rnd(M, K), rnd(N, K, scale=0.05)
-        for tile in (0, 1, 3, 4, 5):
-            ms = timed(lambda: native.gemm(a, w, staging=1, tile=tile), args.iters)
-            print('gemm %-10s M=%d N=%d K=%d tile=%d  %.3f ms  %.1f TF/s' % (name, M, N, K, tile, ms, 2.0 * M * N * K / ms / 1e9))
-    # ---- relation core ----
-    for Mq, Mk in [(4500, 4500), (300, 4500)]:
-        q, k, v = rnd(Mq, 1024), rnd(Mk, 1024), rnd(Mk, 1024)
-        ms = timed(lambda: native.relation_fwd(q, k, v, 1 / 32, staging=1), args.iters)
-        print('relation Mq=%d Mk=%d  %.3f ms  %.1f TF/s' % (Mq, Mk, ms, 4.0 * Mq * Mk * 1024 / ms / 1e9))
+    if want('gemm'):
+        for name, M, N, K in [('fc_new_1', 4500, 1024, 12544), ('qk_proj', 4500, 2048, 1024), ('out_proj', 4500, 1024, 1024),
+                              ('fc_key', 300, 1024, 1024), ('square4k', 4096, 4096, 4096)]:
+            a, w = rnd(M, K), rnd(N, K, scale=0.05)
+            sweep('gemm %s %dx%dx%d' % (name, M, N, K), lambda t: native.gemm(a, w, staging=1, tile=t), 2.0 * M * N * K)
+    # ---- relation core (tiles come from HVR_TILE_SCORES / HVR_TILE_APPLY, read once per process) ----
+    if want('relation'):
+        for Mq, Mk in [(4500, 4500), (300, 4500)]:
+            q, k, v = rnd(Mq, 1024), rnd(Mk, 1024), rnd(Mk, 1024)
+            ms = timed(lambda: native.relation_fwd(q, k, v, 1 / 32, staging=1), args.iters)
+            print('relation Mq=%d Mk=%d  %.3f ms  %.1f TF/s' % (Mq, Mk, ms, 4.0 * Mq * Mk * 1024 / ms / 1e9), flush=True)
+    if not want('conv'):
+        return
     # ---- backbone conv classes (T frames) ----
     convs = [
         ('l1.conv2 3x3 64', 152, 252, 64, 64, 3, 1, 1, 1),
@@ -77,9 +95,7 @@ def main():
         OW = (W + 2 * p - d * (k - 1) - 1) // s + 1
         fl = 2.0 * T * OH * OW * Cout * k * k * Cin
         by = (x.numel() + T * OH * OW * Cout + w.numel()) * x.element_size()
-        for tile in (0, 1, 2, 3, 4, 5):
-            ms = timed(lambda: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=1, tile=tile), args.iters)
-            print('conv %-28s tile=%d  %.3f ms  %.1f TF/s  %.0f GB/s(min-traffic)' % (name, tile, ms, fl / ms / 1e9, by / ms / 1e6))
+        sweep('conv ' + name, lambda t: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=1, tile=t), fl)
     # ---- RoIAlign, all frames in one launch ----
     feat = rnd(T, 38, 63, 256)
     g = torch.Generator(device='cpu').manual_seed(0)

@@ -134,11 +134,15 @@ def main():
     metas = [S.synth_meta() for _ in range(T)]
     n_keys = []
 
-    def step():
+    def step(prev=None):
+        """Enqueues one window; collects the PREVIOUS window's results afterwards (its single host sync), so the host is
+        never waiting on the window it has just launched.  Every window's results are read inside the timed region."""
         with torch.no_grad():
             c4 = model(img=frames, img_meta=metas, backbone_feat=True)[0]       # backbone on all T frames
-            res = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
-        return res
+            pend = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, defer=True)
+        if prev is not None:
+            prev.result()
+        return pend
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -146,13 +150,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    pend = None
     for _ in range(args.warmup):
-        step()
+        pend = step(pend)
+    if pend is not None:
+        pend.result()
     sync()
     native.profile_begin(tags=('relation_full', 'relation_key'))
     t0 = time.perf_counter()
+    pend = None
     for _ in range(args.steps):
-        res = step()
+        pend = step(pend)
+    res = pend.result()
     sync()
     elapsed = time.perf_counter() - t0
     rel = native.profile_end()

@@ -83,18 +83,20 @@ class BBoxHead(nn.Module, PackedMixin):
         return native.det_decode(logits, 0, ncls, ncls, rois, self.target_means, self.target_stds, img_shape,
                                  float(scale_factor) if rescale else 0.0)
 
-    def _nms(self, boxes, scores, cfg):
+    def _nms(self, boxes, scores, cfg, defer=False):
         dets, labels, n = native.multiclass_nms(boxes, scores, cfg.score_thr, cfg.nms['iou_thr'], cfg.max_per_img)
+        if defer:  # (dets [max,5], labels [max], n [1]) stay on the device; the caller reads them later in one go
+            return (dets, labels, n), None
         k = int(n.item())  # the only host read of the read-out
         return dets[:k], labels[:k]
 
-    def get_det_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+    def get_det_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None, defer=False):
         scores, bboxes = self._decode(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale)
         if cfg is None:
             return bboxes, scores
         if cfg.nms.get('type', 'nms') != 'nms':
             raise NotImplementedError('only greedy nms is on the HVR hot path')
-        return self._nms(bboxes, scores, cfg)
+        return self._nms(bboxes, scores, cfg, defer)
 
 
 class _RelationHead(BBoxHead):
@@ -265,7 +267,7 @@ class HRNMPBBoxHead(_RelationHead):
         raise NotImplementedError('HRNMPBBoxHead training forward (mining + TripletNonLocalLoss, whose source is not in '
                                   'the reference tree) is not implemented; use forward_test')
 
-    def get_det_bboxes(self, rois, cls_scores, bbox_preds, img_shape, scale_factor, rescale=False, cfg=None):
+    def get_det_bboxes(self, rois, cls_scores, bbox_preds, img_shape, scale_factor, rescale=False, cfg=None, defer=False):
         """Per-branch read-out -> (list of det_bboxes, list of det_labels), hrnmp_bbox_head.py:1009-1052."""
         boxes_c, scores_c = [], []
         for cls_score, bbox_pred in zip(cls_scores, bbox_preds):
@@ -274,7 +276,7 @@ class HRNMPBBoxHead(_RelationHead):
                 boxes_c.append(bboxes)
                 scores_c.append(scores)
             else:
-                d, lab = self._nms(bboxes, scores, cfg)
+                d, lab = self._nms(bboxes, scores, cfg, defer)
                 boxes_c.append(d)
                 scores_c.append(lab)
         return boxes_c, scores_c

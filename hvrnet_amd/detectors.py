@@ -6,11 +6,16 @@
   HNMBRCNN                             mmdet/models/detectors/hnmb_rcnn.py:19-48, 195-222, 571-613
 
 What differs from the reference is HOW a window executes, not what it computes:
-  * RPN proposals for all T frames come from one device pipeline (one host read of T counts, where
-    the reference synchronises inside every per-frame NMS),
+  * RPN proposals for all T frames come from one device pipeline (where the reference synchronises
+    inside every per-frame NMS),
   * RoIAlign runs once over all frames (batch index = frame) instead of T launches on split maps
     (hnmb_rcnn.py:596-598),
-  * the read-out (softmax, decode, 30-class NMS) stays on the device; one host read of the count.
+  * the read-out (softmax, decode, 30-class NMS) stays on the device,
+  * a window has ONE host synchronisation, at its end (`PendingWindow.result`): the per-frame proposal
+    counts are not read mid-window -- the window runs on the assumption that every frame kept `nms_post`
+    proposals (the normal case) and is re-run through the exact ragged path if the counts, read together
+    with the detections, say otherwise.  `forward_feat(..., defer=True)` hands the PendingWindow to the
+    caller, which can enqueue the next window before collecting this one.
 The reference dump's defects are implemented as intended: SelsaRCNN takes
 `[:2]` of the head's 3-tuple (selsa_rcnn.py:306), `collections.Sequence` -> `collections.abc`.
 Inference only.
@@ -117,6 +122,42 @@ class TwoStageDetector(BaseDetector):
         return self.rpn_head.get_bboxes(*(rpn_outs + (img_meta, rpn_test_cfg)))
 
 
+class PendingWindow(object):
+    """A window whose kernels are enqueued but whose results have not been read.  `result()` is the window's single
+    host synchronisation: detections, labels, counts and the per-frame proposal counts arrive in one batch of
+    asynchronous copies into pinned memory behind one event."""
+
+    def __init__(self, branches, counts_dev, full_count, num_classes, exact, single=False):
+        # branches: list of (dets [max,5], labels [max], n [1]) device tensors; exact: () -> results, the ragged re-run;
+        # single: the detector has one read-out branch and returns its result bare (SelsaRCNN)
+        self._num_classes, self._exact, self._full, self._single = num_classes, exact, full_count, single
+        self._host = [[self._pinned(t) for t in b] for b in branches]
+        self._counts = self._pinned(counts_dev) if counts_dev is not None else None
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(branches[0][0].device))
+        self._result = None
+        self.respeculated = False  # True once result() had to take the exact path
+
+    @staticmethod
+    def _pinned(t):
+        return torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
+
+    def result(self):
+        if self._result is None:
+            self._event.synchronize()
+            if self._counts is not None and any(int(c) != self._full for c in self._counts.tolist()):
+                self.respeculated = True
+                self._result = self._exact()
+            else:
+                out = []
+                for dets, labels, n in self._host:
+                    k = int(n[0])
+                    out.append(bbox2result(dets[:k], labels[:k], self._num_classes))
+                self._result = out[0] if self._single else out
+            self._host = self._counts = self._exact = None
+        return self._result
+
+
 class _WindowDetector(TwoStageDetector):
     """forward_feat / simple_test_bboxes shared by SelsaRCNN and HNMBRCNN."""
 
@@ -142,8 +183,10 @@ class _WindowDetector(TwoStageDetector):
             return torch.cat([t.permute(0, 2, 3, 1) for t in x], dim=0).permute(0, 3, 1, 2)
         return torch.cat(tuple(x), dim=0)
 
-    def window_tensors(self, x, img_meta, proposals=None, rescale=False):
-        """Runs one window up to the head outputs; returns a dict of device tensors (used by forward_feat and tests)."""
+    def window_tensors(self, x, img_meta, proposals=None, rescale=False, speculate=False):
+        """Runs one window up to the head outputs; returns a dict of device tensors (used by forward_feat and tests).
+        speculate: do not read the proposal counts; build the RoIs as if every frame kept all `nms_post` proposals and
+        return the counts tensor as `counts_dev` for the caller to check."""
         xc = self._cat_frames(x)
         assert xc.shape[0] == len(img_meta)
         if proposals is None:
@@ -162,8 +205,9 @@ class _WindowDetector(TwoStageDetector):
             main.wait_event(done)
             props.record_stream(main)
             counts.record_stream(main)
-            counts_h = counts.tolist()  # host read #1: T integers
             T, mx = props.shape[0], props.shape[1]
+            counts_dev = counts if speculate else None
+            counts_h = [mx] * T if speculate else counts.tolist()  # exact path: a mid-window host read of T integers
             frame = torch.arange(T, device=props.device, dtype=props.dtype).view(T, 1, 1).expand(T, mx, 1)
             rois = torch.cat([frame, props[..., :4]], dim=-1)
             if all(c == mx for c in counts_h):
@@ -174,6 +218,7 @@ class _WindowDetector(TwoStageDetector):
         else:
             feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
             proposal_list = list(proposals)
+            counts_dev = None
             counts_h = [p.shape[0] for p in proposal_list]
             rois = bbox2roi([p for p in proposal_list])  # batch index = frame index
         key = self.key_dim
@@ -182,7 +227,8 @@ class _WindowDetector(TwoStageDetector):
         roi_feats = self.get_roi_feat(feats, rois.contiguous())
         key_rois = rois[start:start + cur_range['length']].clone()
         key_rois[:, 0] = 0  # the reference's rois carry batch index 0 (hnmb_rcnn.py:582-584)
-        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range, key_rois=key_rois)
+        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range, key_rois=key_rois,
+                    counts_dev=counts_dev, full_count=int(counts_h[0]) if counts_dev is not None else None)
 
     def simple_test_bboxes(self, x, img_meta, proposals, rcnn_test_cfg, rescale=False):
         raise NotImplementedError
@@ -206,13 +252,16 @@ class SelsaRCNN(_WindowDetector):
             self.bbox_head.t_dim = int(test_cfg.bbox_head.t_dim)
             self.bbox_head.sampler_num = int(test_cfg.bbox_head.sampler_num)
 
-    def forward_feat(self, x=None, img_meta=None, proposals=None, rescale=False):
-        w = self.window_tensors(x, img_meta, proposals, rescale)
+    def forward_feat(self, x=None, img_meta=None, proposals=None, rescale=False, defer=False, speculate=True):
+        """One window -> 30 per-class [k,5] arrays (selsa_rcnn.py:281-338); defer=True -> PendingWindow."""
+        w = self.window_tensors(x, img_meta, proposals, rescale, speculate=speculate and proposals is None)
         cls_score, bbox_pred = self.bbox_head(w['roi_feats'], w['cur_range'], key_dim=self.key_dim, all_res=False)[:2]
-        det_bboxes, det_labels = self.bbox_head.get_det_bboxes(w['key_rois'], cls_score, bbox_pred, img_meta[0]['img_shape'],
-                                                               img_meta[0]['scale_factor'], rescale=rescale,
-                                                               cfg=self.test_cfg.rcnn)
-        return bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+        branch, _ = self.bbox_head.get_det_bboxes(w['key_rois'], cls_score, bbox_pred, img_meta[0]['img_shape'],
+                                                  img_meta[0]['scale_factor'], rescale=rescale, cfg=self.test_cfg.rcnn,
+                                                  defer=True)
+        pending = PendingWindow([branch], w['counts_dev'], w['full_count'], self.bbox_head.num_classes,
+                                lambda: self.forward_feat(x, img_meta, proposals, rescale, speculate=False), single=True)
+        return pending if defer else pending.result()
 
 
 @DETECTORS.register_module
@@ -230,11 +279,14 @@ class HNMBRCNN(_WindowDetector):
             self.bbox_head.t_dim = int(test_cfg.bbox_head.t_dim)
             self.bbox_head.sampler_num = int(test_cfg.bbox_head.sampler_num)
 
-    def forward_feat(self, x=None, img_meta=None, proposals=None, rescale=False):
-        """-> [branch results, final results], each a list of 30 per-class [k,5] arrays (hnmb_rcnn.py:214-218)."""
-        w = self.window_tensors(x, img_meta, proposals, rescale)
+    def forward_feat(self, x=None, img_meta=None, proposals=None, rescale=False, defer=False, speculate=True):
+        """-> [branch results, final results], each a list of 30 per-class [k,5] arrays (hnmb_rcnn.py:214-218);
+        defer=True -> PendingWindow whose result() is that list."""
+        w = self.window_tensors(x, img_meta, proposals, rescale, speculate=speculate and proposals is None)
         cls_score, bbox_pred = self.bbox_head.forward_test(w['roi_feats'], [w['cur_range']], key_dim=self.key_dim, all_res=False)
-        det_bboxes_c, det_labels_c = self.bbox_head.get_det_bboxes(w['key_rois'], cls_score, bbox_pred,
-                                                                   img_meta[0]['img_shape'], img_meta[0]['scale_factor'],
-                                                                   rescale=rescale, cfg=self.test_cfg.rcnn)
-        return [bbox2result(b, l, self.bbox_head.num_classes) for b, l in zip(det_bboxes_c, det_labels_c)]
+        branches, _ = self.bbox_head.get_det_bboxes(w['key_rois'], cls_score, bbox_pred, img_meta[0]['img_shape'],
+                                                    img_meta[0]['scale_factor'], rescale=rescale, cfg=self.test_cfg.rcnn,
+                                                    defer=True)
+        pending = PendingWindow(branches, w['counts_dev'], w['full_count'], self.bbox_head.num_classes,
+                                lambda: self.forward_feat(x, img_meta, proposals, rescale, speculate=False))
+        return pending if defer else pending.result()

@@ -330,6 +330,35 @@ def test_config1_end_to_end_bf16_tracks_reference():
     assert tot > 0 and hit >= 0.95 * tot, (hit, tot)
 
 
+def _same_results(a, b):
+    return len(a) == len(b) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize('head', ['hvr', 'selsa'])
+def test_deferred_window_equals_the_exact_path_and_respeculates_on_ragged_counts(head):
+    """forward_feat runs a window without reading the proposal counts mid-way (one host sync, at the end) on the
+    assumption that every frame kept nms_post proposals; when a frame kept fewer, result() must notice and return what
+    the exact ragged path returns."""
+    T = 3
+    imgs = [S.synth_frame(i).to(DEV) for i in range(T)]
+    metas = [S.synth_meta() for _ in range(T)]
+    make = hvr_config if head == 'hvr' else selsa_config
+    for nms_post, nms_thr, ragged in ((32, 0.7, False), (400, 0.02, True)):  # a harsh RPN NMS leaves < 400 boxes
+        cfg = make(frame_interval=1, nms_post=nms_post)
+        cfg.test_cfg.rpn.nms_thr = nms_thr
+        model = hvrnet_amd.build_model(cfg, S.synth_state_dict(head), torch.float32, DEV)
+        c4 = [model(img=im, img_meta=[m], backbone_feat=True)[0] for im, m in zip(imgs, metas)]
+        exact = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, speculate=False)
+        pend = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, defer=True)
+        got = pend.result()
+        assert pend.respeculated == ragged
+        if head == 'hvr':
+            assert len(got) == 2 and all(_same_results(g_, e_) for g_, e_ in zip(got, exact))
+        else:
+            assert _same_results(got, exact)
+        assert pend.result() is got  # idempotent
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_T15_N300():
     """BASELINE sizes (M = 4500, D = 1024): size-independent properties of the relation kernel."""

@@ -220,21 +220,24 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   constexpr int GN = EPI == EPI_APPLY ? FM : 1;
   f32x4 pacc[GN][EPI == EPI_APPLY ? FN : 1];
   float gcur[GN], gnext[GN];
-  float mstar[GN], invl[GN];  // per-row softmax reference (log2 units) and 1 / normaliser
+  float gref[GN];  // per row: m* + log2(L), so that the block weight is g = 2^(m_t - gref)
   constexpr int STEPS_PER_BLOCK = 128 / BKE;  // K-steps per 128-key statistics block
   const int nk = p.K / BKE;
   const int nblk = nk / STEPS_PER_BLOCK;
-  int grow[GN];
+  // statistics row of fragment row i of this lane (rows past M read row M - 1: their outputs are never stored)
+  auto stat_row = [&](int i) {
+    const int m = m0 + (wm * FM + i) * 16 + (lane & 15);
+    return (m < p.M ? m : p.M - 1) * p.ntile;
+  };
   if constexpr (EPI == EPI_APPLY) {
     // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*):
     // the four lanes that share a row split the key tiles, then merge their (max, sum) pairs.
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      int m = m0 + (wm * FM + i) * 16 + (lane & 15);
-      grow[i] = (m < p.M ? m : p.M - 1) * p.ntile;
+      const int row = stat_row(i);
       float mx = -INFINITY, l = 0.f;
       for (int t = lane >> 4; t < p.ntile; t += 4) {
-        const float mt = p.mstat[grow[i] + t], lt = p.lstat[grow[i] + t];
+        const float mt = p.mstat[row + t], lt = p.lstat[row + t];
         const float mn = fmaxf(mx, mt);
         l = l * exp2f(mx - mn) + lt * exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
         mx = mn;
@@ -246,9 +249,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         l = (mx == mn ? l : l * exp2f(mx - mn)) + (mo == mn ? lo : lo * exp2f(mo - mn));
         mx = mn;
       }
-      mstar[i] = mx;
-      invl[i] = 1.f / l;
-      gcur[i] = exp2f(p.mstat[grow[i]] - mx) * invl[i];
+      gref[i] = mx + log2f(l);
+      gcur[i] = exp2f(p.mstat[row] - gref[i]);
       landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
       gnext[i] = 0.f;
     }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         if (first) {
           if (kt + STEPS_PER_BLOCK < nk) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + grow[i] + kt / STEPS_PER_BLOCK + 1);
+            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + kt / STEPS_PER_BLOCK + 1);
           }
           __builtin_amdgcn_sched_barrier(0);  // the g loads stay ahead of this step's DMA in the vmcnt queue
         }
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
             landed(gnext[i]);
-            gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - mstar[i]) * invl[i];
+            gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - gref[i]);
           }
         }
       }
@@ -433,24 +435,26 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     static_for<NR>([&](auto R) { read_frag(R, std::integral_constant<int, 0>{}, 0u); });
 
     int cs = 0;  // ring slot of the K-step being computed
-    // LOAD: this step issues the DMA of K-step kt + NS - 1.  NEXT: a K-step kt + 1 exists (its first fragments are
-    // requested in half 1).  FIRST / LAST: position inside a 128-key block (EPI_APPLY).
+    // LOAD: this step issues the DMA of K-step kt + NS - 1: 1 / 0 at compile time (the steady-state loop must not
+    // branch between its MFMAs), 2 = decided at run time from kt (loop tails).  NEXT: a K-step kt + 1 exists (its
+    // first fragments are requested in half 1).  FIRST / LAST: position inside a 128-key block (EPI_APPLY).
     auto pipe_step = [&](int kt, auto LOAD, auto NEXT, auto FIRST, auto LAST) {
-      constexpr bool load = decltype(LOAD)::value, next = decltype(NEXT)::value;
-      constexpr bool first = decltype(FIRST)::value, last = decltype(LAST)::value;
+      constexpr int lmode = decltype(LOAD)::value;
+      constexpr bool next = decltype(NEXT)::value, first = decltype(FIRST)::value, last = decltype(LAST)::value;
+      const bool load = lmode == 2 ? kt + NS - 1 < nk : lmode == 1;
       const uint32_t soff = (uint32_t)cs * STAGE_BYTES;
       const int ns = cs + 1 == NS ? 0 : cs + 1;
       char* lstage = smem + (cs == 0 ? NS - 1 : cs - 1) * STAGE_BYTES;  // freed by the previous step's barrier
       if constexpr (EPI == EPI_APPLY && first) {
         if (kt + STEPS_PER_BLOCK < nk) {
 #pragma unroll
-          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + grow[i] + kt / STEPS_PER_BLOCK + 1);
+          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + kt / STEPS_PER_BLOCK + 1);
         }
       }
-      if constexpr (load) tap_of(kt + NS - 1);
+      if (load) tap_of(kt + NS - 1);
       static_for<2>([&](auto KK) {
         constexpr int kk = decltype(KK)::value;
-        constexpr int ND = load ? (kk == 0 ? A_SLOTS : B_SLOTS) : 0;
+        constexpr int ND = kk == 0 ? A_SLOTS : B_SLOTS;
         constexpr bool reads = kk == 0 || next;  // half 1 requests the next step's first fragments
         constexpr int NF = (reads ? NR : 0) + ND;
         constexpr int PER = (NF + NM - 1) / NM;  // fillers after each MFMA
@@ -460,12 +464,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           // loads that may stay in flight: the K-steps after kt + 1 (full groups), plus the A half of the group
           // this step is issuing; an apply block's g loads sit exactly that far back, hence one fewer there
           constexpr int G = (EPI == EPI_APPLY && NS == 4) ? 1 : 0;
-          if constexpr (load) {
-            wait_vmcnt<(NS - 3) * MINL + MIN_A - G>();
-          } else {
-            if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G>();
-            else wait_vmcnt<0>();
-          }
+          if (load) wait_vmcnt<(NS - 3) * MINL + MIN_A - G>();
+          else if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G>();
+          else wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
               if constexpr (fr < NR) {
                 if constexpr (kk == 0) read_frag(std::integral_constant<int, fr>{}, std::integral_constant<int, 1>{}, soff);
                 else read_frag(std::integral_constant<int, fr>{}, std::integral_constant<int, 0>{}, (uint32_t)ns * STAGE_BYTES);
-              } else {
+              } else if (load) {
                 if constexpr (kk == 0) dma_a(std::integral_constant<int, fr - NR>{}, lstage);
                 else dma_b(std::integral_constant<int, fr - NR>{}, kt + NS - 1, lstage);
               }
@@ -502,43 +503,40 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
           landed(gnext[i]);
-          gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - mstar[i]) * invl[i];
+          gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - gref[i]);
         }
       }
       cs = ns;
     };
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
-    if constexpr (EPI == EPI_APPLY) {
-      // nk is even (128-key blocks); a block's two steps share their LOAD / NEXT flags except at the very end
+    constexpr std::integral_constant<int, 1> L1{};
+    constexpr std::integral_constant<int, 0> L0{};
+    constexpr std::integral_constant<int, 2> LR{};
+    if constexpr (EPI == EPI_APPLY) {  // nk is even: 128-key blocks of two K-steps
       int kt = 0;
-      for (; kt + NS < nk; kt += 2) {  // both steps load (kt + 1 + NS - 1 < nk)
-        pipe_step(kt, Y, Y, Y, N);
-        pipe_step(kt + 1, Y, Y, N, Y);
+      for (; kt + NS < nk; kt += 2) {  // both steps of the block load
+        pipe_step(kt, L1, Y, Y, N);
+        pipe_step(kt + 1, L1, Y, N, Y);
       }
-      for (; kt < nk; kt += 2) {
-        if (kt + NS - 1 < nk) pipe_step(kt, Y, Y, Y, N);
-        else pipe_step(kt, N, Y, Y, N);
-        if (kt + 2 < nk) {
-          if (kt + NS < nk) pipe_step(kt + 1, Y, Y, N, Y);
-          else pipe_step(kt + 1, N, Y, N, Y);
-        } else {
-          pipe_step(kt + 1, N, N, N, Y);
-        }
+      for (; kt < nk; kt += 2) {  // the last NS / 2 blocks: the second step never loads
+        pipe_step(kt, LR, Y, Y, N);
+        if (kt + 2 < nk) pipe_step(kt + 1, L0, Y, N, Y);
+        else pipe_step(kt + 1, L0, N, N, Y);
       }
     } else {
       int kt = 0;
-      for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, Y, Y, N, N);
-      for (; kt + 1 < nk; ++kt) pipe_step(kt, N, Y, N, N);
-      if (kt < nk) pipe_step(kt, N, N, N, N);
+      for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, L1, Y, N, N);
+      for (; kt + 1 < nk; ++kt) pipe_step(kt, L0, Y, N, N);
+      if (kt < nk) pipe_step(kt, L0, N, N, N);
     }
   }
 
   // ---------------- residual fetch (RESPRE): all of the tile's residual loads are issued here, at the top of the
   // epilogue (no LDS DMA is in flight any more, so the barriers below do not drain them): one overlapped round
   // trip instead of one per store-phase iteration ----------------
-  constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH) / NT;
-  static_assert(!RESPRE || ((E_ROWS * E_CH) % NT == 0 && sizeof(T) == 2), "RESPRE needs an even store-phase split");
+  constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH + NT - 1) / NT;
+  static_assert(!RESPRE || sizeof(T) == 2, "RESPRE is the bf16 residual path");
   uint4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
   if constexpr (RESPRE) {
 #pragma unroll
@@ -548,7 +546,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         const int c = it * NT + tid, r = c / E_CH, cc = c - r * E_CH;
         const int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
         rres[pass][it] = make_uint4(0u, 0u, 0u, 0u);
-        if (m < p.M && n < p.N) rres[pass][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
+        if (c < E_ROWS * E_CH && m < p.M && n < p.N) rres[pass][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
       }
   }
 
@@ -772,15 +770,19 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
 // Deep-pipeline variants (NS LDS stages, NS - 1 K-steps of DMA in flight):
 //   5: 256x128 NS=3  1 / CU    6: 144x256 NS=3  1 / CU    7: 144x128 NS=4  1 / CU
 //   8: 128x128 NS=4  1 / CU    9: 128x64  NS=3  2 / CU
+//  10: 144x256 NS=3, 8 waves as 1 x 8 (two waves on every SIMD; the 6-wave shapes leave two SIMDs with one)
+//  11: 144x128 NS=4, 8 waves as 1 x 8
 const TileShape kTileShapes[kNumTileShapes] = {
     {128, 128, 2, 1.25f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.90f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f},
-    {256, 128, 1, 1.00f}, {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}, {128, 128, 1, 1.00f}, {128, 64, 2, 1.00f}};
+    {256, 128, 1, 1.00f}, {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}, {128, 128, 1, 1.00f}, {128, 64, 2, 1.00f},
+    {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}};
 
 int choose_tile(const GemmParams& p, int epi) {
   if (p.tile_hint > 0 && p.tile_hint <= kNumTileShapes) {
     const int t = p.tile_hint - 1;
     if (epi == EPI_SCORES && kTileShapes[t].bn != 128) return 0;
-    if (epi == EPI_APPLY && (t == 2 || t == 6)) return 3;
+    if (epi == EPI_APPLY && (t == 2 || t == 6 || t == 10)) return 3;
+    if (epi == EPI_APPLY && t == 5) return 4;  // 256x128 with two accumulator sets has no room for the pipeline's registers
     if (epi != EPI_LINEAR && t == 9) return 0;
     return t;
   }
@@ -794,13 +796,14 @@ int choose_tile(const GemmParams& p, int epi) {
   const int ksteps = p.K / (p.dtype == DT_BF16 ? 64 : 32);
   int best = 0;
   double best_cost = 1e300;
-  // candidates: the base shapes plus the two pipelined variants that win on this path's long-K problems
+  // candidates: the base shapes plus the pipelined variants that win on this path's problems
   // (5 / 8 / 9 stay reachable through tile_hint for tuning)
-  static const int kCandidates[] = {0, 1, 2, 3, 4, 6, 7};
+  static const int kCandidates[] = {0, 1, 2, 3, 4, 6, 7, 10, 11};
   for (int t : kCandidates) {
     const TileShape& s = kTileShapes[t];
     if (epi == EPI_SCORES && (s.bn != 128 || t >= kNumBaseShapes)) continue;
-    if (epi == EPI_APPLY && (t == 2 || t == 6)) continue;  // two accumulator sets do not fit 144x256
+    if (epi == EPI_APPLY && (t == 2 || t == 6 || t >= 10)) continue;  // two accumulator sets do not fit 144x256;
+                                                                       // 1 x 8 waves re-read the whole P~ tile per wave
     if (p.N <= 64 && s.bn > 64 && t != 0) continue;
     const long tiles = (long)((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
     const long slots = 256L * s.wg_per_cu;
@@ -813,6 +816,9 @@ int choose_tile(const GemmParams& p, int epi) {
     if (t == 2) eff = ksteps >= 64 ? 1.33 : s.eff;
     if (t == 6) eff = ksteps >= 24 ? 1.40 : 0.85;
     if (t == 7) eff = ksteps >= 64 ? 1.15 : (epi == EPI_APPLY && ksteps >= 8 ? 1.05 : 0.70);
+    // the 8-wave 1 x 8 layouts keep two waves on every SIMD: ahead of the 6-wave shapes on every K length measured
+    if (t == 10) eff = 1.50;
+    if (t == 11) eff = 1.20;
     const double cost = rounds * s.bm * s.bn * s.wg_per_cu / eff;
     if (cost < best_cost * 0.999) { best_cost = cost; best = t; }
   }
@@ -827,11 +833,13 @@ static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t strea
       case 2: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS>(p, stream); break;
       case 3: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS>(p, stream);
       case 4: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS>(p, stream);
-      case 5: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS, 3>(p, stream);
+      case 5: if constexpr (EPI != EPI_APPLY) return launch_tile<T, 4, 2, 4, 4, EPI, GLDS, 3>(p, stream); break;
       case 6: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
       case 7: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream);
       case 8: return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream);
       case 9: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS, 3>(p, stream); break;
+      case 10: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 1, 8, 9, 2, EPI, GLDS, 3>(p, stream); break;
+      case 11: return launch_tile<T, 1, 8, 9, 1, EPI, GLDS, 4>(p, stream);
       default: break;
     }
     return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);

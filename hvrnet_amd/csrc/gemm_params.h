@@ -43,7 +43,7 @@ struct GemmParams {
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };
-constexpr int kNumTileShapes = 10;
+constexpr int kNumTileShapes = 12;
 constexpr int kNumBaseShapes = 5;  // shapes 5.. are deep-pipeline (3 / 4 LDS stage) variants of the base shapes
 extern const TileShape kTileShapes[kNumTileShapes];
 int choose_tile(const GemmParams& p, int epi);

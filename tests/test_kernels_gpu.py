@@ -181,7 +181,7 @@ def test_transpose_pad_is_exact(R, C, dtype):
     assert not out[:, R:].any()
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (145, 36, 64), (700, 264, 192), (513, 128, 1280)])
 def test_every_tile_shape_gives_the_same_gemm(M, N, K, tile):
     """The tile menu (128x128, 128x64, 144x256, 144x128, 256x128 and their 3 / 4-stage pipelined variants) is a
@@ -197,7 +197,7 @@ def test_every_tile_shape_gives_the_same_gemm(M, N, K, tile):
     torch.testing.assert_close(out32.cpu(), a.float() @ w.float().t() + bias, rtol=2e-4, atol=2e-3)
 
 
-@pytest.mark.parametrize('tile', [1, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('tile', [1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_every_tile_shape_gives_the_same_conv(tile):
     dtype = torch.bfloat16
     x = _rand((2, 128, 17, 21), dtype, 71)

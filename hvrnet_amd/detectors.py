@@ -21,6 +21,7 @@ The reference dump's defects are implemented as intended (SURVEY.md 8c/appendix 
 Inference only.
 """
 import collections.abc
+import os
 
 import numpy as np
 import torch
@@ -113,8 +114,45 @@ class TwoStageDetector(BaseDetector):
             self.bbox_roi_extractor.init_weights()
             self.bbox_head.init_weights()
 
+    # Frames are independent through the backbone.  With `frame_groups` = G > 1 a batch of frames is cut into G
+    # contiguous groups that run on G HIP streams: a bottleneck alternates compute-bound (3x3) and HBM-bound
+    # (1x1 + residual) convolutions, and two groups that are out of step overlap one kind with the other -- the
+    # memory-bound kernel of one group then has the whole chip's bandwidth while the other group computes.
+    frame_groups = int(os.environ.get('HVR_FRAME_GROUPS', '2'))
+
+    def _group_streams(self, device, n):
+        pool = self.__dict__.setdefault('_gstreams', {})
+        key = str(device)
+        while len(pool.setdefault(key, [])) < n:
+            pool[key].append(torch.cuda.Stream(device=device))
+        return pool[key][:n]
+
+    def _run_in_frame_groups(self, fn, x):
+        """fn(frames [b,...]) -> tuple of logical [b,C,H,W] maps (physically NHWC); groups run on separate streams and
+        the per-group results are concatenated along the frame axis."""
+        G = min(self.frame_groups, x.shape[0])
+        if G <= 1 or not x.is_cuda:
+            return fn(x)
+        main = torch.cuda.current_stream(x.device)
+        sides = self._group_streams(x.device, G - 1)
+        bounds = [round(i * x.shape[0] / G) for i in range(G + 1)]
+        start = torch.cuda.Event()
+        start.record(main)
+        outs = [None] * G
+        for g in range(1, G):
+            with torch.cuda.stream(sides[g - 1]):
+                sides[g - 1].wait_event(start)
+                outs[g] = fn(x[bounds[g]:bounds[g + 1]])
+        outs[0] = fn(x[bounds[0]:bounds[1]])
+        for g in range(1, G):
+            main.wait_stream(sides[g - 1])
+            for t in outs[g]:
+                t.record_stream(main)
+        # concatenate in the physical (NHWC) layout, frames outermost
+        return tuple(torch.cat([o[k].permute(0, 2, 3, 1) for o in outs], 0).permute(0, 3, 1, 2) for k in range(len(outs[0])))
+
     def extract_feat(self, img):
-        return self.backbone(img)
+        return self._run_in_frame_groups(self.backbone, img)
 
     def simple_test_rpn(self, x, img_meta, rpn_test_cfg):
         """test_mixins.py:9-13."""

@@ -330,6 +330,22 @@ def test_config1_end_to_end_bf16_tracks_reference():
     assert tot > 0 and hit >= 0.95 * tot, (hit, tot)
 
 
+def test_frame_groups_on_separate_streams_change_nothing():
+    """The backbone may cut a batch of frames into groups that run on separate HIP streams: same C4 maps."""
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=1, nms_post=32), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    frames = torch.cat([S.synth_frame(i) for i in range(5)], 0).to(DEV)
+    metas = [S.synth_meta() for _ in range(5)]
+    outs = []
+    for groups in (1, 2, 3):
+        model.frame_groups = groups
+        outs.append(model(img=frames, img_meta=metas, backbone_feat=True)[0].float())
+        torch.cuda.synchronize()
+    assert outs[0].shape[0] == 5
+    for o in outs[1:]:
+        assert o.shape == outs[0].shape and o.permute(0, 2, 3, 1).is_contiguous()
+        torch.testing.assert_close(o, outs[0], rtol=0, atol=0)
+
+
 def _same_results(a, b):
     return len(a) == len(b) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
 

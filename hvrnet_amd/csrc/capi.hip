@@ -70,6 +70,10 @@ static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int
   if (K % bke) return fail(HVR_EINVAL, "K=%d is not a multiple of the %d-element K-step", K, bke);
   if (N % 4) return fail(HVR_EINVAL, "N=%d is not a multiple of 4", N);
   if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return fail(HVR_EINVAL, "operands must be 16-byte aligned");
+  // the tile loaders keep 32-bit byte offsets into A and B
+  const long es = elem_size(dtype);
+  if ((long)M * lda * es >= (1L << 31) || (long)N * ldb * es >= (1L << 31))
+    return fail(HVR_EUNSUPPORTED, "operand of 2 GiB or more (M=%d lda=%ld N=%d ldb=%ld)", M, lda, N, ldb);
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -101,6 +105,8 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   GemmParams p;
   const long M = (long)d->B * OH * OW;
   if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
+  if ((long)d->B * d->H * d->W * d->Cin * (long)elem_size(d->dtype) >= (1L << 31))
+    return fail(HVR_EUNSUPPORTED, "conv input of 2 GiB or more");
   const int K = d->KH * d->KW * d->Cin;
   int rc = fill_linear(p, d->x, d->w, d->y, (int)M, d->Cout, K, d->Cin, K, d->Cout, d->dtype, d->staging);
   if (rc) return rc;

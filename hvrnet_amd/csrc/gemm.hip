@@ -42,6 +42,12 @@ __device__ __forceinline__ float load_f32_untracked(const float* p) {
   return v;
 }
 __device__ __forceinline__ void landed(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ uint4 load_u128_untracked(const void* p) {
+  uint4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void landed(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // loads one K-step costs the wave that issues the fewest (the last one: slots are dealt to waves in order)
@@ -120,9 +126,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   const int m0 = pid_m * BM, n0 = pid_n * BN;
 
   // ---------------- loader setup: one 16-byte chunk per (thread, slot) ----------------
-  const char* a_ptr[A_SLOTS];
-  int a_iy[A_SLOTS], a_ix[A_SLOTS];
-  const char* b_ptr[B_SLOTS];
+  // 32-bit byte offsets from p.A / p.B (the C ABI rejects operands of 2 GiB and more) and the conv origin of the
+  // row packed as (iy << 16) | (ix & 0xffff): half the registers of pointers + two ints, which the pipelined
+  // shapes need for their fragments
+  int a_off[A_SLOTS], a_yx[A_SLOTS];
+  int b_off[B_SLOTS];
 #pragma unroll
   for (int i = 0; i < A_SLOTS; ++i) {
     const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
@@ -130,13 +138,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     m = m < p.M ? m : p.M - 1;
     if (kConvOk && p.conv) {
       const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
-      a_iy[i] = oy * p.stride - p.pad;
-      a_ix[i] = ox * p.stride - p.pad;
-      a_ptr[i] = (const char*)p.A +
-                 ((((long)b * p.H + a_iy[i]) * p.W + a_ix[i]) * (long)p.Cin + c * EPC) * (long)sizeof(T);
+      const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
+      a_yx[i] = (iy << 16) | (ix & 0xffff);
+      a_off[i] = (int)(((((long)b * p.H + iy) * p.W + ix) * (long)p.Cin + c * EPC) * (long)sizeof(T));
     } else {
-      a_iy[i] = a_ix[i] = 0;
-      a_ptr[i] = (const char*)p.A + ((long)m * p.lda + c * EPC) * (long)sizeof(T);
+      a_yx[i] = 0;
+      a_off[i] = (int)(((long)m * p.lda + c * EPC) * (long)sizeof(T));
     }
   }
 #pragma unroll
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
     int n = n0 + row;
     n = n < p.N ? n : p.N - 1;
-    b_ptr[i] = (const char*)p.B + ((long)n * p.ldb + c * EPC) * (long)sizeof(T);
+    b_off[i] = (int)(((long)n * p.ldb + c * EPC) * (long)sizeof(T));
   }
 
   uint4 a_reg[A_SLOTS], b_reg[B_SLOTS];  // register staging (unused when GLDS)
@@ -164,9 +171,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        const char* src = a_ptr[i] + a_koff;
+        const char* src = (const char*)p.A + ((long)a_off[i] + a_koff);
         if (kConvOk && p.conv) {
-          const bool ok = (unsigned)(a_iy[i] + dy) < (unsigned)p.H && (unsigned)(a_ix[i] + dx) < (unsigned)p.W;
+          const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
           src = ok ? src : (const char*)p.zero;
         }
         if constexpr (GLDS) {
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = b_ptr[i] + (long)kt * 128;
+        const char* src = (const char*)p.B + ((long)b_off[i] + (long)kt * 128);
         if constexpr (GLDS) {
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
@@ -260,6 +267,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // per-lane part of the fragment read addresses (kk = 1 is the same address with bit 6 flipped)
   const uint32_t a_lane = lds_addr(smem) + (wm * FM * 16 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
   const uint32_t b_lane = lds_addr(smem) + BM * 128 + (wn * FN * 16 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+
+  // Residual tile (RESPRE): one 16-byte piece per (thread, store-phase slot).  The pipelined loop fetches it right
+  // after its prologue DMA with loads the compiler does not track, so that it travels under the whole K loop; the
+  // hand-counted waits of the first NS - 2 K-steps let those loads stay in flight (they are younger than the prologue's
+  // DMA groups), every later wait covers them.  Addresses are clamped, not predicated: every wave must issue the
+  // same number of loads for the counts to hold.
+  constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH + NT - 1) / NT;
+  static_assert(!RESPRE || sizeof(T) == 2, "RESPRE is the bf16 residual path");
+  constexpr bool RES_EARLY = RESPRE && NS > 2 && !(WM == 3 && FN == 8);  // (the 6-wave 144x256 has no registers left)
+  constexpr int RES_LOADS = RES_EARLY ? WM * E_ITERS : 0;
+  uint4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
 
   // ---------------- main loop ----------------
   if constexpr (NS == 2) {
@@ -400,9 +418,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_a = [&](auto I, char* stage) {
       constexpr int i = decltype(I)::value;
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        const char* src = a_ptr[i] + a_koff;
+        const char* src = (const char*)p.A + ((long)a_off[i] + a_koff);
         if (kConvOk && p.conv) {
-          const bool ok = (unsigned)(a_iy[i] + dy) < (unsigned)p.H && (unsigned)(a_ix[i] + dx) < (unsigned)p.W;
+          const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
           src = ok ? src : (const char*)p.zero;
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_b = [&](auto I, int kt, char* stage) {
       constexpr int i = decltype(I)::value;
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = b_ptr[i] + (long)kt * 128;
+        const char* src = (const char*)p.B + ((long)b_off[i] + (long)kt * 128);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0,
                                          0);
@@ -429,8 +447,22 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) issue_loads(s, smem + s * STAGE_BYTES);
-    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * MINL>();
-    else wait_vmcnt<0>();
+    if constexpr (RES_EARLY) {
+#pragma unroll
+      for (int pass = 0; pass < WM; ++pass)
+#pragma unroll
+        for (int it = 0; it < E_ITERS; ++it) {
+          int c = it * NT + tid;
+          c = c < E_ROWS * E_CH ? c : E_ROWS * E_CH - 1;
+          const int r = c / E_CH, cc = c - r * E_CH;
+          int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
+          m = m < p.M ? m : p.M - 1;
+          n = n < p.N ? n : p.N - 8;
+          rres[pass][it] = load_u128_untracked(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
+        }
+    }
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * MINL + RES_LOADS>();
+    else wait_vmcnt<RES_LOADS>();
     __builtin_amdgcn_s_barrier();
     static_for<NR>([&](auto R) { read_frag(R, std::integral_constant<int, 0>{}, 0u); });
 
@@ -464,9 +496,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           // loads that may stay in flight: the K-steps after kt + 1 (full groups), plus the A half of the group
           // this step is issuing; an apply block's g loads sit exactly that far back, hence one fewer there
           constexpr int G = (EPI == EPI_APPLY && NS == 4) ? 1 : 0;
-          if (load) wait_vmcnt<(NS - 3) * MINL + MIN_A - G>();
-          else if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G>();
-          else wait_vmcnt<0>();
+          // (the residual prefetch is younger than the DMA groups of K-steps 1 .. NS - 2: it may stay in flight
+          // while those are awaited)
+          if (RES_EARLY && kt <= NS - 3) {
+            if (load) wait_vmcnt<(NS - 3) * MINL + MIN_A - G + RES_LOADS>();
+            else if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G + RES_LOADS>();
+            else wait_vmcnt<RES_LOADS>();
+          } else {
+            if (load) wait_vmcnt<(NS - 3) * MINL + MIN_A - G>();
+            else if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G>();
+            else wait_vmcnt<0>();
+          }
           __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -535,10 +575,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // ---------------- residual fetch (RESPRE): all of the tile's residual loads are issued here, at the top of the
   // epilogue (no LDS DMA is in flight any more, so the barriers below do not drain them): one overlapped round
   // trip instead of one per store-phase iteration ----------------
-  constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH + NT - 1) / NT;
-  static_assert(!RESPRE || sizeof(T) == 2, "RESPRE is the bf16 residual path");
-  uint4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
-  if constexpr (RESPRE) {
+  if constexpr (RES_EARLY) {
+    wait_vmcnt<0>();  // K loops shorter than the ring never reach a wait that covers the residual prefetch
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass)
+#pragma unroll
+      for (int it = 0; it < E_ITERS; ++it) landed(rres[pass][it]);
+  }
+  if constexpr (RESPRE && !RES_EARLY) {
 #pragma unroll
     for (int pass = 0; pass < WM; ++pass)
 #pragma unroll

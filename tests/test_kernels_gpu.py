@@ -182,7 +182,7 @@ def test_transpose_pad_is_exact(R, C, dtype):
 
 
 @pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
-@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (145, 36, 64), (700, 264, 192), (513, 128, 1280)])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (145, 36, 64), (700, 264, 192), (513, 128, 1280), (2394, 256, 64)])
 def test_every_tile_shape_gives_the_same_gemm(M, N, K, tile):
     """The tile menu (128x128, 128x64, 144x256, 144x128, 256x128 and their 3 / 4-stage pipelined variants) is a
     speed choice only.  K = 64 ... 1280 covers 1, 2, 3, 5 and 20 K-steps: shorter than, equal to and longer than

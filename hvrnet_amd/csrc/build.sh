@@ -8,10 +8,16 @@ mkdir -p build
 pids=()
 for f in gemm misc roi_align nms stem capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_params.h -nt build/$f.o ] || [ ../../include/hvr_hip.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    if [ $f = gemm ]; then
+      hipcc $FLAGS -Rpass-analysis=kernel-resource-usage -c $f.hip -o build/$f.o 2> build/gemm.remarks &
+    else
+      hipcc $FLAGS -c $f.hip -o build/$f.o &
+    fi
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+if grep -q "error:" build/gemm.remarks 2>/dev/null; then grep -A3 "error:" build/gemm.remarks; rm -f build/gemm.o; exit 1; fi
+python3 check_regs.py build/gemm.remarks
 hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/misc.o build/roi_align.o build/nms.o build/stem.o build/capi.o -o $OUT
 echo "built $(realpath $OUT)"

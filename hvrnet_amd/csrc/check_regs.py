@@ -1,0 +1,36 @@
+"""Build-time check on the tile kernels' register allocation (run by build.sh on the compiler's
+-Rpass-analysis=kernel-resource-usage remarks).
+
+Kernels that use loads the compiler does not track (the pipelined relation apply pass: its block weights; the
+pipelined residual kernels that prefetch the residual tile, i.e. every RESPRE kernel with NS > 2 except the 144x256
+shapes) keep the destination registers untouched until the hand-counted wait has passed.  A register spill in such a
+kernel could store a destination before its load has landed, so the build fails if one of them spills.
+"""
+import re
+import sys
+
+
+def main(path):
+    text = open(path).read()
+    blocks = re.split(r'remark: Function Name: ', text)[1:]
+    bad, seen = [], 0
+    for b in blocks:
+        name = b.split()[0]
+        m = re.match(r'_ZN3hvr11tile_kernelI[tf]Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)E', name)
+        if not m:
+            continue
+        wm, wn, fm, fn, epi, glds, respre, ns = [int(x) for x in m.groups()]
+        spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
+        bn = wn * fn * 16
+        untracked = epi == 2 or (ns > 2 and respre == 1 and bn != 256)
+        if untracked:
+            seen += 1
+            if spill:
+                bad.append('%s: %d VGPRs spilled' % (name, spill))
+    if bad:
+        sys.exit('check_regs: kernels with untracked loads must not spill:\n  ' + '\n  '.join(bad))
+    print('check_regs: %d kernels with untracked loads, none spills' % seen)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

@@ -42,12 +42,16 @@ __device__ __forceinline__ float load_f32_untracked(const float* p) {
   return v;
 }
 __device__ __forceinline__ void landed(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ uint4 load_u128_untracked(const void* p) {
-  uint4 v;
+// 16-byte flavour.  The destination must stay where it is until `landed()`: a kernel that uses untracked loads must
+// not spill (a spill would store the register before the load has written it) -- hvrnet_amd/csrc/check_regs.py
+// verifies that on every build from the compiler's resource remarks.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 load_u128_untracked(const void* p) {
+  u32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
-__device__ __forceinline__ void landed(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void landed(u32x4& v) { asm volatile("" : "+v"(v)); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // loads one K-step costs the wave that issues the fewest (the last one: slots are dealt to waves in order)
@@ -130,7 +134,13 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // row packed as (iy << 16) | (ix & 0xffff): half the registers of pointers + two ints, which the pipelined
   // shapes need for their fragments
   int a_off[A_SLOTS], a_yx[A_SLOTS];
-  int b_off[B_SLOTS];
+  // (B rows are weights / keys: their offsets are recomputed at issue time, two VALU ops per 1 KiB piece)
+  auto b_off = [&](int i) {
+    const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
+    return (int)(((long)n * p.ldb + c * EPC) * (long)sizeof(T));
+  };
 #pragma unroll
   for (int i = 0; i < A_SLOTS; ++i) {
     const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
@@ -146,14 +156,6 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       a_off[i] = (int)(((long)m * p.lda + c * EPC) * (long)sizeof(T));
     }
   }
-#pragma unroll
-  for (int i = 0; i < B_SLOTS; ++i) {
-    const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
-    int n = n0 + row;
-    n = n < p.N ? n : p.N - 1;
-    b_off[i] = (int)(((long)n * p.ldb + c * EPC) * (long)sizeof(T));
-  }
-
   uint4 a_reg[A_SLOTS], b_reg[B_SLOTS];  // register staging (unused when GLDS)
 
   auto issue_loads = [&](int kt, char* stage) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = (const char*)p.B + ((long)b_off[i] + (long)kt * 128);
+        const char* src = (const char*)p.B + ((long)b_off(i) + (long)kt * 128);
         if constexpr (GLDS) {
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
@@ -275,9 +277,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // same number of loads for the counts to hold.
   constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH + NT - 1) / NT;
   static_assert(!RESPRE || sizeof(T) == 2, "RESPRE is the bf16 residual path");
-  constexpr bool RES_EARLY = RESPRE && NS > 2 && !(WM == 3 && FN == 8);  // (the 6-wave 144x256 has no registers left)
+  constexpr bool RES_EARLY = RESPRE && NS > 2 && BN != 256;  // (the 144x256 shapes have no registers left)
   constexpr int RES_LOADS = RES_EARLY ? WM * E_ITERS : 0;
-  uint4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
+  u32x4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
 
   // ---------------- main loop ----------------
   if constexpr (NS == 2) {
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_b = [&](auto I, int kt, char* stage) {
       constexpr int i = decltype(I)::value;
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = (const char*)p.B + ((long)b_off[i] + (long)kt * 128);
+        const char* src = (const char*)p.B + ((long)b_off(i) + (long)kt * 128);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0,
                                          0);
@@ -589,8 +591,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       for (int it = 0; it < E_ITERS; ++it) {
         const int c = it * NT + tid, r = c / E_CH, cc = c - r * E_CH;
         const int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
-        rres[pass][it] = make_uint4(0u, 0u, 0u, 0u);
-        if (c < E_ROWS * E_CH && m < p.M && n < p.N) rres[pass][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
+        rres[pass][it] = u32x4{0u, 0u, 0u, 0u};
+        if (c < E_ROWS * E_CH && m < p.M && n < p.N) rres[pass][it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
       }
   }
 
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
         const bool full = n + 8 <= p.N;  // N % 4 == 0: a chunk is either 8 or 4 valid columns
         if constexpr (RESPRE) {
-          const uint4 t = rres[pass][it];
+          const uint4 t = make_uint4(rres[pass][it][0], rres[pass][it][1], rres[pass][it][2], rres[pass][it][3]);
           v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
           v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
           v[4] += __uint_as_float(t.z << 16); v[5] += __uint_as_float(t.z & 0xffff0000u);

@@ -95,7 +95,10 @@ def main():
         OW = (W + 2 * p - d * (k - 1) - 1) // s + 1
         fl = 2.0 * T * OH * OW * Cout * k * k * Cin
         by = (x.numel() + T * OH * OW * Cout + w.numel()) * x.element_size()
-        sweep('conv ' + name, lambda t: native.conv2d_nhwc(x, w, b, None, relu=True, stride=s, pad=p, dil=d, staging=1, tile=t), fl)
+        # the block-closing 1x1 convs carry the residual add, as in the network
+        res = rnd(T, OH, OW, Cout) if 'conv3' in name else None
+        sweep('conv ' + name + ('+res' if res is not None else ''),
+              lambda t: native.conv2d_nhwc(x, w, b, res, relu=True, stride=s, pad=p, dil=d, staging=1, tile=t), fl)
     # ---- RoIAlign, all frames in one launch ----
     feat = rnd(T, 38, 63, 256)
     g = torch.Generator(device='cpu').manual_seed(0)

@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "gemm_params.h"
+#include "relation_bt.h"
 
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
@@ -158,6 +159,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
                      void* stream) {
   if (!Q || !K || !V || !O || !ws) return fail(HVR_EINVAL, "null pointer");
   if (Mq <= 0 || Mk <= 0) return fail(HVR_EINVAL, "empty relation Mq=%d Mk=%d", Mq, Mk);
+  if (!(scale > 0.f)) return fail(HVR_EINVAL, "relation scale must be positive (the reference uses 1/sqrt(D)), got %g", (double)scale);
   if (ws_bytes < hvr_relation_workspace_bytes(Mq, Mk, D, dtype))
     return fail(HVR_EWORKSPACE, "relation workspace %zu < %zu", ws_bytes, hvr_relation_workspace_bytes(Mq, Mk, D, dtype));
   const long ldp = rel_ldp(Mk);
@@ -170,25 +172,48 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   float* lstat = (float*)w;
   hipStream_t s = (hipStream_t)stream;
 
-  int rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
-  if (rc) return rc;
   GemmParams p;
-  rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
-  if (rc) return rc;
-  p.N = Mk;  // keys beyond Mk are masked inside the score epilogue
-  p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+  int rc;
+  // tuning overrides, read once
   static const int tile_scores = env_tile("HVR_TILE_SCORES"), tile_apply = env_tile("HVR_TILE_APPLY");
-  p.tile_hint = tile_scores;
   static const int gm_scores = std::getenv("HVR_GM_SCORES") ? std::atoi(std::getenv("HVR_GM_SCORES")) : 8;
   static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
-  p.group_m = gm_scores;
-  rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
-  if (rc) return rc;
+  static const int no_bt = env_tile("HVR_NO_BT");  // force the tile-engine scores pass
+#ifdef HVR_DEBUG_KNOBS  // tuning builds only (tools/build_dbg.sh): alias every operand row to row 0 (no memory-system cost)
+  static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
+#endif
+  const bool bt = dtype == HVR_BF16 && staging && !no_bt && scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt);
+  if (bt) {
+    // window-sized problems: one 336 x 256 score tile per CU, V^T written by the same launch (relation_bt.hip)
+    ScoresBTParams b;
+    b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
+    b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
+    b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f;
+    rc = check_launch(run_scores_bt(b, s), "relation: scores (big tile)");
+    if (rc) return rc;
+  } else {
+    rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
+    if (rc) return rc;
+    rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
+    if (rc) return rc;
+    p.N = Mk;  // keys beyond Mk are masked inside the score epilogue
+    p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+    p.tile_hint = tile_scores;
+    p.group_m = gm_scores;
+#ifdef HVR_DEBUG_KNOBS
+    if (dbg_ld0 & 1) { p.lda = 0; p.ldb = 0; }
+#endif
+    rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
+    if (rc) return rc;
+  }
   rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
   if (rc) return rc;
   p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
   p.tile_hint = tile_apply;
   p.group_m = gm_apply;
+#ifdef HVR_DEBUG_KNOBS
+  if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
+#endif
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
 }
 

@@ -65,6 +65,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) -- the MFMA fragment layout keeps one
+// output row in those four lanes.  gfx950's v_permlane{32,16}_swap exchange half-waves / 16-lane rows between two
+// registers in one VALU op each (no LDS round trip as with ds_bpermute).
+__device__ __forceinline__ float quad_group_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // {lo,lo} , {hi,hi}
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned v = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // rows {0,0,2,2} , {1,1,3,3}
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_group_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned v = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 template <typename F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {

@@ -425,24 +425,36 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
           src = ok ? src : (const char*)p.zero;
         }
+#ifndef HVR_DBG_NODMA
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + (i * NT + wave * 64) * 16), 16, 0, 0);
+#else
+        asm volatile("" ::"v"(src), "v"(stage));
+#endif
       }
     };
     auto dma_b = [&](auto I, int kt, char* stage) {
       constexpr int i = decltype(I)::value;
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
         const char* src = (const char*)p.B + ((long)b_off(i) + (long)kt * 128);
+#ifndef HVR_DBG_NODMA
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0,
                                          0);
+#else
+        asm volatile("" ::"v"(src), "v"(stage));
+#endif
       }
     };
     // fragment read r of half kk from the slot at byte offset soff
     auto read_frag = [&](auto R, auto KK, uint32_t soff) {
       constexpr int r = decltype(R)::value, kk = decltype(KK)::value;
+#ifdef HVR_DBG_NOLDSREAD
+      (void)soff;
+#else
       if constexpr (r < FM) fa[kk][r] = lds_read128_off<r * 2048>((a_lane + soff) ^ (kk ? 64u : 0u));
       else fb[kk][r - FM] = lds_read128_off<(r - FM) * 2048>((b_lane + soff) ^ (kk ? 64u : 0u));
+#endif
     };
 
     // prologue: NS - 1 K-steps in flight, K-step 0 landed, its first half's fragments requested
@@ -686,6 +698,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     }
   } else {  // EPI_SCORES: per (row, 128-key tile) max / sum and P~ = exp(s - tilemax)
     static_assert(EPI != EPI_SCORES || BN == 128, "score tiles are 128 keys wide");
+#ifdef HVR_DBG_NOSCORE_EPI
+    if (p.scale != 12345.f) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 12345.f) p.mstat[0] = t;
+      return;
+    }
+#endif
     // LDS scratch (the main loop is done): the P~ tile, staged so that it leaves in whole 16-byte row segments,
     // and [WN][BM] floats for the max / sum exchange between the column waves
     constexpr int PITCH = BN * (int)sizeof(T) + 8;  // bytes per staged row; 66 dwords: the 8-byte writes of a lane
@@ -703,7 +726,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         const int n = n0 + (wn * FN + j) * 16 + frag_grp * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float s = acc[i][j][r] * sl2;
+          float s = acc[i][j][r];  // raw dot products: the (positive) scale is folded into the exponent's FMA below
           if (ragged) s = (n + r < p.N) ? s : -INFINITY;
           acc[i][j][r] = s;
           mx = fmaxf(mx, s);
@@ -719,6 +742,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
       for (int w = 0; w < WN; ++w) tmax[i] = fmaxf(tmax[i], red[w * BM + (wm * FM + i) * 16 + frag_row]);
+      tmax[i] *= sl2;  // log2 units from here on
     }
     __syncthreads();
 #pragma unroll
@@ -730,12 +754,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         const int col = (wn * FN + j) * 16 + frag_grp * 4;
         float e[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(acc[i][j][r] - tmax[i]);  // masked keys: exp2(-inf) = 0
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], sl2, -tmax[i]));  // masked keys: exp2(-inf) = 0
         if constexpr (sizeof(T) == 2) {
-          // the row sum is taken over the rounded values the apply pass will actually multiply
+          // (the row sum is taken before rounding: the rounding errors of a tile's 128 values average out far below
+          // the bf16 resolution of the output, and re-expanding the packed values costs as much VALU as the exponentials)
           const uint32_t lo = pack2bf(e[0], e[1]), hi = pack2bf(e[2], e[3]);
-          sum += (__uint_as_float(lo << 16) + __uint_as_float(lo & 0xffff0000u)) +
-                 (__uint_as_float(hi << 16) + __uint_as_float(hi & 0xffff0000u));
+          sum += (e[0] + e[1]) + (e[2] + e[3]);
           *reinterpret_cast<uint2*>(pbuf + row * PITCH + col * 2) = make_uint2(lo, hi);
         } else {
           sum += (e[0] + e[1]) + (e[2] + e[3]);
@@ -757,7 +781,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         const int r = c / CH, cc = c - r * CH, m = m0 + r;
         const uint2 lo = *reinterpret_cast<const uint2*>(pbuf + r * PITCH + cc * 16);
         const uint2 hi = *reinterpret_cast<const uint2*>(pbuf + r * PITCH + cc * 16 + 8);
+#ifdef HVR_DBG_NOPSTORE
+        if (m < p.M && p.scale == 12345.f)
+#else
         if (m < p.M)
+#endif
           *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + ((long)m * p.ldc + n0) * (long)sizeof(T) + cc * 16) =
               make_uint4(lo.x, lo.y, hi.x, hi.y);
       }

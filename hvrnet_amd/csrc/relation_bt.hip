@@ -1,0 +1,320 @@
+// Relation scores pass, big-tile form (bf16, gfx950):  P~ = exp2(scale*log2e * Q K^T - blockmax), per (row, 128-key
+// block) max / sum, and -- riding in the same launch -- the V^T copy the apply pass reads.
+//
+// Replaces the bmm / scale / softmax head of one relation stage (mmdet/models/bbox_heads/selsa_bbox_head.py:166-176,
+// hrnmp_bbox_head.py:293-330) for the window-sized problem (Mq = Mk = 4 500, D = 1 024).
+//
+// Why a second scores kernel next to the tile engine (gemm.hip): with 128 x 128 tiles the 4 500 x 4 500 score matrix is
+// 1 296 tiles = 2.53 rounds of the chip's 512 resident workgroups, every round ends in an un-overlapped softmax
+// epilogue, and the small wave tiles (64 x 64) read 0.5 LDS fragments per MFMA -- measured on this chip, every
+// ds_read_b128 returning into a SIMD's registers costs about as much matrix-pipe time as an MFMA, so the loop runs at
+// half rate.  Here ONE workgroup per CU owns a 352 x 256 tile: 13 x 18 = 234 tiles = one round on 256 CUs, 148 flop per
+// operand byte, one prologue and one epilogue per CU.
+//   * 8 waves as 2 x 4: every wave owns 176 rows x 64 keys (11 x 4 fragments, 176 accumulator registers, 0.34 LDS
+//     fragment reads per MFMA), two waves on every SIMD;
+//   * K-step = 128 bytes of D per row, two LDS stages of (352 + 256) x 128 B = 76 KB filled by global_load_lds (same
+//     XOR-swizzled image as gemm.hip); the next K-step's DMA is issued piecewise between this step's MFMAs;
+//   * the 11 query fragments of a half K-step stream through a small register ring: fragment t + AHEAD is requested
+//     when fragment t is consumed, waits are counted (LDS returns in order); the other half's key fragments are
+//     requested in the shadow of the first items;
+//   * epilogue: row max over the wave's 64 columns by shuffles, over the 128-key block (2 waves) through LDS, exp2 with
+//     the scale folded into one FMA, bf16 pack, row segments staged per wave through LDS so that they leave as whole
+//     128-byte lines;
+//   * every workgroup also transposes its share of V into V^T[D][ldp] (64 x 64 tiles through LDS) while its first
+//     K-step is in flight, which removes the separate transpose launch in front of the apply pass.
+#include "common.h"
+#include "relation_bt.h"
+
+namespace hvr {
+
+namespace {
+
+constexpr int BT_BM = 352, BT_BN = 256, BT_NT = 512;
+constexpr int BT_WN = 4, BT_FM = 11, BT_FN = 4;               // 2 x 4 waves of 176 x 64
+constexpr int BT_WROWS = BT_FM * 16, BT_WCOLS = BT_FN * 16;
+constexpr int BT_A_BYTES = BT_BM * 128, BT_B_BYTES = BT_BN * 128, BT_STAGE = BT_A_BYTES + BT_B_BYTES;
+constexpr int BT_A_SLOTS = (BT_BM * 8 + BT_NT - 1) / BT_NT;  // 6 (the last one: waves 0..3 only)
+constexpr int BT_B_SLOTS = BT_BN * 8 / BT_NT;                // 4
+constexpr int BT_LDS = 2 * BT_STAGE;                         // 155 648 B
+#ifndef HVR_BT_AHEAD
+#define HVR_BT_AHEAD 3
+#endif
+constexpr int BT_AHEAD = HVR_BT_AHEAD, BT_RING = BT_AHEAD + 2;  // query-fragment read-ahead distance / ring slots
+constexpr int BT_ITEMS = 2 * BT_FM;                          // (half, row fragment) items per K-step
+constexpr int BT_KB_AT = 2;                                  // the second half's key fragments are requested after this item
+static_assert(BT_LDS <= 160 * 1024, "LDS budget");
+static_assert(BT_A_SLOTS + BT_B_SLOTS <= BT_ITEMS / 2, "one DMA piece after every second item");
+
+__device__ __forceinline__ uint32_t lds_off(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF> __device__ __forceinline__ uint4 lds_read128(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void mma(const uint4& keys, const uint4& queries, f32x4& acc) {
+  // keys as the MFMA "A" operand: lane ends up with 4 consecutive keys of one query row (see gemm.hip)
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, keys), __builtin_bit_cast(bf16x8, queries), acc, 0, 0, 0);
+}
+
+// LDS reads that may still be outstanding when item t's query fragment is needed: the fragments requested after it
+// (read-ahead, bounded by the end of the K-step) and, around BT_KB_AT, the four key fragments of the second half
+constexpr int pending_after(int t) {
+  int n = 0;
+  for (int u = t + 1; u <= t + BT_AHEAD - 1 && u < BT_ITEMS; ++u) ++n;  // q(t+1) .. q(t+AHEAD-1) exist at wait time
+  // the key fragments are issued after item BT_KB_AT's own read-ahead q(BT_KB_AT + AHEAD): they are younger than
+  // q(t) for t <= BT_KB_AT + AHEAD and already issued when item t > BT_KB_AT waits
+  if (t > BT_KB_AT && t <= BT_KB_AT + BT_AHEAD) n += BT_FN;
+  return n;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresBTParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / BT_WN, wn = wave % BT_WN;
+  const int tiles_n = (int)((p.ldp + BT_BN - 1) / BT_BN);
+  const int tiles_m = (p.Mq + BT_BM - 1) / BT_BM;
+  const int ntiles = tiles_m * tiles_n;
+  const bool has_tile = (int)blockIdx.x < ntiles;
+  // n fastest inside an XCD's contiguous range: the 352-row query panel is shared by neighbouring tiles
+  const int tile = has_tile ? xcd_remap(blockIdx.x, ntiles) : 0;
+  const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;
+  const int m0 = pid_m * BT_BM, n0 = pid_n * BT_BN;
+
+  // ---- loader: a thread's 16-byte pieces sit 64 rows apart (slot s = i * 512 + tid -> row i * 64 + tid / 8), all in
+  // the same swizzled chunk; offsets are rebuilt at issue time (three VALU ops) instead of living in registers ----
+  const int l_row = tid >> 3, l_chunk = ((tid & 7) ^ (l_row & 7)) * 16;
+  auto dma_a = [&](auto I, int kt, char* stage) {
+    constexpr int i = decltype(I)::value;
+    if (i < BT_A_SLOTS - 1 || wave < (BT_BM * 8 - (BT_A_SLOTS - 1) * BT_NT) / 64) {
+      int m = m0 + i * 64 + l_row;
+      m = m < p.Mq ? m : p.Mq - 1;
+      const char* src = (const char*)p.Q + ((long)m * p.ldq * 2 + l_chunk + kt * 128);
+#ifdef HVR_DBG_BT_NODMA
+      if (kt == 0)
+#endif
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + (i * BT_NT + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto dma_b = [&](auto I, int kt, char* stage) {
+    constexpr int i = decltype(I)::value;
+    int n = n0 + i * 64 + l_row;
+    n = n < p.Mk ? n : p.Mk - 1;
+    const char* src = (const char*)p.K + ((long)n * p.ldk * 2 + l_chunk + kt * 128);
+#ifdef HVR_DBG_BT_NODMA
+    if (kt == 0)
+#endif
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(stage + BT_A_BYTES + (i * BT_NT + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // first K-step into stage 0; it lands while the workgroup transposes its share of V through stage 1's memory
+  if (has_tile) {
+    static_for<BT_A_SLOTS>([&](auto I) { dma_a(I, 0, smem); });
+    static_for<BT_B_SLOTS>([&](auto I) { dma_b(I, 0, smem); });
+  }
+
+  // ---------------- V^T[D][ldp] = V[Mk][ldv]^T, zero-filled for keys Mk .. ldp - 1 ----------------
+  // 64 x 64 tiles, one per half workgroup (256 threads) and pass; 16-byte global accesses on both sides
+#ifndef HVR_DBG_BT_NOTRANSPOSE
+  {
+    constexpr int PITCH = 64 * 2 + 16;
+    const int half = tid >> 8, ht = tid & 255;
+    char* tbuf = smem + BT_STAGE + half * (64 * PITCH);
+    const int tr_c = p.D / 64, tr_r = (int)(p.ldp / 64), ntr = tr_c * tr_r;
+    const int per_pass = (int)gridDim.x * 2;
+    for (int base = 0; base < ntr; base += per_pass) {
+      const int tt = base + (int)blockIdx.x * 2 + half;
+      const bool live = tt < ntr;
+      const int r0 = (tt / tr_c) * 64, c0 = (tt % tr_c) * 64;
+      if (live) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int s = it * 256 + ht, i = s >> 3, q = s & 7;
+          const int r = r0 + i, c = c0 + q * 8;
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (r < p.Mk) v = *reinterpret_cast<const uint4*>(p.V + (long)r * p.ldv + c);
+          *reinterpret_cast<uint4*>(tbuf + i * PITCH + q * 16) = v;
+        }
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int s = it * 256 + ht, q = s >> 6, i = s & 63;
+          uint32_t w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = *reinterpret_cast<const bf16_t*>(tbuf + (q * 8 + 2 * e) * PITCH + i * 2);
+            const uint32_t hi = *reinterpret_cast<const bf16_t*>(tbuf + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+            w[e] = lo | (hi << 16);
+          }
+          *reinterpret_cast<uint4*>(p.Vt + (long)(c0 + i) * p.ldp + r0 + q * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+#endif
+  if (!has_tile) return;
+
+  f32x4 acc[BT_FM][BT_FN];
+#pragma unroll
+  for (int i = 0; i < BT_FM; ++i)
+#pragma unroll
+    for (int j = 0; j < BT_FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
+  const uint32_t a_lane = lds_off(smem) + (wm * BT_WROWS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+  const uint32_t b_lane = lds_off(smem) + BT_A_BYTES + (wn * BT_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+
+  const int nk = p.D / 64;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * BT_STAGE;
+    const int kn = kt + 1 < nk ? kt + 1 : kt;
+    const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
+    uint4 kb[2][BT_FN];  // key fragments: [half][column fragment]
+    uint4 qa[BT_RING];   // query-fragment ring: item t = half * FM + i lives in slot t % RING
+    auto read_q = [&](auto T) {
+      constexpr int t = decltype(T)::value, kk = t / BT_FM, i = t % BT_FM;
+      qa[t % BT_RING] = lds_read128<i * 2048>(kk ? (a0 ^ 64u) : a0);
+    };
+    static_for<BT_FN>([&](auto J) { kb[0][decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(b0); });
+    static_for<BT_AHEAD>([&](auto T) { read_q(T); });
+    static_for<BT_ITEMS>([&](auto T) {
+      constexpr int t = decltype(T)::value, kk = t / BT_FM, i = t % BT_FM;
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm<pending_after(t)>();
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<BT_FN>([&](auto J) { mma(kb[kk][decltype(J)::value], qa[t % BT_RING], acc[i][decltype(J)::value]); });
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (t + BT_AHEAD < BT_ITEMS) read_q(std::integral_constant<int, t + BT_AHEAD>{});
+      if constexpr (t == BT_KB_AT)
+        static_for<BT_FN>([&](auto J) { kb[1][decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(b0 ^ 64u); });
+      // the next K-step's DMA, one piece after every second item (the last step re-fetches its own K-step into the
+      // idle stage: one uniform instruction stream, no tail copy)
+      if constexpr (t % 2 == 1 && t / 2 < BT_A_SLOTS + BT_B_SLOTS) {
+        constexpr int d = t / 2;
+        if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
+        else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+#ifdef HVR_DBG_BT_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < BT_FM; ++i)
+#pragma unroll
+      for (int j = 0; j < BT_FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 12345.f) p.mstat[0] = t;
+    return;
+  }
+#endif
+  // ---------------- epilogue: block max / exp2 / pack / sums ----------------
+  // LDS (the ring is idle): [8][176] maxima, [8][176] sums, then one 16-row x 64-key bf16 staging block per wave
+  float* red_max = reinterpret_cast<float*>(smem);
+  float* red_sum = red_max + 8 * BT_WROWS;
+  constexpr int SPITCH = BT_WCOLS * 2 + 16;  // bytes per staged row (144: 16-byte aligned, rows 4 banks apart)
+  char* stg = smem + 2 * 8 * BT_WROWS * 4 + wave * (16 * SPITCH);
+  const int blk = wn >> 1;                                          // 128-key block of this wave inside the tile
+  const bool blk_live = n0 + blk * 128 < p.ldp;                     // an odd block count leaves the last tile half empty
+  const int ncol0 = n0 + wn * BT_WCOLS + frag_grp * 4;              // first key of this lane's fragment-0 columns
+  float tmax[BT_FM];
+#pragma unroll
+  for (int i = 0; i < BT_FM; ++i) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < BT_FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = acc[i][j][r];
+        s = (ncol0 + j * 16 + r < p.Mk) ? s : -INFINITY;  // keys past Mk never win the max and get weight 0
+        acc[i][j][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = quad_group_max(mx);
+    tmax[i] = mx;
+    if (frag_grp == 0) red_max[wave * BT_WROWS + i * 16 + frag_row] = mx;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BT_FM; ++i)
+    tmax[i] = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * p.sl2;  // block max, log2 units
+  const int st_row = lane >> 3, st_chunk = lane & 7;  // store phase: lane -> (row, 16-byte piece) of the staged block
+#pragma unroll
+  for (int i = 0; i < BT_FM; ++i) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < BT_FN; ++j) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], p.sl2, -tmax[i]));
+      sum += (e[0] + e[1]) + (e[2] + e[3]);
+      *reinterpret_cast<uint2*>(stg + frag_row * SPITCH + (j * 16 + frag_grp * 4) * 2) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+    }
+    sum = quad_group_sum(sum);
+    if (frag_grp == 0) red_sum[wave * BT_WROWS + i * 16 + frag_row] = sum;
+    // the wave's 16 x 64 block leaves as two stores of eight whole 128-byte row segments (wave-private staging: the
+    // LDS returns in order, no barrier)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = h * 8 + st_row, m = m0 + wm * BT_WROWS + i * 16 + row;
+      const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + st_chunk * 16);
+      if (m < p.Mq && blk_live)
+        *reinterpret_cast<uint4*>(p.P + (long)m * p.ldp + n0 + wn * BT_WCOLS + st_chunk * 8) = v;
+    }
+  }
+  __syncthreads();
+  if ((wn & 1) == 0 && frag_grp == 0 && blk_live) {
+    const int t = n0 / 128 + blk;
+#pragma unroll
+    for (int i = 0; i < BT_FM; ++i) {
+      const int row = i * 16 + frag_row, m = m0 + wm * BT_WROWS + row;
+      const float sum = red_sum[wave * BT_WROWS + row] + red_sum[(wave + 1) * BT_WROWS + row];
+      if (m < p.Mq) {
+        p.mstat[(long)m * p.ntile + t] = tmax[i];
+        p.lstat[(long)m * p.ntile + t] = sum;
+      }
+    }
+  }
+}
+
+bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, long ldp, const void* Q, const void* K,
+                         const void* V, const void* P, const void* Vt) {
+  const uintptr_t al = reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
+                       reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Vt);
+  if (al & 15) return false;
+  if (D % 64 || ldq % 8 || ldk % 8 || ldv % 8 || ldp % 128) return false;
+  if ((long)Mq * ldq * 2 >= (1L << 31) || (long)Mk * ldk * 2 >= (1L << 31)) return false;
+  // the single-round shape only pays once the tile grid fills most of the chip
+  const long tiles = (long)((Mq + BT_BM - 1) / BT_BM) * ((ldp + BT_BN - 1) / BT_BN);
+  return tiles >= 160 && tiles <= 256 && Mk >= 128;
+}
+
+hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(relation_scores_bt_kernel, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace hvr

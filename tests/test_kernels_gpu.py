@@ -98,6 +98,28 @@ def test_relation_peaky_rows_and_tile_max_jumps(dtype):
     torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
 
 
+@pytest.mark.parametrize('Mq,Mk', [(4500, 4500), (3300, 4417), (4321, 4100)])
+def test_relation_window_size_big_tile_path(Mq, Mk):
+    """Window-sized bf16 problems take the one-round 352 x 256 scores kernel (relation_bt.hip, V^T written by the same
+    launch): ragged last row / key tiles, a spike in the last 128-key block, and the same answer as the tile-engine path
+    gives on a row subset (computed as its own small problem)."""
+    D = 1024
+    q, k, v = _rand((Mq, D), torch.bfloat16, 41, 1.5), _rand((Mk, D), torch.bfloat16, 42, 1.5), _rand((Mk, D), torch.bfloat16, 43)
+    k[Mk - 2] = (q[7].float() * 3).to(torch.bfloat16)        # a late-block maximum ~ 96 above the rest of row 7
+    k[5] = (q[Mq - 1].float() * 2).to(torch.bfloat16)        # an early-block maximum for the last row
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out = native.relation_fwd(qd, kd, vd, 1.0 / 32)
+    assert torch.isfinite(out.float()).all()
+    rows = torch.cat([torch.arange(0, 16), torch.arange(340, 370), torch.arange(Mq - 40, Mq)])  # tile seams + the ragged tail
+    ref = _relation_ref(q[rows], k, v, 1.0 / 32)
+    torch.testing.assert_close(out[rows.to(DEV)].float().cpu(), ref, **_tol(torch.bfloat16))
+    small = native.relation_fwd(qd[rows.to(DEV)].contiguous(), kd, vd, 1.0 / 32)  # 86 rows: the tile-engine scores pass
+    torch.testing.assert_close(out[rows.to(DEV)].float(), small.float(), rtol=2e-2, atol=2e-2)
+    # every output row is a convex combination of V rows
+    ones = native.relation_fwd(qd, kd, torch.ones_like(vd), 1.0 / 32)
+    torch.testing.assert_close(ones.float(), torch.ones_like(ones.float()), rtol=0, atol=8e-3)
+
+
 def test_maxpool_and_stem_patches():
     x = _rand((2, 64, 21, 30), torch.float32, 31)
     ref = F.max_pool2d(x, 3, 2, 1)

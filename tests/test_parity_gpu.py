@@ -392,9 +392,15 @@ def test_full_size_properties_T15_N300():
     perm = torch.randperm(M, generator=g).to(DEV)
     op = native.relation_fwd(q, k[perm].contiguous(), v[perm].contiguous(), 1 / 32)
     assert (op.float() - o.float()).abs().max().item() < 2e-2
-    # (3) query rows are independent: the key-frame slice equals the full result's slice
+    # (3) query rows are independent.  Bit-exact inside one kernel path: reversing the row order of the window-sized
+    # problem (the one-round scores kernel) and splitting the key-frame slice (the tile-engine scores kernel) change
+    # which tile / lane owns a row, not its arithmetic; across the two paths the block sums are taken in a different
+    # order, so the key-frame slice matches the full result to bf16 resolution.
+    orev = native.relation_fwd(q.flip(0).contiguous(), k, v, 1 / 32)
+    assert torch.equal(orev.flip(0), o)
     ok = native.relation_fwd(q[2100:2400], k, v, 1 / 32)
-    assert torch.equal(ok, o[2100:2400])
+    assert torch.equal(native.relation_fwd(q[2100:2250], k, v, 1 / 32), ok[:150])
+    assert (ok.float() - o[2100:2400].float()).abs().max().item() < 8e-3
     # (4) convex combination: outputs stay inside the value range
     assert o.float().max().item() <= v.float().max().item() + 1e-2 and o.float().min().item() >= v.float().min().item() - 1e-2
     # (5) spot rows against an f64 statement of the same rows

@@ -1,0 +1,37 @@
+"""Full-stage relation core only (Mq = Mk = 4500, D = 1024), for profiler passes that should not mix shapes.
+
+    python tools/rel_bench.py [--iters 10] [--mq 4500] [--mk 4500]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hvrnet_amd import native  # noqa: E402
+
+if os.environ.get('HVR_BENCH_LIB'):  # A/B a privately built library (tuning experiments only)
+    native.LIB_PATH = os.path.abspath(os.environ['HVR_BENCH_LIB'])
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--mq', type=int, default=4500)
+ap.add_argument('--mk', type=int, default=4500)
+ap.add_argument('--d', type=int, default=1024)
+args = ap.parse_args()
+torch.manual_seed(0)
+q = torch.randn(args.mq, args.d, device='cuda').bfloat16()
+k = torch.randn(args.mk, args.d, device='cuda').bfloat16()
+v = torch.randn(args.mk, args.d, device='cuda').bfloat16()
+for _ in range(3):
+    native.relation_fwd(q, k, v, 1 / 32, staging=1)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(args.iters):
+    native.relation_fwd(q, k, v, 1 / 32, staging=1)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / args.iters
+print('relation Mq=%d Mk=%d D=%d  %.4f ms  %.1f TF/s' % (args.mq, args.mk, args.d, ms, 4.0 * args.mq * args.mk * args.d / ms / 1e9))

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void rpn_gather_kernel(const float* __restrict
 constexpr int MC_MAX_R = 512;
 
 // one workgroup per foreground class: keepflag[c-1][r], kcount[c-1]
-__global__ __launch_bounds__(256) void mc_nms_class_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+__global__ __launch_bounds__(1024) void mc_nms_class_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                            int R, int ncls, float score_thr, float iou_thr,
                                                            unsigned char* __restrict__ keepflag, int* __restrict__ kcount) {
   __shared__ float4 bx[MC_MAX_R];
@@ -379,16 +379,32 @@ __global__ __launch_bounds__(256) void mc_nms_class_kernel(const float* __restri
   __syncthreads();
   bitonic_sort_pairs(key, idx, MC_MAX_R);
   if (threadIdx.x < 64) {
+    // Greedy sweep in score order by one wave; lane w holds word w of the suppression set (w < 8).  The serial part
+    // is register-only: per chunk of 64 candidates the lanes first fetch the candidates' indices (one LDS read) and
+    // this lane's word of every candidate's IoU row (64 independent LDS reads in flight), then the chain
+    // "suppressed? -> keep -> OR the row in" runs on readlanes, with no memory access in its dependency path.
     const int lane = threadIdx.x;
-    unsigned long long supp = 0ull;  // lane w holds word w (w < 8)
+    unsigned long long supp = 0ull;
     int kept = 0;
-    for (int i = 0; i < ncand; ++i) {
-      const int r = (int)idx[i];
-      const unsigned long long wv = readlane64(supp, r >> 6);
-      if (!((wv >> (r & 63)) & 1ull)) {
-        if (lane == 0) kf[r] = 1;
-        ++kept;
-        if (lane < words) supp |= iou[r][lane];
+    for (int base = 0; base < ncand; base += 64) {
+      const int mine = base + lane < ncand ? (int)idx[base + lane] : 0;
+      unsigned long long rows[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const int r = __builtin_amdgcn_readlane(mine, j);
+        rows[j] = lane < words ? iou[r][lane] : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        if (base + j < ncand) {  // wave-uniform
+          const int r = __builtin_amdgcn_readlane(mine, j);
+          const unsigned long long wv = readlane64(supp, r >> 6);
+          if (!((wv >> (r & 63)) & 1ull)) {
+            if (lane == 0) kf[r] = 1;
+            ++kept;
+            supp |= rows[j];
+          }
+        }
       }
     }
     if (lane == 0) kcount[c - 1] = kept;
@@ -439,7 +455,71 @@ __global__ __launch_bounds__(1024) void mc_nms_merge_kernel(const float* __restr
   __syncthreads();
   int nout = total;
   if (total > max_num) {
-    bitonic_sort_pairs(key, idx, np2);
+    // top max_num by (score desc, list position asc): radix-select the max_num-th key (4 passes over the LDS list),
+    // gather the entries above it plus the first ties, and sort only those (bbox_nms.py:54-61 sorts everything and
+    // cuts; the survivors and their order are the same)
+    __shared__ int hist[256];
+    __shared__ uint32_t sh_prefix, sh_remaining;
+    __shared__ int sh_count;
+    const int sp2 = next_pow2(max_num);
+    uint32_t* skey = idx + np2;
+    uint32_t* sidx = skey + sp2;
+    uint32_t prefix = 0u, remaining = (uint32_t)max_num;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+      __syncthreads();
+      const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint32_t u = key[i];
+        if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t rem = remaining;
+        int b = 255;
+        for (; b > 0; --b) {
+          if ((uint32_t)hist[b] >= rem) break;
+          rem -= hist[b];
+        }
+        sh_prefix = prefix | ((uint32_t)b << shift);
+        sh_remaining = rem;
+      }
+      __syncthreads();
+      prefix = sh_prefix;
+      remaining = sh_remaining;
+      __syncthreads();
+    }
+    const uint32_t thr_key = prefix;  // key of the max_num-th entry; `remaining` of the entries equal to it are taken
+    if (threadIdx.x == 0) sh_count = 0;
+    for (int i = threadIdx.x; i < sp2; i += blockDim.x) { skey[i] = 0u; sidx[i] = 0xffffffffu; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      if (key[i] > thr_key) {
+        const int pos = atomicAdd(&sh_count, 1);
+        skey[pos] = key[i];
+        sidx[pos] = idx[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // ties at the threshold, lowest list position first (the list is in ascending idx order)
+      int taken = 0;
+      const int base = sh_count;
+      for (int i0 = 0; i0 < total && taken < (int)remaining; i0 += 64) {
+        const int i = i0 + threadIdx.x;
+        const bool eq = i < total && key[i] == thr_key;
+        const unsigned long long m = __ballot(eq);
+        const int before = __popcll(m & ((1ull << threadIdx.x) - 1ull));
+        if (eq && taken + before < (int)remaining) {
+          skey[base + taken + before] = thr_key;
+          sidx[base + taken + before] = idx[i];
+        }
+        taken += __popcll(m);
+      }
+    }
+    __syncthreads();
+    bitonic_sort_pairs(skey, sidx, sp2);
+    idx = sidx;
     nout = max_num;
   }
   for (int j = threadIdx.x; j < nout; j += blockDim.x) {
@@ -523,14 +603,16 @@ hipError_t run_multiclass_nms(const float* boxes, const float* scores, int R, in
   if (R > MC_MAX_R || ncls - 1 > 128 || R <= 0) return hipErrorInvalidValue;
   unsigned char* keepflag = (unsigned char*)ws;
   int* kcount = (int*)((char*)ws + (((size_t)(ncls - 1) * R + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(mc_nms_class_kernel, dim3(ncls - 1), dim3(256), 0, s, boxes, scores, R, ncls, score_thr, iou_thr, keepflag, kcount);
+  hipLaunchKernelGGL(mc_nms_class_kernel, dim3(ncls - 1), dim3(1024), 0, s, boxes, scores, R, ncls, score_thr, iou_thr, keepflag, kcount);
   int np2 = 1;
   while (np2 < (ncls - 1) * R) np2 <<= 1;
-  const size_t lds = (size_t)np2 * 8;
-  if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
+  int sp2 = 1;
+  while (sp2 < max_num) sp2 <<= 1;
+  const size_t lds = (size_t)np2 * 8 + (size_t)sp2 * 8;
+  if (lds > 160 * 1024 - 3072) return hipErrorInvalidValue;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mc_nms_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mc_nms_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 3072);
     attr = true;
   }
   hipLaunchKernelGGL(mc_nms_merge_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, R, ncls, keepflag, kcount, max_num, dets, labels, n_out);

@@ -170,6 +170,24 @@ def test_det_readout_matches_reference_golden():
     close(db, g['det_bboxes'], 0, 1e-6)
 
 
+@pytest.mark.parametrize('max_num', [300, 100, 7])
+def test_multiclass_nms_full_size_with_ties(O, max_num):
+    """R = 300 rois x 30 classes, far more survivors than max_num and many exactly tied scores: the radix-select +
+    short-sort merge must reproduce the oracle (score desc, concatenation order on ties) index for index."""
+    g = torch.Generator().manual_seed(77)
+    R, ncls = 300, 31
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([900.0, 500.0])
+    wh = torch.rand((R, 2), generator=g) * 120 + 8
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.softmax(torch.randn((R, ncls), generator=g) * 2, 1)
+    scores = (scores * 64).round() / 64       # coarse grid: hundreds of exact ties, many of them at the cut
+    want_b, want_l = O.multiclass_nms(boxes, scores, 0.001, 0.3, max_num)
+    assert want_b.shape[0] == max_num
+    db, dl = multiclass_nms(boxes.to(DEV), scores.to(DEV), 0.001, dict(type='nms', iou_thr=0.3), max_num)
+    assert dl.cpu().tolist() == want_l.tolist()
+    close(db, want_b.numpy(), 0, 1e-6)
+
+
 # ------------------------------------------------------------------------------- relation + heads
 def _head(kind, dtype, sampler_num=32, t_dim=3):
     cfg = (selsa_config if kind == 'selsa' else hvr_config)(frame_interval=1, nms_post=sampler_num)

@@ -209,7 +209,7 @@ def main():
             traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         if full['calls']:
             ach = full['work'] / (full['ms'] * 1e-3) / 1e12
-            roofline = dict(kernel='relation core (V^T + scores + stats + apply), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
+            roofline = dict(kernel='relation core (scores incl. V^T copy + apply: 2 launches), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
                             launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
                             flops_per_launch=full['work'] / full['calls'])

@@ -18,7 +18,7 @@ struct ScoresBTParams {
   float sl2;        // scale * log2(e)
 };
 
-// true when the one-round 336 x 256 tiling applies (bf16, aligned operands, a tile grid that fills most of the chip)
+// true when the one-round 352 x 256 tiling applies (bf16, aligned operands, a tile grid that fills most of the chip)
 bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, long ldp, const void* Q, const void* K,
                          const void* V, const void* P, const void* Vt);
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream);

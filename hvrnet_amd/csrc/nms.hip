@@ -122,21 +122,32 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int p = blockIdx.x;
   const int nb = (n + 63) >> 6;  // <= 128
+  const int nbs = nb;            // mask row stride in words
   unsigned char* flag = reinterpret_cast<unsigned char*>(smem);  // [n] by original index
   int* wsum = reinterpret_cast<int*>(smem + ((n + 15) & ~15));   // [blockDim/64 + 1]
   for (int i = threadIdx.x; i < n; i += blockDim.x) flag[i] = 0;
   __syncthreads();
-  const unsigned long long* mk = mask + (long)p * n * nb;
+  const unsigned long long* mk = mask + (long)p * n * nbs;
   const int* ord = order + (long)p * n;
   if (threadIdx.x < 64) {
+    // One wave walks the score-sorted boxes chunk by chunk (64 boxes).  Only the "is this box already suppressed /
+    // does it suppress later boxes of its own chunk" chain is serial, and it runs on readlanes of the chunk's
+    // diagonal mask word; everything that touches memory is kept off that chain: the next chunk's diagonal words are
+    // requested one chunk ahead, and the mask rows of the chunk's survivors are fetched eight rows (16 independent
+    // loads) at a time before they are OR-ed into the running suppression set.
     const int lane = threadIdx.x;
     unsigned long long remv0 = 0ull, remv1 = 0ull;
     int nkept = 0;
     bool done = false;
+    unsigned long long diag_next = lane < n ? mk[(long)lane * nbs] : 0ull;
     for (int cb = 0; cb < nb && !done; ++cb) {
       unsigned long long cur = cb < 64 ? readlane64(remv0, cb) : readlane64(remv1, cb - 64);
       const int bi = cb * 64 + lane;
-      const unsigned long long diag = bi < n ? mk[(long)bi * nb + cb] : 0ull;
+      const unsigned long long diag = diag_next;
+      if (cb + 1 < nb) {
+        const int bn = bi + 64;
+        diag_next = bn < n ? mk[(long)bn * nbs + cb + 1] : 0ull;
+      }
       const int cnt = min(64, n - cb * 64);
       unsigned long long kept = 0ull;
       for (int j = 0; j < cnt; ++j) {
@@ -148,13 +159,23 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long
       }
       if (bi < n && ((kept >> lane) & 1ull)) flag[ord[bi]] = 1;
       if (!done) {
-        unsigned long long kb = kept;
+        unsigned long long kb = kept;  // wave-uniform
+        const bool lo_on = lane > cb && lane < nb, hi_on = lane + 64 > cb && lane + 64 < nb;
         while (kb) {
-          const int j = __builtin_ctzll(kb);
-          kb &= kb - 1;
-          const unsigned long long* row = mk + (long)(cb * 64 + j) * nb;
-          if (lane > cb && lane < nb) remv0 |= row[lane];
-          if (lane + 64 > cb && lane + 64 < nb) remv1 |= row[lane + 64];
+          unsigned long long r0[8], r1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            r0[u] = r1[u] = 0ull;
+            if (kb) {
+              const int j = __builtin_ctzll(kb);
+              kb &= kb - 1;
+              const unsigned long long* row = mk + (long)(cb * 64 + j) * nbs;
+              if (lo_on) r0[u] = row[lane];
+              if (hi_on) r1[u] = row[lane + 64];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { remv0 |= r0[u]; remv1 |= r1[u]; }
         }
       }
     }
@@ -564,8 +585,8 @@ hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, i
     attr = true;
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(1024), (size_t)np2 * 8, s, dets, n, presorted, order, boxes4);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, P), dim3(64), 0, s, boxes4, n, thr, ge, mask);
   const size_t sweep_lds = ((n + 15) & ~15) + 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, P), dim3(64), 0, s, boxes4, n, thr, ge, mask);
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(P), dim3(256), sweep_lds, s, mask, order, n, max_keep, keep, n_keep, n);
   return hipGetLastError();
 }

@@ -147,6 +147,35 @@ def test_rpn_proposals_match_oracle(O, H, W):
         close(props[t, :n], want, 1e-5, 2e-3)
 
 
+def test_rpn_proposals_heavy_overlap_fewer_than_nms_post(O):
+    """Frames 0 and 2: the largest anchors win everywhere and the deltas are small, so neighbours overlap by > 0.7, the
+    sweep walks all 6 000 candidates and far fewer than nms_post boxes survive; frame 1 is ordinary (stops early after
+    nms_post survivors) - both kinds in one launch."""
+    T, A, H, W = 3, 12, 38, 63
+    g = torch.Generator().manual_seed(29)
+    cls = torch.randn((T, A, H, W), generator=g) * 1.5
+    reg = torch.randn((T, 4 * A, H, W), generator=g) * 0.3
+    big = torch.tensor([3, 7, 11])                       # scale-32 anchors of the three ratios (ratio-major base anchors)
+    for t in (0, 2):
+        cls[t] = torch.randn((A, H, W), generator=g) * 0.5 - 6.0
+        cls[t, big] += 12.0
+        reg[t] = torch.randn((4 * A, H, W), generator=g) * 0.02
+    gen = AnchorGenerator(16, [4, 8, 16, 32], [0.5, 1.0, 2.0])
+    anchors = O.grid_anchors(O.gen_base_anchors(16, [4, 8, 16, 32], [0.5, 1.0, 2.0]), (H, W), 16)
+    cfg = dict(O.RPN_TEST_CFG)
+    props, counts = native.rpn_proposals(cls.permute(0, 2, 3, 1).contiguous().to(DEV), reg.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                         gen.base_anchors, 16, (0., 0., 0., 0.), (1., 1., 1., 1.), (600, 1000), cfg['nms_pre'],
+                                         cfg['nms_post'], cfg['max_num'], cfg['nms_thr'])
+    ns = []
+    for t in range(T):
+        want = O.rpn_get_bboxes_single(cls[t], reg[t], anchors, (600, 1000, 3), cfg)
+        n = int(counts[t].item())
+        ns.append(n)
+        assert n == want.shape[0]
+        close(props[t, :n], want, 1e-5, 2e-3)
+    assert ns[0] < cfg['nms_post'] and ns[2] < cfg['nms_post'] and ns[1] == cfg['nms_post'], ns
+
+
 # ------------------------------------------------------------------------------- read-out
 def test_det_readout_matches_reference_golden():
     g = gold('g8_det')

@@ -181,6 +181,10 @@ class _RelationHead(BBoxHead):
             x, w = bbox_feat.contiguous().view(bbox_feat.size(0), -1), p['fc1_chw']
         return native.gemm(native.cast(x, self.compute_dtype), w, p['fcb1'])
 
+    def fc1_rows(self, bbox_feat):
+        """fc_new_1 of RoI features [K,256,7,7] -> [K,1024] (selsa_bbox_head.py:222-224); one row per RoI."""
+        return self._fc1(self.packed(bbox_feat.device), bbox_feat)
+
     def _stage(self, p, k, x, q_range=None):
         """relu(Xq + relation_k(X)): rows `q_range` as queries (all rows when None), keys = X[:nongt_dim]."""
         D = self.fc_feat_dim
@@ -208,12 +212,15 @@ class SelsaBBoxHead(_RelationHead):
 
     def forward(self, bbox_feat, cur_range=None, key_dim=0, all_res=False):
         """-> (cls_score, bbox_pred, None), selsa_bbox_head.py:203-261 (output_cur_only=False)."""
+        return self.forward_from_f1(self.fc1_rows(bbox_feat), cur_range, key_dim, all_res)
+
+    def forward_from_f1(self, f1, cur_range=None, key_dim=0, all_res=False):
+        """The head from the fc_new_1 rows on (rows are per-RoI: a video runner may cache them per frame)."""
         assert cur_range is not None, 'Feature num range along axis need specified'
         self.key_dim = key_dim
         self.nongt_dim = self.sampler_num * self.t_dim
         s, l = int(cur_range['start']), int(cur_range['length'])
-        p = self.packed(bbox_feat.device)
-        f1 = self._fc1(p, bbox_feat)
+        p = self.packed(f1.device)
         h1 = self._stage(p, 1, f1)
         f2 = native.gemm(h1, p['fc2'], p['fcb2'])
         if all_res:
@@ -239,14 +246,17 @@ class HRNMPBBoxHead(_RelationHead):
 
     def forward_test(self, bbox_feat_s, cur_range_s=None, key_dim=0, all_res=False):
         """-> ([cls_branch, cls], [reg_branch, reg]), hrnmp_bbox_head.py:800-909."""
+        return self.forward_from_f1(self.fc1_rows(bbox_feat_s), cur_range_s, key_dim, all_res)
+
+    def forward_from_f1(self, f1, cur_range_s=None, key_dim=0, all_res=False):
+        """The head from the fc_new_1 rows on (rows are per-RoI: a video runner may cache them per frame)."""
         assert cur_range_s is not None, 'Feature num range along axis need specified'
         self.key_dim = key_dim
         self.nongt_dim = self.sampler_num * self.t_dim
-        assert self.nongt_dim >= bbox_feat_s.shape[0]  # hrnmp_bbox_head.py:249
+        assert self.nongt_dim >= f1.shape[0]  # hrnmp_bbox_head.py:249
         cur = cur_range_s[0]
         s, l = int(cur['start']), int(cur['length'])
-        p = self.packed(bbox_feat_s.device)
-        f1 = self._fc1(p, bbox_feat_s)
+        p = self.packed(f1.device)
         h1 = self._stage(p, 1, f1)
         f2 = native.gemm(h1, p['fc2'], p['fcb2'])
         if self.dead_row_elimination:

@@ -227,6 +227,18 @@ class _WindowDetector(TwoStageDetector):
         return the counts tensor as `counts_dev` for the caller to check."""
         xc = self._cat_frames(x)
         assert xc.shape[0] == len(img_meta)
+        feats, proposal_list, rois, counts_dev, counts_h = self._c5_and_rois(xc, img_meta, proposals, speculate)
+        key = self.key_dim
+        start = int(np.sum(counts_h[:key]))
+        cur_range = dict(start=start, length=int(counts_h[key]))
+        roi_feats = self.get_roi_feat(feats, rois.contiguous())
+        key_rois = rois[start:start + cur_range['length']].clone()
+        key_rois[:, 0] = 0  # the reference's rois carry batch index 0 (hnmb_rcnn.py:582-584)
+        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range, key_rois=key_rois,
+                    counts_dev=counts_dev, full_count=int(counts_h[0]) if counts_dev is not None else None)
+
+    def _c5_and_rois(self, xc, img_meta, proposals=None, speculate=False):
+        """res5 and the RPN proposals of the frames in xc -> (feats, proposal_list, rois [n,5], counts_dev, counts_h)."""
         if proposals is None:
             # The RPN branch (3x3 conv, heads, select / NMS: a few latency-bound workgroups) and res5 both
             # depend only on C4: run the RPN on a second HIP stream underneath res5.
@@ -259,14 +271,29 @@ class _WindowDetector(TwoStageDetector):
             counts_dev = None
             counts_h = [p.shape[0] for p in proposal_list]
             rois = bbox2roi([p for p in proposal_list])  # batch index = frame index
+        return feats, proposal_list, rois, counts_dev, counts_h
+
+    # ---- per-frame cache -------------------------------------------------------------------
+    # Everything up to the fc_new_1 rows is a function of ONE frame: res5, the RPN and its proposals, RoIAlign and
+    # fc_new_1 (hnmb_rcnn.py:195-222 recomputes them for all T frames of every window).  `frame_tensors` computes them
+    # once per frame, `forward_feat_frames` assembles a window from T such entries and runs only what mixes frames
+    # (the relation stages and the read-out).  Bit-identical to `forward_feat` on the same frames: every kernel on the
+    # per-frame part accumulates an output element in the same order whatever the batch size.
+    def frame_tensors(self, c4, img_meta):
+        """c4: the frame's backbone map [1,1024,h,w]; -> dict(props [mx,5], count [1] int32 device, f1 [mx,1024]).
+        The proposal count is not read here: a short frame (count < mx) is detected when the window is read out."""
+        feats, proposal_list, rois, counts_dev, _ = self._c5_and_rois(c4, [img_meta], None, speculate=True)
+        f1 = self.bbox_head.fc1_rows(self.get_roi_feat(feats, rois.contiguous()))
+        return dict(props=proposal_list[0], count=counts_dev, f1=f1, meta=img_meta)
+
+    def _frames_window(self, entries):
+        mx = entries[0]['props'].shape[0]
         key = self.key_dim
-        start = int(np.sum(counts_h[:key]))
-        cur_range = dict(start=start, length=int(counts_h[key]))
-        roi_feats = self.get_roi_feat(feats, rois.contiguous())
-        key_rois = rois[start:start + cur_range['length']].clone()
-        key_rois[:, 0] = 0  # the reference's rois carry batch index 0 (hnmb_rcnn.py:582-584)
-        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range, key_rois=key_rois,
-                    counts_dev=counts_dev, full_count=int(counts_h[0]) if counts_dev is not None else None)
+        f1 = torch.cat([e['f1'] for e in entries], dim=0)
+        cur_range = dict(start=key * mx, length=mx)
+        key_rois = torch.cat([entries[key]['props'].new_zeros((mx, 1)), entries[key]['props'][:, :4]], dim=1)
+        counts_dev = torch.cat([e['count'] for e in entries])
+        return f1, cur_range, key_rois, counts_dev, mx
 
     def simple_test_bboxes(self, x, img_meta, proposals, rcnn_test_cfg, rescale=False):
         raise NotImplementedError
@@ -302,6 +329,20 @@ class SelsaRCNN(_WindowDetector):
         return pending if defer else pending.result()
 
 
+    def forward_feat_frames(self, entries, c4s=None, rescale=False, defer=False):
+        """forward_feat from T cached `frame_tensors` entries; c4s (the frames' C4 maps) back the exact re-run that
+        replaces the speculative result when some frame kept fewer than nms_post proposals."""
+        f1, cur_range, key_rois, counts_dev, mx = self._frames_window(entries)
+        meta0 = entries[0]['meta']
+        cls_score, bbox_pred = self.bbox_head.forward_from_f1(f1, cur_range, key_dim=self.key_dim, all_res=False)[:2]
+        branch, _ = self.bbox_head.get_det_bboxes(key_rois, cls_score, bbox_pred, meta0['img_shape'], meta0['scale_factor'],
+                                                  rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
+        metas = [e['meta'] for e in entries]
+        pending = PendingWindow([branch], counts_dev, mx, self.bbox_head.num_classes,
+                                lambda: self.forward_feat(c4s, metas, None, rescale, speculate=False), single=True)
+        return pending if defer else pending.result()
+
+
 @DETECTORS.register_module
 class HNMBRCNN(_WindowDetector):
 
@@ -327,4 +368,16 @@ class HNMBRCNN(_WindowDetector):
                                                     defer=True)
         pending = PendingWindow(branches, w['counts_dev'], w['full_count'], self.bbox_head.num_classes,
                                 lambda: self.forward_feat(x, img_meta, proposals, rescale, speculate=False))
+        return pending if defer else pending.result()
+
+    def forward_feat_frames(self, entries, c4s=None, rescale=False, defer=False):
+        """forward_feat from T cached `frame_tensors` entries (see _WindowDetector.frame_tensors)."""
+        f1, cur_range, key_rois, counts_dev, mx = self._frames_window(entries)
+        meta0 = entries[0]['meta']
+        cls_score, bbox_pred = self.bbox_head.forward_from_f1(f1, [cur_range], key_dim=self.key_dim, all_res=False)
+        branches, _ = self.bbox_head.get_det_bboxes(key_rois, cls_score, bbox_pred, meta0['img_shape'], meta0['scale_factor'],
+                                                    rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
+        metas = [e['meta'] for e in entries]
+        pending = PendingWindow(branches, counts_dev, mx, self.bbox_head.num_classes,
+                                lambda: self.forward_feat(c4s, metas, None, rescale, speculate=False))
         return pending if defer else pending.result()

@@ -422,6 +422,33 @@ def test_deferred_window_equals_the_exact_path_and_respeculates_on_ragged_counts
         assert pend.result() is got  # idempotent
 
 
+# ------------------------------------------------------------------------------- per-frame cache
+@pytest.mark.parametrize('kind', ['selsa', 'hvr'])
+def test_cached_frame_loop_matches_clip_mode(kind):
+    """VideoWindowRunner(cache_frames=True) computes res5 / RPN / RoIAlign / fc_new_1 once per frame and runs a window
+    on the cached rows; the per-class detection arrays must equal the uncached loop's bit for bit, including the
+    padded first / last windows of the video (repeated deque entries)."""
+    from hvrnet_amd.window import VideoWindowRunner
+    cfgf = selsa_config if kind == 'selsa' else hvr_config
+    hw, pad, n_prop, fi = (150, 250), (160, 256), 24, 2
+    model = hvrnet_amd.build_model(cfgf(frame_interval=fi, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    frames = [S.synth_frame(i, img_hw=hw, pad_hw=pad).to(DEV) for i in range(8)]
+    metas = [S.synth_meta(hw, pad) for _ in frames]
+    with torch.no_grad():
+        plain = VideoWindowRunner(model, 2 * fi + 1).run_video(frames, metas)
+        cached = VideoWindowRunner(model, 2 * fi + 1, cache_frames=True).run_video(frames, metas)
+    assert sorted(plain) == sorted(cached) == list(range(len(frames)))
+    n_det = 0
+    for off in plain:
+        a, b = plain[off], cached[off]
+        branches = zip(a, b) if kind == 'hvr' else [(a, b)]
+        for ra, rb in branches:
+            for ca, cb in zip(ra, rb):
+                assert np.array_equal(np.asarray(ca), np.asarray(cb)), 'frame %d differs' % off
+                n_det += len(ca)
+    assert n_det > 0
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_T15_N300():
     """BASELINE sizes (M = 4500, D = 1024): size-independent properties of the relation kernel."""

@@ -15,6 +15,8 @@
 
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
+hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
+hipError_t run_relation_dscore(const void*, const void*, const void*, const void*, void*, int, long, int, long, long, float, int, hipStream_t);
 hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_cast(const void*, void*, long, int, int, hipStream_t);
@@ -215,6 +217,41 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
 #endif
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
+}
+
+// ---- relation backward (attention backward of one stage) ----
+size_t hvr_relation_probs_workspace_bytes(int Mq, int Mk) {
+  const long nt = rel_ldp(Mk) / 128;
+  return 2 * align256((size_t)Mq * nt * 4);
+}
+
+int hvr_relation_probs(const void* Q, int64_t ldq, const void* K, int64_t ldk, void* P, int64_t ldp, int Mq, int Mk, int D,
+                       float scale, int dtype, int staging, void* ws, size_t ws_bytes, void* stream) {
+  if (!Q || !K || !P || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (Mq <= 0 || Mk <= 0) return fail(HVR_EINVAL, "empty relation Mq=%d Mk=%d", Mq, Mk);
+  if (!(scale > 0.f)) return fail(HVR_EINVAL, "relation scale must be positive, got %g", (double)scale);
+  if (ldp != rel_ldp(Mk)) return fail(HVR_EINVAL, "P rows must be %ld elements (keys padded to 128), got %ld", rel_ldp(Mk), (long)ldp);
+  if (ws_bytes < hvr_relation_probs_workspace_bytes(Mq, Mk)) return fail(HVR_EWORKSPACE, "relation probs workspace too small");
+  const int nt = (int)(ldp / 128);
+  float* mstat = (float*)ws;
+  float* lstat = (float*)((char*)ws + align256((size_t)Mq * nt * 4));
+  hipStream_t s = (hipStream_t)stream;
+  GemmParams p;
+  int rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
+  if (rc) return rc;
+  p.N = Mk;
+  p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
+  rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation probs: scores");
+  if (rc) return rc;
+  return check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, s), "relation probs: normalise");
+}
+
+int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t ldgo, const void* O, int64_t ldo, void* dS,
+                        int Mq, int64_t ldp, int D, float scale, int dtype, void* stream) {
+  if (!P || !dP || !dO || !O || !dS) return fail(HVR_EINVAL, "null pointer");
+  if (Mq <= 0 || D <= 0 || D % 4 || ldp % 4 || ldgo % 4 || ldo % 4) return fail(HVR_EINVAL, "bad relation dscore shape");
+  return check_launch(run_relation_dscore(P, dP, dO, O, dS, Mq, ldp, D, ldgo, ldo, scale, dtype, (hipStream_t)stream),
+                      "hvr_relation_dscore");
 }
 
 // ---- RoIAlign ----

@@ -207,6 +207,83 @@ __global__ __launch_bounds__(256) void transpose_pad_bf16x8_kernel(const bf16_t*
   }
 }
 
+// ---- relation backward helpers (attention backward of one relation stage; the products are tile-engine GEMMs) ----
+// P[m][:] *= 2^(m_t - m*) / L per 128-key block t: turns the score pass's block-relative exponentials into the softmax
+// probabilities (selsa_bbox_head.py:172, nn.Softmax(dim=2)); padding columns of P are zero and stay zero.
+template <typename T>
+__global__ __launch_bounds__(256) void relation_normalize_kernel(T* __restrict__ P, const float* __restrict__ mstat,
+                                                                 const float* __restrict__ lstat, int ntile, long ldp) {
+  __shared__ float g[128];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    float mx = -INFINITY;
+    for (int t = tid; t < ntile; t += 64) mx = fmaxf(mx, mstat[(long)m * ntile + t]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float l = 0.f;
+    for (int t = tid; t < ntile; t += 64) l += lstat[(long)m * ntile + t] * exp2f(mstat[(long)m * ntile + t] - mx);
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    for (int t = tid; t < ntile; t += 64) g[t] = exp2f(mstat[(long)m * ntile + t] - mx) / l;
+  }
+  __syncthreads();
+  T* row = P + (long)m * ldp;
+  for (long j = (long)tid * 4; j < ldp; j += 256 * 4) {
+    float v[4];
+    load4(row + j, v);
+    const float w = g[j >> 7];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= w;
+    store4(row + j, v);
+  }
+}
+
+// dS[m][:] = scale * P[m][:] * (dP[m][:] - sum_d dO[m][d] * O[m][d])   (softmax backward folded with the logit scale)
+template <typename T>
+__global__ __launch_bounds__(256) void relation_dscore_kernel(const T* __restrict__ P, const T* __restrict__ dP,
+                                                              const T* __restrict__ dO, const T* __restrict__ O,
+                                                              T* __restrict__ dS, long ldp, int D, long ldgo, long ldo,
+                                                              float scale) {
+  __shared__ float part[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  float acc = 0.f;
+  for (int d = tid * 4; d < D; d += 256 * 4) {
+    float a[4], b[4];
+    load4(dO + (long)m * ldgo + d, a);
+    load4(O + (long)m * ldo + d, b);
+    acc += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((tid & 63) == 0) part[tid >> 6] = acc;
+  __syncthreads();
+  const float delta = (part[0] + part[1]) + (part[2] + part[3]);
+  for (long j = (long)tid * 4; j < ldp; j += 256 * 4) {
+    float p[4], g[4], o[4];
+    load4(P + (long)m * ldp + j, p);
+    load4(dP + (long)m * ldp + j, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = scale * p[e] * (g[e] - delta);
+    store4(dS + (long)m * ldp + j, o);
+  }
+}
+
+hipError_t run_relation_normalize(void* P, const float* mstat, const float* lstat, int Mq, int ntile, long ldp, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(relation_normalize_kernel<bf16_t>, dim3(Mq), dim3(256), 0, s, (bf16_t*)P, mstat, lstat, ntile, ldp);
+  else
+    hipLaunchKernelGGL(relation_normalize_kernel<float>, dim3(Mq), dim3(256), 0, s, (float*)P, mstat, lstat, ntile, ldp);
+  return hipGetLastError();
+}
+
+hipError_t run_relation_dscore(const void* P, const void* dP, const void* dO, const void* O, void* dS, int Mq, long ldp, int D,
+                               long ldgo, long ldo, float scale, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(relation_dscore_kernel<bf16_t>, dim3(Mq), dim3(256), 0, s, (const bf16_t*)P, (const bf16_t*)dP,
+                       (const bf16_t*)dO, (const bf16_t*)O, (bf16_t*)dS, ldp, D, ldgo, ldo, scale);
+  else
+    hipLaunchKernelGGL(relation_dscore_kernel<float>, dim3(Mq), dim3(256), 0, s, (const float*)P, (const float*)dP, (const float*)dO,
+                       (const float*)O, (float*)dS, ldp, D, ldgo, ldo, scale);
+  return hipGetLastError();
+}
+
 hipError_t run_transpose_pad(const void* in, void* out, int R, int C, long ldx, long ldt, int dtype, hipStream_t s) {
   dim3 grid((C + 63) / 64, (int)((ldt + 63) / 64));
   const bool wide = dtype == DT_BF16 && C % 8 == 0 && ldx % 8 == 0 && ldt % 8 == 0 &&

@@ -75,6 +75,9 @@ SYMBOLS = {
     'hvr_stem_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'hvr_relation_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_relation_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    'hvr_relation_probs_workspace_bytes': (_sz, [_i, _i]),
+    'hvr_relation_probs': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    'hvr_relation_dscore': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _f, _i, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'hvr_nms_workspace_bytes': (_sz, [_i]),
@@ -321,6 +324,34 @@ def relation_fwd(q, k, v, scale, staging=None):
                                       Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging,
                                       _ptr(ws), ws.numel(), _stream()), 'hvr_relation_fwd')
     return o
+
+
+def relation_ldp(Mk):
+    """Row length of the relation's probability matrix: keys padded to a multiple of 128."""
+    return (Mk + 127) // 128 * 128
+
+
+def relation_probs(q, k, scale, staging=None):
+    """softmax(scale * q @ k^T, dim=1) as a [Mq, ldp] matrix of q's dtype (padding columns zero)."""
+    _need_cuda(q, k)
+    Mq, D = q.shape
+    Mk = k.shape[0]
+    ldp = relation_ldp(Mk)
+    P = torch.empty((Mq, ldp), dtype=q.dtype, device=q.device)
+    ws = _workspace(lib().hvr_relation_probs_workspace_bytes(Mq, Mk), q.device, 'relation_probs')
+    _check(lib().hvr_relation_probs(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(P), ldp, Mq, Mk, D, float(scale), _dt(q),
+                                    STAGING if staging is None else staging, _ptr(ws), ws.numel(), _stream()), 'hvr_relation_probs')
+    return P
+
+
+def relation_dscore(P, dP, dO, O, scale):
+    """scale * P * (dP - rowsum(dO * O)): gradient w.r.t. the un-scaled logits q @ k^T, same shape / dtype as P."""
+    _need_cuda(P, dP, dO, O)
+    assert P.shape == dP.shape and P.is_contiguous() and dP.is_contiguous() and dO.stride(1) == 1 and O.stride(1) == 1
+    dS = torch.empty_like(P)
+    _check(lib().hvr_relation_dscore(_ptr(P), _ptr(dP), _ptr(dO), dO.stride(0), _ptr(O), O.stride(0), _ptr(dS), P.shape[0],
+                                     P.shape[1], dO.shape[1], float(scale), _dt(P), _stream()), 'hvr_relation_dscore')
+    return dS
 
 
 def roi_align_fwd(feat, rois, out_h, out_w, spatial_scale, sample_num, layout):

@@ -7,6 +7,7 @@ signatures and error behaviour:
   RoIAlign(out_size, spatial_scale, sample_num=0, use_torchvision=False)   roi_align/roi_align.py:59-87
   roi_align(features, rois, out_size, spatial_scale, sample_num)           roi_align/roi_align.py:56
   nms(dets, iou_thr, device_id=None) -> (dets[inds], inds)                  nms/nms_wrapper.py:8-61
+plus `relation(q, k, v, scale)`: the relation core as an autograd Function with a HIP backward (training path).
 CPU tensors raise NotImplementedError exactly like the reference's RoIAlign (roi_align.py:27-28);
 NMS follows the reference's CPU semantics (`IoU >= thr` suppresses, nms_cpu.cpp:55).
 """
@@ -83,6 +84,47 @@ class RoIAlign(nn.Module):
     def __repr__(self):
         return '%s(out_size=%s, spatial_scale=%s, sample_num=%s, use_torchvision=%s)' % (
             self.__class__.__name__, self.out_size, self.spatial_scale, self.sample_num, self.use_torchvision)
+
+
+class RelationFunction(Function):
+    """o = softmax(scale * q k^T) v with a HIP backward (the reference differentiates torch.bmm / nn.Softmax / torch.mm,
+    selsa_bbox_head.py:166-182, through autograd).  Backward = one score pass (probabilities recomputed, not stored),
+    one fused softmax-backward kernel and four tile-engine GEMMs:
+        dV = P^T dO      dP = dO V^T      dS = scale * P * (dP - rowsum(dO * O))      dQ = dS K      dK = dS^T Q
+    K-contiguous operands for the transposed products come from hvr_transpose_pad (zero-padded to the K-step)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        if not q.is_cuda:
+            raise NotImplementedError('the relation core runs on the GPU only (no CPU fallback)')
+        o = native.relation_fwd(q.contiguous(), k.contiguous(), v.contiguous(), scale)
+        ctx.save_for_backward(q, k, v, o)
+        ctx.scale = float(scale)
+        return o
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_o):
+        q, k, v, o = ctx.saved_tensors
+        q, k, v, go = q.contiguous(), k.contiguous(), v.contiguous(), grad_o.contiguous().to(q.dtype)
+        Mq, D = q.shape
+        Mk = k.shape[0]
+        step = 64 if q.dtype == torch.bfloat16 else 32              # K-step of the tile engine, in elements
+        ldq = (Mq + step - 1) // step * step
+        P = native.relation_probs(q, k, ctx.scale)                   # [Mq, ldp], padding columns zero
+        ldp = P.shape[1]
+        vp = v.new_zeros((ldp, D))                                   # V with zero rows for the padded keys
+        vp[:Mk] = v
+        dP = native.gemm(go, vp)                                     # [Mq, ldp]
+        dS = native.relation_dscore(P, dP, go, o, ctx.scale)         # [Mq, ldp]
+        go_t = native.transpose_pad(go, ldq)                         # [D, ldq]
+        dv = native.gemm(native.transpose_pad(P, ldq)[:Mk], go_t)    # P^T dO        -> [Mk, D]
+        dq = native.gemm(dS, native.transpose_pad(k, ldp))           # dS K          -> [Mq, D]
+        dk = native.gemm(native.transpose_pad(dS, ldq)[:Mk], native.transpose_pad(q, ldq))  # dS^T Q -> [Mk, D]
+        return dq, dk, dv, None
+
+
+relation = RelationFunction.apply
 
 
 def nms(dets, iou_thr, device_id=None):

@@ -101,6 +101,19 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
                      void* O, int64_t ldo, int Mq, int Mk, int D, float scale, int dtype, int staging,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of the relation core (training path; the reference gets it from autograd through
+ * torch.bmm / nn.Softmax / torch.mm, selsa_bbox_head.py:166-182).  Two pieces that are not plain GEMMs:
+ *   hvr_relation_probs : P = softmax(scale * Q K^T) as a [Mq][ldp] matrix in `dtype` (ldp = keys padded to 128, padding
+ *                        columns zero), the f32 logits never materialised;
+ *   hvr_relation_dscore: dS = scale * P * (dP - rowsum(dO * O))  (softmax backward, logit scale folded in).
+ * With them  dV = P^T dO,  dP = dO V^T,  dQ = dS K,  dK = dS^T Q  are hvr_gemm / hvr_transpose_pad calls
+ * (hvrnet_amd/ops.py: RelationFunction). */
+size_t hvr_relation_probs_workspace_bytes(int Mq, int Mk);
+int hvr_relation_probs(const void* Q, int64_t ldq, const void* K, int64_t ldk, void* P, int64_t ldp, int Mq, int Mk, int D,
+                       float scale, int dtype, int staging, void* ws, size_t ws_bytes, void* stream);
+int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t ldgo, const void* O, int64_t ldo, void* dS,
+                        int Mq, int64_t ldp, int D, float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * RoIAlign (legacy "+1" convention).  Replaces roi_align_cuda.forward / .backward:
  *   mmdet/ops/roi_align/src/roi_align_cuda.cpp:27-80, roi_align_kernel.cu:63-141,187-282.

@@ -120,6 +120,48 @@ def test_relation_window_size_big_tile_path(Mq, Mk):
     torch.testing.assert_close(ones.float(), torch.ones_like(ones.float()), rtol=0, atol=8e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Mq,Mk', [(96, 96), (200, 333), (333, 130)])
+def test_relation_backward_matches_autograd(Mq, Mk, dtype):
+    """ops.relation's HIP backward (score pass + fused softmax backward + four tile-engine GEMMs) against torch autograd
+    of the f64 statement of the same function, on the operands as stored (bf16-rounded inputs for the bf16 case)."""
+    from hvrnet_amd import ops
+    D = 1024
+    q, k, v = _rand((Mq, D), dtype, 51, 1.2), _rand((Mk, D), dtype, 52, 1.2), _rand((Mk, D), dtype, 53)
+    go = _rand((Mq, D), dtype, 54)
+    k[Mk - 2] = (q[3].float() * 2).to(dtype)                  # one peaky row
+    qr, kr, vr = [t.double().requires_grad_(True) for t in (q, k, v)]
+    ref = torch.softmax((qr @ kr.t()) / 32, dim=1) @ vr
+    ref.backward(go.double())
+    qd, kd, vd = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    out = ops.relation(qd, kd, vd, 1.0 / 32)
+    out.backward(go.to(DEV))
+    tol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(out.detach().float().cpu(), ref.detach().float(), **_tol(dtype))
+    for name, got, want in (('dq', qd.grad, qr.grad), ('dk', kd.grad, kr.grad), ('dv', vd.grad, vr.grad)):
+        assert got.shape == want.shape and got.dtype == dtype, name
+        scale = want.abs().max().item()
+        err = (got.float().cpu().double() - want).abs().max().item()
+        assert err <= tol['atol'] + tol['rtol'] * scale, '%s: max err %g (scale %g)' % (name, err, scale)
+
+
+def test_relation_backward_window_size_bf16():
+    """Window size (4 500 x 4 500): dV / dQ / dK of the HIP backward against a row / column sample of the f64 statement."""
+    from hvrnet_amd import ops
+    M, D = 4500, 1024
+    q, k, v = _rand((M, D), torch.bfloat16, 61, 1.2), _rand((M, D), torch.bfloat16, 62, 1.2), _rand((M, D), torch.bfloat16, 63)
+    go = _rand((M, D), torch.bfloat16, 64)
+    qd, kd, vd = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    ops.relation(qd, kd, vd, 1.0 / 32).backward(go.to(DEV))
+    # f64 reference on the device (the full 4 500 x 4 500 problem is cheap in f64 there)
+    qr, kr, vr = [t.to(DEV).double().requires_grad_(True) for t in (q, k, v)]
+    (torch.softmax((qr @ kr.t()) / 32, dim=1) @ vr).backward(go.to(DEV).double())
+    for name, got, want in (('dq', qd.grad, qr.grad), ('dk', kd.grad, kr.grad), ('dv', vd.grad, vr.grad)):
+        scale = want.abs().max().item()
+        err = (got.double() - want).abs().max().item()
+        assert torch.isfinite(got.float()).all() and err <= 3e-2 * scale + 1e-3, '%s: max err %g (scale %g)' % (name, err, scale)
+
+
 def test_maxpool_and_stem_patches():
     x = _rand((2, 64, 21, 30), torch.float32, 31)
     ref = F.max_pool2d(x, 3, 2, 1)

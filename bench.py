@@ -16,6 +16,7 @@ Extra JSON keys: `roofline` (relation core, measured with HIP events inside the 
 region) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--proposals', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--inflight', type=int, default=int(os.environ.get('HVR_INFLIGHT', '1')),
+                    help='independent windows enqueued on that many HIP streams in turn (throughput mode)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
     return ap.parse_args()
 
@@ -134,10 +137,19 @@ def main():
     metas = [S.synth_meta() for _ in range(T)]
     n_keys = []
 
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 else [None]
+    if args.inflight > 1 and 'HVR_FRAME_GROUPS' not in os.environ:
+        type(model).frame_groups = 1  # the second stream's work comes from the other window instead
+    turn = [0]
+
     def step(prev=None):
         """Enqueues one window; collects the PREVIOUS window's results afterwards (its single host sync), so the host is
-        never waiting on the window it has just launched.  Every window's results are read inside the timed region."""
-        with torch.no_grad():
+        never waiting on the window it has just launched.  Every window's results are read inside the timed region.
+        With --inflight N > 1 consecutive windows go to N HIP streams in turn: they are independent clips, and the
+        latency-bound phases of one (proposals, read-out) run under the dense phases of another."""
+        lane = lanes[turn[0] % len(lanes)]
+        turn[0] += 1
+        with torch.no_grad(), (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
             c4 = model(img=frames, img_meta=metas, backbone_feat=True)[0]       # backbone on all T frames
             pend = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, defer=True)
         if prev is not None:
@@ -207,6 +219,30 @@ def main():
     sync()
     cached_loop_fps = n_loop / (time.perf_counter() - t2)
 
+    # clip mode again with TWO independent windows in flight on two HIP streams (frame groups off): the latency-bound
+    # phases of one window (proposals, read-out) run under the dense phases of the other.  Reported beside the headline:
+    # the headline run stays single-lane so that the HIP-event times around the relation core are that kernel's own
+    overlap2_fps = None
+    if args.inflight == 1 and world == 1:
+        lanes[:] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        groups0 = type(model).frame_groups
+        type(model).frame_groups = 1
+        pend = None
+        for _ in range(2):
+            pend = step(pend)
+        pend.result()
+        sync()
+        n2 = max(4, min(args.steps, 12))
+        t3 = time.perf_counter()
+        pend = None
+        for _ in range(n2):
+            pend = step(pend)
+        pend.result()
+        sync()
+        overlap2_fps = n2 / (time.perf_counter() - t3)
+        lanes[:] = [None]
+        type(model).frame_groups = groups0
+
     # per-class breakdown from one extra, fully instrumented window (outside the timed region)
     native.profile_begin(tags=('*',))
     step()
@@ -252,12 +288,16 @@ def main():
                                else 'configs[1]: faster_rcnn_r101_selsa_c5 inference, clip mode',
                                frames_per_window=T, proposals_per_frame=n_prop, input='3x600x1000 padded to 608x1008',
                                mode='clip (all T frames through backbone+res5+RPN+RoIAlign+head every step)',
-                               parallelism='dp%d independent clips, no collectives' % world, key_frame_detections=n_det),
+                               parallelism='dp%d independent clips, no collectives' % world, windows_in_flight=args.inflight,
+                               key_frame_detections=n_det),
                    roofline=roofline, kernel_classes=kc,
                    ref_loop=dict(frames_per_s_per_gpu=round(ref_loop_fps, 2), steps=n_loop,
                                  what='tools/test.py steady state: 1 new backbone frame + res5/RPN/RoIAlign/head on all T per output frame'),
                    cached_loop=dict(frames_per_s_per_gpu=round(cached_loop_fps, 2), steps=n_loop,
                                     what='the same loop with per-frame caching of res5/RPN/RoIAlign/fc_new_1 (identical detections)'))
+        if overlap2_fps is not None:
+            out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2),
+                                        what='clip mode, two independent windows in flight on two HIP streams (--inflight 2)')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.head, T, n_prop, sd)
         print(json.dumps(out))

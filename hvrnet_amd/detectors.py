@@ -122,7 +122,7 @@ class TwoStageDetector(BaseDetector):
 
     def _group_streams(self, device, n):
         pool = self.__dict__.setdefault('_gstreams', {})
-        key = str(device)
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # helper streams belong to one main stream
         while len(pool.setdefault(key, [])) < n:
             pool[key].append(torch.cuda.Stream(device=device))
         return pool[key][:n]
@@ -206,7 +206,7 @@ class _WindowDetector(TwoStageDetector):
 
     def _side_stream(self, device):
         streams = self.__dict__.setdefault('_side_streams', {})
-        key = str(device)
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # one RPN side stream per main stream
         if key not in streams:
             streams[key] = torch.cuda.Stream(device=device)
         return streams[key]

@@ -302,7 +302,8 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, tag):
-    key = (tag, device)
+    # one buffer per (use, stream): windows enqueued on different HIP streams run concurrently and must not share scratch
+    key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

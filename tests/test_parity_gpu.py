@@ -449,6 +449,35 @@ def test_cached_frame_loop_matches_clip_mode(kind):
     assert n_det > 0
 
 
+def test_two_windows_in_flight_on_two_streams_match_sequential():
+    """bench.py --inflight 2 enqueues independent windows on two HIP streams: scratch buffers and helper streams are
+    per stream, so the interleaved windows must reproduce their sequential results bit for bit."""
+    hw, pad, n_prop, fi = (150, 250), (160, 256), 24, 2
+    T = 2 * fi + 1
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=fi, nms_post=n_prop), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    clips = [torch.cat([S.synth_frame(100 * c + i, img_hw=hw, pad_hw=pad) for i in range(T)], 0).to(DEV) for c in range(4)]
+    metas = [S.synth_meta(hw, pad) for _ in range(T)]
+
+    def window(frames, defer):
+        c4 = model(img=frames, img_meta=metas, backbone_feat=True)[0]
+        return model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, defer=defer)
+
+    with torch.no_grad():
+        want = [window(c, False) for c in clips]
+        torch.cuda.synchronize()
+        lanes = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+        pend = []
+        for rep in range(3):                                  # several rounds: buffers are reused while the other lane runs
+            for i, c in enumerate(clips):
+                with torch.cuda.stream(lanes[i % 2]):
+                    pend.append((i, window(c, True)))
+        got = [(i, p.result()) for i, p in pend]
+    for i, res in got:
+        for ba, bb in zip(want[i], res):
+            for ca, cb in zip(ba, bb):
+                assert np.array_equal(np.asarray(ca), np.asarray(cb)), 'clip %d differs under concurrency' % i
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_T15_N300():
     """BASELINE sizes (M = 4500, D = 1024): size-independent properties of the relation kernel."""

@@ -61,3 +61,18 @@ def det_case(r=300, ncls=31, seed=203):
 
 def small_image(seed=204):
     return torch.randn((1, 3, 64, 96), generator=_gen(seed)) * 50.0
+
+
+def head_train_case(n=32, ncls=31, seed=205):
+    """Targets for the key frame's n sampled RoIs of the SELSA head's training step (bbox_head.py:87-130 argument order:
+    labels, label_weights, bbox_targets, bbox_weights): a third of the RoIs are positives (class 1..30, weight-1 boxes)."""
+    g = _gen(seed)
+    labels = torch.zeros(n, dtype=torch.long)
+    npos = n // 3
+    labels[:npos] = torch.randint(1, ncls, (npos,), generator=g)
+    label_weights = torch.ones(n)
+    bbox_targets = torch.zeros(n, 4)
+    bbox_targets[:npos] = torch.randn((npos, 4), generator=g) * 0.8   # both branches of the smooth-L1 (|d| < 1 and > 1)
+    bbox_weights = torch.zeros(n, 4)
+    bbox_weights[:npos] = 1.0
+    return labels, label_weights, bbox_targets, bbox_weights

@@ -247,6 +247,29 @@ def main():
     save('g6_selsa_head', cls=cls_s, reg=reg_s)
     save('g7_hvr_head', cls_branch=cls_h[0], cls=cls_h[1], reg_branch=reg_h[0], reg=reg_h[1])
 
+    # ---- G11 SELSA head training step: forward, BBoxHead.loss (bbox_head.py:100-130), backward through the reference
+    # modules (selsa_rcnn.py:201,242-243: `bbox_head(bbox_feats_cat, cur_range)` then `bbox_head.loss(cls, reg, *targets)`) ----
+    labels, label_w, bbox_t, bbox_w = C.head_train_case()
+    selsa.zero_grad()
+    feats_g = feats.clone().requires_grad_(True)
+    cls_t, reg_t, _ = selsa(feats_g, cur_range=cur, key_dim=1)
+    losses = selsa.loss(cls_t, reg_t, labels, label_w, bbox_t, bbox_w)
+    (losses['loss_cls'] + losses['loss_bbox']).backward()
+    g11 = dict(loss_cls=losses['loss_cls'].detach(), loss_bbox=losses['loss_bbox'].detach(), acc=losses['acc'].detach(),
+               d_feats_sum=feats_g.grad.double().sum(), d_feats_abs=feats_g.grad.double().abs().sum(),
+               d_feats_sample=feats_g.grad.reshape(-1)[::4099].clone())
+    for name, prm in selsa.named_parameters():
+        gr = prm.grad
+        key = name.replace('.', '__')
+        g11['sum__' + key] = gr.double().sum()
+        g11['abs__' + key] = gr.double().abs().sum()
+        if gr.numel() <= 40000:
+            g11['full__' + key] = gr.clone()
+        else:
+            g11['sample__' + key] = gr.reshape(-1)[::4099].clone()
+    save('g11_selsa_train', **g11)
+    selsa.zero_grad()
+
     # ---- G8 get_det_bboxes + multiclass_nms (bbox_head.py:132-169, bbox_nms.py) ----
     rois8, cls8, reg8 = C.det_case()
     rcnn_cfg = AttrDict(score_thr=0.001, nms=AttrDict(type='nms', iou_thr=0.3), max_per_img=300)

@@ -147,6 +147,29 @@ def test_g6_g7_heads(O):
     close(reg_l[1], g7['reg'], 1e-4, 1e-4)
 
 
+def test_g11_selsa_head_training_step(O):
+    """Losses and every parameter gradient of one SELSA-head training step against the reference modules' own
+    loss() + backward() (G11): small tensors element for element, large ones by sum / abs-sum / a strided sample."""
+    g = gold('g11_selsa_train')
+    labels, lw, bt, bw = C.head_train_case()
+    losses, grads, dx = O.selsa_head_train_step(C.roi_feat_input(), S.synth_state_dict('selsa'), dict(start=32, length=32), 32, 3,
+                                                labels, lw, bt, bw)
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        close(losses[k], g[k], 1e-5, 1e-6)
+    close(dx.reshape(-1)[::4099], g['d_feats_sample'], 1e-4, 1e-7)
+    assert abs(float(dx.double().abs().sum()) - float(g['d_feats_abs'])) <= 1e-4 * float(g['d_feats_abs'])
+    seen = 0
+    for name, gr in grads.items():
+        key = name.replace('.', '__')
+        assert abs(float(gr.double().abs().sum()) - float(g['abs__' + key])) <= 1e-4 * float(g['abs__' + key]) + 1e-9, name
+        if 'full__' + key in g.files:
+            close(gr, g['full__' + key], 1e-4, 1e-6)
+        else:
+            close(gr.reshape(-1)[::4099], g['sample__' + key], 1e-4, 1e-7)
+        seen += 1
+    assert seen == 20  # fc_new_1/2, two relation stages (q, k, out), fc_cls, fc_reg: weights and biases
+
+
 def test_g8_det_readout(O):
     g = gold('g8_det')
     rois, cls, reg = C.det_case()

@@ -233,6 +233,41 @@ class SelsaBBoxHead(_RelationHead):
         return cls, reg, None
 
 
+    # ---- training step (f32 parameters; selsa_rcnn.py:201,242-243) ------------------------------------------
+    def forward_train(self, bbox_feat, cur_range):
+        """The head's forward as an autograd graph of HIP ops (train_ops.linear / ops.relation): -> f32 logits [l, 36] of
+        the key frame's rows, class logits in columns 0..num_classes-1, box deltas in the next 4 (fused fc_cls | fc_reg)."""
+        from . import ops, train_ops as TO
+        if self.compute_dtype != torch.float32:
+            raise NotImplementedError('the training step runs the f32 path (set_compute_dtype(model, torch.float32))')
+        s, l = int(cur_range['start']), int(cur_range['length'])
+        scale = 1.0 / math.sqrt(float(self.dim[1]))
+        x = bbox_feat.contiguous().view(bbox_feat.size(0), -1)      # (c, ph, pw) order, as the reference flattens
+
+        def stage(k, f):
+            sel = getattr(self, 'selsa_%d' % k)
+            q = TO.linear(f, sel['q_data_fc_%d' % k].weight, sel['q_data_fc_%d' % k].bias)
+            kk = TO.linear(f, sel['k_data_fc_%d' % k].weight, sel['k_data_fc_%d' % k].bias)
+            o = ops.relation(q, kk, f, scale)
+            z = sel['linear_out_%d' % k]
+            return TO.linear(o, z.weight.view(z.weight.shape[0], -1), z.bias, resid=f, relu=True)
+
+        f1 = TO.linear(x, self.fc_new_1.weight, self.fc_new_1.bias)
+        h1 = stage(1, f1)
+        f2 = TO.linear(h1, self.fc_new_2.weight, self.fc_new_2.bias)
+        h2 = stage(2, f2)[s:s + l]
+        nc = self.num_classes
+        w = torch.cat([self.fc_cls.weight, self.fc_reg.weight, self.fc_cls.weight.new_zeros((-(nc + 4) % 4, self.fc_cls.weight.shape[1]))], 0)
+        b = torch.cat([self.fc_cls.bias, self.fc_reg.bias, self.fc_cls.bias.new_zeros(-(nc + 4) % 4)], 0)
+        return TO.linear(h2.contiguous(), w, b)
+
+    def loss_train(self, logits, labels, label_weights, bbox_targets, bbox_weights):
+        """BBoxHead.loss on forward_train's fused logits (bbox_head.py:100-130) -> dict(loss_cls, loss_bbox, acc, total)."""
+        from . import train_ops as TO
+        nc = self.num_classes
+        return TO.det_loss(logits, 0, nc, nc, labels, label_weights, bbox_targets, bbox_weights, beta=1.0)
+
+
 @HEADS.register_module
 class HRNMPBBoxHead(_RelationHead):
     NUM_STAGES = 4

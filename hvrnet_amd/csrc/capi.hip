@@ -16,6 +16,10 @@
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
+hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
+hipError_t run_colsum(const void*, float*, int, int, long, int, hipStream_t);
+hipError_t run_det_loss(const float*, int, int, int, int, const long long*, const float*, const float*, const float*, int, float, float,
+                        float, float*, float*, hipStream_t);
 hipError_t run_relation_dscore(const void*, const void*, const void*, const void*, void*, int, long, int, long, long, float, int, hipStream_t);
 hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -252,6 +256,29 @@ int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t l
   if (Mq <= 0 || D <= 0 || D % 4 || ldp % 4 || ldgo % 4 || ldo % 4) return fail(HVR_EINVAL, "bad relation dscore shape");
   return check_launch(run_relation_dscore(P, dP, dO, O, dS, Mq, ldp, D, ldgo, ldo, scale, dtype, (hipStream_t)stream),
                       "hvr_relation_dscore");
+}
+
+// ---- head training helpers ----
+int hvr_relu_bwd(const void* dY, const void* Y, void* dZ, int64_t n, int dtype, void* stream) {
+  if (n == 0) return HVR_OK;
+  if (!dY || !Y || !dZ || n < 0 || n % 4) return fail(HVR_EINVAL, "bad relu_bwd arguments (n %% 4 == 0 required)");
+  return check_launch(run_relu_bwd(dY, Y, dZ, n, dtype, (hipStream_t)stream), "hvr_relu_bwd");
+}
+
+int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, void* stream) {
+  if (!dY || !db || M <= 0 || N <= 0) return fail(HVR_EINVAL, "bad colsum arguments");
+  return check_launch(run_colsum(dY, db, M, N, ld, dtype, (hipStream_t)stream), "hvr_colsum");
+}
+
+int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels, const float* label_weights,
+                 const float* bbox_targets, const float* bbox_weights, int R, float beta, float w_cls, float w_bbox, float* out3,
+                 float* dlogits, void* stream) {
+  if (!logits || !labels || !label_weights || !bbox_targets || !bbox_weights || !out3 || !dlogits) return fail(HVR_EINVAL, "null pointer");
+  if (R <= 0 || ncls <= 1 || cls_off < 0 || reg_off < 0 || cls_off + ncls > ldl || reg_off + 4 > ldl || !(beta > 0.f))
+    return fail(HVR_EINVAL, "bad det_loss shape");
+  return check_launch(run_det_loss(logits, ldl, cls_off, reg_off, ncls, (const long long*)labels, label_weights, bbox_targets,
+                                   bbox_weights, R, beta, w_cls, w_bbox, out3, dlogits, (hipStream_t)stream),
+                      "hvr_det_loss");
 }
 
 // ---- RoIAlign ----

@@ -265,6 +265,118 @@ __global__ __launch_bounds__(256) void relation_dscore_kernel(const T* __restric
   }
 }
 
+// ---- training-path helpers (head backward) ----
+// dZ = dY where Y > 0 else 0: backward of the ReLU fused into a GEMM epilogue (Y is that epilogue's output)
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ Y, T* __restrict__ dZ, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    float g[4], y[4];
+    load4(dY + i, g);
+    load4(Y + i, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+    store4(dZ + i, g);
+  }
+}
+
+// db[n] = sum_m dY[m][n] (f32): bias gradient of a linear layer; 64 columns per workgroup, fixed summation order
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, float* __restrict__ db, int M, int N, long ld) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < N)
+    for (int m = r0; m < M; m += 4) acc += ElemTraits<T>::load(dY + (long)m * ld + c);
+  part[r0][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (r0 == 0 && c < N) db[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// BBoxHead.loss for class-agnostic regression (bbox_heads/bbox_head.py:100-130): softmax cross entropy over ncls logits
+// (row weight, sum / avg_cls), smooth-L1(beta) on the rows with label > 0 (element weight, sum / R), top-1 accuracy in
+// percent, and the gradient of  w_cls * loss_cls + w_bbox * loss_bbox  w.r.t. the logit matrix [R][ldl] whose columns
+// cls_off .. +ncls are class logits and reg_off .. +4 box deltas.  One workgroup, fixed reduction order.
+__global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__ logits, int ldl, int cls_off, int reg_off, int ncls,
+                                                       const long long* __restrict__ labels, const float* __restrict__ label_w,
+                                                       const float* __restrict__ bbox_t, const float* __restrict__ bbox_w, int R,
+                                                       float beta, float w_cls, float w_bbox, float* __restrict__ out3,
+                                                       float* __restrict__ dlogits) {
+  __shared__ float red[3][256];
+  __shared__ float sh_avg;
+  const int tid = threadIdx.x;
+  float npos = 0.f;
+  for (int r = tid; r < R; r += 256) npos += label_w[r] > 0.f ? 1.f : 0.f;
+  red[0][tid] = npos;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[0][tid] += red[0][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) sh_avg = fmaxf(red[0][0], 1.f);
+  __syncthreads();
+  const float avg = sh_avg;
+  __syncthreads();
+  float lc = 0.f, lb = 0.f, hit = 0.f;
+  for (int r = tid; r < R; r += 256) {
+    const float* row = logits + (long)r * ldl;
+    float* drow = dlogits + (long)r * ldl;
+    const int lab = (int)labels[r];
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < ncls; ++c) {
+      const float v = row[cls_off + c];
+      if (v > mx) { mx = v; arg = c; }
+    }
+    float se = 0.f;
+    for (int c = 0; c < ncls; ++c) se += expf(row[cls_off + c] - mx);
+    const float lse = mx + logf(se), w = label_w[r];
+    lc += (lse - row[cls_off + lab]) * w;
+    hit += arg == lab ? 1.f : 0.f;
+    for (int c = 0; c < ldl; ++c) drow[c] = 0.f;
+    for (int c = 0; c < ncls; ++c)
+      drow[cls_off + c] = w_cls * w / avg * (expf(row[cls_off + c] - lse) - (c == lab ? 1.f : 0.f));
+    if (lab > 0) {
+      for (int e = 0; e < 4; ++e) {
+        const float d = row[reg_off + e] - bbox_t[r * 4 + e], a = fabsf(d), bw = bbox_w[r * 4 + e];
+        lb += (a < beta ? 0.5f * a * a / beta : a - 0.5f * beta) * bw;
+        drow[reg_off + e] = w_bbox * bw / (float)R * (a < beta ? d / beta : (d > 0.f ? 1.f : -1.f));
+      }
+    }
+  }
+  red[0][tid] = lc; red[1][tid] = lb; red[2][tid] = hit;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out3[0] = red[0][0] / avg;
+    out3[1] = red[1][0] / (float)R;
+    out3[2] = red[2][0] * (100.f / (float)R);
+  }
+}
+
+hipError_t run_relu_bwd(const void* dY, const void* Y, void* dZ, long n, int dtype, hipStream_t s) {
+  const int g = grid_for((n + 3) / 4, 256);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dY, (const bf16_t*)Y, (bf16_t*)dZ, n);
+  else hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dY, (const float*)Y, (float*)dZ, n);
+  return hipGetLastError();
+}
+
+hipError_t run_colsum(const void* dY, float* db, int M, int N, long ld, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, s, (const bf16_t*)dY, db, M, N, ld);
+  else hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)dY, db, M, N, ld);
+  return hipGetLastError();
+}
+
+hipError_t run_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const long long* labels, const float* label_w,
+                        const float* bbox_t, const float* bbox_w, int R, float beta, float w_cls, float w_bbox, float* out3,
+                        float* dlogits, hipStream_t s) {
+  hipLaunchKernelGGL(det_loss_kernel, dim3(1), dim3(256), 0, s, logits, ldl, cls_off, reg_off, ncls, labels, label_w, bbox_t, bbox_w, R,
+                     beta, w_cls, w_bbox, out3, dlogits);
+  return hipGetLastError();
+}
+
 hipError_t run_relation_normalize(void* P, const float* mstat, const float* lstat, int Mq, int ntile, long ldp, int dtype, hipStream_t s) {
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(relation_normalize_kernel<bf16_t>, dim3(Mq), dim3(256), 0, s, (bf16_t*)P, mstat, lstat, ntile, ldp);

@@ -78,6 +78,9 @@ SYMBOLS = {
     'hvr_relation_probs_workspace_bytes': (_sz, [_i, _i]),
     'hvr_relation_probs': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     'hvr_relation_dscore': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _f, _i, _vp]),
+    'hvr_relu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
+    'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'hvr_nms_workspace_bytes': (_sz, [_i]),
@@ -353,6 +356,38 @@ def relation_dscore(P, dP, dO, O, scale):
     _check(lib().hvr_relation_dscore(_ptr(P), _ptr(dP), _ptr(dO), dO.stride(0), _ptr(O), O.stride(0), _ptr(dS), P.shape[0],
                                      P.shape[1], dO.shape[1], float(scale), _dt(P), _stream()), 'hvr_relation_dscore')
     return dS
+
+
+def relu_bwd(dy, y):
+    """dy where y > 0 else 0 (y: the output of a GEMM epilogue with relu=True)."""
+    _need_cuda(dy, y)
+    dy, y = dy.contiguous(), y.contiguous()
+    assert dy.shape == y.shape and dy.dtype == y.dtype and dy.numel() % 4 == 0
+    dz = torch.empty_like(dy)
+    _check(lib().hvr_relu_bwd(_ptr(dy), _ptr(y), _ptr(dz), dy.numel(), _dt(dy), _stream()), 'hvr_relu_bwd')
+    return dz
+
+
+def colsum(dy):
+    """[M, N] -> f32 [N] column sums (bias gradient)."""
+    _need_cuda(dy)
+    assert dy.dim() == 2 and dy.stride(1) == 1
+    db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+    _check(lib().hvr_colsum(_ptr(dy), _ptr(db), dy.shape[0], dy.shape[1], dy.stride(0), _dt(dy), _stream()), 'hvr_colsum')
+    return db
+
+
+def det_loss(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, beta=1.0, w_cls=1.0, w_bbox=1.0):
+    """BBoxHead.loss on a fused [R, ld] f32 logit matrix -> (out3 = [loss_cls, loss_bbox, acc] f32, dlogits [R, ld] f32)."""
+    _need_cuda(logits, labels, label_weights, bbox_targets, bbox_weights)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and labels.dtype == torch.long
+    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    _check(lib().hvr_det_loss(_ptr(logits), logits.shape[1], cls_off, reg_off, ncls, _ptr(labels.contiguous()),
+                              _ptr(label_weights.float().contiguous()), _ptr(bbox_targets.float().contiguous()),
+                              _ptr(bbox_weights.float().contiguous()), logits.shape[0], float(beta), float(w_cls), float(w_bbox),
+                              _ptr(out3), _ptr(dlogits), _stream()), 'hvr_det_loss')
+    return out3, dlogits
 
 
 def roi_align_fwd(feat, rois, out_h, out_w, spatial_scale, sample_num, layout):

@@ -114,6 +114,19 @@ int hvr_relation_probs(const void* Q, int64_t ldq, const void* K, int64_t ldk, v
 int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t ldgo, const void* O, int64_t ldo, void* dS,
                         int Mq, int64_t ldp, int D, float scale, int dtype, void* stream);
 
+/* Head training helpers.  The reference gets all of these from autograd:
+ *   hvr_relu_bwd : dZ = dY where Y > 0 (ReLU fused into a GEMM epilogue; Y is that epilogue's output);
+ *   hvr_colsum   : db[n] = sum_m dY[m][n]  (bias gradient, f32);
+ *   hvr_det_loss : BBoxHead.loss for class-agnostic boxes (mmdet/models/bbox_heads/bbox_head.py:100-130 with
+ *                  losses/cross_entropy_loss.py:9-20, losses/smooth_l1_loss.py:9-18, losses/accuracy.py:4-21):
+ *                  out3 = (loss_cls, loss_bbox, acc) and dlogits = d(w_cls*loss_cls + w_bbox*loss_bbox)/d logits for a
+ *                  logit matrix [R][ldl] holding ncls class logits at cls_off and 4 box deltas at reg_off. */
+int hvr_relu_bwd(const void* dY, const void* Y, void* dZ, int64_t n, int dtype, void* stream);
+int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, void* stream);
+int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels, const float* label_weights,
+                 const float* bbox_targets, const float* bbox_weights, int R, float beta, float w_cls, float w_bbox, float* out3,
+                 float* dlogits, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * RoIAlign (legacy "+1" convention).  Replaces roi_align_cuda.forward / .backward:
  *   mmdet/ops/roi_align/src/roi_align_cuda.cpp:27-80, roi_align_kernel.cu:63-141,187-282.

@@ -161,6 +161,10 @@ def test_g11_selsa_head_training_step(O):
     seen = 0
     for name, gr in grads.items():
         key = name.replace('.', '__')
+        if 'k_data_fc' in name and name.endswith('bias'):  # analytically zero (softmax is shift-invariant): round-off only
+            assert float(gr.double().abs().sum()) <= 1e-4 * float(g['abs__' + key.replace('k_data_fc', 'q_data_fc')]), name
+            seen += 1
+            continue
         assert abs(float(gr.double().abs().sum()) - float(g['abs__' + key])) <= 1e-4 * float(g['abs__' + key]) + 1e-9, name
         if 'full__' + key in g.files:
             close(gr, g['full__' + key], 1e-4, 1e-6)

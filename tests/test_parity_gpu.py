@@ -422,6 +422,49 @@ def test_deferred_window_equals_the_exact_path_and_respeculates_on_ragged_counts
         assert pend.result() is got  # idempotent
 
 
+# ------------------------------------------------------------------------------- training step of the SELSA head
+def test_selsa_head_training_step_matches_reference_golden():
+    """forward_train + loss_train + backward on the HIP path (exact-f32 MFMA GEMMs forward and backward, relation core
+    backward, fused loss kernel) against G11 = the reference modules' own loss() / backward(): the three loss outputs,
+    every parameter gradient (small tensors element for element, large ones by abs-sum and a strided sample) and the
+    gradient w.r.t. the RoI features."""
+    g = gold('g11_selsa_train')
+    head = hvrnet_amd.SelsaBBoxHead(sampler_num=32, t_dim=3, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    sd = {k[len('bbox_head.'):]: v for k, v in S.synth_state_dict('selsa').items() if k.startswith('bbox_head.')}
+    head.load_state_dict(sd, strict=True)
+    head = head.to(DEV)
+    hvrnet_amd.set_compute_dtype(head, torch.float32)
+    labels, lw, bt, bw = [t.to(DEV) for t in C.head_train_case()]
+    feats = C.roi_feat_input().to(DEV).requires_grad_(True)
+    logits = head.forward_train(feats, dict(start=32, length=32))
+    losses = head.loss_train(logits, labels, lw, bt, bw)
+    losses['total'].sum().backward()
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        close(losses[k], g[k], 2e-4, 1e-5)
+    close(feats.grad.reshape(-1)[::4099], g['d_feats_sample'], 2e-3, 1e-6)
+    assert abs(float(feats.grad.double().abs().sum()) - float(g['d_feats_abs'])) <= 1e-3 * float(g['d_feats_abs'])
+    seen = 0
+    for name, prm in head.named_parameters():
+        key = name.replace('.', '__')
+        assert prm.grad is not None, name
+        want_abs = float(g['abs__' + key])
+        if 'k_data_fc' in name and name.endswith('bias'):
+            # a bias on the keys shifts every logit of a row alike, so this gradient is analytically zero (the reference's
+            # 5e-6 is round-off): compare against the sibling query-bias gradient's size instead
+            q_abs = float(g['abs__' + key.replace('k_data_fc', 'q_data_fc')])
+            assert float(prm.grad.double().abs().sum()) <= 1e-3 * q_abs and want_abs <= 1e-3 * q_abs, name
+            seen += 1
+            continue
+        assert abs(float(prm.grad.double().abs().sum()) - want_abs) <= 1e-3 * want_abs + 1e-8, name
+        scale = want_abs / prm.numel()
+        if 'full__' + key in g.files:
+            close(prm.grad, g['full__' + key], 2e-3, 2e-3 * scale + 1e-9)
+        else:
+            close(prm.grad.reshape(-1)[::4099], g['sample__' + key], 2e-3, 2e-3 * scale + 1e-9)
+        seen += 1
+    assert seen == 20
+
+
 # ------------------------------------------------------------------------------- per-frame cache
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):

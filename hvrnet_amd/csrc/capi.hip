@@ -17,6 +17,7 @@ namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
+hipError_t run_sgd_step(float*, const float*, float*, long, float, float, float, float, float, float*, int, hipStream_t);
 hipError_t run_colsum(const void*, float*, int, int, long, int, hipStream_t);
 hipError_t run_det_loss(const float*, int, int, int, int, const long long*, const float*, const float*, const float*, int, float, float,
                         float, float*, float*, hipStream_t);
@@ -258,6 +259,8 @@ int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t l
                       "hvr_relation_dscore");
 }
 
+size_t hvr_sgd_workspace_bytes(void) { return 256 * sizeof(float); }
+
 // ---- head training helpers ----
 int hvr_relu_bwd(const void* dY, const void* Y, void* dZ, int64_t n, int dtype, void* stream) {
   if (n == 0) return HVR_OK;
@@ -279,6 +282,16 @@ int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncl
   return check_launch(run_det_loss(logits, ldl, cls_off, reg_off, ncls, (const long long*)labels, label_weights, bbox_targets,
                                    bbox_weights, R, beta, w_cls, w_bbox, out3, dlogits, (hipStream_t)stream),
                       "hvr_det_loss");
+}
+
+int hvr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                 float grad_scale, float max_norm, float* ws, size_t ws_bytes, int first_step, void* stream) {
+  if (n == 0) return HVR_OK;
+  if (!param || !grad || !momentum_buf || !ws || n < 0) return fail(HVR_EINVAL, "bad sgd_step arguments");
+  if (ws_bytes < hvr_sgd_workspace_bytes()) return fail(HVR_EWORKSPACE, "sgd workspace too small");
+  return check_launch(run_sgd_step(param, grad, momentum_buf, n, lr, momentum, weight_decay, grad_scale, max_norm, ws, first_step,
+                                   (hipStream_t)stream),
+                      "hvr_sgd_step");
 }
 
 // ---- RoIAlign ----

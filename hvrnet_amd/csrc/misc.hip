@@ -356,6 +356,59 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
   }
 }
 
+// ---- optimizer step (configs/faster_rcnn_r101_selsa_c5.py:215-222: SGD momentum 0.9, weight decay 1e-4, grad clip 35) ----
+// partial sums of squares of a flat f32 gradient buffer: one value per workgroup, fixed order (the clip norm)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += g[i] * g[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov off) on a flat f32 buffer, with the two scalings the
+// reference applies to the gradient first folded in: 1 / world_size (dist_utils.py:24-25) and the clip coefficient
+// min(1, max_norm / (norm + 1e-6)) of clip_grad_norm_ over the AVERAGED gradient (max_norm <= 0: no clipping).
+//   d = g * gscale * clip + wd * p;   buf = first ? d : mom * buf + d;   p -= lr * buf
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+                                                       float lr, float mom, float wd, float gscale, float max_norm,
+                                                       const float* __restrict__ part, int nparts, int first) {
+  __shared__ float sh_clip;
+  if (threadIdx.x == 0) {
+    float clip = 1.f;
+    if (max_norm > 0.f) {
+      float ss = 0.f;
+      for (int i = 0; i < nparts; ++i) ss += part[i];
+      const float norm = sqrtf(ss) * gscale;  // norm of the averaged gradient
+      const float c = max_norm / (norm + 1e-6f);
+      clip = c < 1.f ? c : 1.f;
+    }
+    sh_clip = clip;
+  }
+  __syncthreads();
+  const float k = gscale * sh_clip;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = g[i] * k + wd * p[i];
+    const float b = first ? d : mom * buf[i] + d;
+    buf[i] = b;
+    p[i] -= lr * b;
+  }
+}
+
+constexpr int kSumsqParts = 256;
+hipError_t run_sgd_step(float* p, const float* g, float* buf, long n, float lr, float mom, float wd, float gscale, float max_norm,
+                        float* part, int first, hipStream_t s) {
+  if (max_norm > 0.f) hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqParts), dim3(256), 0, s, g, n, part);
+  hipLaunchKernelGGL(sgd_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, buf, n, lr, mom, wd, gscale, max_norm, part,
+                     kSumsqParts, first);
+  return hipGetLastError();
+}
+
 hipError_t run_relu_bwd(const void* dY, const void* Y, void* dZ, long n, int dtype, hipStream_t s) {
   const int g = grid_for((n + 3) / 4, 256);
   if (dtype == DT_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dY, (const bf16_t*)Y, (bf16_t*)dZ, n);

@@ -1,0 +1,65 @@
+"""The training step's exchange + update for data-parallel replicas.
+
+Reference: `DistOptimizerHook.after_train_iter` (mmdet/core/utils/dist_utils.py:44-58) = zero_grad, backward,
+`allreduce_grads` (flatten per dtype, all_reduce, / world_size, copy back; :9-41), clip_grad_norm_(max_norm 35),
+SGD step.  Here one process per GPU, RCCL through torch.distributed (backend "nccl"; "gloo" in the CPU tests):
+
+  * `FlatParams` owns ONE flat f32 buffer for the parameters, one for the gradients and one for the momentum; every
+    nn.Parameter (and its .grad) is a view into them, so there is nothing to flatten, copy back or bucket: the exchange
+    is a single `all_reduce` of the gradient buffer (the reference makes the same single call per dtype);
+  * the division by world_size and the clip coefficient are folded into the update kernel (`hvr_sgd_step`), which reads
+    the clip norm from a device-side reduction -- no host synchronisation anywhere in the step.
+"""
+import torch
+import torch.distributed as dist
+
+from . import native
+
+
+class FlatParams(object):
+    """Re-homes the trainable parameters of `module` into one flat f32 buffer (parameters keep their shapes as views)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        assert self.params and all(p.dtype == torch.float32 for p in self.params), 'f32 parameters only'
+        dev = self.params[0].device
+        al = 64                                            # every view starts on a 256-byte boundary (GEMM operands need 16)
+        n = sum((p.numel() + al - 1) // al * al for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)   # padding stays zero: zero gradient, zero update
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.momentum = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.steps = 0
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += (k + al - 1) // al * al
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def allreduce_grads(self):
+        """Sum over the replicas (the reference's allreduce_grads without its division, which the update applies)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad)
+            return dist.get_world_size()
+        return 1
+
+    def sgd_step(self, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, world_size=1):
+        """clip_grad_norm_(max_norm) on the averaged gradient + torch.optim.SGD step, on the device (hvr_sgd_step)."""
+        native.sgd_step(self.flat, self.grad, self.momentum, lr, momentum, weight_decay, grad_scale=1.0 / world_size,
+                        max_norm=max_norm, first_step=self.steps == 0)
+        self.steps += 1
+
+
+def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0):
+    """One iteration in the reference's order (dist_utils.py:52-58): zero_grad, backward, all-reduce, clip, step.
+    loss_fn() builds the graph and returns the scalar to differentiate."""
+    flat.zero_grad()
+    loss = loss_fn()
+    loss.backward()
+    world = flat.allreduce_grads()
+    flat.sgd_step(lr, momentum, weight_decay, max_norm, world)
+    return loss

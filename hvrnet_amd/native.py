@@ -79,6 +79,8 @@ SYMBOLS = {
     'hvr_relation_probs': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     'hvr_relation_dscore': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _f, _i, _vp]),
     'hvr_relu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    'hvr_sgd_workspace_bytes': (_sz, []),
+    'hvr_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _sz, _i, _vp]),
     'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
     'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
@@ -356,6 +358,18 @@ def relation_dscore(P, dP, dO, O, scale):
     _check(lib().hvr_relation_dscore(_ptr(P), _ptr(dP), _ptr(dO), dO.stride(0), _ptr(O), O.stride(0), _ptr(dS), P.shape[0],
                                      P.shape[1], dO.shape[1], float(scale), _dt(P), _stream()), 'hvr_relation_dscore')
     return dS
+
+
+def sgd_step(param_flat, grad_flat, momentum_buf, lr, momentum, weight_decay, grad_scale=1.0, max_norm=0.0, first_step=False):
+    """In-place SGD-with-momentum update of a flat f32 parameter buffer (see hvr_sgd_step in include/hvr_hip.h)."""
+    _need_cuda(param_flat, grad_flat, momentum_buf)
+    assert param_flat.dtype == grad_flat.dtype == momentum_buf.dtype == torch.float32
+    assert param_flat.is_contiguous() and grad_flat.is_contiguous() and momentum_buf.is_contiguous()
+    assert param_flat.numel() == grad_flat.numel() == momentum_buf.numel()
+    ws = _workspace(lib().hvr_sgd_workspace_bytes(), param_flat.device, 'sgd')
+    _check(lib().hvr_sgd_step(_ptr(param_flat), _ptr(grad_flat), _ptr(momentum_buf), param_flat.numel(), float(lr), float(momentum),
+                              float(weight_decay), float(grad_scale), float(max_norm), _ptr(ws), ws.numel(), int(first_step),
+                              _stream()), 'hvr_sgd_step')
 
 
 def relu_bwd(dy, y):

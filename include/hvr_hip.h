@@ -127,6 +127,16 @@ int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncl
                  const float* bbox_targets, const float* bbox_weights, int R, float beta, float w_cls, float w_bbox, float* out3,
                  float* dlogits, void* stream);
 
+/* Optimizer step on a flat f32 buffer (the training configs: SGD lr 5e-4, momentum 0.9, weight decay 1e-4, gradient
+ * clipping max_norm 35, configs/faster_rcnn_r101_selsa_c5.py:215-222; torch.optim.SGD semantics, dampening 0).  The two
+ * scalings the reference applies to the summed gradient first are folded in: grad_scale = 1 / world_size
+ * (mmdet/core/utils/dist_utils.py:24-25) and the clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)), norm taken
+ * over the scaled gradient, on the device (max_norm <= 0: no clipping).  first_step: the momentum buffer is initialised
+ * with the first update, as torch does. */
+size_t hvr_sgd_workspace_bytes(void);
+int hvr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                 float grad_scale, float max_norm, float* ws, size_t ws_bytes, int first_step, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * RoIAlign (legacy "+1" convention).  Replaces roi_align_cuda.forward / .backward:
  *   mmdet/ops/roi_align/src/roi_align_cuda.cpp:27-80, roi_align_kernel.cu:63-141,187-282.

@@ -465,6 +465,70 @@ def test_selsa_head_training_step_matches_reference_golden():
     assert seen == 20
 
 
+def test_sgd_step_kernel_matches_torch_sgd_with_clipping():
+    """hvr_sgd_step (grad_scale = 1 / world, device-side clip norm, momentum, weight decay) against
+    clip_grad_norm_ + torch.optim.SGD over three steps, once with the clip active and once without."""
+    g = torch.Generator().manual_seed(91)
+    n = 100003
+    for max_norm, gmag in ((35.0, 3.0), (35.0, 0.01), (0.0, 1.0)):
+        p0 = torch.randn(n, generator=g)
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.SGD([ref], lr=5e-4, momentum=0.9, weight_decay=1e-4)
+        p, buf = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+        for step in range(3):
+            grad_sum = torch.randn(n, generator=g) * gmag          # sum over two replicas
+            ref.grad = grad_sum / 2
+            if max_norm > 0:
+                torch.nn.utils.clip_grad_norm_([ref], max_norm)
+            opt.step()
+            native.sgd_step(p, grad_sum.to(DEV), buf, 5e-4, 0.9, 1e-4, grad_scale=0.5, max_norm=max_norm, first_step=step == 0)
+        close(p, ref.detach(), 1e-5, 1e-6)
+
+
+def test_selsa_head_two_training_iterations_match_the_oracle():
+    """dist_train.train_iteration on the SELSA head (zero_grad, HIP forward / losses / backward, clip 35, SGD) twice,
+    against the oracle's gradients fed to clip_grad_norm_ + torch.optim.SGD: parameters after two updates."""
+    from hvrnet_amd import dist_train
+    from oracle import hvr_oracle as O
+    sd = S.synth_state_dict('selsa')
+    head = hvrnet_amd.SelsaBBoxHead(sampler_num=32, t_dim=3, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
+    head = head.to(DEV)
+    hvrnet_amd.set_compute_dtype(head, torch.float32)
+    flat = dist_train.FlatParams(head)
+    labels, lw, bt, bw = C.head_train_case()
+    feats, cur = C.roi_feat_input(), dict(start=32, length=32)
+    lr = 0.002                                                     # large enough for two steps to move the parameters visibly
+    dev_args = [t.to(DEV) for t in (labels, lw, bt, bw)]
+    losses = []
+    for _ in range(2):
+        losses.append(float(dist_train.train_iteration(
+            flat, lambda: head.loss_train(head.forward_train(feats.to(DEV), cur), *dev_args)['total'].sum(), lr).detach()))
+    # oracle side: same two iterations on the CPU
+    names = [k for k in sd if k.startswith('bbox_head.')]
+    prm = {k: torch.nn.Parameter(sd[k].clone()) for k in names}
+    opt = torch.optim.SGD(list(prm.values()), lr=lr, momentum=0.9, weight_decay=1e-4)
+    ref_losses = []
+    for _ in range(2):
+        ls, grads, _ = O.selsa_head_train_step(feats, {k: v.detach() for k, v in prm.items()}, cur, 32, 3, labels, lw, bt, bw)
+        ref_losses.append(float(ls['loss_cls'] + ls['loss_bbox']))
+        for k in names:
+            prm[k].grad = grads[k[len('bbox_head.'):]].clone()
+        torch.nn.utils.clip_grad_norm_(list(prm.values()), 35.0)
+        opt.step()
+    assert abs(losses[0] - ref_losses[0]) <= 1e-4 * ref_losses[0] and abs(losses[1] - ref_losses[1]) <= 2e-3 * ref_losses[1]
+    assert losses[1] < losses[0]
+    moved = 0.0
+    for name, p in head.named_parameters():
+        want = prm['bbox_head.' + name].detach()
+        start = sd['bbox_head.' + name]
+        step_size = (want - start).abs().max().item()
+        err = (p.detach().cpu() - want).abs().max().item()
+        assert err <= 2e-2 * step_size + 1e-7, '%s: err %g vs step %g' % (name, err, step_size)
+        moved = max(moved, step_size)
+    assert moved > 1e-4
+
+
 # ------------------------------------------------------------------------------- per-frame cache
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):

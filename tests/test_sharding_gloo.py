@@ -88,3 +88,52 @@ def test_two_ranks_over_gloo_cover_every_frame_once():
             assert centre == vid * 1000 + f
             assert all(vid * 1000 <= w < vid * 1000 + n for w in out[k])  # windows never mix videos
             k += 1
+
+
+# ------------------------------------------------------------------------------- training step's exchange (config 5)
+def _grad_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from hvrnet_amd import dist_train
+        torch.manual_seed(0)  # identical replicas
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+        flat = dist_train.FlatParams(net)
+        # parameters and their gradients are views of the flat buffers: nothing to flatten or copy back
+        assert all(p.data_ptr() >= flat.flat.data_ptr() for p in net.parameters())
+        flat.zero_grad()
+        x = torch.full((4, 6), float(rank + 1))
+        net(x).sum().backward()                       # rank-dependent gradients, accumulated in place into flat.grad
+        mine = [p.grad.clone() for p in net.parameters()]
+        world_seen = flat.allreduce_grads()           # one all_reduce of the whole gradient buffer
+        q.put((rank, world_seen, mine, float(flat.grad.sum()), [p.grad.clone() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_gradient_allreduce_over_gloo_sums_the_replicas():
+    """dist_train.FlatParams: the reference's allreduce_grads (dist_utils.py:9-41) as ONE all_reduce over a flat buffer
+    the parameters' .grad tensors are views of; the division by world_size is applied by the update kernel."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, world_seen, mine, summed, views = q.get(timeout=240)
+        got[rank] = (world_seen, mine, summed, views)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = [a + b for a, b in zip(got[0][1], got[1][1])]
+    for r in range(world):
+        assert got[r][0] == world
+        for view, want in zip(got[r][3], total):      # the parameters' .grad views see the reduced values
+            assert torch.allclose(view, want)
+        assert abs(got[r][2] - sum(float(t.sum()) for t in total)) < 1e-4   # (alignment padding stays zero)
+    assert not torch.allclose(got[0][1][0], got[1][1][0])

@@ -120,6 +120,15 @@ class Bottleneck(nn.Module, PackedMixin):
     def forward(self, x):
         return as_logical(self.forward_nhwc(as_nhwc(x, self.compute_dtype)))
 
+    def forward_train_nhwc(self, x):
+        """The block as an autograd graph of HIP convs (train_ops.conv_bn): frozen BatchNorm statistics and affine
+        (norm_eval=True, requires_grad=False in both configs), trainable conv weights; f32, physical NHWC."""
+        from . import train_ops as TO
+        out = TO.conv_bn(x, self.conv1, self.bn1, relu=True)
+        out = TO.conv_bn(out, self.conv2, self.bn2, relu=True)
+        identity = x if self.downsample is None else TO.conv_bn(x, self.downsample[0], self.downsample[1])
+        return TO.conv_bn(out, self.conv3, self.bn3, resid=identity, relu=True)
+
 
 def make_res_layer(block, inplanes, planes, blocks, stride=1, dilation=1, style='pytorch', norm_cfg=None, **_unused):
     downsample = None

@@ -17,6 +17,8 @@ namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
+hipError_t run_im2col_nhwc(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+hipError_t run_scale_rows(const void*, const float*, void*, int, long, int, hipStream_t);
 hipError_t run_sgd_step(float*, const float*, float*, long, float, float, float, float, float, float*, int, hipStream_t);
 hipError_t run_colsum(const void*, float*, int, int, long, int, hipStream_t);
 hipError_t run_det_loss(const float*, int, int, int, int, const long long*, const float*, const float*, const float*, int, float, float,
@@ -257,6 +259,19 @@ int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t l
   if (Mq <= 0 || D <= 0 || D % 4 || ldp % 4 || ldgo % 4 || ldo % 4) return fail(HVR_EINVAL, "bad relation dscore shape");
   return check_launch(run_relation_dscore(P, dP, dO, O, dS, Mq, ldp, D, ldgo, ldo, scale, dtype, (hipStream_t)stream),
                       "hvr_relation_dscore");
+}
+
+int hvr_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int dtype, void* stream) {
+  if (!x || !cols || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 4 || KH <= 0 || KW <= 0 || pad < 0 || dil <= 0)
+    return fail(HVR_EINVAL, "bad im2col arguments (Cin %% 4 == 0 required)");
+  const int OH = H + 2 * pad - dil * (KH - 1), OW = W + 2 * pad - dil * (KW - 1);
+  if (OH <= 0 || OW <= 0) return fail(HVR_EINVAL, "empty im2col output");
+  return check_launch(run_im2col_nhwc(x, cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW, dtype, (hipStream_t)stream), "hvr_im2col_nhwc");
+}
+
+int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t C, int dtype, void* stream) {
+  if (!w || !scale || !out || R <= 0 || C <= 0 || C % 4) return fail(HVR_EINVAL, "bad scale_rows arguments (C %% 4 == 0 required)");
+  return check_launch(run_scale_rows(w, scale, out, R, C, dtype, (hipStream_t)stream), "hvr_scale_rows");
 }
 
 size_t hvr_sgd_workspace_bytes(void) { return 256 * sizeof(float); }

@@ -356,6 +356,62 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
   }
 }
 
+// ---- conv backward helpers ----
+// cols[p][(ky*KW + kx)*Cin + c] = x[b][oy - pad + ky*dil][ox - pad + kx*dil][c] (zero outside), p = (b*OH + oy)*OW + ox,
+// stride 1: the patch matrix whose transpose times dY^T is the weight gradient of a KHxKW conv (torch: conv2d backward)
+template <typename T>
+__global__ void im2col_nhwc_kernel(const T* __restrict__ x, T* __restrict__ cols, int B, int H, int W, int Cin, int KH, int KW,
+                                   int pad, int dil, int OH, int OW) {
+  const int c4 = Cin / 4;
+  const long total = (long)B * OH * OW * KH * KW * c4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(idx % c4);
+    long r = idx / c4;
+    const int tap = (int)(r % (KH * KW));
+    const long pix = r / (KH * KW);
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((long)OW * OH));
+    const int ky = tap / KW, kx = tap - ky * KW;
+    const int iy = oy - pad + ky * dil, ix = ox - pad + kx * dil;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) load4(x + (((long)b * H + iy) * W + ix) * Cin + cq * 4, v);
+    store4(cols + (pix * (KH * KW) + tap) * Cin + cq * 4, v);
+  }
+}
+
+// out[r][:] = w[r][:] * s[r]: folds a frozen BatchNorm's per-channel scale into conv weights (and back into their gradient)
+template <typename T>
+__global__ void scale_rows_kernel(const T* __restrict__ w, const float* __restrict__ s, T* __restrict__ out, int R, long C) {
+  const long total = (long)R * (C / 4);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / (C / 4), c = (idx - r * (C / 4)) * 4;
+    float v[4];
+    load4(w + r * C + c, v);
+    const float k = s[r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= k;
+    store4(out + r * C + c, v);
+  }
+}
+
+hipError_t run_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int OH, int OW,
+                           int dtype, hipStream_t s) {
+  const long work = (long)B * OH * OW * KH * KW * (Cin / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(im2col_nhwc_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW);
+  else
+    hipLaunchKernelGGL(im2col_nhwc_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const float*)x, (float*)cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW);
+  return hipGetLastError();
+}
+
+hipError_t run_scale_rows(const void* w, const float* sc, void* out, int R, long C, int dtype, hipStream_t s) {
+  const long work = (long)R * (C / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const bf16_t*)w, sc, (bf16_t*)out, R, C);
+  else
+    hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const float*)w, sc, (float*)out, R, C);
+  return hipGetLastError();
+}
+
 // ---- optimizer step (configs/faster_rcnn_r101_selsa_c5.py:215-222: SGD momentum 0.9, weight decay 1e-4, grad clip 35) ----
 // partial sums of squares of a flat f32 gradient buffer: one value per workgroup, fixed order (the clip norm)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {

@@ -79,6 +79,8 @@ SYMBOLS = {
     'hvr_relation_probs': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     'hvr_relation_dscore': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _f, _i, _vp]),
     'hvr_relu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    'hvr_im2col_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'hvr_scale_rows': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
     'hvr_sgd_workspace_bytes': (_sz, []),
     'hvr_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _sz, _i, _vp]),
     'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
@@ -358,6 +360,27 @@ def relation_dscore(P, dP, dO, O, scale):
     _check(lib().hvr_relation_dscore(_ptr(P), _ptr(dP), _ptr(dO), dO.stride(0), _ptr(O), O.stride(0), _ptr(dS), P.shape[0],
                                      P.shape[1], dO.shape[1], float(scale), _dt(P), _stream()), 'hvr_relation_dscore')
     return dS
+
+
+def im2col_nhwc(x, KH, KW, pad, dil):
+    """x [B,H,W,Cin] -> patch matrix [B*OH*OW, KH*KW*Cin] (stride 1, zero padding)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    B, H, W, Cin = x.shape
+    OH, OW = H + 2 * pad - dil * (KH - 1), W + 2 * pad - dil * (KW - 1)
+    cols = torch.empty((B * OH * OW, KH * KW * Cin), dtype=x.dtype, device=x.device)
+    _check(lib().hvr_im2col_nhwc(_ptr(x), _ptr(cols), B, H, W, Cin, KH, KW, pad, dil, _dt(x), _stream()), 'hvr_im2col_nhwc')
+    return cols
+
+
+def scale_rows(w, scale):
+    """[R, ...] * scale[R] per leading row (f32 scale)."""
+    _need_cuda(w, scale)
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    R = w.shape[0]
+    _check(lib().hvr_scale_rows(_ptr(w), _ptr(scale.float().contiguous()), _ptr(out), R, w.numel() // R, _dt(w), _stream()), 'hvr_scale_rows')
+    return out
 
 
 def sgd_step(param_flat, grad_flat, momentum_buf, lr, momentum, weight_decay, grad_scale=1.0, max_norm=0.0, first_step=False):

@@ -98,3 +98,70 @@ def det_loss(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets
     total, lc, lb, acc = DetLossFunction.apply(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights,
                                                float(beta), float(w_cls), float(w_bbox))
     return dict(total=total, loss_cls=lc, loss_bbox=lb, acc=acc)
+
+
+class ConvFunction(Function):
+    """y = act(conv(x, w * s) + t (+ resid)) on physical NHWC tensors: an nn.Conv2d (no bias) followed by a frozen
+    BatchNorm (scale s, shift t per output channel; pass s = ones / t = bias for a plain conv with bias) and optionally the
+    residual add and ReLU of a Bottleneck (resnet.py:220-266).  x [B,H,W,Cin], w [Cout,Cin,KH,KW] (the nn.Conv2d
+    parameter), stride 1 for KxK kernels; a strided 1x1 conv is a row subset followed by a linear layer.
+    Backward: ReLU mask, dX by the same implicit-GEMM conv kernel on the rotated weights (or a GEMM for 1x1), dW^T as a
+    GEMM of dZ^T with the patch matrix, both scaled by s; s and t are frozen and get no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, t, resid, relu, stride, pad, dil):
+        if not x.is_cuda:
+            raise NotImplementedError('convs run on the GPU only (no CPU fallback)')
+        Cout, Cin, KH, KW = w.shape
+        assert (KH, KW) == (1, 1) or stride == 1, 'strided KxK convs are not on this path (caffe-style ResNet strides its 1x1s)'
+        xs = x[:, ::stride, ::stride, :].contiguous() if stride > 1 else x.contiguous()
+        w_eff = native.scale_rows(w.permute(0, 2, 3, 1).contiguous(), s)                 # [Cout][KH][KW][Cin] * s
+        y = native.conv2d_nhwc(xs, w_eff, t, resid.contiguous() if resid is not None else None, relu=bool(relu), pad=pad, dil=dil)
+        ctx.cfg = (bool(relu), int(stride), int(pad), int(dil), resid is not None, tuple(x.shape))
+        ctx.save_for_backward(xs, w_eff, s, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xs, w_eff, s, y = ctx.saved_tensors
+        relu, stride, pad, dil, has_resid, x_shape = ctx.cfg
+        dz = native.relu_bwd(dy.contiguous(), y) if relu else dy.contiguous()
+        Cout, KH, KW, Cin = w_eff.shape
+        B, OH, OW, _ = dz.shape
+        P = B * OH * OW
+        step = native.kstep(dz.dtype)
+        ldp = (P + step - 1) // step * step
+        dz2 = dz.view(P, Cout)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if (KH, KW) == (1, 1):
+                dxs = native.gemm(dz2, native.transpose_pad(w_eff.view(Cout, Cin), Cout)).view(B, OH, OW, Cin)   # dz W
+            else:
+                w_rot = w_eff.flip(1, 2).permute(3, 1, 2, 0).contiguous()               # [Cin][KH][KW][Cout], taps reversed
+                dxs = native.conv2d_nhwc(dz, w_rot, None, None, relu=False, pad=dil * (KH - 1) - pad, dil=dil)
+            if stride > 1:
+                dx = dxs.new_zeros(x_shape)
+                dx[:, ::stride, ::stride, :] = dxs
+            else:
+                dx = dxs
+        if ctx.needs_input_grad[1]:
+            cols = xs.view(P, Cin) if (KH, KW) == (1, 1) else native.im2col_nhwc(xs, KH, KW, pad, dil)   # [P, KH*KW*Cin]
+            dw_eff = native.gemm(native.transpose_pad(dz2, ldp), native.transpose_pad(cols, ldp))        # [Cout, KH*KW*Cin]
+            dw = native.scale_rows(dw_eff, s).view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+        dt = native.colsum(dz2) if ctx.needs_input_grad[3] else None   # a trainable bias passed as the shift (RPN / 1x1 heads)
+        dr = dz if (has_resid and ctx.needs_input_grad[4]) else None
+        return dx, dw, None, dt, dr, None, None, None, None
+
+
+def conv_bn(x, conv, bn, resid=None, relu=False):
+    """nn.Conv2d (bias-free) + frozen nn.BatchNorm2d (eval statistics, models/utils/norm.py eps) on an NHWC tensor."""
+    s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+    t = (bn.bias - bn.running_mean * s).detach()
+    return ConvFunction.apply(x, conv.weight, s, t, resid, relu, conv.stride[0], conv.padding[0], conv.dilation[0])
+
+
+def conv_bias(x, conv, relu=False):
+    """nn.Conv2d with a trainable bias and no norm (RPN convs, res5's external 1x1) on an NHWC tensor."""
+    ones = torch.ones(conv.weight.shape[0], dtype=torch.float32, device=x.device)
+    return ConvFunction.apply(x, conv.weight, ones, conv.bias, None, relu, conv.stride[0], conv.padding[0], conv.dilation[0])

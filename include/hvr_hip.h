@@ -127,6 +127,15 @@ int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncl
                  const float* bbox_targets, const float* bbox_weights, int R, float beta, float w_cls, float w_bbox, float* out3,
                  float* dlogits, void* stream);
 
+/* Conv backward helpers (training path; the reference differentiates nn.Conv2d + frozen BatchNorm through autograd,
+ * mmdet/models/backbones/resnet.py:220-266).  Input and weight gradients are tile-engine products:
+ *   dX   = hvr_conv2d_nhwc(dZ, weights rotated 180 degrees with the channel axes swapped)      (stride-1 KxK convs)
+ *   dW^T = hvr_gemm(dZ^T, cols^T)   with cols = hvr_im2col_nhwc(X): [B*OH*OW][KH*KW*Cin], stride 1, zero padding
+ * hvr_scale_rows multiplies row r of a [R][C] matrix by scale[r]: the frozen BatchNorm scale folded into the weights on
+ * the way in and into their gradient on the way out. */
+int hvr_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int dtype, void* stream);
+int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t C, int dtype, void* stream);
+
 /* Optimizer step on a flat f32 buffer (the training configs: SGD lr 5e-4, momentum 0.9, weight decay 1e-4, gradient
  * clipping max_norm 35, configs/faster_rcnn_r101_selsa_c5.py:215-222; torch.optim.SGD semantics, dampening 0).  The two
  * scalings the reference applies to the summed gradient first are folded in: grad_scale = 1 / world_size

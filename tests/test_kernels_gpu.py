@@ -162,6 +162,32 @@ def test_relation_backward_window_size_bf16():
         assert torch.isfinite(got.float()).all() and err <= 3e-2 * scale + 1e-3, '%s: max err %g (scale %g)' % (name, err, scale)
 
 
+@pytest.mark.parametrize('cfg', [dict(k=3, s=1, p=1, d=1), dict(k=3, s=1, p=2, d=2), dict(k=1, s=1, p=0, d=1), dict(k=1, s=2, p=0, d=1)])
+def test_conv_bn_backward_matches_autograd(cfg):
+    """train_ops.ConvFunction (conv + frozen BN + residual + ReLU; dX by the conv kernel on rotated weights or a GEMM,
+    dW by im2col + GEMM, both through the BN scale) against torch autograd of F.conv2d on the same f32 operands."""
+    from hvrnet_amd import train_ops as TO
+    B, Cin, Cout, H, W = 2, 64, 96, 13, 18
+    k, st, p, d = cfg['k'], cfg['s'], cfg['p'], cfg['d']
+    x = _rand((B, Cin, H, W), torch.float32, 71)
+    w = _rand((Cout, Cin, k, k), torch.float32, 72, 0.05)
+    sc, sh = torch.rand(Cout, generator=torch.Generator().manual_seed(73)) + 0.5, _rand((Cout,), torch.float32, 74, 0.1)
+    OH, OW = (H - 1) // st + 1, (W - 1) // st + 1
+    res, go = _rand((B, Cout, OH, OW), torch.float32, 75), _rand((B, Cout, OH, OW), torch.float32, 76)
+    xr, wr, rr = [t.clone().requires_grad_(True) for t in (x, w, res)]
+    ref = torch.relu(F.conv2d(xr, wr, None, stride=st, padding=p, dilation=d) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + rr)
+    ref.backward(go)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    y = TO.ConvFunction.apply(xd, wd, sc.to(DEV), sh.to(DEV), rd, True, st, p, d)
+    y.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
+    torch.testing.assert_close(y.detach().cpu().permute(0, 3, 1, 2), ref.detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(rd.grad.cpu().permute(0, 3, 1, 2), rr.grad, rtol=0, atol=0)
+
+
 def test_maxpool_and_stem_patches():
     x = _rand((2, 64, 21, 30), torch.float32, 31)
     ref = F.max_pool2d(x, 3, 2, 1)

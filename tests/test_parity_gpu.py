@@ -529,6 +529,43 @@ def test_selsa_head_two_training_iterations_match_the_oracle():
     assert moved > 1e-4
 
 
+def test_bottleneck_training_backward_matches_the_oracle(O):
+    """Two Bottlenecks of layer 3 (the strided first block with its downsample branch, then a plain one) as autograd
+    graphs of HIP convs with frozen BatchNorm, against autograd over the oracle's restatement (resnet.py:220-266):
+    output, input gradient and every conv-weight gradient."""
+    from hvrnet_amd.backbone import Bottleneck, make_res_layer
+    sd = S.synth_state_dict('selsa')
+    layer = make_res_layer(Bottleneck, 512, 256, 2, stride=2, dilation=1, style='caffe')
+    layer.load_state_dict({k[len('backbone.layer3.'):]: v for k, v in sd.items()
+                           if k.startswith('backbone.layer3.0.') or k.startswith('backbone.layer3.1.')}, strict=True)
+    layer = layer.to(DEV).eval()
+    g = torch.Generator().manual_seed(81)
+    x = torch.randn((1, 512, 12, 16), generator=g).abs()
+    go = torch.randn((1, 1024, 6, 8), generator=g)
+    # oracle: autograd over the functional restatement
+    leaf = {k: (v.clone().requires_grad_(True) if k.endswith('.weight') and '.bn' not in k and 'downsample.1' not in k else v)
+            for k, v in sd.items() if k.startswith('backbone.layer3.0.') or k.startswith('backbone.layer3.1.')}
+    xr = x.clone().requires_grad_(True)
+    y = O.bottleneck(xr, leaf, 'backbone.layer3.0', 2, 1, True)
+    y = O.bottleneck(y, leaf, 'backbone.layer3.1', 1, 1, False)
+    y.backward(go)
+    # HIP path
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    out = layer[1].forward_train_nhwc(layer[0].forward_train_nhwc(xd))
+    out.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close(out.permute(0, 3, 1, 2), y, 1e-3, 1e-3)
+    close(xd.grad.permute(0, 3, 1, 2), xr.grad, 2e-3, 2e-3 * xr.grad.abs().max().item())
+    n = 0
+    for name, prm in layer.named_parameters():
+        want = leaf['backbone.layer3.' + name]
+        if not (isinstance(want, torch.Tensor) and want.requires_grad):
+            assert prm.grad is None or float(prm.grad.abs().sum()) == 0.0, name  # frozen BatchNorm
+            continue
+        close(prm.grad, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
+        n += 1
+    assert n == 7  # 3 + 3 conv weights and the downsample conv
+
+
 # ------------------------------------------------------------------------------- per-frame cache
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):

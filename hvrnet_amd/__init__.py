@@ -6,7 +6,7 @@ Importing the package registers the hot-path components under the reference's na
 __version__ = '0.1.0'
 
 from . import registry  # noqa: F401
-from .backbone import ResLayer, ResNet, set_compute_dtype  # noqa: F401
+from .backbone import ResLayer, ResNet, enable_training, set_compute_dtype  # noqa: F401
 from .bbox_heads import BBoxHead, HRNMPBBoxHead, SelsaBBoxHead  # noqa: F401
 from .config import Config, hvr_config, selsa_config  # noqa: F401
 from .detectors import HNMBRCNN, SelsaRCNN  # noqa: F401

@@ -81,6 +81,25 @@ def set_compute_dtype(module, dtype):
     return module
 
 
+def enable_training(module):
+    """Marks the parameters the reference trains as requires_grad (the builders freeze everything for inference):
+    all conv / linear weights and biases EXCEPT BatchNorm parameters (norm_cfg requires_grad=False, norm_eval=True in both
+    configs) and a ResNet's stem + first `frozen_stages` stages (resnet.py:484-494).  Use with
+    set_compute_dtype(module, torch.float32); the forward_train_* methods then build autograd graphs of HIP ops."""
+    for m in module.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            continue
+        for p in m.parameters(recurse=False):
+            p.requires_grad = True
+    for m in module.modules():
+        if isinstance(m, ResNet):
+            frozen = [m.conv1, m.bn1] + [getattr(m, 'layer%d' % i) for i in range(1, m.frozen_stages + 1)]
+            for f in frozen:
+                for p in f.parameters():
+                    p.requires_grad = False
+    return module
+
+
 class Bottleneck(nn.Module, PackedMixin):
     expansion = 4
 
@@ -235,8 +254,29 @@ class ResNet(nn.Module, PackedMixin):
                 outs.append(as_logical(y))
         return tuple(outs)
 
+    def forward_train_nhwc(self, x):
+        """Training forward (f32): the frozen stem and stages (`frozen_stages`, BatchNorm everywhere) run the inference
+        kernels without a graph, the remaining stages are autograd graphs of HIP convs (Bottleneck.forward_train_nhwc).
+        -> the last out_indices map, physical NHWC."""
+        if self.compute_dtype != torch.float32:
+            raise NotImplementedError('the training step runs the f32 path (set_compute_dtype(model, torch.float32))')
+        p = self.packed(x.device)
+        with torch.no_grad():
+            cols, OH, OW = native.im2col_stem(x.contiguous().float(), torch.float32, STEM_KP)
+            y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
+            y = native.maxpool3x3s2_nhwc(y)
+            for i, name in enumerate(self.res_layers):
+                if i + 1 <= self.frozen_stages:
+                    for blk in getattr(self, name):
+                        y = blk.forward_nhwc(y)
+        for i, name in enumerate(self.res_layers):
+            if i + 1 > self.frozen_stages:
+                for blk in getattr(self, name):
+                    y = blk.forward_train_nhwc(y)
+        return y
+
     def train(self, mode=True):
-        super(ResNet, self).train(False)  # frozen: inference-only build
+        super(ResNet, self).train(False)  # BatchNorm stays in eval mode (norm_eval=True); forward_train_* build the graphs
         return self
 
 
@@ -292,6 +332,15 @@ class ResLayer(nn.Module, PackedMixin):
             w, b = self.packed(x.device)['ext']
             y = native.conv2d_nhwc(y, w, b, relu=True)
         return as_logical(y)
+
+    def forward_train_nhwc(self, y):
+        """res5 + the external 1x1 conv as an autograd graph of HIP convs (f32, physical NHWC in and out)."""
+        from . import train_ops as TO
+        for blk in getattr(self, 'layer{}'.format(self.stage + 1)):
+            y = blk.forward_train_nhwc(y)
+        if self.external_conv:
+            y = TO.conv_bias(y, self.new_layer_1.conv, relu=True)
+        return y
 
     def train(self, mode=True):
         super(ResLayer, self).train(False)

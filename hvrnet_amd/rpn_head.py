@@ -69,6 +69,21 @@ class RPNHead(nn.Module, PackedMixin):
         o = native.conv2d_nhwc(y, p['heads'][0], p['heads'][1], relu=False, out_f32=True)  # [T,H,W,5A(+pad)] f32
         return as_logical(o[..., :A]), as_logical(o[..., A:5 * A])
 
+    def forward_train_nhwc(self, x):
+        """rpn_head.py:30-35 as an autograd graph of HIP convs: x [T,H,W,C] f32 NHWC -> (cls [T,H,W,A], reg [T,H,W,4A]).
+        The two 1x1 heads run as one conv over the concatenated weights (rows padded to a K-step multiple)."""
+        from . import train_ops as TO
+        A = self.num_anchors
+        y = TO.conv_bias(x, self.rpn_conv, relu=True)
+        w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight], 0)
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
+        pad = -w.shape[0] % 32
+        w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
+        b = torch.cat([b, b.new_zeros(pad)], 0)
+        ones = torch.ones(w.shape[0], dtype=torch.float32, device=x.device)
+        o = TO.ConvFunction.apply(y, w, ones, b, None, False, 1, 0, 1)
+        return o[..., :A], o[..., A:5 * A]
+
     def forward(self, feats):
         outs = [self.forward_single(f) for f in feats]
         return [o[0] for o in outs], [o[1] for o in outs]

@@ -136,7 +136,8 @@ class ConvFunction(Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if (KH, KW) == (1, 1):
-                dxs = native.gemm(dz2, native.transpose_pad(w_eff.view(Cout, Cin), Cout)).view(B, OH, OW, Cin)   # dz W
+                ldn = (Cout + step - 1) // step * step
+                dxs = native.gemm(_pad_cols(dz2, ldn), native.transpose_pad(w_eff.view(Cout, Cin), ldn)).view(B, OH, OW, Cin)  # dz W
             else:
                 w_rot = w_eff.flip(1, 2).permute(3, 1, 2, 0).contiguous()               # [Cin][KH][KW][Cout], taps reversed
                 dxs = native.conv2d_nhwc(dz, w_rot, None, None, relu=False, pad=dil * (KH - 1) - pad, dil=dil)

@@ -566,6 +566,44 @@ def test_bottleneck_training_backward_matches_the_oracle(O):
     assert n == 7  # 3 + 3 conv weights and the downsample conv
 
 
+def test_trunk_training_backward_matches_the_oracle(O):
+    """The trainable trunk of the training step on a small image: frozen stem + layer 1 (frozen_stages=1), layers 2-3,
+    res5 + its external conv and the RPN convs as autograd graphs of HIP convs, against autograd over the oracle's
+    restatement of the same modules: C5 and RPN maps, and the gradients of a conv weight from every trainable part."""
+    sd = S.synth_state_dict('selsa')
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(selsa_config(frame_interval=1, nms_post=16), sd, torch.float32, DEV))
+    img = C.small_image()                                       # [1,3,64,96]
+    g = torch.Generator().manual_seed(83)
+    g5, gc, gr = torch.randn((1, 256, 4, 6), generator=g), torch.randn((1, 12, 4, 6), generator=g), torch.randn((1, 48, 4, 6), generator=g)
+    watch = ['backbone.layer2.0.conv1.weight', 'backbone.layer2.3.conv2.weight', 'backbone.layer3.0.downsample.0.weight',
+             'backbone.layer3.22.conv3.weight', 'shared_head.layer4.0.conv2.weight', 'shared_head.new_layer_1.conv.weight',
+             'shared_head.new_layer_1.conv.bias', 'rpn_head.rpn_conv.weight', 'rpn_head.rpn_cls.bias', 'rpn_head.rpn_reg.weight']
+    # oracle
+    leaf = dict(sd)
+    for k in watch:
+        leaf[k] = sd[k].clone().requires_grad_(True)
+    c4 = O.resnet_c4(img, leaf)
+    c5 = O.shared_head(c4, leaf)
+    cls, reg = O.rpn_forward(c4, leaf)
+    ((c5 * g5).sum() + (cls * gc).sum() + (reg * gr).sum()).backward()
+    # HIP path
+    y4 = model.backbone.forward_train_nhwc(img.to(DEV))
+    y5 = model.shared_head.forward_train_nhwc(y4)
+    ycls, yreg = model.rpn_head.forward_train_nhwc(y4)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ((y5 * nhwc(g5)).sum() + (ycls * nhwc(gc)).sum() + (yreg * nhwc(gr)).sum()).backward()
+    close(y5.permute(0, 3, 1, 2), c5, 2e-3, 2e-3 * c5.abs().max().item())
+    close(ycls.permute(0, 3, 1, 2), cls, 2e-3, 2e-3 * cls.abs().max().item())
+    close(yreg.permute(0, 3, 1, 2), reg, 2e-3, 2e-3 * reg.abs().max().item())
+    params = dict(model.named_parameters())
+    for k in watch:
+        want = leaf[k].grad
+        got = params[k].grad
+        assert got is not None, k
+        close(got, want, 5e-3, 5e-3 * want.abs().max().item())
+    assert params['backbone.layer1.0.conv1.weight'].grad is None and params['backbone.conv1.weight'].grad is None  # frozen
+
+
 # ------------------------------------------------------------------------------- per-frame cache
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):

@@ -329,6 +329,20 @@ class SelsaRCNN(_WindowDetector):
         return pending if defer else pending.result()
 
 
+    def forward_train_sampled(self, img, rois, cur_range, labels, label_weights, bbox_targets, bbox_weights):
+        """The RCNN half of forward_train (selsa_rcnn.py:85-279) on FIXED sampled RoIs: backbone on the T frames, res5,
+        RoIAlign of every frame's sampled RoIs (rois [K,5] = (frame index, box), frames in order), the SELSA head and
+        BBoxHead.loss on the key frame's targets (`bbox_head.get_target` output).  Every forward and backward kernel is
+        HIP (f32; enable_training + set_compute_dtype(float32) first).  The assigner / sampler / RPN-loss steps that
+        produce rois and targets in the reference are not part of this build yet.  -> dict(loss_cls, loss_bbox, acc, total)."""
+        from . import ops
+        c4 = self.backbone.forward_train_nhwc(img)
+        c5 = self.shared_head.forward_train_nhwc(c4)
+        feats = ops.roi_align(c5.permute(0, 3, 1, 2), rois, self.bbox_roi_extractor.roi_layers[0].out_size,
+                              self.bbox_roi_extractor.roi_layers[0].spatial_scale, self.bbox_roi_extractor.roi_layers[0].sample_num)
+        logits = self.bbox_head.forward_train(feats, cur_range)
+        return self.bbox_head.loss_train(logits, labels, label_weights, bbox_targets, bbox_weights)
+
     def forward_feat_frames(self, entries, c4s=None, rescale=False, defer=False):
         """forward_feat from T cached `frame_tensors` entries; c4s (the frames' C4 maps) back the exact re-run that
         replaces the speculative result when some frame kept fewer than nms_post proposals."""

@@ -604,6 +604,40 @@ def test_trunk_training_backward_matches_the_oracle(O):
     assert params['backbone.layer1.0.conv1.weight'].grad is None and params['backbone.conv1.weight'].grad is None  # frozen
 
 
+def test_selsa_rcnn_training_step_on_sampled_rois_matches_the_oracle(O):
+    """SelsaRCNN.forward_train_sampled end to end on three small frames: backbone -> res5 -> RoIAlign -> SELSA head ->
+    BBoxHead.loss, backward through all of it on the HIP path (conv / GEMM / relation / RoIAlign backwards), against
+    autograd over the oracle: losses and the gradients of one weight from every part of the network."""
+    sd = S.synth_state_dict('selsa')
+    n, T = 8, 3
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(selsa_config(frame_interval=1, nms_post=n), sd, torch.float32, DEV))
+    g = torch.Generator().manual_seed(85)
+    imgs = torch.randn((T, 3, 64, 96), generator=g) * 50.0
+    xy = torch.rand((T * n, 2), generator=g) * torch.tensor([60.0, 36.0])
+    wh = torch.rand((T * n, 2), generator=g) * 30 + 6
+    rois = torch.cat([torch.arange(T).repeat_interleave(n)[:, None].float(), xy, xy + wh], 1)
+    labels, lw, bt, bw = C.head_train_case(n=n)
+    cur = dict(start=n, length=n)
+    watch = ['backbone.layer2.0.conv1.weight', 'backbone.layer3.5.conv2.weight', 'shared_head.layer4.2.conv3.weight',
+             'shared_head.new_layer_1.conv.weight', 'bbox_head.fc_new_1.bias', 'bbox_head.selsa_1.q_data_fc_1.weight',
+             'bbox_head.selsa_2.linear_out_2.weight', 'bbox_head.fc_cls.weight', 'bbox_head.fc_reg.bias']
+    leaf = dict(sd)
+    for k in watch:
+        leaf[k] = sd[k].clone().requires_grad_(True)
+    want = O.selsa_train_step_sampled(imgs, leaf, rois, cur, n, T, labels, lw, bt, bw)
+    (want['loss_cls'] + want['loss_bbox']).backward()
+    model.bbox_head.sampler_num, model.bbox_head.t_dim = n, T
+    got = model.forward_train_sampled(imgs.to(DEV), rois.to(DEV), cur, labels.to(DEV), lw.to(DEV), bt.to(DEV), bw.to(DEV))
+    got['total'].sum().backward()
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        close(got[k], want[k], 1e-3, 1e-5)
+    params = dict(model.named_parameters())
+    for k in watch:
+        w = leaf[k].grad
+        assert params[k].grad is not None, k
+        close(params[k].grad, w, 1e-2, 1e-2 * w.abs().max().item())
+
+
 # ------------------------------------------------------------------------------- per-frame cache
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):

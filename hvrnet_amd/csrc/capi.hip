@@ -22,7 +22,16 @@ hipError_t run_scale_rows(const void*, const float*, void*, int, long, int, hipS
 hipError_t run_sgd_step(float*, const float*, float*, long, float, float, float, float, float, float*, int, hipStream_t);
 hipError_t run_colsum(const void*, float*, int, int, long, int, hipStream_t);
 hipError_t run_det_loss(const float*, int, int, int, int, const long long*, const float*, const float*, const float*, int, float, float,
-                        float, float*, float*, hipStream_t);
+                        float, float*, float*, const int*, hipStream_t);
+size_t assign_workspace_bytes(int n, int k);
+hipError_t run_max_iou_assign(const float*, int, int, const float*, int, const uint8_t*, float, float, float, float, long long*, float*,
+                              void*, hipStream_t);
+hipError_t run_sample(const long long*, const float*, int, int, int, float, long long*, int*, hipStream_t);
+hipError_t run_box_targets(const float*, int, int, const float*, const long long*, const long long*, const long long*, const int*, int,
+                           const float*, const float*, float, int, long long*, float*, float*, float*, hipStream_t);
+hipError_t run_rpn_loss(const float*, int, int, int, const long long*, const float*, const float*, const float*, const int*, float, float*,
+                        float*, hipStream_t);
+hipError_t run_ce_rows(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 hipError_t run_relation_dscore(const void*, const void*, const void*, const void*, void*, int, long, int, long, long, float, int, hipStream_t);
 hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -295,8 +304,73 @@ int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncl
   if (R <= 0 || ncls <= 1 || cls_off < 0 || reg_off < 0 || cls_off + ncls > ldl || reg_off + 4 > ldl || !(beta > 0.f))
     return fail(HVR_EINVAL, "bad det_loss shape");
   return check_launch(run_det_loss(logits, ldl, cls_off, reg_off, ncls, (const long long*)labels, label_weights, bbox_targets,
-                                   bbox_weights, R, beta, w_cls, w_bbox, out3, dlogits, (hipStream_t)stream),
+                                   bbox_weights, R, beta, w_cls, w_bbox, out3, dlogits, nullptr, (hipStream_t)stream),
                       "hvr_det_loss");
+}
+
+int hvr_det_loss_sampled(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels,
+                         const float* label_weights, const float* bbox_targets, const float* bbox_weights, int R,
+                         const int32_t* sel_counts, float beta, float* out3, float* dlogits, void* stream) {
+  if (!logits || !labels || !label_weights || !bbox_targets || !bbox_weights || !out3 || !dlogits || !sel_counts)
+    return fail(HVR_EINVAL, "null pointer");
+  if (R <= 0 || ncls <= 1 || cls_off < 0 || reg_off < 0 || cls_off + ncls > ldl || reg_off + 4 > ldl || !(beta > 0.f))
+    return fail(HVR_EINVAL, "bad det_loss shape");
+  return check_launch(run_det_loss(logits, ldl, cls_off, reg_off, ncls, (const long long*)labels, label_weights, bbox_targets,
+                                   bbox_weights, R, beta, 1.f, 1.f, out3, dlogits, sel_counts, (hipStream_t)stream),
+                      "hvr_det_loss_sampled");
+}
+
+size_t hvr_max_iou_assign_workspace_bytes(int n, int k) { return n > 0 && k > 0 ? assign_workspace_bytes(n, k) : 0; }
+
+int hvr_max_iou_assign(const float* boxes, int ldb, int n, const float* gts, int k, const uint8_t* valid, float pos_iou_thr,
+                       float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int64_t* gt_inds, float* max_overlaps, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!boxes || !gts || !gt_inds || !max_overlaps || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (n <= 0 || k <= 0) return fail(HVR_EINVAL, "No gt or bboxes");  // max_iou_assigner.py:77-78 raises ValueError
+  if (k > 256) return fail(HVR_EUNSUPPORTED, "at most 256 ground-truth boxes per assignment (got %d)", k);
+  if (ldb < 4) return fail(HVR_EINVAL, "boxes need 4 coordinates per row");
+  if (ws_bytes < assign_workspace_bytes(n, k)) return fail(HVR_EINVAL, "assign workspace too small");
+  return check_launch(run_max_iou_assign(boxes, ldb, n, gts, k, valid, pos_iou_thr, neg_iou_lo, neg_iou_hi, min_pos_iou,
+                                         (long long*)gt_inds, max_overlaps, ws, (hipStream_t)stream),
+                      "hvr_max_iou_assign");
+}
+
+int hvr_sample_pos_neg(const int64_t* cls, const float* keys, int n, int num, int num_expected_pos, float neg_pos_ub, int64_t* inds,
+                       int32_t* counts, void* stream) {
+  if (!cls || !keys || !inds || !counts) return fail(HVR_EINVAL, "null pointer");
+  if (n <= 0 || num <= 0 || num_expected_pos < 0 || num_expected_pos > num) return fail(HVR_EINVAL, "bad sampler sizes");
+  return check_launch(run_sample((const long long*)cls, keys, n, num, num_expected_pos, neg_pos_ub, (long long*)inds, counts,
+                                 (hipStream_t)stream),
+                      "hvr_sample_pos_neg");
+}
+
+int hvr_box_targets(const float* boxes, int ldb, int n, const float* gts, const int64_t* gt_labels, const int64_t* gt_inds,
+                    const int64_t* inds, const int32_t* counts, int num, const float* means4, const float* stds4, float pos_weight,
+                    int scatter, int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights, void* stream) {
+  if (!boxes || !gts || !gt_inds || !inds || !counts || !means4 || !stds4 || !labels || !label_weights || !bbox_targets || !bbox_weights)
+    return fail(HVR_EINVAL, "null pointer");
+  if (n <= 0 || num <= 0 || ldb < 4) return fail(HVR_EINVAL, "bad box_targets sizes");
+  for (int i = 0; i < 4; ++i)
+    if (stds4[i] == 0.f) return fail(HVR_EINVAL, "target_stds must be non-zero");
+  return check_launch(run_box_targets(boxes, ldb, n, gts, (const long long*)gt_labels, (const long long*)gt_inds, (const long long*)inds,
+                                      counts, num, means4, stds4, pos_weight, scatter, (long long*)labels, label_weights, bbox_targets,
+                                      bbox_weights, (hipStream_t)stream),
+                      "hvr_box_targets");
+}
+
+int hvr_rpn_loss(const float* o, int ldo, int A, int rows, const int64_t* labels, const float* label_weights, const float* bbox_targets,
+                 const float* bbox_weights, const int32_t* counts, float beta, float* out2, float* d_o, void* stream) {
+  if (!o || !labels || !label_weights || !bbox_targets || !bbox_weights || !counts || !out2 || !d_o) return fail(HVR_EINVAL, "null pointer");
+  if (A <= 0 || rows <= 0 || ldo < 5 * A || !(beta > 0.f)) return fail(HVR_EINVAL, "bad rpn_loss shape");
+  return check_launch(run_rpn_loss(o, ldo, A, rows, (const long long*)labels, label_weights, bbox_targets, bbox_weights, counts, beta,
+                                   out2, d_o, (hipStream_t)stream),
+                      "hvr_rpn_loss");
+}
+
+int hvr_ce_rows(const float* logits, int ldl, int cls_off, int ncls, const int64_t* labels, int R, float* loss, void* stream) {
+  if (!logits || !labels || !loss) return fail(HVR_EINVAL, "null pointer");
+  if (R <= 0 || ncls <= 1 || cls_off < 0 || cls_off + ncls > ldl) return fail(HVR_EINVAL, "bad ce_rows shape");
+  return check_launch(run_ce_rows(logits, ldl, cls_off, ncls, (const long long*)labels, R, loss, (hipStream_t)stream), "hvr_ce_rows");
 }
 
 int hvr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,

@@ -300,7 +300,10 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
                                                        const long long* __restrict__ labels, const float* __restrict__ label_w,
                                                        const float* __restrict__ bbox_t, const float* __restrict__ bbox_w, int R,
                                                        float beta, float w_cls, float w_bbox, float* __restrict__ out3,
-                                                       float* __restrict__ dlogits) {
+                                                       float* __restrict__ dlogits, const int* __restrict__ sel_counts) {
+  // sel_counts != null: the OHEM form of the loss (selsa_rcnn.py:224-232) -- the reference evaluates it on the gathered rows
+  // cat(pos_inds, neg_inds); rows outside carry zero weights here, so only the smooth-L1 denominator (the number of gathered
+  // rows) and the accuracy's row set differ from the plain form.
   __shared__ float red[3][256];
   __shared__ float sh_avg;
   const int tid = threadIdx.x;
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
   if (tid == 0) sh_avg = fmaxf(red[0][0], 1.f);
   __syncthreads();
   const float avg = sh_avg;
+  const float rows_bbox = sel_counts ? fmaxf((float)(sel_counts[0] + sel_counts[1]), 1.f) : (float)R;
   __syncthreads();
   float lc = 0.f, lb = 0.f, hit = 0.f;
   for (int r = tid; r < R; r += 256) {
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
     for (int c = 0; c < ncls; ++c) se += expf(row[cls_off + c] - mx);
     const float lse = mx + logf(se), w = label_w[r];
     lc += (lse - row[cls_off + lab]) * w;
-    hit += arg == lab ? 1.f : 0.f;
+    hit += (arg == lab && (!sel_counts || w > 0.f)) ? 1.f : 0.f;
     for (int c = 0; c < ldl; ++c) drow[c] = 0.f;
     for (int c = 0; c < ncls; ++c)
       drow[cls_off + c] = w_cls * w / avg * (expf(row[cls_off + c] - lse) - (c == lab ? 1.f : 0.f));
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) {
         const float d = row[reg_off + e] - bbox_t[r * 4 + e], a = fabsf(d), bw = bbox_w[r * 4 + e];
         lb += (a < beta ? 0.5f * a * a / beta : a - 0.5f * beta) * bw;
-        drow[reg_off + e] = w_bbox * bw / (float)R * (a < beta ? d / beta : (d > 0.f ? 1.f : -1.f));
+        drow[reg_off + e] = w_bbox * bw / rows_bbox * (a < beta ? d / beta : (d > 0.f ? 1.f : -1.f));
       }
     }
   }
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float* __restrict__
   }
   if (tid == 0) {
     out3[0] = red[0][0] / avg;
-    out3[1] = red[1][0] / (float)R;
-    out3[2] = red[2][0] * (100.f / (float)R);
+    out3[1] = red[1][0] / rows_bbox;
+    out3[2] = red[2][0] * (100.f / rows_bbox);
   }
 }
 
@@ -480,9 +484,9 @@ hipError_t run_colsum(const void* dY, float* db, int M, int N, long ld, int dtyp
 
 hipError_t run_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const long long* labels, const float* label_w,
                         const float* bbox_t, const float* bbox_w, int R, float beta, float w_cls, float w_bbox, float* out3,
-                        float* dlogits, hipStream_t s) {
+                        float* dlogits, const int* sel_counts, hipStream_t s) {
   hipLaunchKernelGGL(det_loss_kernel, dim3(1), dim3(256), 0, s, logits, ldl, cls_off, reg_off, ncls, labels, label_w, bbox_t, bbox_w, R,
-                     beta, w_cls, w_bbox, out3, dlogits);
+                     beta, w_cls, w_bbox, out3, dlogits, sel_counts);
   return hipGetLastError();
 }
 

@@ -85,6 +85,13 @@ SYMBOLS = {
     'hvr_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _sz, _i, _vp]),
     'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
     'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
+    'hvr_det_loss_sampled': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp]),
+    'hvr_max_iou_assign_workspace_bytes': (_sz, [_i, _i]),
+    'hvr_max_iou_assign': (_i, [_vp, _i, _i, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    'hvr_sample_pos_neg': (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    'hvr_box_targets': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    'hvr_rpn_loss': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    'hvr_ce_rows': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'hvr_nms_workspace_bytes': (_sz, [_i]),
@@ -424,6 +431,100 @@ def det_loss(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets
                               _ptr(label_weights.float().contiguous()), _ptr(bbox_targets.float().contiguous()),
                               _ptr(bbox_weights.float().contiguous()), logits.shape[0], float(beta), float(w_cls), float(w_bbox),
                               _ptr(out3), _ptr(dlogits), _stream()), 'hvr_det_loss')
+    return out3, dlogits
+
+
+
+# ---- training targets (include/hvr_hip.h "Training targets") ----
+def max_iou_assign(boxes, gts, pos_iou_thr, neg_iou_thr, min_pos_iou, valid=None):
+    """boxes [n, >=4] f32, gts [k,4] f32, valid [n] uint8/bool or None -> (gt_inds int64 [n], max_overlaps f32 [n]).
+    neg_iou_thr: float (background = [0, thr)) or a (lo, hi) pair."""
+    _need_cuda(boxes, gts, valid)
+    assert boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.stride(1) == 1 and boxes.shape[1] >= 4
+    gts = gts.contiguous().float()
+    n, k = boxes.shape[0], gts.shape[0]
+    if n == 0 or k == 0:
+        raise ValueError('No gt or bboxes')  # max_iou_assigner.py:77-78
+    lo, hi = (0.0, float(neg_iou_thr)) if isinstance(neg_iou_thr, (int, float)) else (float(neg_iou_thr[0]), float(neg_iou_thr[1]))
+    if valid is not None:
+        valid = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.contiguous()
+        assert valid.dtype == torch.uint8 and valid.numel() == n
+    gt_inds = torch.empty(n, dtype=torch.long, device=boxes.device)
+    max_ov = torch.empty(n, dtype=torch.float32, device=boxes.device)
+    nbytes = lib().hvr_max_iou_assign_workspace_bytes(n, k)
+    ws = _workspace(nbytes, boxes.device, 'assign')
+    _check(lib().hvr_max_iou_assign(_ptr(boxes), boxes.stride(0), n, _ptr(gts), k, _ptr(valid), float(pos_iou_thr), lo, hi,
+                                    float(min_pos_iou), _ptr(gt_inds), _ptr(max_ov), _ptr(ws), nbytes, _stream()), 'hvr_max_iou_assign')
+    return gt_inds, max_ov
+
+
+def sample_pos_neg(cls, keys, num, num_expected_pos, neg_pos_ub=-1.0):
+    """cls int64 [n] (>0 positive, ==0 negative), keys f32 [n] -> (inds int64 [num]: positives then negatives, counts int32 [2])."""
+    _need_cuda(cls, keys)
+    assert cls.dtype == torch.long and cls.is_contiguous() and keys.dtype == torch.float32 and keys.is_contiguous()
+    assert cls.numel() == keys.numel()
+    inds = torch.empty(int(num), dtype=torch.long, device=cls.device)
+    counts = torch.empty(2, dtype=torch.int32, device=cls.device)
+    _check(lib().hvr_sample_pos_neg(_ptr(cls), _ptr(keys), cls.numel(), int(num), int(num_expected_pos), float(neg_pos_ub), _ptr(inds),
+                                    _ptr(counts), _stream()), 'hvr_sample_pos_neg')
+    return inds, counts
+
+
+def box_targets(boxes, gts, gt_labels, gt_inds, inds, counts, means, stds, pos_weight=-1.0, scatter=False):
+    """-> (labels int64, label_weights, bbox_targets [.,4], bbox_weights [.,4]) with n rows (scatter) or num rows."""
+    _need_cuda(boxes, gts, gt_labels, gt_inds, inds, counts)
+    assert boxes.dtype == torch.float32 and boxes.stride(1) == 1 and gt_inds.dtype == torch.long and inds.dtype == torch.long
+    gts = gts.contiguous().float()
+    n, num = boxes.shape[0], inds.numel()
+    rows = n if scatter else num
+    dev = boxes.device
+    labels = torch.empty(rows, dtype=torch.long, device=dev)
+    label_w = torch.empty(rows, dtype=torch.float32, device=dev)
+    bbox_t = torch.empty((rows, 4), dtype=torch.float32, device=dev)
+    bbox_w = torch.empty((rows, 4), dtype=torch.float32, device=dev)
+    m4, s4 = (ctypes.c_float * 4)(*[float(v) for v in means]), (ctypes.c_float * 4)(*[float(v) for v in stds])
+    gl = gt_labels.contiguous() if gt_labels is not None else None
+    _check(lib().hvr_box_targets(_ptr(boxes), boxes.stride(0), n, _ptr(gts), _ptr(gl), _ptr(gt_inds.contiguous()), _ptr(inds),
+                                 _ptr(counts), num, ctypes.cast(m4, ctypes.c_void_p), ctypes.cast(s4, ctypes.c_void_p),
+                                 float(pos_weight), int(bool(scatter)), _ptr(labels), _ptr(label_w), _ptr(bbox_t), _ptr(bbox_w),
+                                 _stream()), 'hvr_box_targets')
+    return labels, label_w, bbox_t, bbox_w
+
+
+def rpn_loss(o, A, labels, label_weights, bbox_targets, bbox_weights, counts, beta):
+    """o [rows, ldo] f32 (A objectness logits then 4A deltas per row) -> (out2 = [loss_rpn_cls, loss_rpn_bbox], d_o like o)."""
+    _need_cuda(o, labels, label_weights, bbox_targets, bbox_weights, counts)
+    assert o.dtype == torch.float32 and o.dim() == 2 and o.is_contiguous() and labels.dtype == torch.long
+    rows = o.shape[0]
+    assert labels.numel() == rows * A and counts.dtype == torch.int32
+    out2 = torch.empty(2, dtype=torch.float32, device=o.device)
+    d_o = torch.empty_like(o)
+    _check(lib().hvr_rpn_loss(_ptr(o), o.shape[1], int(A), rows, _ptr(labels.contiguous()), _ptr(label_weights.contiguous()),
+                              _ptr(bbox_targets.contiguous()), _ptr(bbox_weights.contiguous()), _ptr(counts), float(beta), _ptr(out2),
+                              _ptr(d_o), _stream()), 'hvr_rpn_loss')
+    return out2, d_o
+
+
+def ce_rows(logits, cls_off, ncls, labels):
+    """per-row softmax cross entropy of logits[:, cls_off:cls_off+ncls] -> f32 [R]."""
+    _need_cuda(logits, labels)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and labels.dtype == torch.long
+    loss = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+    _check(lib().hvr_ce_rows(_ptr(logits), logits.shape[1], cls_off, ncls, _ptr(labels.contiguous()), logits.shape[0], _ptr(loss),
+                             _stream()), 'hvr_ce_rows')
+    return loss
+
+
+def det_loss_sampled(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, sel_counts, beta=1.0):
+    """hvr_det_loss in the OHEM form: weights are zero outside the selected rows, sel_counts int32 [2] their number."""
+    _need_cuda(logits, labels, label_weights, bbox_targets, bbox_weights, sel_counts)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and labels.dtype == torch.long and sel_counts.dtype == torch.int32
+    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    _check(lib().hvr_det_loss_sampled(_ptr(logits), logits.shape[1], cls_off, reg_off, ncls, _ptr(labels.contiguous()),
+                                      _ptr(label_weights.float().contiguous()), _ptr(bbox_targets.float().contiguous()),
+                                      _ptr(bbox_weights.float().contiguous()), logits.shape[0], _ptr(sel_counts), float(beta),
+                                      _ptr(out3), _ptr(dlogits), _stream()), 'hvr_det_loss_sampled')
     return out3, dlogits
 
 

@@ -100,6 +100,63 @@ def det_loss(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets
     return dict(total=total, loss_cls=lc, loss_bbox=lb, acc=acc)
 
 
+class DetLossSampledFunction(Function):
+    """DetLossFunction in the OHEM form (selsa_rcnn.py:224-232): the rows cat(pos_inds, neg_inds) picked by the loss-ranked
+    sampler carry weight 1, all others 0; `sel_counts` int32 [2] (device) = how many were picked of each kind."""
+
+    @staticmethod
+    def forward(ctx, logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, sel_counts, beta):
+        out3, dlogits = native.det_loss_sampled(logits.contiguous(), cls_off, reg_off, ncls, labels, label_weights, bbox_targets,
+                                                bbox_weights, sel_counts, beta)
+        ctx.save_for_backward(dlogits)
+        loss_cls, loss_bbox, acc = out3[0], out3[1], out3[2:3]
+        total = out3[0:2].clone()
+        ctx.mark_non_differentiable(loss_cls, loss_bbox, acc)
+        return total, loss_cls, loss_bbox, acc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, g_cls, g_bbox, g_acc):
+        dlogits, = ctx.saved_tensors
+        if not bool((g_total == 1).all()):
+            raise NotImplementedError('DetLossSampledFunction supports the unit upstream gradient of sum(total) only')
+        return (dlogits,) + (None,) * 9
+
+
+def det_loss_sampled(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, sel_counts, beta=1.0):
+    total, lc, lb, acc = DetLossSampledFunction.apply(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights,
+                                                      sel_counts, float(beta))
+    return dict(total=total, loss_cls=lc, loss_bbox=lb, acc=acc)
+
+
+class RpnLossFunction(Function):
+    """AnchorHead.loss_single (anchor_head.py:141-160) on the fused RPN head output o [rows, ld] of ONE frame (A objectness
+    logits, then 4A deltas per position): -> (total [2], loss_rpn_cls, loss_rpn_bbox); only `total` carries a gradient.
+    counts int32 [2] (device): sampled positives / negatives; avg_factor = max(c0,1) + max(c1,1)."""
+
+    @staticmethod
+    def forward(ctx, o, A, labels, label_weights, bbox_targets, bbox_weights, counts, beta):
+        out2, d_o = native.rpn_loss(o.contiguous(), A, labels, label_weights, bbox_targets, bbox_weights, counts, beta)
+        ctx.save_for_backward(d_o)
+        loss_cls, loss_bbox = out2[0], out2[1]
+        total = out2.clone()
+        ctx.mark_non_differentiable(loss_cls, loss_bbox)
+        return total, loss_cls, loss_bbox
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, g_cls, g_bbox):
+        d_o, = ctx.saved_tensors
+        if not bool((g_total == 1).all()):
+            raise NotImplementedError('RpnLossFunction supports the unit upstream gradient of sum(total) only')
+        return (d_o,) + (None,) * 7
+
+
+def rpn_loss(o, A, labels, label_weights, bbox_targets, bbox_weights, counts, beta=1.0 / 9.0):
+    total, lc, lb = RpnLossFunction.apply(o, int(A), labels, label_weights, bbox_targets, bbox_weights, counts, float(beta))
+    return dict(total=total, loss_rpn_cls=lc, loss_rpn_bbox=lb)
+
+
 class ConvFunction(Function):
     """y = act(conv(x, w * s) + t (+ resid)) on physical NHWC tensors: an nn.Conv2d (no bias) followed by a frozen
     BatchNorm (scale s, shift t per output channel; pass s = ones / t = bias for a plain conv with bias) and optionally the

@@ -218,6 +218,46 @@ int hvr_permute_nchw_nhwc(const void* in, void* out, int B, int C, int HW, int t
 /* out[C][ldt] = in[R][ldx]^T, zero-filled for columns >= R */
 int hvr_transpose_pad(const void* in, void* out, int R, int C, int64_t ldx, int64_t ldt, int dtype, void* stream);
 
+/* Training targets: ground truth -> assigned, sampled boxes -> loss targets, all on the device.
+ *   hvr_max_iou_assign : MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:48-173, IoU of
+ *                        mmdet/core/bbox/geometry.py:46-60) for float thresholds, gt_max_assign_all=True and no ignore
+ *                        boxes: gt_inds[i] = -1 ignore / 0 background / g+1 assigned to gt g; max_overlaps[i].
+ *                        `valid` (nullable, one byte per box) marks the boxes that take part: anchor_target_single's
+ *                        inside_flags (mmdet/core/anchor/anchor_target.py:104-112) without compacting the anchors;
+ *                        boxes outside get gt_inds -1 and max_overlaps -1.  n == 0 or k == 0 is HVR_EINVAL where the
+ *                        reference raises ValueError('No gt or bboxes').
+ *   hvr_sample_pos_neg : BaseSampler.sample (mmdet/core/bbox/samplers/base_sampler.py:32-78) over boxes classed by
+ *                        cls[i] (> 0 positive, == 0 negative, < 0 neither).  From each class the boxes with the
+ *                        smallest keys[i] win (ties: lower index); RandomSampler = uniform random keys
+ *                        (random_sampler.py:37-53 shuffles on the host instead), OHEMHNLSampler.get_ohem_weights =
+ *                        keys -loss (ohem_hnl_sampler.py:50-113).  inds[0..counts[0]) positives, then counts[1]
+ *                        negatives, each ascending -- SamplingResult's order (sampling_result.py:9-12 after .unique()).
+ *   hvr_box_targets    : regression / classification targets of the sampled boxes (transforms.py:6-31 bbox2delta).
+ *                        scatter = 1: [n]-row outputs, row inds[j]  (anchor_target.py:121-155 after `unmap`);
+ *                        scatter = 0: [num]-row outputs, row j      (bbox_target.py:35-62).  gt_labels null: label 1.
+ *   hvr_rpn_loss       : AnchorHead.loss_single for one level, sigmoid objectness (anchor_head.py:141-160 with
+ *                        losses/cross_entropy_loss.py:23-37 and losses/smooth_l1_loss.py:9-18) on the fused RPN head
+ *                        output o [rows][ldo] (A logits then 4A deltas per position): out2 = (loss_rpn_cls,
+ *                        loss_rpn_bbox), d_o = d(sum of both)/d o; avg_factor = max(counts[0],1) + max(counts[1],1).
+ *   hvr_ce_rows        : per-row softmax cross entropy (`reduction_override='none'`, selsa_rcnn.py:209-218).
+ *   hvr_det_loss_sampled: hvr_det_loss in the OHEM form (selsa_rcnn.py:224-232): rows outside cat(pos_inds, neg_inds)
+ *                        carry zero weights; smooth-L1 and the accuracy are averaged over sel_counts[0]+sel_counts[1]. */
+size_t hvr_max_iou_assign_workspace_bytes(int n, int k);
+int hvr_max_iou_assign(const float* boxes, int ldb, int n, const float* gts, int k, const uint8_t* valid, float pos_iou_thr,
+                       float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int64_t* gt_inds, float* max_overlaps, void* ws,
+                       size_t ws_bytes, void* stream);
+int hvr_sample_pos_neg(const int64_t* cls, const float* keys, int n, int num, int num_expected_pos, float neg_pos_ub, int64_t* inds,
+                       int32_t* counts, void* stream);
+int hvr_box_targets(const float* boxes, int ldb, int n, const float* gts, const int64_t* gt_labels, const int64_t* gt_inds,
+                    const int64_t* inds, const int32_t* counts, int num, const float* means4, const float* stds4, float pos_weight,
+                    int scatter, int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights, void* stream);
+int hvr_rpn_loss(const float* o, int ldo, int A, int rows, const int64_t* labels, const float* label_weights, const float* bbox_targets,
+                 const float* bbox_weights, const int32_t* counts, float beta, float* out2, float* d_o, void* stream);
+int hvr_ce_rows(const float* logits, int ldl, int cls_off, int ncls, const int64_t* labels, int R, float* loss, void* stream);
+int hvr_det_loss_sampled(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels,
+                         const float* label_weights, const float* bbox_targets, const float* bbox_weights, int R,
+                         const int32_t* sel_counts, float beta, float* out3, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,43 @@ def head_train_case(n=32, ncls=31, seed=205):
     bbox_weights = torch.zeros(n, 4)
     bbox_weights[:npos] = 1.0
     return labels, label_weights, bbox_targets, bbox_weights
+
+
+def target_case(n_prop=300, ncls=31, seed=206):
+    """Inputs of the target-generation steps of one training iteration on a 600x1000 key frame: ground truth (one box
+    equal to an anchor so an IoU of exactly 1 occurs; one tiny box whose best anchor stays under pos_iou_thr, the
+    "each gt keeps its best boxes" branch), RPN head maps of the key frame, `n_prop` proposals (jittered copies of the ground truth + background) and the
+    head's outputs on them for the OHEM ranking."""
+    g = _gen(seed)
+    gt_bboxes = torch.tensor([[120., 80., 420., 330.],      # large
+                              [296., 136., 359., 199.],      # == the 64x64 anchor centred on cell (10, 20): IoU exactly 1
+                              [700., 400., 716., 420.],      # tiny: best anchor IoU < min_pos_iou, gets no anchor
+                              [500., 100., 780., 300.],
+                              [820., 420., 865., 460.]])     # best anchor between min_pos_iou and pos_iou_thr: low-quality match
+    gt_labels = torch.tensor([3, 17, 30, 9, 22])
+    rpn_cls = torch.randn((1, 12, 38, 63), generator=g) * 1.5
+    rpn_reg = torch.randn((1, 48, 38, 63), generator=g) * 0.3
+    props = []
+    for k in range(5):
+        b = gt_bboxes[k]
+        w, h = b[2] - b[0], b[3] - b[1]
+        jit = (torch.rand((24, 4), generator=g) - 0.5) * torch.stack([w, h, w, h]) * 0.5
+        props.append(b[None] + jit)
+    props.append(boxes(n_prop - 120, seed + 1, span=(900.0, 520.0), size=(10.0, 200.0))[:, :4])
+    props = torch.cat(props, 0)
+    props[:, 0::2] = props[:, 0::2].clamp(0, 999)
+    props[:, 1::2] = props[:, 1::2].clamp(0, 599)
+    props = torch.cat([props[:, :2], torch.max(props[:, 2:], props[:, :2] + 1)], 1)
+    props = props[torch.randperm(n_prop, generator=g)]
+    proposals = torch.cat([props, torch.rand((n_prop, 1), generator=g)], 1)
+    cls_score = torch.randn((n_prop + 5, ncls), generator=g) * 2.0
+    bbox_pred = torch.randn((n_prop + 5, 4), generator=g) * 0.7
+    return dict(gt_bboxes=gt_bboxes, gt_labels=gt_labels, rpn_cls=rpn_cls, rpn_reg=rpn_reg, proposals=proposals,
+                cls_score=cls_score, bbox_pred=bbox_pred)
+
+
+RPN_TRAIN_CFG = dict(assigner=dict(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3), allowed_border=0, pos_weight=-1,
+                     sampler=dict(num=256, pos_fraction=0.5, neg_pos_ub=-1, add_gt_as_proposals=False))
+RCNN_TRAIN_CFG = dict(assigner=dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5), pos_weight=-1,
+                      sampler=dict(num=300, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
+                      ohem=dict(num=128, pos_fraction=0.25, neg_pos_ub=-1))

@@ -48,6 +48,15 @@ def _load(name, rel):
     return m
 
 
+def _obj_from_dict(info, parent=None, default_args=None):
+    """mmcv.runner.obj_from_dict's contract: build `parent.<info['type']>(**rest, **default_args)`."""
+    args = dict(info)
+    cls = getattr(parent, args.pop('type'))
+    for k, v in (default_args or {}).items():
+        args.setdefault(k, v)
+    return cls(**args)
+
+
 def install_reference():
     import torch.nn as nn
     # fake mmcv
@@ -127,7 +136,30 @@ def install_reference():
         setattr(core, n, getattr(tr, n))
     core.auto_fp16, core.force_fp32 = dec.auto_fp16, dec.force_fp32
     core.multi_apply = misc.multi_apply
-    core.anchor_target = core.bbox_target = None
+    # target generation (training path): assigner / samplers / anchor_target / bbox_target, loaded where they lie
+    mmcv.runner.obj_from_dict = _obj_from_dict
+    cb = sys.modules['mmdet.core.bbox']
+    geo = _load('mmdet.core.bbox.geometry', 'mmdet/core/bbox/geometry.py')
+    asg = _pkg('mmdet.core.bbox.assigners')
+    _load('mmdet.core.bbox.assigners.base_assigner', 'mmdet/core/bbox/assigners/base_assigner.py')
+    ar = _load('mmdet.core.bbox.assigners.assign_result', 'mmdet/core/bbox/assigners/assign_result.py')
+    mia = _load('mmdet.core.bbox.assigners.max_iou_assigner', 'mmdet/core/bbox/assigners/max_iou_assigner.py')
+    asg.BaseAssigner = sys.modules['mmdet.core.bbox.assigners.base_assigner'].BaseAssigner
+    asg.MaxIoUAssigner, asg.AssignResult = mia.MaxIoUAssigner, ar.AssignResult
+    smp = _pkg('mmdet.core.bbox.samplers')
+    _load('mmdet.core.bbox.samplers.sampling_result', 'mmdet/core/bbox/samplers/sampling_result.py')
+    bs = _load('mmdet.core.bbox.samplers.base_sampler', 'mmdet/core/bbox/samplers/base_sampler.py')
+    ps = _load('mmdet.core.bbox.samplers.pseudo_sampler', 'mmdet/core/bbox/samplers/pseudo_sampler.py')
+    rs = _load('mmdet.core.bbox.samplers.random_sampler', 'mmdet/core/bbox/samplers/random_sampler.py')
+    oh = _load('mmdet.core.bbox.samplers.ohem_hnl_sampler', 'mmdet/core/bbox/samplers/ohem_hnl_sampler.py')
+    smp.BaseSampler, smp.PseudoSampler, smp.RandomSampler, smp.OHEMHNLSampler = bs.BaseSampler, ps.PseudoSampler, rs.RandomSampler, oh.OHEMHNLSampler
+    asmp = _load('mmdet.core.bbox.assign_sampling', 'mmdet/core/bbox/assign_sampling.py')
+    cb.PseudoSampler, cb.assign_and_sample, cb.build_assigner, cb.build_sampler = ps.PseudoSampler, asmp.assign_and_sample, asmp.build_assigner, asmp.build_sampler
+    cb.bbox2delta, cb.bbox_overlaps = tr.bbox2delta, geo.bbox_overlaps
+    core.utils.multi_apply = misc.multi_apply
+    bt = _load('mmdet.core.bbox.bbox_target', 'mmdet/core/bbox/bbox_target.py')
+    at = _load('mmdet.core.anchor.anchor_target', 'mmdet/core/anchor/anchor_target.py')
+    core.anchor_target, core.bbox_target = at.anchor_target, bt.bbox_target
     core.merge_aug_bboxes = core.merge_aug_masks = core.merge_aug_proposals = None
     bn = _load('mmdet.core.post_processing.bbox_nms', 'mmdet/core/post_processing/bbox_nms.py')
     core.multiclass_nms = bn.multiclass_nms
@@ -163,7 +195,10 @@ def install_reference():
     # defect D1
     orig = hh.HRNMPBBoxHead._add_selsa_with_fc
     hh.HRNMPBBoxHead._add_selsa_with_fc = lambda self, *a, **k: tuple(orig(self, *a, **k)) + (None, None)
-    return types.SimpleNamespace(AnchorGenerator=ag.AnchorGenerator, tr=tr, nms=nms, nms_cpu=nms_cpu, multiclass_nms=bn.multiclass_nms,
+    return types.SimpleNamespace(MaxIoUAssigner=mia.MaxIoUAssigner, RandomSampler=rs.RandomSampler, OHEMHNLSampler=oh.OHEMHNLSampler,
+                                 anchor_target=at.anchor_target, bbox_target=bt.bbox_target, build_assigner=asmp.build_assigner,
+                                 build_sampler=asmp.build_sampler,
+                                 AnchorGenerator=ag.AnchorGenerator, tr=tr, nms=nms, nms_cpu=nms_cpu, multiclass_nms=bn.multiclass_nms,
                                  ResNet=rn.ResNet, ResLayer=rl.ResLayer, RPNHead=rp.RPNHead, BBoxHead=bh.BBoxHead,
                                  SelsaBBoxHead=sh.SelsaBBoxHead, HRNMPBBoxHead=hh.HRNMPBBoxHead)
 
@@ -330,6 +365,56 @@ def main():
             out['hvr_det_bboxes_%d' % b], out['hvr_det_labels_%d' % b] = dbs[b], dls[b]
     save('g10_config1', **out)
 
+
+    # ---- G12 training targets through the reference's assigner / samplers / anchor_target / bbox_target / losses ----
+    tc = C.target_case()
+    gt_b, gt_l = tc['gt_bboxes'], tc['gt_labels']
+    meta12 = dict(img_shape=(600, 1000, 3), pad_shape=(608, 1008, 3), scale_factor=1.0, flip=False)
+    rpn_train = AttrDict(assigner=dict(type='MaxIoUAssigner', ignore_iof_thr=-1, **C.RPN_TRAIN_CFG['assigner']),
+                         sampler=dict(type='RandomSampler', **C.RPN_TRAIN_CFG['sampler']), allowed_border=0, pos_weight=-1, debug=False)
+    anchors12 = agen.grid_anchors((38, 63), 16, device='cpu')
+    inside12 = (anchors12[:, 0] >= 0) & (anchors12[:, 1] >= 0) & (anchors12[:, 2] < 1000) & (anchors12[:, 3] < 600)
+    ares = ref.build_assigner(rpn_train.assigner).assign(anchors12[inside12], gt_b, None, None)
+    out12 = dict(rpn_gt_inds=ares.gt_inds, rpn_max_overlaps=ares.max_overlaps, inside=inside12)
+    np.random.seed(1234)
+    valid12 = torch.ones(anchors12.shape[0], dtype=torch.uint8)
+    lab, lw, bt_, bw, npos, nneg = ref.anchor_target([[anchors12]], [[valid12]], [gt_b], [meta12], [0., 0., 0., 0.], [1., 1., 1., 1.],
+                                                     rpn_train, sampling=True)
+    out12.update(rpn_labels=lab[0], rpn_label_weights=lw[0], rpn_bbox_targets=bt_[0], rpn_bbox_weights=bw[0],
+                 rpn_num_pos=npos, rpn_num_neg=nneg)
+    np.random.seed(1234)  # the same shuffle again inside RPNHead.loss
+    rcls12, rreg12 = tc['rpn_cls'].clone().requires_grad_(True), tc['rpn_reg'].clone().requires_grad_(True)
+    rl = rpn.loss([rcls12], [rreg12], [gt_b], [meta12], rpn_train)
+    (rl['loss_rpn_cls'][0] + rl['loss_rpn_bbox'][0]).backward()
+    out12.update(loss_rpn_cls=rl['loss_rpn_cls'][0].detach(), loss_rpn_bbox=rl['loss_rpn_bbox'][0].detach(),
+                 d_rpn_cls=rcls12.grad, d_rpn_reg_sum=rreg12.grad.double().sum(), d_rpn_reg_abs=rreg12.grad.double().abs().sum(),
+                 d_rpn_reg_nz=rreg12.grad[rreg12.grad != 0])
+    # RCNN: assign + RandomSampler(add_gt_as_proposals) + bbox_target (selsa_rcnn.py:151-173, 204-206)
+    rcnn_train = AttrDict(assigner=dict(type='MaxIoUAssigner', ignore_iof_thr=-1, **C.RCNN_TRAIN_CFG['assigner']), pos_weight=-1)
+    np.random.seed(4321)
+    a2 = ref.build_assigner(rcnn_train.assigner).assign(tc['proposals'], gt_b, None, gt_l)
+    out12.update(rcnn_gt_inds=a2.gt_inds.clone(), rcnn_max_overlaps=a2.max_overlaps.clone())
+    sres = ref.RandomSampler(**C.RCNN_TRAIN_CFG['sampler']).sample(a2, tc['proposals'], gt_b, gt_l)
+    tl, tlw, tbt, tbw = selsa.get_target([sres], [gt_b], [gt_l], rcnn_train)
+    out12.update(rcnn_pos_inds=sres.pos_inds, rcnn_neg_inds=sres.neg_inds, rcnn_rois=sres.bboxes, rcnn_labels=tl,
+                 rcnn_label_weights=tlw, rcnn_bbox_targets=tbt, rcnn_bbox_weights=tbw)
+    # OHEM (selsa_rcnn.py:207-232) on fixed head outputs for the sampled rows
+    nrow = tl.shape[0]
+    cs12 = tc['cls_score'][:nrow].clone().requires_grad_(True)
+    bp12 = tc['bbox_pred'][:nrow].clone().requires_grad_(True)
+    ctx = types.SimpleNamespace(bbox_roi_extractor=None, bbox_head=selsa)
+    post = ref.OHEMHNLSampler(context=ctx, **C.RCNN_TRAIN_CFG['ohem'])
+    with torch.no_grad():
+        lcls = selsa.loss(cls_score=cs12, bbox_pred=None, labels=tl, label_weights=cs12.new_ones(nrow), bbox_targets=None,
+                          bbox_weights=None, reduction_override='none')['loss_cls']
+        olw, obw, opos, oneg = post.get_ohem_weights(tl, tlw.clone(), tbw.clone(), lcls)
+    allinds = torch.cat([opos, oneg], 0)
+    lo = selsa.loss(cls_score=cs12[allinds], bbox_pred=bp12[allinds], labels=tl[allinds], label_weights=olw[allinds],
+                    bbox_targets=tbt[allinds], bbox_weights=obw[allinds], reduction_override=None)
+    (lo['loss_cls'] + lo['loss_bbox']).backward()
+    out12.update(ohem_row_loss=lcls, ohem_pos_inds=opos, ohem_neg_inds=oneg, ohem_loss_cls=lo['loss_cls'].detach(),
+                 ohem_loss_bbox=lo['loss_bbox'].detach(), ohem_acc=lo['acc'].detach(), ohem_d_cls=cs12.grad, ohem_d_reg=bp12.grad)
+    save('g12_targets', **out12)
 
 if __name__ == '__main__':
     main()

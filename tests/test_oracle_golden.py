@@ -174,6 +174,79 @@ def test_g11_selsa_head_training_step(O):
     assert seen == 20  # fc_new_1/2, two relation stages (q, k, out), fc_cls, fc_reg: weights and biases
 
 
+def _replay_keys(n, chosen):
+    """Sampler keys under which the oracle's / the HIP path's "smallest keys win" rule picks exactly `chosen`:
+    the reference drew its subset with a host-side numpy shuffle (random_sampler.py:19-35); the subset is the fixture."""
+    keys = torch.ones(n)
+    keys[torch.as_tensor(np.asarray(chosen)).long()] = 0.0
+    return keys
+
+
+def test_g12_training_targets(O):
+    """Assigner, samplers, anchor_target, RPN loss, bbox_target and the OHEM loss against the reference's own classes (G12)."""
+    g = gold('g12_targets')
+    tc = C.target_case()
+    gt_b, gt_l = tc['gt_bboxes'], tc['gt_labels']
+    anchors = O.grid_anchors(O.gen_base_anchors(16, [4, 8, 16, 32], [0.5, 1.0, 2.0]), (38, 63), 16)
+    inside = O.anchor_inside_flags(anchors, (600, 1000, 3), 0)
+    assert np.array_equal(inside.numpy(), g['inside'])
+    a = C.RPN_TRAIN_CFG['assigner']
+    gt_inds, max_ov = O.max_iou_assign(anchors[inside], gt_b, a['pos_iou_thr'], a['neg_iou_thr'], a['min_pos_iou'])
+    assert np.array_equal(gt_inds.numpy(), g['rpn_gt_inds'])
+    assert np.array_equal(max_ov.numpy(), g['rpn_max_overlaps'])
+    assert (gt_inds == 3).sum() == 0 and (gt_inds == 5).sum() == 1 and float(max_ov[gt_inds == 5]) < 0.7   # both step-4 branches
+    keys = _replay_keys(anchors.shape[0], np.nonzero(g['rpn_label_weights'] > 0)[0])
+    lab, lw, bt, bw, npos, nneg = O.anchor_target_single(anchors, gt_b, (600, 1000, 3), keys, C.RPN_TRAIN_CFG)
+    assert (npos, nneg) == (int(g['rpn_num_pos']), int(g['rpn_num_neg']))
+    assert np.array_equal(lab.numpy(), g['rpn_labels']) and np.array_equal(lw.numpy(), g['rpn_label_weights'])
+    assert np.array_equal(bw.numpy(), g['rpn_bbox_weights'])
+    close(bt, g['rpn_bbox_targets'], 1e-6, 1e-7)
+    cls, reg = tc['rpn_cls'].clone().requires_grad_(True), tc['rpn_reg'].clone().requires_grad_(True)
+    lc, lb = O.rpn_loss(cls, reg, lab, lw, bt, bw, max(npos, 1) + max(nneg, 1))
+    close(lc.detach(), g['loss_rpn_cls'], 1e-5, 1e-6)
+    close(lb.detach(), g['loss_rpn_bbox'], 1e-5, 1e-6)
+    (lc + lb).backward()
+    close(cls.grad, g['d_rpn_cls'], 1e-5, 1e-8)
+    close(reg.grad[reg.grad != 0], g['d_rpn_reg_nz'], 1e-5, 1e-8)
+    # RCNN sampling + targets
+    k = gt_b.shape[0]
+    chosen = np.concatenate([g['rcnn_pos_inds'], g['rcnn_neg_inds']])
+    samp = O.rcnn_assign_sample(tc['proposals'], gt_b, gt_l, _replay_keys(k + tc['proposals'].shape[0], chosen), C.RCNN_TRAIN_CFG)
+    assert np.array_equal(samp['gt_inds'][k:].numpy(), g['rcnn_gt_inds'])
+    assert np.array_equal(samp['pos_inds'].numpy(), g['rcnn_pos_inds']) and np.array_equal(samp['neg_inds'].numpy(), g['rcnn_neg_inds'])
+    rois = torch.cat([samp['bboxes'][samp['pos_inds']], samp['bboxes'][samp['neg_inds']]])
+    assert np.array_equal(rois.numpy(), g['rcnn_rois'])
+    labels, label_w, bbox_t, bbox_w = O.bbox_target_single(samp, gt_b, gt_l)
+    assert np.array_equal(labels.numpy(), g['rcnn_labels']) and np.array_equal(label_w.numpy(), g['rcnn_label_weights'])
+    assert np.array_equal(bbox_w.numpy(), g['rcnn_bbox_weights'])
+    close(bbox_t, g['rcnn_bbox_targets'], 1e-5, 1e-6)
+    # OHEM: the ranking is deterministic (top-k of the row losses), no replay keys needed
+    n = labels.shape[0]
+    cs, bp = tc['cls_score'][:n].clone().requires_grad_(True), tc['bbox_pred'][:n].clone().requires_grad_(True)
+    oh = C.RCNN_TRAIN_CFG['ohem']
+    losses, opos, oneg = O.ohem_loss(cs, bp, labels, bbox_t, oh['num'], oh['pos_fraction'], oh['neg_pos_ub'])
+    assert np.array_equal(opos.numpy(), g['ohem_pos_inds']) and np.array_equal(oneg.numpy(), g['ohem_neg_inds'])
+    close(losses['loss_cls'].detach(), g['ohem_loss_cls'], 1e-5, 1e-6)
+    close(losses['loss_bbox'].detach(), g['ohem_loss_bbox'], 1e-5, 1e-6)
+    close(losses['acc'], g['ohem_acc'], 1e-5, 1e-6)
+    (losses['loss_cls'] + losses['loss_bbox']).backward()
+    close(cs.grad, g['ohem_d_cls'], 1e-5, 1e-8)
+    close(bp.grad, g['ohem_d_reg'], 1e-5, 1e-8)
+
+
+def test_sampler_keys_pick_the_smallest_with_index_ties(O):
+    """The key rule itself: fewer candidates than expected -> all of them; more -> the smallest keys, ties by lower index;
+    neg_pos_ub caps the negatives; output sorted."""
+    cls = torch.tensor([1, 0, 0, 2, -1, 0, 1, 0, 0, 3])
+    keys = torch.tensor([.5, .9, .1, .5, 0., .1, .2, .1, .7, .5])
+    pos, neg = O.sample_pos_neg(cls, keys, num=6, pos_fraction=0.5)
+    assert pos.tolist() == [0, 3, 6] and neg.tolist() == [2, 5, 7]
+    pos, neg = O.sample_pos_neg(cls, keys, num=4, pos_fraction=0.5)
+    assert pos.tolist() == [0, 6] and neg.tolist() == [2, 5]
+    pos, neg = O.sample_pos_neg(cls, keys, num=10, pos_fraction=0.2, neg_pos_ub=1.5)
+    assert pos.tolist() == [0, 6] and neg.tolist() == [2, 5, 7]
+
+
 def test_g8_det_readout(O):
     g = gold('g8_det')
     rois, cls, reg = C.det_case()

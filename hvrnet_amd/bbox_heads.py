@@ -244,11 +244,14 @@ class SelsaBBoxHead(_RelationHead):
         scale = 1.0 / math.sqrt(float(self.dim[1]))
         x = bbox_feat.contiguous().view(bbox_feat.size(0), -1)      # (c, ph, pw) order, as the reference flattens
 
+        self.nongt_dim = self.sampler_num * self.t_dim      # selsa_bbox_head.py:214
+
         def stage(k, f):
             sel = getattr(self, 'selsa_%d' % k)
+            kv = f if self.nongt_dim >= f.shape[0] else f[:self.nongt_dim]   # keys / values: the first nongt_dim rows (:130)
             q = TO.linear(f, sel['q_data_fc_%d' % k].weight, sel['q_data_fc_%d' % k].bias)
-            kk = TO.linear(f, sel['k_data_fc_%d' % k].weight, sel['k_data_fc_%d' % k].bias)
-            o = ops.relation(q, kk, f, scale)
+            kk = TO.linear(kv, sel['k_data_fc_%d' % k].weight, sel['k_data_fc_%d' % k].bias)
+            o = ops.relation(q, kk, kv, scale)
             z = sel['linear_out_%d' % k]
             return TO.linear(o, z.weight.view(z.weight.shape[0], -1), z.bias, resid=f, relu=True)
 

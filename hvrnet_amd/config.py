@@ -130,6 +130,25 @@ def selsa_config(frame_interval=7, nms_post=300):
     return Config(dict(model=model, train_cfg=None, test_cfg=_test_cfg(frame_interval, nms_post)))
 
 
+def _train_cfg(nms_post, rcnn_sampler_num, ohem=True):
+    # configs/faster_rcnn_r101_selsa_c5.py:74-122
+    first = dict(type='RandomSampler', num=nms_post, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    second = dict(type='OHEMHNLSampler', num=rcnn_sampler_num, pos_fraction=0.25, neg_pos_ub=-1)
+    return dict(
+        rpn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, ignore_iof_thr=-1),
+                 sampler=dict(type='RandomSampler', num=256, pos_fraction=0.5, neg_pos_ub=-1, add_gt_as_proposals=False),
+                 allowed_border=0, pos_weight=-1, debug=False),
+        rpn_proposal=dict(nms_across_levels=False, nms_pre=6000, nms_post=nms_post, max_num=nms_post, nms_thr=0.7, min_bbox_size=0),
+        rcnn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=-1),
+                  sampler=[first, second] if ohem else first, key_dim=0, pos_weight=-1, debug=False))
+
+
+def selsa_train_config(nms_post=300, rcnn_sampler_num=128, t_dim=3, ohem=True):
+    """SelsaRCNN with its training settings (configs/faster_rcnn_r101_selsa_c5.py: model + train_cfg, key frame first)."""
+    model = _model('SelsaRCNN', 'SelsaBBoxHead', dict(sampler_num=rcnn_sampler_num, t_dim=t_dim))
+    return Config(dict(model=model, train_cfg=_train_cfg(nms_post, rcnn_sampler_num, ohem), test_cfg=_test_cfg((t_dim - 1) // 2, nms_post)))
+
+
 def hvr_config(frame_interval=7, nms_post=300):
     """HNMBRCNN + HRNMPBBoxHead (configs/faster_rcnn_r101_hrnmp_c5.py), test-time settings."""
     model = _model('HNMBRCNN', 'HRNMPBBoxHead', dict(sampler_num=128, imgs_per_video=3, t_dim=9))

@@ -18,7 +18,7 @@ What differs from the reference is HOW a window executes, not what it computes:
     caller, which can enqueue the next window before collecting this one.
 The reference dump's defects are implemented as intended: SelsaRCNN takes
 `[:2]` of the head's 3-tuple (selsa_rcnn.py:306), `collections.Sequence` -> `collections.abc`.
-Inference only.
+Training: SelsaRCNN.forward_train (selsa_rcnn.py:85-279) runs on the HIP path end to end; HNMBRCNN is inference only.
 """
 import collections.abc
 import os
@@ -66,8 +66,13 @@ class BaseDetector(nn.Module):
                 raise NotImplementedError('multi-scale test-time augmentation (forward_feat_aug) is outside the hot path')
             return self.forward_feat(img_meta=img_meta, **kwargs)
         if return_loss:
-            raise NotImplementedError('the training step is not part of this round (SURVEY.md 8f.2)')
+            return self.forward_train(img, img_meta, **kwargs)
         return self.forward_test(img, img_meta, **kwargs)
+
+    def forward_train(self, img, img_meta, **kwargs):
+        raise NotImplementedError('%s has no training step on the HIP path (SelsaRCNN does; HNMBRCNN.forward_train needs the '
+                                  'triplet loss of pytorch_metric_learning, which is not part of the reference tree)'
+                                  % type(self).__name__)
 
     def forward_test(self, imgs, img_metas, **kwargs):
         for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
@@ -342,6 +347,81 @@ class SelsaRCNN(_WindowDetector):
                               self.bbox_roi_extractor.roi_layers[0].spatial_scale, self.bbox_roi_extractor.roi_layers[0].sample_num)
         logits = self.bbox_head.forward_train(feats, cur_range)
         return self.bbox_head.loss_train(logits, labels, label_weights, bbox_targets, bbox_weights)
+
+    def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
+                      keys=None, generator=None):
+        """SelsaRCNN.forward_train (selsa_rcnn.py:85-279) with every forward and backward kernel on the HIP path (f32;
+        enable_training + set_compute_dtype(float32) first): backbone on the T frames; RPN loss on the key frame only (:127-136);
+        proposals of all frames (:138-141, no gradient); per frame MaxIoUAssigner + RandomSampler against the KEY frame's ground
+        truth (:151-173); res5 + RoIAlign of the sampled boxes (:177-195); the SELSA head (:201); the key frame's targets
+        (:204-206) and, when train_cfg.rcnn.sampler is a list, the loss-ranked second sampler and the loss on its rows (:207-232).
+        img [T,3,H,W] with the key frame first (train_cfg.rcnn.key_dim = 0, as the reference's roi bookkeeping assumes, :177-182).
+        keys: optional dict(rpn=f32 [H/16 * W/16 * A], rcnn=[f32 [num_gt + nms_post] per frame]) replacing the samplers' random
+        draws.  -> dict(loss_rpn_cls [1-list], loss_rpn_bbox [1-list], loss_cls, loss_bbox, acc); summing the 'loss' entries
+        and calling backward() trains (the reference's parse_losses does the same sum)."""
+        from . import native, ops, targets as T, train_ops as TO
+        key = self.key_dim
+        if key != 0:
+            raise NotImplementedError('training keeps the key frame first (train_cfg.rcnn.key_dim = 0 in both configs)')
+        if gt_bboxes_ignore is not None and any(g is not None and g.numel() for g in gt_bboxes_ignore):
+            raise NotImplementedError('gt_bboxes_ignore is not on the HIP training path (ignore_iof_thr = -1 in both configs)')
+        keys = keys or {}
+        rcnn_cfg = self.train_cfg.rcnn
+        c4 = self.backbone.forward_train_nhwc(img)
+        losses = dict()
+        if self.with_rpn:
+            A = self.rpn_head.num_anchors
+            o = self.rpn_head.forward_train_fused(c4)
+            rl = self.rpn_head.loss_train(o[key], gt_bboxes[key], img_meta[key], self.train_cfg.rpn, keys=keys.get('rpn'),
+                                          generator=generator)
+            losses.update(loss_rpn_cls=[rl['total'][0]], loss_rpn_bbox=[rl['total'][1]])
+            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            with torch.no_grad():
+                od = o.detach()
+                proposal_list = self.rpn_head.get_bboxes([od[..., :A].permute(0, 3, 1, 2)], [od[..., A:5 * A].permute(0, 3, 1, 2)],
+                                                         img_meta, proposal_cfg)
+        else:
+            proposal_list = proposals
+        # assign gts and sample proposals: every frame against the key frame's boxes
+        bbox_assigner = T.build_assigner(rcnn_cfg.assigner)
+        post_sampler = None
+        if isinstance(rcnn_cfg.sampler, (list, tuple)):
+            bbox_sampler, post_sampler = T.build_sampler(rcnn_cfg.sampler, context=self)
+        else:
+            bbox_sampler = T.build_sampler(rcnn_cfg.sampler, context=self)
+        gt_b, gt_l = gt_bboxes[key], gt_labels[key]
+        sampling_results = []
+        for i in range(img.size(0)):
+            props = proposal_list[i].contiguous()
+            assign_result = bbox_assigner.assign(props, gt_b, None, gt_l)
+            k_i = keys['rcnn'][i][:gt_b.shape[0] * int(bbox_sampler.add_gt_as_proposals) + props.shape[0]] if 'rcnn' in keys else None
+            sampling_results.append(bbox_sampler.sample(assign_result, props, gt_b, gt_l, keys=k_i, generator=generator))
+        rois = torch.cat([torch.cat([r.bboxes.new_full((r.bboxes.shape[0], 1), float(i)), r.bboxes], 1)
+                          for i, r in enumerate(sampling_results)], 0)
+        n_key = sampling_results[key].bboxes.shape[0]
+        cur_range = dict(start=key * n_key, length=n_key)
+        c5 = self.shared_head.forward_train_nhwc(c4)
+        layer = self.bbox_roi_extractor.roi_layers[0]
+        feats = ops.roi_align(c5.permute(0, 3, 1, 2), rois, layer.out_size, layer.spatial_scale, layer.sample_num)
+        logits = self.bbox_head.forward_train(feats, cur_range)
+        labels, label_w, bbox_t, bbox_w = T.bbox_target([sampling_results[key]], [gt_b], [gt_l], rcnn_cfg,
+                                                        target_means=self.bbox_head.target_means, target_stds=self.bbox_head.target_stds)
+        nc = self.bbox_head.num_classes
+        if post_sampler is not None:
+            with torch.no_grad():
+                row_loss = native.ce_rows(logits.detach(), 0, nc, labels)
+                inds, counts = post_sampler.select(labels, row_loss)
+                # weights of get_ohem_weights (ohem_hnl_sampler.py:104-111) built on the device: 1 on the picked rows
+                slot = torch.arange(inds.numel(), device=inds.device)
+                picked = (slot < counts.sum()).float()
+                safe = inds.clamp(0, n_key - 1)
+                label_w = torch.zeros_like(label_w).scatter_add_(0, safe, picked)
+                bbox_w = torch.zeros_like(bbox_w).index_add_(0, safe, ((slot < counts[0]).float())[:, None].expand(-1, 4))
+            hl = TO.det_loss_sampled(logits, 0, nc, nc, labels, label_w, bbox_t, bbox_w, counts, beta=1.0)
+        else:
+            hl = self.bbox_head.loss_train(logits, labels, label_w, bbox_t, bbox_w)
+        losses.update(loss_cls=hl['total'][0], loss_bbox=hl['total'][1], acc=hl['acc'])
+        return losses
 
     def forward_feat_frames(self, entries, c4s=None, rescale=False, defer=False):
         """forward_feat from T cached `frame_tensors` entries; c4s (the frames' C4 maps) back the exact re-run that

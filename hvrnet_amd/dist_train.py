@@ -63,3 +63,32 @@ def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm
     world = flat.allreduce_grads()
     flat.sgd_step(lr, momentum, weight_decay, max_norm, world)
     return loss
+
+
+def parse_losses(losses):
+    """mmdet/apis/train.py:17-34 without the per-entry `.item()` host copies: -> (loss to differentiate, {name: 0-dim tensor});
+    the log values stay on the device (read them once per logging interval, not once per entry per iteration)."""
+    log_vars = {}
+    for name, value in losses.items():
+        if isinstance(value, torch.Tensor):
+            log_vars[name] = value.mean()
+        elif isinstance(value, list):
+            log_vars[name] = sum(v.mean() for v in value)
+        else:
+            raise TypeError('{} is not a tensor or list of tensors'.format(name))
+    loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+    log_vars['loss'] = loss
+    return loss, {k: v.detach() for k, v in log_vars.items()}
+
+
+def train_detector_iteration(model, flat, data, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0):
+    """batch_processor + the optimizer hook (mmdet/apis/train.py:37-54, mmdet/core/utils/dist_utils.py:52-58) for one rank's
+    batch: model(**data) -> parse_losses -> backward -> one flat all-reduce over RCCL -> fused clip + SGD.  -> log_vars."""
+    box = {}
+
+    def loss_fn():
+        loss, box['log'] = parse_losses(model(**data))
+        return loss
+
+    train_iteration(flat, loss_fn, lr, momentum, weight_decay, max_norm)
+    return box['log']

@@ -69,11 +69,11 @@ class RPNHead(nn.Module, PackedMixin):
         o = native.conv2d_nhwc(y, p['heads'][0], p['heads'][1], relu=False, out_f32=True)  # [T,H,W,5A(+pad)] f32
         return as_logical(o[..., :A]), as_logical(o[..., A:5 * A])
 
-    def forward_train_nhwc(self, x):
-        """rpn_head.py:30-35 as an autograd graph of HIP convs: x [T,H,W,C] f32 NHWC -> (cls [T,H,W,A], reg [T,H,W,4A]).
-        The two 1x1 heads run as one conv over the concatenated weights (rows padded to a K-step multiple)."""
+    def forward_train_fused(self, x):
+        """rpn_head.py:30-35 as an autograd graph of HIP convs: x [T,H,W,C] f32 NHWC -> o [T,H,W,ld] f32 whose columns
+        0..A are the objectness logits and A..5A the deltas (anchor a's four at A + 4a); ld = 5A padded to a K-step multiple.
+        The two 1x1 heads run as one conv over the concatenated weights."""
         from . import train_ops as TO
-        A = self.num_anchors
         y = TO.conv_bias(x, self.rpn_conv, relu=True)
         w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight], 0)
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
@@ -81,8 +81,46 @@ class RPNHead(nn.Module, PackedMixin):
         w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
         b = torch.cat([b, b.new_zeros(pad)], 0)
         ones = torch.ones(w.shape[0], dtype=torch.float32, device=x.device)
-        o = TO.ConvFunction.apply(y, w, ones, b, None, False, 1, 0, 1)
+        return TO.ConvFunction.apply(y, w, ones, b, None, False, 1, 0, 1)
+
+    def forward_train_nhwc(self, x):
+        """-> (cls [T,H,W,A], reg [T,H,W,4A]) views of forward_train_fused's output."""
+        A = self.num_anchors
+        o = self.forward_train_fused(x)
         return o[..., :A], o[..., A:5 * A]
+
+    def _train_anchors(self, featmap_size, img_meta, device):
+        """get_anchors (anchor_head.py:100-139) for the single level: grid anchors and their valid flags, cached per shape."""
+        key = (tuple(featmap_size), tuple(img_meta['pad_shape'][:2]), str(device))
+        cache = self.__dict__.setdefault('_anchor_cache', {})
+        if key not in cache:
+            stride, gen = self.anchor_strides[0], self.anchor_generators[0]
+            feat_h, feat_w = featmap_size
+            anchors = gen.grid_anchors(featmap_size, stride, device=device).contiguous()
+            h, w = img_meta['pad_shape'][:2]
+            vh, vw = min(-(-h // stride), feat_h), min(-(-w // stride), feat_w)
+            vy = torch.arange(feat_h, device=device) < vh
+            vx = torch.arange(feat_w, device=device) < vw
+            valid = (vy[:, None] & vx[None, :]).reshape(-1, 1).expand(-1, self.num_anchors).reshape(-1).to(torch.uint8)
+            cache[key] = (anchors, valid.contiguous())
+        return cache[key]
+
+    def loss_train(self, o_key, gt_bboxes, img_meta, cfg, keys=None, generator=None):
+        """AnchorHead.loss / RPNHead.loss (anchor_head.py:162-206, rpn_head.py:36-53) for ONE image -- SelsaRCNN trains the
+        RPN on the key frame only (selsa_rcnn.py:127-136) -- on forward_train_fused's output of that frame, o_key [H,W,ld].
+        Targets (assign, sample, deltas) and the loss run on the device without a host copy; `keys` [H*W*A] replaces the
+        sampler's random draw.  -> dict(loss_rpn_cls, loss_rpn_bbox, total [2])."""
+        from . import targets as T, train_ops as TO
+        if len(self.anchor_strides) != 1:
+            raise NotImplementedError('single-level RPN only (anchor_strides=[16])')
+        H, W, ld = o_key.shape
+        anchors, valid = self._train_anchors((H, W), img_meta, o_key.device)
+        labels, label_w, bbox_t, bbox_w, counts = T.anchor_target_single(anchors, valid, gt_bboxes, img_meta, self.target_means,
+                                                                         self.target_stds, cfg, keys=keys, generator=generator)
+        if self.loss_cls_cfg.get('loss_weight', 1.0) != 1.0 or self.loss_bbox_cfg.get('loss_weight', 1.0) != 1.0:
+            raise NotImplementedError('RPN loss weights other than 1.0')
+        return TO.rpn_loss(o_key.reshape(H * W, ld), self.num_anchors, labels, label_w, bbox_t, bbox_w, counts,
+                           beta=self.loss_bbox_cfg.get('beta', 1.0))
 
     def forward(self, feats):
         outs = [self.forward_single(f) for f in feats]

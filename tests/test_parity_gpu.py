@@ -638,6 +638,93 @@ def test_selsa_rcnn_training_step_on_sampled_rois_matches_the_oracle(O):
         close(params[k].grad, w, 1e-2, 1e-2 * w.abs().max().item())
 
 
+@pytest.mark.parametrize('ohem', [True, False])
+def test_selsa_rcnn_forward_train_matches_the_oracle(O, ohem):
+    """The whole SelsaRCNN.forward_train on three 128x192 frames through the detector's own dispatch
+    (model(img, img_meta, return_loss=True, gt_bboxes=..., gt_labels=...)): RPN loss on the key frame, proposals, per-frame
+    assignment + sampling against the key frame's ground truth, res5, RoIAlign, SELSA head (keys truncated to
+    sampler_num * t_dim rows, as the reference does in training), targets, the loss-ranked second sampler and the loss --
+    against the oracle's restatement of selsa_rcnn.py:85-279 on the same sampler keys.  Integer decisions (sampled boxes,
+    labels, OHEM rows) must agree exactly; losses to 1e-3; gradients of one weight per network part to 1e-2 of their scale."""
+    from hvrnet_amd.config import selsa_train_config
+    sd = S.synth_state_dict('selsa')
+    n_post, n_sel, T = 24, 16, 3
+    cfg = selsa_train_config(nms_post=n_post, rcnn_sampler_num=n_sel, t_dim=T, ohem=ohem)
+    cfg.train_cfg.rpn.sampler.num = 16     # fewer than the 28 anchors inside a 128x192 frame: the RPN sampler has to choose
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, sd, torch.float32, DEV))
+    g = torch.Generator().manual_seed(91)
+    hw = (128, 192)
+    imgs = torch.randn((T, 3) + hw, generator=g) * 50.0
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(T)]
+    gt_b = torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.], [40., 60., 103., 123.]])
+    gt_l = torch.tensor([5, 12, 30])
+    n_anchor = (hw[0] // 16) * (hw[1] // 16) * 12
+    keys = dict(rpn=torch.rand(n_anchor, generator=g), rcnn=[torch.rand(gt_b.shape[0] + n_post, generator=g) for _ in range(T)])
+    watch = ['backbone.layer2.0.conv1.weight', 'backbone.layer3.5.conv2.weight', 'shared_head.layer4.2.conv3.weight',
+             'shared_head.new_layer_1.conv.weight', 'rpn_head.rpn_conv.weight', 'rpn_head.rpn_cls.bias', 'rpn_head.rpn_reg.weight',
+             'bbox_head.fc_new_1.bias', 'bbox_head.selsa_1.q_data_fc_1.weight', 'bbox_head.selsa_2.linear_out_2.weight',
+             'bbox_head.fc_cls.weight', 'bbox_head.fc_reg.bias']
+    leaf = dict(sd)
+    for k in watch:
+        leaf[k] = sd[k].clone().requires_grad_(True)
+    tc = cfg.train_cfg
+    rcnn_o = dict(assigner=dict(tc.rcnn.assigner), sampler=dict(tc.rcnn.sampler[0] if ohem else tc.rcnn.sampler), pos_weight=-1,
+                  ohem=dict(tc.rcnn.sampler[1]) if ohem else None)
+    want, mid = O.selsa_forward_train(imgs, leaf, metas, gt_b, gt_l, keys, dict(tc.rpn), dict(tc.rpn_proposal), rcnn_o, n_sel, T)
+    (want['loss_cls'] + want['loss_bbox'] + want['loss_rpn_cls'] + want['loss_rpn_bbox']).backward()
+    assert all(0 < s_['pos_inds'].numel() and 0 < s_['neg_inds'].numel() for s_ in mid['samples'])   # the case exercises both
+    assert mid['rois'].shape[0] > n_sel * T                     # more rows than nongt_dim: the key truncation is live
+
+    dkeys = dict(rpn=keys['rpn'].to(DEV), rcnn=[k_.to(DEV) for k_ in keys['rcnn']])
+    got = model(imgs.to(DEV), metas, return_loss=True, gt_bboxes=[gt_b.to(DEV)] * T, gt_labels=[gt_l.to(DEV)] * T, keys=dkeys)
+    total = sum(v if isinstance(v, torch.Tensor) else sum(v) for k, v in got.items() if 'loss' in k)   # parse_losses' sum
+    total.backward()
+    close(got['loss_rpn_cls'][0], want['loss_rpn_cls'], 1e-3, 1e-5)
+    close(got['loss_rpn_bbox'][0], want['loss_rpn_bbox'], 1e-3, 1e-5)
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        close(got[k], want[k], 1e-3, 1e-5)
+    params = dict(model.named_parameters())
+    for k in watch:
+        w = leaf[k].grad
+        assert params[k].grad is not None, k
+        close(params[k].grad, w, 1e-2, 1e-2 * w.abs().max().item())
+
+
+
+def test_full_detector_training_iterations_descend():
+    """dist_train.train_detector_iteration on the whole SelsaRCNN (the reference's batch_processor + optimizer hook): with the
+    sampler keys held fixed, three SGD iterations lower the summed loss, every trainable parameter moves, frozen ones
+    (stem, stage 1, every BatchNorm) stay bit-identical, and nothing goes non-finite."""
+    from hvrnet_amd.config import selsa_train_config
+    from hvrnet_amd.dist_train import FlatParams, train_detector_iteration
+    n_post, n_sel, T = 24, 16, 3
+    cfg = selsa_train_config(nms_post=n_post, rcnn_sampler_num=n_sel, t_dim=T)
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict('selsa'), torch.float32, DEV))
+    g = torch.Generator().manual_seed(93)
+    hw = (128, 192)
+    imgs = (torch.randn((T, 3) + hw, generator=g) * 50.0).to(DEV)
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(T)]
+    gt_b = torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]).to(DEV)
+    gt_l = torch.tensor([5, 12]).to(DEV)
+    keys = dict(rpn=torch.rand((hw[0] // 16) * (hw[1] // 16) * 12, generator=g).to(DEV),
+                rcnn=[torch.rand(2 + n_post, generator=g).to(DEV) for _ in range(T)])
+    data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, keys=keys)
+    flat = FlatParams(model)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    logs = [train_detector_iteration(model, flat, data, lr=2e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0) for _ in range(3)]
+    vals = [float(l['loss']) for l in logs]
+    assert all(math.isfinite(v) for v in vals) and vals[2] < vals[0], vals
+    assert set(logs[0]) == {'loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'loss_bbox', 'acc', 'loss'}
+    after = model.state_dict()
+    moved = [k for k in trainable if not torch.equal(after[k], before[k])]
+    assert len(moved) == len(trainable) and len(trainable) > 100
+    for k in before:
+        if k not in trainable:
+            assert torch.equal(after[k], before[k]), k
+        assert bool(torch.isfinite(after[k].float()).all()), k
+
+
 # ------------------------------------------------------------------------------- per-frame cache
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):

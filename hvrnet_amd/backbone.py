@@ -255,16 +255,18 @@ class ResNet(nn.Module, PackedMixin):
         return tuple(outs)
 
     def forward_train_nhwc(self, x):
-        """Training forward (f32): the frozen stem and stages (`frozen_stages`, BatchNorm everywhere) run the inference
-        kernels without a graph, the remaining stages are autograd graphs of HIP convs (Bottleneck.forward_train_nhwc).
+        """Training forward in the compute dtype (f32 = parity mode, bf16 = throughput mode with f32 master weights): the
+        frozen stem and stages (`frozen_stages`, BatchNorm everywhere) run the inference kernels without a graph, the remaining stages are autograd graphs of HIP convs (Bottleneck.forward_train_nhwc).
         -> the last out_indices map, physical NHWC."""
-        if self.compute_dtype != torch.float32:
-            raise NotImplementedError('the training step runs the f32 path (set_compute_dtype(model, torch.float32))')
         p = self.packed(x.device)
+        dt = self.compute_dtype
         with torch.no_grad():
-            cols, OH, OW = native.im2col_stem(x.contiguous().float(), torch.float32, STEM_KP)
-            y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
-            y = native.maxpool3x3s2_nhwc(y)
+            if dt == torch.bfloat16 and self.fused_stem:
+                y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
+            else:
+                cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
+                y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
+                y = native.maxpool3x3s2_nhwc(y)
             for i, name in enumerate(self.res_layers):
                 if i + 1 <= self.frozen_stages:
                     for blk in getattr(self, name):

@@ -238,11 +238,13 @@ class SelsaBBoxHead(_RelationHead):
         """The head's forward as an autograd graph of HIP ops (train_ops.linear / ops.relation): -> f32 logits [l, 36] of
         the key frame's rows, class logits in columns 0..num_classes-1, box deltas in the next 4 (fused fc_cls | fc_reg)."""
         from . import ops, train_ops as TO
-        if self.compute_dtype != torch.float32:
-            raise NotImplementedError('the training step runs the f32 path (set_compute_dtype(model, torch.float32))')
         s, l = int(cur_range['start']), int(cur_range['length'])
         scale = 1.0 / math.sqrt(float(self.dim[1]))
         x = bbox_feat.contiguous().view(bbox_feat.size(0), -1)      # (c, ph, pw) order, as the reference flattens
+        if x.dtype != self.compute_dtype:   # f32: parity mode; bf16: operands rounded to bf16, f32 accumulation
+            if x.requires_grad:
+                raise NotImplementedError('RoI features must arrive in the compute dtype (%s) when they carry a gradient' % self.compute_dtype)
+            x = native.cast(x, self.compute_dtype)
 
         self.nongt_dim = self.sampler_num * self.t_dim      # selsa_bbox_head.py:214
 
@@ -262,7 +264,7 @@ class SelsaBBoxHead(_RelationHead):
         nc = self.num_classes
         w = torch.cat([self.fc_cls.weight, self.fc_reg.weight, self.fc_cls.weight.new_zeros((-(nc + 4) % 4, self.fc_cls.weight.shape[1]))], 0)
         b = torch.cat([self.fc_cls.bias, self.fc_reg.bias, self.fc_cls.bias.new_zeros(-(nc + 4) % 4)], 0)
-        return TO.linear(h2.contiguous(), w, b)
+        return TO.linear(h2.contiguous(), w, b, out_f32=True)
 
     def loss_train(self, logits, labels, label_weights, bbox_targets, bbox_weights):
         """BBoxHead.loss on forward_train's fused logits (bbox_head.py:100-130) -> dict(loss_cls, loss_bbox, acc, total)."""

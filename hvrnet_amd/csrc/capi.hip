@@ -15,12 +15,17 @@
 
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
+hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
 hipError_t run_im2col_nhwc(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_scale_rows(const void*, const float*, void*, int, long, int, hipStream_t);
 hipError_t run_sgd_step(float*, const float*, float*, long, float, float, float, float, float, float*, int, hipStream_t);
-hipError_t run_colsum(const void*, float*, int, int, long, int, hipStream_t);
+hipError_t run_colsum(const void*, float*, int, int, long, int, float*, hipStream_t);
+int colsum_slices(int M, int N);
+size_t sgd_workspace_bytes();
+hipError_t run_pack_conv_weight(const float*, const float*, void*, int, int, int, int, hipStream_t);
+hipError_t run_unpack_conv_wgrad(const float*, const float*, float*, int, int, int, hipStream_t);
 hipError_t run_det_loss(const float*, int, int, int, int, const long long*, const float*, const float*, const float*, int, float, float,
                         float, float*, float*, const int*, hipStream_t);
 size_t assign_workspace_bytes(int n, int k);
@@ -112,6 +117,50 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm");
+}
+
+// slices for a GEMM whose output has too few tiles to fill the chip and whose K loop is long (weight gradients)
+static int splitk_slices(int M, int N, int K, int dtype) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const int ksteps = K / (128 / elem_size(dtype));
+  if (tiles >= 192 || ksteps < 32) return 1;
+  long s = (512 + tiles - 1) / tiles;
+  if (s > ksteps / 8) s = ksteps / 8;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : (int)s;
+}
+
+size_t hvr_gemm_splitk_workspace_bytes(int M, int N, int K, int dtype) {
+  if (M <= 0 || N <= 0 || K <= 0 || (dtype != HVR_F32 && dtype != HVR_BF16)) return 0;
+  const int s = splitk_slices(M, N, K, dtype);
+  return s > 1 ? (size_t)s * M * N * 4 : 0;
+}
+
+int hvr_gemm_splitk(const hvr_gemm_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  if (!d) return fail(HVR_EINVAL, "null descriptor");
+  if (d->bias || d->resid || d->relu) return fail(HVR_EINVAL, "split-K products have no epilogue (bias / residual / ReLU)");
+  if (d->dtype != HVR_F32 && !d->out_f32) return fail(HVR_EINVAL, "split-K products are f32 (set out_f32)");
+  GemmParams p;
+  int rc = fill_linear(p, d->A, d->B, d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->dtype, d->staging);
+  if (rc) return rc;
+  const int es = elem_size(d->dtype);
+  if ((d->lda * es) % 16 || (d->ldb * es) % 16) return fail(HVR_EINVAL, "lda/ldb rows must be 16-byte multiples");
+  if ((d->ldc * 4) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
+  p.out_f32 = d->out_f32;
+  p.tile_hint = d->tile_hint;
+  const int slices = splitk_slices(d->M, d->N, d->K, d->dtype);
+  if (slices <= 1) return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm_splitk");
+  const size_t need = (size_t)slices * d->M * d->N * 4;
+  if (!ws || ws_bytes < need || !aligned16(ws)) return fail(HVR_EINVAL, "split-K workspace too small (%zu < %zu) or unaligned", ws_bytes, need);
+  const int ksteps = d->K / (128 / es);
+  p.ksplit_steps = (ksteps + slices - 1) / slices;
+  p.ksplit_count = (ksteps + p.ksplit_steps - 1) / p.ksplit_steps;
+  p.csplit_bytes = (long)d->M * d->N * 4;
+  p.C = ws;
+  p.ldc = d->N;
+  hipError_t e = run_tile_op(p, EPI_LINEAR, (hipStream_t)stream);
+  if (e == hipSuccess) e = run_splitk_reduce((const float*)ws, (float*)d->C, d->M, d->N, d->ldc, p.ksplit_count, (hipStream_t)stream);
+  return check_launch(e, "hvr_gemm_splitk");
 }
 
 int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
@@ -283,7 +332,7 @@ int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t 
   return check_launch(run_scale_rows(w, scale, out, R, C, dtype, (hipStream_t)stream), "hvr_scale_rows");
 }
 
-size_t hvr_sgd_workspace_bytes(void) { return 256 * sizeof(float); }
+size_t hvr_sgd_workspace_bytes(void) { return sgd_workspace_bytes(); }
 
 // ---- head training helpers ----
 int hvr_relu_bwd(const void* dY, const void* Y, void* dZ, int64_t n, int dtype, void* stream) {
@@ -292,9 +341,28 @@ int hvr_relu_bwd(const void* dY, const void* Y, void* dZ, int64_t n, int dtype, 
   return check_launch(run_relu_bwd(dY, Y, dZ, n, dtype, (hipStream_t)stream), "hvr_relu_bwd");
 }
 
-int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, void* stream) {
+size_t hvr_colsum_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  const int s = colsum_slices(M, N);
+  return s > 1 ? (size_t)s * N * sizeof(float) : 0;
+}
+
+int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, void* ws, size_t ws_bytes, void* stream) {
   if (!dY || !db || M <= 0 || N <= 0) return fail(HVR_EINVAL, "bad colsum arguments");
-  return check_launch(run_colsum(dY, db, M, N, ld, dtype, (hipStream_t)stream), "hvr_colsum");
+  const size_t need = hvr_colsum_workspace_bytes(M, N);
+  if (need && (!ws || ws_bytes < need)) return fail(HVR_EWORKSPACE, "colsum workspace too small");
+  return check_launch(run_colsum(dY, db, M, N, ld, dtype, (float*)ws, (hipStream_t)stream), "hvr_colsum");
+}
+
+int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout, int Cin, int KH, int KW, int out_dtype, void* stream) {
+  if (!w || !scale || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return fail(HVR_EINVAL, "bad pack_conv_weight arguments");
+  if (out_dtype != HVR_F32 && out_dtype != HVR_BF16) return fail(HVR_EINVAL, "bad dtype");
+  return check_launch(run_pack_conv_weight(w, scale, out, Cout, Cin, KH * KW, out_dtype, (hipStream_t)stream), "hvr_pack_conv_weight");
+}
+
+int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, void* stream) {
+  if (!dw || !scale || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return fail(HVR_EINVAL, "bad unpack_conv_wgrad arguments");
+  return check_launch(run_unpack_conv_wgrad(dw, scale, out, Cout, Cin, KH * KW, (hipStream_t)stream), "hvr_unpack_conv_wgrad");
 }
 
 int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels, const float* label_weights,

@@ -129,6 +129,23 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   }
   const int m0 = pid_m * BM, n0 = pid_n * BN;
 
+  // split-K (EPI_LINEAR, plain GEMM only): gridDim.y slices of `ksplit_steps` K-steps each write their own f32 partial
+  // [M][N] at C + blockIdx.y * csplit_bytes; a weight-gradient GEMM has a few output tiles and a K of 10^4..10^5, which
+  // one workgroup per tile would walk alone while most of the chip idles.  The slice is folded into the base pointers.
+  const char* Ab = (const char*)p.A;
+  const char* Bb = (const char*)p.B;
+  char* Cb = (char*)p.C;
+  int nk_slice = p.K / BKE;
+  if constexpr (EPI == EPI_LINEAR) {
+    if (p.ksplit_steps > 0) {
+      const int kt0 = blockIdx.y * p.ksplit_steps;
+      Ab += (long)kt0 * 128;
+      Bb += (long)kt0 * 128;
+      Cb += (long)blockIdx.y * p.csplit_bytes;
+      nk_slice = nk_slice - kt0 < p.ksplit_steps ? nk_slice - kt0 : p.ksplit_steps;
+    }
+  }
+
   // ---------------- loader setup: one 16-byte chunk per (thread, slot) ----------------
   // 32-bit byte offsets from p.A / p.B (the C ABI rejects operands of 2 GiB and more) and the conv origin of the
   // row packed as (iy << 16) | (ix & 0xffff): half the registers of pointers + two ints, which the pipelined
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        const char* src = (const char*)p.A + ((long)a_off[i] + a_koff);
+        const char* src = Ab + ((long)a_off[i] + a_koff);
         if (kConvOk && p.conv) {
           const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
           src = ok ? src : (const char*)p.zero;
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = (const char*)p.B + ((long)b_off(i) + (long)kt * 128);
+        const char* src = Bb + ((long)b_off(i) + (long)kt * 128);
         if constexpr (GLDS) {
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   float gcur[GN], gnext[GN];
   float gref[GN];  // per row: m* + log2(L), so that the block weight is g = 2^(m_t - gref)
   constexpr int STEPS_PER_BLOCK = 128 / BKE;  // K-steps per 128-key statistics block
-  const int nk = p.K / BKE;
+  const int nk = nk_slice;
   const int nblk = nk / STEPS_PER_BLOCK;
   // statistics row of fragment row i of this lane (rows past M read row M - 1: their outputs are never stored)
   auto stat_row = [&](int i) {
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_a = [&](auto I, char* stage) {
       constexpr int i = decltype(I)::value;
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        const char* src = (const char*)p.A + ((long)a_off[i] + a_koff);
+        const char* src = Ab + ((long)a_off[i] + a_koff);
         if (kConvOk && p.conv) {
           const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
           src = ok ? src : (const char*)p.zero;
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_b = [&](auto I, int kt, char* stage) {
       constexpr int i = decltype(I)::value;
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = (const char*)p.B + ((long)b_off(i) + (long)kt * 128);
+        const char* src = Bb + ((long)b_off(i) + (long)kt * 128);
 #ifndef HVR_DBG_NODMA
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0,
@@ -617,7 +634,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     constexpr int ROWS = FM * 16, LDW = BN + 4, CH = BN / 8;
     float* ebuf = reinterpret_cast<float*>(smem);
     const int out_es = p.out_f32 ? 4 : (int)sizeof(T);
-    const bool wide_c = ((p.ldc * out_es) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.N & 7) == 0;
+    const bool wide_c = ((p.ldc * out_es) & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && (p.N & 7) == 0;
     const bool wide_r = p.resid && ((p.ldr * (long)sizeof(T)) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
 #pragma unroll
     for (int pass = 0; pass < WM; ++pass) {
@@ -681,11 +698,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.out_f32 || sizeof(T) == 4) {
-          float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+          float* cp = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n;
           store4(cp, v);
           if (full) store4(cp + 4, v + 4);
         } else {
-          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+          bf16_t* cp = reinterpret_cast<bf16_t*>(Cb) + (long)m * p.ldc + n;
           if (full && wide_c) {
             *reinterpret_cast<uint4*>(cp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
           } else {
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #else
         if (m < p.M)
 #endif
-          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.C) + ((long)m * p.ldc + n0) * (long)sizeof(T) + cc * 16) =
+          *reinterpret_cast<uint4*>(Cb + ((long)m * p.ldc + n0) * (long)sizeof(T) + cc * 16) =
               make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
@@ -823,7 +840,7 @@ static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, EPI == EPI_LINEAR && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
 }
 

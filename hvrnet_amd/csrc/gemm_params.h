@@ -40,6 +40,9 @@ struct GemmParams {
   float* lstat;    // [M][ntile] tile sum
   int ntile;
   int group_m;  // > 1: tile order walks `group_m` row tiles per B panel (see tile_kernel)
+  // split-K (EPI_LINEAR, no conv): ksplit_count slices of ksplit_steps K-steps, partial s at C + s * csplit_bytes (0 = off)
+  int ksplit_steps, ksplit_count;
+  long csplit_bytes;
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };

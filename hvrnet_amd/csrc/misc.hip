@@ -279,17 +279,27 @@ __global__ void relu_bwd_kernel(const T* __restrict__ dY, const T* __restrict__ 
   }
 }
 
-// db[n] = sum_m dY[m][n] (f32): bias gradient of a linear layer; 64 columns per workgroup, fixed summation order
+// db[n] = sum_m dY[m][n] (f32): bias gradient of a linear layer.  Two stages, fixed summation order: workgroup (x, y) sums
+// rows y, y + S, ... of 64 columns (4 row lanes) into part[y][n]; the second kernel adds the S partials.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, float* __restrict__ db, int M, int N, long ld) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dY, float* __restrict__ part_out, int M, int N, long ld) {
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), r0 = threadIdx.x >> 6;
   float acc = 0.f;
   if (c < N)
-    for (int m = r0; m < M; m += 4) acc += ElemTraits<T>::load(dY + (long)m * ld + c);
+    for (int m = blockIdx.y * 4 + r0; m < M; m += 4 * gridDim.y) acc += ElemTraits<T>::load(dY + (long)m * ld + c);
   part[r0][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (r0 == 0 && c < N) db[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (r0 == 0 && c < N)
+    part_out[(long)blockIdx.y * N + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int S) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int y = 0; y < S; ++y) acc += part[(long)y * N + c];
+  db[c] = acc;
 }
 
 // BBoxHead.loss for class-agnostic regression (bbox_heads/bbox_head.py:100-130): softmax cross entropy over ncls logits
@@ -397,6 +407,47 @@ __global__ void scale_rows_kernel(const T* __restrict__ w, const float* __restri
   }
 }
 
+// nn.Conv2d weight [Cout][Cin][KH][KW] (f32 master) * s[Cout] -> the conv kernel's operand [Cout][KH][KW][Cin] in T:
+// the permute, the frozen BatchNorm scale and the rounding to the compute dtype in one pass
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ s, T* __restrict__ out, int Cout, int Cin,
+                                        int KK) {
+  const long total = (long)Cout * KK * Cin;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Cin);
+    const long r = idx / Cin;
+    const int t = (int)(r % KK), o = (int)(r / KK);
+    ElemTraits<T>::store(out + idx, w[((long)o * Cin + c) * KK + t] * s[o]);
+  }
+}
+
+// the way back for the gradient: dW_eff [Cout][KH*KW][Cin] (f32) * s[Cout] -> [Cout][Cin][KH][KW]
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ dw, const float* __restrict__ s, float* __restrict__ out, int Cout,
+                                         int Cin, int KK) {
+  const long total = (long)Cout * KK * Cin;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % KK);
+    const long r = idx / KK;
+    const int c = (int)(r % Cin), o = (int)(r / Cin);
+    out[idx] = dw[((long)o * KK + t) * Cin + c] * s[o];
+  }
+}
+
+hipError_t run_pack_conv_weight(const float* w, const float* sc, void* out, int Cout, int Cin, int KK, int dtype, hipStream_t s) {
+  const long total = (long)Cout * Cin * KK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, w, sc, (bf16_t*)out, Cout, Cin, KK);
+  else
+    hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, w, sc, (float*)out, Cout, Cin, KK);
+  return hipGetLastError();
+}
+
+hipError_t run_unpack_conv_wgrad(const float* dw, const float* sc, float* out, int Cout, int Cin, int KK, hipStream_t s) {
+  const long total = (long)Cout * Cin * KK;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, dw, sc, out, Cout, Cin, KK);
+  return hipGetLastError();
+}
+
 hipError_t run_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int OH, int OW,
                            int dtype, hipStream_t s) {
   const long work = (long)B * OH * OW * KH * KW * (Cin / 4);
@@ -421,14 +472,34 @@ hipError_t run_scale_rows(const void* w, const float* sc, void* out, int R, long
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
   __shared__ float red[256];
   float acc = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += g[i] * g[i];
+  const long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);   // the flat buffers are 256-byte aligned
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = g4[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc += g[n4 * 4 + threadIdx.x] * g[n4 * 4 + threadIdx.x];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) part[1 + blockIdx.x] = red[0];
+}
+
+// part[0] = sum of part[1 .. nparts] in a fixed tree order
+__global__ __launch_bounds__(256) void sumsq_final_kernel(float* __restrict__ part, int nparts) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[1 + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[0] = red[0];
 }
 
 // torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov off) on a flat f32 buffer, with the two scalings the
@@ -460,12 +531,16 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
   }
 }
 
-constexpr int kSumsqParts = 256;
+constexpr int kSumsqParts = 1024;
+size_t sgd_workspace_bytes() { return (size_t)(kSumsqParts + 1) * sizeof(float); }
 hipError_t run_sgd_step(float* p, const float* g, float* buf, long n, float lr, float mom, float wd, float gscale, float max_norm,
                         float* part, int first, hipStream_t s) {
-  if (max_norm > 0.f) hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqParts), dim3(256), 0, s, g, n, part);
+  if (max_norm > 0.f) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqParts), dim3(256), 0, s, g, n, part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, part, kSumsqParts);
+  }
   hipLaunchKernelGGL(sgd_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, buf, n, lr, mom, wd, gscale, max_norm, part,
-                     kSumsqParts, first);
+                     1, first);
   return hipGetLastError();
 }
 
@@ -476,9 +551,41 @@ hipError_t run_relu_bwd(const void* dY, const void* Y, void* dZ, long n, int dty
   return hipGetLastError();
 }
 
-hipError_t run_colsum(const void* dY, float* db, int M, int N, long ld, int dtype, hipStream_t s) {
-  if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, s, (const bf16_t*)dY, db, M, N, ld);
-  else hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)dY, db, M, N, ld);
+int colsum_slices(int M, int N) {
+  const int cols = (N + 63) / 64;
+  int s = (1024 + cols - 1) / cols;          // ~1024 workgroups in all
+  if (s > (M + 63) / 64) s = (M + 63) / 64;  // at least 16 rows per row lane
+  return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+hipError_t run_colsum(const void* dY, float* db, int M, int N, long ld, int dtype, float* ws, hipStream_t s) {
+  const int S = colsum_slices(M, N);
+  float* part = S == 1 ? db : ws;
+  const dim3 grid((N + 63) / 64, S);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dY, part, M, N, ld);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, part, M, N, ld);
+  if (S > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, db, N, S);
+  return hipGetLastError();
+}
+
+// C[m][n] = sum over the S split-K partials ws[s][m][n] (fixed order); N % 4 == 0
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, long ldc,
+                                                            int S) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x, per_row = N / 4, total = (long)M * per_row;
+  if (q >= total) return;
+  const long m = q / per_row, n = (q - m * per_row) * 4, stride = (long)M * N;
+  const float* src = ws + m * N + n;
+  float4 acc = *reinterpret_cast<const float4*>(src);
+  for (int s = 1; s < S; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(src + s * stride);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float* dst = C + m * ldc + n;
+  dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
+}
+
+hipError_t run_splitk_reduce(const float* ws, float* C, int M, int N, long ldc, int S, hipStream_t s) {
+  const long total = (long)M * (N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, C, M, N, ldc, S);
   return hipGetLastError();
 }
 

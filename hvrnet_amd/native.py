@@ -69,6 +69,8 @@ SYMBOLS = {
     'hvr_abi_version': (_i, []),
     'hvr_last_error': (ctypes.c_char_p, []),
     'hvr_gemm': (_i, [ctypes.POINTER(GemmDesc), _vp]),
+    'hvr_gemm_splitk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'hvr_gemm_splitk': (_i, [ctypes.POINTER(GemmDesc), _vp, _sz, _vp]),
     'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -83,7 +85,10 @@ SYMBOLS = {
     'hvr_scale_rows': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
     'hvr_sgd_workspace_bytes': (_sz, []),
     'hvr_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _sz, _i, _vp]),
-    'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
+    'hvr_colsum_workspace_bytes': (_sz, [_i, _i]),
+    'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
+    'hvr_pack_conv_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'hvr_unpack_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_det_loss_sampled': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     'hvr_max_iou_assign_workspace_bytes': (_sz, [_i, _i]),
@@ -258,6 +263,24 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
     return out
 
 
+def gemm_splitk(a, w, staging=None, tile=None):
+    """f32 out[M,N] = a[M,K] @ w[N,K]^T for few-tile / long-K products (weight gradients): K slices in one launch + a reduce."""
+    _need_cuda(a, w)
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.dtype == w.dtype, (a.shape, w.shape)
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    d = GemmDesc(A=a.data_ptr(), B=w.data_ptr(), C=out.data_ptr(), M=M, N=N, K=K, lda=a.stride(0), ldb=w.stride(0), ldc=N,
+                 bias=None, resid=None, ldr=0, relu=0, out_f32=int(a.dtype != torch.float32), dtype=_dt(a),
+                 staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile)
+    nbytes = lib().hvr_gemm_splitk_workspace_bytes(M, N, K, _dt(a))
+    ws = _workspace(nbytes, a.device, 'splitk') if nbytes else None
+    with _span('gemm' if not (_prof and _prof['detail']) else 'gemm M%d N%d K%d splitk' % (M, N, K), 2.0 * M * N * K):
+        _check(lib().hvr_gemm_splitk(ctypes.byref(d), _ptr(ws), nbytes, _stream()), 'hvr_gemm_splitk')
+    return out
+
+
 def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None, tile=None):
     """x [B,H,W,Cin] (physical NHWC), w [Cout,KH,KW,Cin] -> [B,OH,OW,Cout]."""
     _need_cuda(x, w, bias, resid)
@@ -417,8 +440,30 @@ def colsum(dy):
     _need_cuda(dy)
     assert dy.dim() == 2 and dy.stride(1) == 1
     db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
-    _check(lib().hvr_colsum(_ptr(dy), _ptr(db), dy.shape[0], dy.shape[1], dy.stride(0), _dt(dy), _stream()), 'hvr_colsum')
+    nbytes = lib().hvr_colsum_workspace_bytes(dy.shape[0], dy.shape[1])
+    ws = _workspace(nbytes, dy.device, 'colsum') if nbytes else None
+    _check(lib().hvr_colsum(_ptr(dy), _ptr(db), dy.shape[0], dy.shape[1], dy.stride(0), _dt(dy), _ptr(ws), nbytes, _stream()), 'hvr_colsum')
     return db
+
+
+def pack_conv_weight(w, scale, dtype):
+    """nn.Conv2d weight [Cout,Cin,KH,KW] f32 * scale[Cout] -> [Cout,KH,KW,Cin] in `dtype` (the conv kernel's operand)."""
+    _need_cuda(w, scale)
+    assert w.dtype == torch.float32 and w.is_contiguous() and scale.dtype == torch.float32 and scale.is_contiguous()
+    Cout, Cin, KH, KW = w.shape
+    out = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=w.device)
+    _check(lib().hvr_pack_conv_weight(_ptr(w), _ptr(scale), _ptr(out), Cout, Cin, KH, KW, _dt(out), _stream()), 'hvr_pack_conv_weight')
+    return out
+
+
+def unpack_conv_wgrad(dw, scale, shape):
+    """dW_eff [Cout, KH*KW*Cin] f32 * scale[Cout] -> [Cout,Cin,KH,KW] f32 (the nn.Conv2d parameter's layout)."""
+    _need_cuda(dw, scale)
+    Cout, Cin, KH, KW = shape
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == Cout * Cin * KH * KW
+    out = torch.empty(shape, dtype=torch.float32, device=dw.device)
+    _check(lib().hvr_unpack_conv_wgrad(_ptr(dw), _ptr(scale), _ptr(out), Cout, Cin, KH, KW, _stream()), 'hvr_unpack_conv_wgrad')
+    return out
 
 
 def det_loss(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, beta=1.0, w_cls=1.0, w_bbox=1.0):

@@ -38,7 +38,7 @@ class RoIAlignFunction(Function):
             raise ValueError('wrong roi size: expected [K, 5], got %s' % (tuple(rois.shape),))
         ctx.spatial_scale, ctx.sample_num = spatial_scale, sample_num
         ctx.save_for_backward(rois)
-        ctx.feature_size = features.size()
+        ctx.feature_size, ctx.feature_dtype = features.size(), features.dtype
         ctx.nhwc = _channels_last(features)
         if ctx.nhwc:
             out = native.roi_align_fwd(features.permute(0, 2, 3, 1), rois, out_h, out_w, spatial_scale, sample_num,
@@ -57,10 +57,10 @@ class RoIAlignFunction(Function):
             if ctx.nhwc:
                 g = native.roi_align_bwd(grad_output.permute(0, 2, 3, 1), rois, (B, H, W, C), ctx.spatial_scale,
                                          ctx.sample_num, native.LAYOUT_NHWC)
-                grad_input = g.permute(0, 3, 1, 2)
+                grad_input = native.cast(g, ctx.feature_dtype).permute(0, 3, 1, 2)   # accumulated in f32, handed back in the map's dtype
             else:
-                grad_input = native.roi_align_bwd(grad_output, rois, (B, C, H, W), ctx.spatial_scale, ctx.sample_num,
-                                                  native.LAYOUT_NCHW)
+                grad_input = native.cast(native.roi_align_bwd(grad_output, rois, (B, C, H, W), ctx.spatial_scale, ctx.sample_num,
+                                                              native.LAYOUT_NCHW), ctx.feature_dtype)
         return grad_input, None, None, None, None
 
 

@@ -80,8 +80,7 @@ class RPNHead(nn.Module, PackedMixin):
         pad = -w.shape[0] % 32
         w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
         b = torch.cat([b, b.new_zeros(pad)], 0)
-        ones = torch.ones(w.shape[0], dtype=torch.float32, device=x.device)
-        return TO.ConvFunction.apply(y, w, ones, b, None, False, 1, 0, 1)
+        return TO.ConvFunction.apply(y, w, TO.ones(w.shape[0], x.device), b, None, False, 1, 0, 1, True)      # f32 out: feeds the loss / proposal kernels
 
     def forward_train_nhwc(self, x):
         """-> (cls [T,H,W,A], reg [T,H,W,4A]) views of forward_train_fused's output."""

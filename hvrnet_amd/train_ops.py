@@ -1,4 +1,6 @@
-"""Training-path ops of the relation heads with HIP backwards (f32 parameters, exact-f32 MFMA path).
+"""Training-path ops of the relation heads with HIP backwards.  Parameters are f32 masters; the compute
+dtype is the activations': f32 (exact-f32 MFMA path, the parity mode) or bf16 (operands rounded to bf16, f32 accumulation,
+f32 weight gradients -- the throughput mode, `set_compute_dtype(model, torch.bfloat16)`).
 
 The reference trains through plain autograd over nn.Linear / nn.Conv2d / torch.bmm / nn.Softmax and its loss modules
 (selsa_bbox_head.py:108-261, bbox_head.py:100-130).  Here every forward AND backward product is a tile-engine GEMM:
@@ -30,23 +32,29 @@ def _pad_cols(t, n):
 
 
 class LinearFunction(Function):
-    """y = act(x @ w^T + b (+ resid)); x [M, K], w [N, K], b [N]; N a multiple of 4, K a multiple of the K-step."""
+    """y = act(x @ w^T + b (+ resid)); x [M, K], w [N, K], b [N]; N a multiple of 4, K a multiple of the K-step.
+    x's dtype is the compute dtype: with bf16 activations the f32 master weight is rounded to bf16 on the way in, products
+    accumulate in f32, dx comes back in bf16 and dW / db in f32 (the master's dtype).  out_f32: f32 output from bf16 operands
+    (the layer that feeds a loss kernel)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, relu):
+    def forward(ctx, x, w, b, resid, relu, out_f32=False):
         if not x.is_cuda:
             raise NotImplementedError('the head runs on the GPU only (no CPU fallback)')
-        x, w = x.contiguous(), w.contiguous()
-        y = native.gemm(x, w, b, resid=resid.contiguous() if resid is not None else None, relu=bool(relu))
+        x = x.contiguous()
+        wc = native.cast(w.contiguous(), x.dtype)
+        assert not (relu and out_f32 and x.dtype != torch.float32), 'the ReLU mask is kept in the compute dtype'
+        y = native.gemm(x, wc, b, resid=resid.contiguous() if resid is not None else None, relu=bool(relu), out_f32=bool(out_f32))
         ctx.relu, ctx.has_resid, ctx.has_bias = bool(relu), resid is not None, b is not None
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.save_for_backward(x, wc, y if relu else None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dz = native.relu_bwd(dy.contiguous(), y) if ctx.relu else dy.contiguous()
+        dy = native.cast(dy.contiguous(), x.dtype)
+        dz = native.relu_bwd(dy, y) if ctx.relu else dy
         M, K = x.shape
         N = w.shape[0]
         step = native.kstep(x.dtype)
@@ -55,15 +63,15 @@ class LinearFunction(Function):
         if ctx.needs_input_grad[0]:
             dx = native.gemm(_pad_cols(dz, ldn), native.transpose_pad(w, ldn))           # [M, K] = dz [M, N] W [N, K]
         if ctx.needs_input_grad[1]:
-            dw = native.gemm(native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))  # [N, K] = dz^T [N, M] x [M, K]
+            dw = native.gemm_splitk(native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))       # [N, K] = dz^T x, f32
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = native.colsum(dz)
         dr = dz if (ctx.has_resid and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dr, None
+        return dx, dw, db, dr, None, None
 
 
-def linear(x, w, b=None, resid=None, relu=False):
-    return LinearFunction.apply(x, w, b, resid, relu)
+def linear(x, w, b=None, resid=None, relu=False, out_f32=False):
+    return LinearFunction.apply(x, w, b, resid, relu, out_f32)
 
 
 class DetLossFunction(Function):
@@ -163,17 +171,21 @@ class ConvFunction(Function):
     residual add and ReLU of a Bottleneck (resnet.py:220-266).  x [B,H,W,Cin], w [Cout,Cin,KH,KW] (the nn.Conv2d
     parameter), stride 1 for KxK kernels; a strided 1x1 conv is a row subset followed by a linear layer.
     Backward: ReLU mask, dX by the same implicit-GEMM conv kernel on the rotated weights (or a GEMM for 1x1), dW^T as a
-    GEMM of dZ^T with the patch matrix, both scaled by s; s and t are frozen and get no gradient."""
+    GEMM of dZ^T with the patch matrix, both scaled by s; s and t are frozen and get no gradient.
+    x's dtype is the compute dtype (bf16 activations: the scaled f32 master weight is rounded to bf16 on the way in, dX is
+    bf16, dW accumulates and is returned in f32); out_f32 asks for an f32 output from bf16 operands (the RPN's 1x1 heads)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, t, resid, relu, stride, pad, dil):
+    def forward(ctx, x, w, s, t, resid, relu, stride, pad, dil, out_f32=False):
         if not x.is_cuda:
             raise NotImplementedError('convs run on the GPU only (no CPU fallback)')
         Cout, Cin, KH, KW = w.shape
         assert (KH, KW) == (1, 1) or stride == 1, 'strided KxK convs are not on this path (caffe-style ResNet strides its 1x1s)'
         xs = x[:, ::stride, ::stride, :].contiguous() if stride > 1 else x.contiguous()
-        w_eff = native.scale_rows(w.permute(0, 2, 3, 1).contiguous(), s)                 # [Cout][KH][KW][Cin] * s
-        y = native.conv2d_nhwc(xs, w_eff, t, resid.contiguous() if resid is not None else None, relu=bool(relu), pad=pad, dil=dil)
+        s = s.float().contiguous()
+        w_eff = native.pack_conv_weight(w.contiguous(), s, x.dtype)                      # [Cout][KH][KW][Cin] * s, compute dtype
+        y = native.conv2d_nhwc(xs, w_eff, t, resid.contiguous() if resid is not None else None, relu=bool(relu), pad=pad, dil=dil,
+                               out_f32=bool(out_f32))
         ctx.cfg = (bool(relu), int(stride), int(pad), int(dil), resid is not None, tuple(x.shape))
         ctx.save_for_backward(xs, w_eff, s, y if relu else None)
         return y
@@ -183,7 +195,8 @@ class ConvFunction(Function):
     def backward(ctx, dy):
         xs, w_eff, s, y = ctx.saved_tensors
         relu, stride, pad, dil, has_resid, x_shape = ctx.cfg
-        dz = native.relu_bwd(dy.contiguous(), y) if relu else dy.contiguous()
+        dy = native.cast(dy.contiguous(), xs.dtype)
+        dz = native.relu_bwd(dy, y) if relu else dy
         Cout, KH, KW, Cin = w_eff.shape
         B, OH, OW, _ = dz.shape
         P = B * OH * OW
@@ -205,21 +218,48 @@ class ConvFunction(Function):
                 dx = dxs
         if ctx.needs_input_grad[1]:
             cols = xs.view(P, Cin) if (KH, KW) == (1, 1) else native.im2col_nhwc(xs, KH, KW, pad, dil)   # [P, KH*KW*Cin]
-            dw_eff = native.gemm(native.transpose_pad(dz2, ldp), native.transpose_pad(cols, ldp))        # [Cout, KH*KW*Cin]
-            dw = native.scale_rows(dw_eff, s).view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+            dw_eff = native.gemm_splitk(native.transpose_pad(dz2, ldp), native.transpose_pad(cols, ldp))   # [Cout, KH*KW*Cin], f32
+            dw = native.unpack_conv_wgrad(dw_eff, s, (Cout, Cin, KH, KW))                # * s, back in the parameter's layout
         dt = native.colsum(dz2) if ctx.needs_input_grad[3] else None   # a trainable bias passed as the shift (RPN / 1x1 heads)
         dr = dz if (has_resid and ctx.needs_input_grad[4]) else None
-        return dx, dw, None, dt, dr, None, None, None, None
+        return dx, dw, None, dt, dr, None, None, None, None, None
+
+
+def _frozen_bn_affine(bn):
+    """(scale, shift) of a frozen BatchNorm (eval statistics): s = weight / sqrt(var + eps), t = bias - mean * s.  Constant
+    while the statistics and the affine stay frozen, so it is computed once and kept until one of the four tensors changes."""
+    key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    hit = bn.__dict__.get('_hvr_affine')
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            t = (bn.bias - bn.running_mean * s).float().contiguous()
+        hit = (key, s, t)
+        bn.__dict__['_hvr_affine'] = hit
+    return hit[1], hit[2]
 
 
 def conv_bn(x, conv, bn, resid=None, relu=False):
     """nn.Conv2d (bias-free) + frozen nn.BatchNorm2d (eval statistics, models/utils/norm.py eps) on an NHWC tensor."""
-    s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
-    t = (bn.bias - bn.running_mean * s).detach()
+    if bn.training:
+        raise NotImplementedError('conv_bn folds a FROZEN BatchNorm: eval statistics (norm_eval=True in both configs); its affine '
+                                  'gets no gradient (norm_cfg requires_grad=False)')
+    s, t = _frozen_bn_affine(bn)
     return ConvFunction.apply(x, conv.weight, s, t, resid, relu, conv.stride[0], conv.padding[0], conv.dilation[0])
 
 
 def conv_bias(x, conv, relu=False):
     """nn.Conv2d with a trainable bias and no norm (RPN convs, res5's external 1x1) on an NHWC tensor."""
-    ones = torch.ones(conv.weight.shape[0], dtype=torch.float32, device=x.device)
-    return ConvFunction.apply(x, conv.weight, ones, conv.bias, None, relu, conv.stride[0], conv.padding[0], conv.dilation[0])
+    return ConvFunction.apply(x, conv.weight, ones(conv.weight.shape[0], x.device), conv.bias, None, relu, conv.stride[0],
+                              conv.padding[0], conv.dilation[0])
+
+
+_ones = {}
+
+
+def ones(n, device):
+    """f32 ones [n] (the unit BatchNorm scale of a plain conv), one tensor per (n, device)."""
+    key = (int(n), str(device))
+    if key not in _ones:
+        _ones[key] = torch.ones(int(n), dtype=torch.float32, device=device)
+    return _ones[key]

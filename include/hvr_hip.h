@@ -61,6 +61,12 @@ typedef struct hvr_gemm_desc {
   int32_t tile_hint;       /* 0 = library picks the tile shape; k > 0 forces shape k-1 (tuning) */
 } hvr_gemm_desc;
 int hvr_gemm(const hvr_gemm_desc* d, void* stream);
+/* The same product for outputs with few tiles and a long K (weight gradients: dW = dZ^T X has K = pixels): the K loop is cut
+ * into slices that run as one launch, each writing an f32 partial into `ws`, and a second kernel sums them in a fixed order.
+ * f32 output only (dtype f32, or out_f32 with bf16 operands), no bias / residual / ReLU.  The library picks the slice count
+ * (1 = falls back to hvr_gemm's single pass; hvr_gemm_splitk_workspace_bytes then returns 0). */
+size_t hvr_gemm_splitk_workspace_bytes(int M, int N, int K, int dtype);
+int hvr_gemm_splitk(const hvr_gemm_desc* d, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * NHWC convolution as implicit GEMM (frozen BatchNorm folded into w / bias by the caller)
@@ -122,7 +128,8 @@ int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t l
  *                  out3 = (loss_cls, loss_bbox, acc) and dlogits = d(w_cls*loss_cls + w_bbox*loss_bbox)/d logits for a
  *                  logit matrix [R][ldl] holding ncls class logits at cls_off and 4 box deltas at reg_off. */
 int hvr_relu_bwd(const void* dY, const void* Y, void* dZ, int64_t n, int dtype, void* stream);
-int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, void* stream);
+size_t hvr_colsum_workspace_bytes(int M, int N);
+int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, void* ws, size_t ws_bytes, void* stream);
 int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels, const float* label_weights,
                  const float* bbox_targets, const float* bbox_weights, int R, float beta, float w_cls, float w_bbox, float* out3,
                  float* dlogits, void* stream);
@@ -135,6 +142,11 @@ int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncl
  * the way in and into their gradient on the way out. */
 int hvr_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int dtype, void* stream);
 int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t C, int dtype, void* stream);
+/* The two layout + scale passes of a trainable conv in one kernel each: the f32 master weight [Cout][Cin][KH][KW] times the
+ * frozen BatchNorm scale, permuted to the conv kernel's [Cout][KH][KW][Cin] and rounded to the compute dtype; and the way back
+ * for the f32 weight gradient. */
+int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout, int Cin, int KH, int KW, int out_dtype, void* stream);
+int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, void* stream);
 
 /* Optimizer step on a flat f32 buffer (the training configs: SGD lr 5e-4, momentum 0.9, weight decay 1e-4, gradient
  * clipping max_norm 35, configs/faster_rcnn_r101_selsa_c5.py:215-222; torch.optim.SGD semantics, dampening 0).  The two

@@ -311,3 +311,29 @@ def test_fused_stem_matches_conv_relu_pool(H, W):
     y = native.stem_fused(img.to(DEV), wf.view(64, 7, 32).to(torch.bfloat16).to(DEV), bias.to(DEV))
     assert y.shape == (2, ref.shape[2], ref.shape[3], 64)
     torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,N,K', [(256, 1024, 7232), (128, 1152, 28736), (64, 512, 7232), (1024, 256, 7232), (36, 1024, 960),
+                                   (512, 4608, 7232), (128, 128, 2048 + 64)])
+def test_gemm_splitk_matches_the_single_pass_product(dtype, M, N, K):
+    """hvr_gemm_splitk (K slices in one launch + ordered reduce; the weight-gradient product) against hvr_gemm with f32 output
+    on the same operands: same products, different summation order -> 1e-5 of the output scale; shapes the library does not
+    split (many tiles / short K) must fall through to the single pass bit for bit."""
+    if dtype == torch.float32:
+        K = K // 2 if K > 8000 else K          # keep the f32 case quick
+        K = K // 32 * 32
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn((M, K), generator=g)).to(DEV).to(dtype)
+    w = (torch.randn((N, K), generator=g)).to(DEV).to(dtype)
+    want = native.gemm(a, w, out_f32=True)
+    got = native.gemm_splitk(a, w)
+    assert got.dtype == torch.float32 and got.shape == (M, N)
+    nbytes = native.lib().hvr_gemm_splitk_workspace_bytes(M, N, K, native._dt(a))
+    if nbytes == 0:
+        assert torch.equal(got, want)
+    else:
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 1e-5 * scale + 1e-6
+        ref = a.double() @ w.double().t()
+        assert float((got.double() - ref).abs().max()) <= float((want.double() - ref).abs().max()) * 2 + 1e-4 * scale

@@ -185,6 +185,42 @@ class _RelationHead(BBoxHead):
         """fc_new_1 of RoI features [K,256,7,7] -> [K,1024] (selsa_bbox_head.py:222-224); one row per RoI."""
         return self._fc1(self.packed(bbox_feat.device), bbox_feat)
 
+    # ---- training-path building blocks (autograd graphs of HIP ops; f32 master parameters) -------------------
+    def _train_rows(self, bbox_feat):
+        """RoI features [K,256,7,7] -> [K, 12544] rows in the compute dtype ((c, ph, pw) order, as the reference flattens)."""
+        x = bbox_feat.contiguous().view(bbox_feat.size(0), -1)
+        if x.dtype != self.compute_dtype:   # f32: parity mode; bf16: operands rounded to bf16, f32 accumulation
+            if x.requires_grad:
+                raise NotImplementedError('RoI features must arrive in the compute dtype (%s) when they carry a gradient' % self.compute_dtype)
+            x = native.cast(x, self.compute_dtype)
+        return x
+
+    def _train_qk(self, k, f, q_rows, nongt_dim):
+        """q / k projections of relation stage k: queries = rows `q_rows` (slice or None = all) of f, keys = f[:nongt_dim]."""
+        from . import train_ops as TO
+        sel = getattr(self, 'selsa_%d' % k)
+        kv = f if nongt_dim >= f.shape[0] else f[:nongt_dim]
+        fq = f if q_rows is None else f[q_rows]
+        q = TO.linear(fq, sel['q_data_fc_%d' % k].weight, sel['q_data_fc_%d' % k].bias)
+        kk = TO.linear(kv, sel['k_data_fc_%d' % k].weight, sel['k_data_fc_%d' % k].bias)
+        return q, kk, kv, fq
+
+    def _train_stage(self, k, f, q_rows=None, nongt_dim=None, qk=None):
+        """relu(f[q_rows] + linear_out_k(softmax(q k^T / sqrt(d)) f[:nongt_dim]))  (selsa_bbox_head.py:108-200)."""
+        from . import ops, train_ops as TO
+        q, kk, kv, fq = qk if qk is not None else self._train_qk(k, f, q_rows, self.nongt_dim if nongt_dim is None else nongt_dim)
+        o = ops.relation(q, kk, kv, 1.0 / math.sqrt(float(self.dim[1])))
+        z = getattr(self, 'selsa_%d' % k)['linear_out_%d' % k]
+        return TO.linear(o, z.weight.view(z.weight.shape[0], -1), z.bias, resid=fq.contiguous(), relu=True)
+
+    def _train_readout(self, h, fc_cls, fc_reg):
+        """fused [fc_cls | fc_reg | pad] readout -> f32 logits [rows, num_classes + 4 (+ pad)]."""
+        from . import train_ops as TO
+        nc = self.num_classes
+        w = torch.cat([fc_cls.weight, fc_reg.weight, fc_cls.weight.new_zeros((-(nc + 4) % 4, fc_cls.weight.shape[1]))], 0)
+        b = torch.cat([fc_cls.bias, fc_reg.bias, fc_cls.bias.new_zeros(-(nc + 4) % 4)], 0)
+        return TO.linear(h.contiguous(), w, b, out_f32=True)
+
     def _stage(self, p, k, x, q_range=None):
         """relu(Xq + relation_k(X)): rows `q_range` as queries (all rows when None), keys = X[:nongt_dim]."""
         D = self.fc_feat_dim
@@ -237,34 +273,14 @@ class SelsaBBoxHead(_RelationHead):
     def forward_train(self, bbox_feat, cur_range):
         """The head's forward as an autograd graph of HIP ops (train_ops.linear / ops.relation): -> f32 logits [l, 36] of
         the key frame's rows, class logits in columns 0..num_classes-1, box deltas in the next 4 (fused fc_cls | fc_reg)."""
-        from . import ops, train_ops as TO
+        from . import train_ops as TO
         s, l = int(cur_range['start']), int(cur_range['length'])
-        scale = 1.0 / math.sqrt(float(self.dim[1]))
-        x = bbox_feat.contiguous().view(bbox_feat.size(0), -1)      # (c, ph, pw) order, as the reference flattens
-        if x.dtype != self.compute_dtype:   # f32: parity mode; bf16: operands rounded to bf16, f32 accumulation
-            if x.requires_grad:
-                raise NotImplementedError('RoI features must arrive in the compute dtype (%s) when they carry a gradient' % self.compute_dtype)
-            x = native.cast(x, self.compute_dtype)
-
-        self.nongt_dim = self.sampler_num * self.t_dim      # selsa_bbox_head.py:214
-
-        def stage(k, f):
-            sel = getattr(self, 'selsa_%d' % k)
-            kv = f if self.nongt_dim >= f.shape[0] else f[:self.nongt_dim]   # keys / values: the first nongt_dim rows (:130)
-            q = TO.linear(f, sel['q_data_fc_%d' % k].weight, sel['q_data_fc_%d' % k].bias)
-            kk = TO.linear(kv, sel['k_data_fc_%d' % k].weight, sel['k_data_fc_%d' % k].bias)
-            o = ops.relation(q, kk, kv, scale)
-            z = sel['linear_out_%d' % k]
-            return TO.linear(o, z.weight.view(z.weight.shape[0], -1), z.bias, resid=f, relu=True)
-
-        f1 = TO.linear(x, self.fc_new_1.weight, self.fc_new_1.bias)
-        h1 = stage(1, f1)
+        self.nongt_dim = self.sampler_num * self.t_dim      # selsa_bbox_head.py:214; keys / values: the first nongt_dim rows (:130)
+        f1 = TO.linear(self._train_rows(bbox_feat), self.fc_new_1.weight, self.fc_new_1.bias)
+        h1 = self._train_stage(1, f1)
         f2 = TO.linear(h1, self.fc_new_2.weight, self.fc_new_2.bias)
-        h2 = stage(2, f2)[s:s + l]
-        nc = self.num_classes
-        w = torch.cat([self.fc_cls.weight, self.fc_reg.weight, self.fc_cls.weight.new_zeros((-(nc + 4) % 4, self.fc_cls.weight.shape[1]))], 0)
-        b = torch.cat([self.fc_cls.bias, self.fc_reg.bias, self.fc_cls.bias.new_zeros(-(nc + 4) % 4)], 0)
-        return TO.linear(h2.contiguous(), w, b, out_f32=True)
+        h2 = self._train_stage(2, f2)[s:s + l]
+        return self._train_readout(h2, self.fc_cls, self.fc_reg)
 
     def loss_train(self, logits, labels, label_weights, bbox_targets, bbox_weights):
         """BBoxHead.loss on forward_train's fused logits (bbox_head.py:100-130) -> dict(loss_cls, loss_bbox, acc, total)."""
@@ -283,6 +299,18 @@ class HRNMPBBoxHead(_RelationHead):
         self.output_cur_only = False
         self.fc_cls_2 = nn.Linear(self.dim[2], self.num_classes)
         self.fc_reg_2 = nn.Linear(self.dim[2], 4)
+
+    def hardest_proposal_mining(self, labels, all_labels, aff_scale, metric_loss=None):
+        """hrnmp_bbox_head.py:357-414: per non-background query row of the scaled affinities aff_scale [1, Mq, Mk] (or
+        [Mq, Mk]) the same-label key with the lowest and the different-label key with the highest affinity -- one
+        wavefront per row on the device (hvr_mining_argreduce) where the reference builds three masked copies of the matrix
+        and calls topk on each.  -> [anchor rows, hardest positive, hardest negative], the reference's return order (:413)."""
+        aff = aff_scale.reshape(-1, aff_scale.shape[-1])
+        if aff.dtype != torch.float32 or aff.stride(1) != 1:
+            aff = aff.float().contiguous()
+        picks = native.mining_argreduce(aff, labels, all_labels)
+        anchors = torch.nonzero(labels != 0).reshape(-1)
+        return [anchors, picks[anchors, 1], picks[anchors, 0]]
 
     def forward_test(self, bbox_feat_s, cur_range_s=None, key_dim=0, all_res=False):
         """-> ([cls_branch, cls], [reg_branch, reg]), hrnmp_bbox_head.py:800-909."""
@@ -313,9 +341,70 @@ class HRNMPBBoxHead(_RelationHead):
         cls, reg = self._readout(p, 'out2', h4)
         return [cls_b, cls], [reg_b, reg]
 
+    TRIPLET_MARGIN = 10.0   # TripletNonLocalLoss(margin=10) of the inter-video stage (hrnmp_bbox_head.py:741)
+
+    def forward_train(self, bbox_feat_s, cur_range_s, others, key_dim=0):
+        """HRNMPBBoxHead.forward with dynamic=False (hrnmp_bbox_head.py:609-798) as an autograd graph of HIP ops.
+        bbox_feat_s: per video the RoI features of its imgs_per_video frames (key frame's rows first); cur_range_s: the key
+        rows of each video; others: the key rows' class labels, all videos concatenated (`bbox_targets_key[0]`).
+          per video   fc_new_1 -> relation 1 (all rows) -> fc_new_2 -> relation 2 (key rows as queries) -> branch logits;
+                      [stage-2 key rows | fc_new_1 rows of the other frames] -> fc_new_3 -> relation 3 (key rows)   (:652-733)
+          all videos  key rows concatenated -> fc_new_4 -> relation 4 over all of them, with hard-proposal mining on its
+                      affinities and the triplet loss on its q / k projections -> final logits                   (:735-790)
+        The triplet term is the documented STAND-IN (train_ops.TripletMarginFunction): the reference's TripletNonLocalLoss
+        is not in its tree.  The mined triple is passed in the reference's order, including its acknowledged swap
+        ("pos_sm and pos_nsm are in wrong (inversed) positions", :408): positives = the different-label key with the highest
+        affinity, negatives = the same-label key with the lowest.
+        -> ([branch logits, final logits] f32 fused [rows, num_classes + 4 (+pad)], dict(loss_trip))."""
+        from . import train_ops as TO
+        assert cur_range_s is not None and len(cur_range_s) == len(bbox_feat_s)
+        self.key_dim, self.nongt_dim = key_dim, self.sampler_num * self.t_dim
+        per_video = self.imgs_per_video * self.sampler_num
+        branch, key_rows = [], []
+        for feat, cur in zip(bbox_feat_s, cur_range_s):
+            s, l = int(cur['start']), int(cur['length'])
+            assert s == 0, 'training keeps the key frame first (hnmb_rcnn.py:263: key_dim has to be 0)'
+            rows = slice(s, s + l)
+            f1 = TO.linear(self._train_rows(feat), self.fc_new_1.weight, self.fc_new_1.bias)
+            h1 = self._train_stage(1, f1, None, per_video)
+            f2 = TO.linear(h1, self.fc_new_2.weight, self.fc_new_2.bias)
+            h2 = self._train_stage(2, f2, rows, per_video)                           # [l, 1024]: idx_output_cur_only
+            branch.append(self._train_readout(h2, self.fc_cls, self.fc_reg))
+            x3 = torch.cat([h2[s:s + l], f1[s + l:]], dim=0)                          # :700-702 (key rows lead: start = 0)
+            f3 = TO.linear(x3.contiguous(), self.fc_new_3.weight, self.fc_new_3.bias)
+            key_rows.append(self._train_stage(3, f3, rows, per_video))
+        video_feats = torch.cat(key_rows, dim=0)
+        assert self.nongt_dim >= video_feats.shape[0]                                 # :451
+        f4 = TO.linear(video_feats.contiguous(), self.fc_new_4.weight, self.fc_new_4.bias)
+        qk = self._train_qk(4, f4, None, self.nongt_dim)
+        q4, k4 = qk[0], qk[1]
+        with torch.no_grad():
+            ld = -(-k4.shape[0] // 4) * 4
+            kpad = k4.detach() if ld == k4.shape[0] else torch.cat([k4.detach(), k4.new_zeros((ld - k4.shape[0], k4.shape[1]))], 0)
+            aff = native.gemm(q4.detach().contiguous(), kpad.contiguous(), out_f32=True)[:, :k4.shape[0]]   # ordering only: unscaled
+            anchors, same_min, diff_max = self.hardest_proposal_mining(others, others[:k4.shape[0]], aff)
+        losses = dict()
+        if anchors.numel() > 0:
+            loss_trip, _ = TO.triplet_margin(q4, k4, anchors, diff_max, same_min, self.TRIPLET_MARGIN)
+            losses['loss_trip'] = loss_trip
+        h4 = self._train_stage(4, f4, qk=qk)                                          # cur_only_for_4 = False: every key row
+        final = self._train_readout(h4, self.fc_cls_2, self.fc_reg_2)
+        return [torch.cat(branch, dim=0), final], losses
+
+    def loss_train(self, logits_list, labels, label_weights, bbox_targets, bbox_weights):
+        """HRNMPBBoxHead.loss (hrnmp_bbox_head.py:970-1007) on the fused logits of each branch:
+        -> dict(loss_cls_1, acc_1, loss_bbox_1, loss_cls_2, acc_2, loss_bbox_2); the loss entries carry the gradient."""
+        from . import train_ops as TO
+        nc = self.num_classes
+        out = dict()
+        for i, logits in enumerate(logits_list):
+            assert logits.shape[0] == labels.shape[0]
+            d = TO.det_loss(logits, 0, nc, nc, labels, label_weights, bbox_targets, bbox_weights, beta=1.0)
+            out['loss_cls_%d' % (i + 1)], out['loss_bbox_%d' % (i + 1)], out['acc_%d' % (i + 1)] = d['total'][0], d['total'][1], d['acc']
+        return out
+
     def forward(self, *args, **kwargs):
-        raise NotImplementedError('HRNMPBBoxHead training forward (mining + TripletNonLocalLoss, whose source is not in '
-                                  'the reference tree) is not implemented; use forward_test')
+        raise NotImplementedError('HRNMPBBoxHead.forward: use forward_test (inference) or forward_train (training, dynamic=False)')
 
     def get_det_bboxes(self, rois, cls_scores, bbox_preds, img_shape, scale_factor, rescale=False, cfg=None, defer=False):
         """Per-branch read-out -> (list of det_bboxes, list of det_labels), hrnmp_bbox_head.py:1009-1052."""

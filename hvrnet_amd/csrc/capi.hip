@@ -37,6 +37,9 @@ hipError_t run_box_targets(const float*, int, int, const float*, const long long
 hipError_t run_rpn_loss(const float*, int, int, int, const long long*, const float*, const float*, const float*, const int*, float, float*,
                         float*, hipStream_t);
 hipError_t run_ce_rows(const float*, int, int, int, const long long*, int, float*, hipStream_t);
+hipError_t run_triplet_margin(const void*, long, const void*, long, int, int, int, const long long*, const long long*, const long long*, int,
+                              float, int, float*, float*, float*, float*, hipStream_t);
+hipError_t run_mining_argreduce(const float*, int, int, long, const long long*, const long long*, long long*, hipStream_t);
 hipError_t run_relation_dscore(const void*, const void*, const void*, const void*, void*, int, long, int, long, long, float, int, hipStream_t);
 hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -433,6 +436,27 @@ int hvr_rpn_loss(const float* o, int ldo, int A, int rows, const int64_t* labels
   return check_launch(run_rpn_loss(o, ldo, A, rows, (const long long*)labels, label_weights, bbox_targets, bbox_weights, counts, beta,
                                    out2, d_o, (hipStream_t)stream),
                       "hvr_rpn_loss");
+}
+
+int hvr_mining_argreduce(const float* aff, int Mq, int Mk, int64_t ld, const int64_t* labels, const int64_t* all_labels, int64_t* out4,
+                         void* stream) {
+  if (!aff || !labels || !all_labels || !out4) return fail(HVR_EINVAL, "null pointer");
+  if (Mq <= 0 || Mk <= 0 || ld < Mk) return fail(HVR_EINVAL, "bad mining shape");
+  return check_launch(run_mining_argreduce(aff, Mq, Mk, ld, (const long long*)labels, (const long long*)all_labels, (long long*)out4,
+                                           (hipStream_t)stream),
+                      "hvr_mining_argreduce");
+}
+
+int hvr_triplet_margin(const void* q, int64_t ldq, const void* k, int64_t ldk, int D, int Mq, int Mk, const int64_t* anchor_idx,
+                       const int64_t* pos_idx, const int64_t* neg_idx, int n, float margin, int dtype, float* ws, size_t ws_bytes,
+                       float* out2, float* dq, float* dk, void* stream) {
+  if (!q || !k || !anchor_idx || !pos_idx || !neg_idx || !ws || !out2) return fail(HVR_EINVAL, "null pointer");
+  if (D <= 0 || Mq <= 0 || Mk <= 0 || n <= 0 || ldq < D || ldk < D) return fail(HVR_EINVAL, "bad triplet shape");
+  if (dtype != HVR_F32 && dtype != HVR_BF16) return fail(HVR_EINVAL, "bad dtype");
+  if (ws_bytes < (size_t)n * 3 * sizeof(float)) return fail(HVR_EWORKSPACE, "triplet workspace too small");
+  return check_launch(run_triplet_margin(q, ldq, k, ldk, D, Mq, Mk, (const long long*)anchor_idx, (const long long*)pos_idx,
+                                         (const long long*)neg_idx, n, margin, dtype == HVR_BF16, ws, out2, dq, dk, (hipStream_t)stream),
+                      "hvr_triplet_margin");
 }
 
 int hvr_ce_rows(const float* logits, int ldl, int cls_off, int ncls, const int64_t* labels, int R, float* loss, void* stream) {

@@ -7,6 +7,7 @@
 //   targets  mmdet/core/anchor/anchor_target.py:121-155, mmdet/core/bbox/bbox_target.py:35-62, transforms.py:6-31
 //   rpn loss mmdet/models/anchor_heads/anchor_head.py:141-160 (sigmoid BCE + smooth-L1, both / num_total_samples)
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 
 #include <cstdint>
 
@@ -285,6 +286,159 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   float se = 0.f;
   for (int c = 0; c < ncls; ++c) se += expf(row[c] - mx);
   loss[r] = mx + logf(se) - row[(int)labels[r]];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hard-proposal mining (hrnmp_bbox_head.py:357-414 `hardest_proposal_mining`): per query row of the scaled affinity
+// matrix aff [Mq][ld], under the label masks the reference builds with masked_fill + topk:
+//   out[r][0] = argmax over keys whose label differs from the row's   (`inds_for_pos_sm`,  topk(1))
+//   out[r][1] = argmin over keys with the row's label                 (`inds_for_pos_nsm`, topk(1, largest=False))
+//   out[r][2..3] = the two largest among keys whose label differs     (`inds_for_bg`, topk(2); used for label-0 rows)
+// Masked-out keys count as -inf (+inf for the minimum), ties go to the lower index: a row without candidates answers 0
+// (0, 1 for the pair).  One wavefront per row.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Best { float v; int i; };
+
+__device__ __forceinline__ Best better_max(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ Best better_min(Best a, Best b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+
+template <bool MAX>
+__device__ __forceinline__ Best wave_best(Best x) {
+  for (int o = 32; o > 0; o >>= 1) {
+    Best y;
+    y.v = __shfl_xor(x.v, o);
+    y.i = __shfl_xor(x.i, o);
+    x = MAX ? better_max(x, y) : better_min(x, y);
+  }
+  return x;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void mining_argreduce_kernel(const float* __restrict__ aff, int Mq, int Mk, long ld,
+                                                               const long long* __restrict__ labels,
+                                                               const long long* __restrict__ all_labels, long long* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= Mq) return;
+  const float* row = aff + (long)r * ld;
+  const long long lab = labels[r];
+  Best dmax = {-INFINITY, 0x7fffffff}, smin = {INFINITY, 0x7fffffff};
+  for (int k = lane; k < Mk; k += 64) {
+    const bool diff = all_labels[k] != lab;
+    const float v = row[k];
+    dmax = better_max(dmax, Best{diff ? v : -INFINITY, k});
+    smin = better_min(smin, Best{diff ? INFINITY : v, k});
+  }
+  dmax = wave_best<true>(dmax);
+  smin = wave_best<false>(smin);
+  Best second = {-INFINITY, 0x7fffffff};
+  for (int k = lane; k < Mk; k += 64) {
+    if (k == dmax.i) continue;
+    const bool diff = all_labels[k] != lab;
+    second = better_max(second, Best{diff ? row[k] : -INFINITY, k});
+  }
+  second = wave_best<true>(second);
+  if (lane == 0) {
+    long long* o = out + (long)r * 4;
+    o[0] = dmax.i; o[1] = smin.i; o[2] = dmax.i; o[3] = Mk > 1 ? second.i : 0;
+  }
+}
+
+hipError_t run_mining_argreduce(const float* aff, int Mq, int Mk, long ld, const long long* labels, const long long* all_labels,
+                                long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(mining_argreduce_kernel, dim3((Mq + 3) / 4), dim3(256), 0, s, aff, Mq, Mk, ld, labels, all_labels, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Triplet margin loss over mined (anchor, positive, negative) index triples -- a STAND-IN: the reference calls
+// `TripletNonLocalLoss(margin).compute_loss(q, k, labels, [anchors, pos, neg])` (hrnmp_bbox_head.py:555-561,672,741) from a
+// fork of pytorch_metric_learning that is not part of the reference tree.  What is computed here is that library's
+// published TripletMarginLoss with the anchors taken from q and the positives / negatives from k:
+//   d(x, y) = || x - y + 1e-6 ||_2 (F.pairwise_distance),  l_i = max(d(q_a, k_p) - d(q_a, k_n) + margin, 0),
+//   loss = sum l_i / max(#{l_i > 0}, 1)   (AvgNonZeroReducer).
+// Forward and both gradients; fixed summation order (anchors are walked in order per column, no atomics).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void triplet_dist_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ k, long ldk, int D,
+                                                           const long long* __restrict__ a_idx, const long long* __restrict__ p_idx,
+                                                           const long long* __restrict__ n_idx, int n, float margin,
+                                                           float* __restrict__ ws) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const T* qa = q + a_idx[i] * ldq;
+  const T* kp = k + p_idx[i] * ldk;
+  const T* kn = k + n_idx[i] * ldk;
+  float sp = 0.f, sn = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float x = (float)qa[d];
+    const float ep = x - (float)kp[d] + 1e-6f, en = x - (float)kn[d] + 1e-6f;
+    sp += ep * ep;
+    sn += en * en;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sp += __shfl_xor(sp, o);
+    sn += __shfl_xor(sn, o);
+  }
+  if (lane == 0) {
+    const float dp = sqrtf(sp), dn = sqrtf(sn), l = dp - dn + margin;
+    ws[i * 3] = dp; ws[i * 3 + 1] = dn; ws[i * 3 + 2] = l > 0.f ? l : 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void triplet_grad_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ k, long ldk, int D,
+                                                           const long long* __restrict__ a_idx, const long long* __restrict__ p_idx,
+                                                           const long long* __restrict__ n_idx, int n, const float* __restrict__ ws,
+                                                           float* __restrict__ out2, float* __restrict__ dq, float* __restrict__ dk) {
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x;
+  float ls = 0.f, cnt = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    ls += ws[i * 3 + 2];
+    cnt += ws[i * 3 + 2] > 0.f ? 1.f : 0.f;
+  }
+  red[0][tid] = ls; red[1][tid] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    __syncthreads();
+  }
+  const float active = red[1][0], g = 1.f / fmaxf(active, 1.f);
+  if (blockIdx.x == 0 && tid == 0) { out2[0] = red[0][0] * g; out2[1] = active; }
+  if (!dq && !dk) return;
+  for (int d = blockIdx.x * 256 + tid; d < D; d += gridDim.x * 256)
+    for (int i = 0; i < n; ++i) {
+      if (!(ws[i * 3 + 2] > 0.f)) continue;
+      const long a = a_idx[i], p = p_idx[i], m = n_idx[i];
+      const float x = (float)q[a * ldq + d];
+      const float up = (x - (float)k[p * ldk + d] + 1e-6f) / ws[i * 3], un = (x - (float)k[m * ldk + d] + 1e-6f) / ws[i * 3 + 1];
+      if (dq) dq[a * D + d] += g * (up - un);
+      if (dk) { dk[p * D + d] -= g * up; dk[m * D + d] += g * un; }
+    }
+}
+
+template <typename T>
+static hipError_t launch_triplet(const void* q, long ldq, const void* k, long ldk, int D, const long long* a, const long long* p,
+                                 const long long* n_, int n, float margin, float* ws, float* out2, float* dq, float* dk, hipStream_t s) {
+  hipLaunchKernelGGL(triplet_dist_kernel<T>, dim3((n + 3) / 4), dim3(256), 0, s, (const T*)q, ldq, (const T*)k, ldk, D, a, p, n_, n, margin,
+                     ws);
+  hipLaunchKernelGGL(triplet_grad_kernel<T>, dim3((D + 255) / 256), dim3(256), 0, s, (const T*)q, ldq, (const T*)k, ldk, D, a, p, n_, n, ws,
+                     out2, dq, dk);
+  return hipGetLastError();
+}
+
+hipError_t run_triplet_margin(const void* q, long ldq, const void* k, long ldk, int D, int Mq, int Mk, const long long* a, const long long* p,
+                              const long long* n_, int n, float margin, int bf16, float* ws, float* out2, float* dq, float* dk,
+                              hipStream_t s) {
+  hipError_t e = hipSuccess;
+  if (dq) e = hipMemsetAsync(dq, 0, (size_t)Mq * D * 4, s);
+  if (e == hipSuccess && dk) e = hipMemsetAsync(dk, 0, (size_t)Mk * D * 4, s);
+  if (e != hipSuccess) return e;
+  return bf16 ? launch_triplet<__hip_bfloat16>(q, ldq, k, ldk, D, a, p, n_, n, margin, ws, out2, dq, dk, s)
+              : launch_triplet<float>(q, ldq, k, ldk, D, a, p, n_, n, margin, ws, out2, dq, dk, s);
 }
 
 // ---- launchers ----

@@ -97,6 +97,8 @@ SYMBOLS = {
     'hvr_box_targets': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     'hvr_rpn_loss': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'hvr_ce_rows': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'hvr_triplet_margin': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'hvr_mining_argreduce': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'hvr_nms_workspace_bytes': (_sz, [_i]),
@@ -558,6 +560,37 @@ def ce_rows(logits, cls_off, ncls, labels):
     _check(lib().hvr_ce_rows(_ptr(logits), logits.shape[1], cls_off, ncls, _ptr(labels.contiguous()), logits.shape[0], _ptr(loss),
                              _stream()), 'hvr_ce_rows')
     return loss
+
+
+def triplet_margin(q, k, anchor_idx, pos_idx, neg_idx, margin, need_grad=True):
+    """Stand-in triplet margin loss (see include/hvr_hip.h) -> (out2 = [loss, active triples] f32, dq f32 [Mq,D], dk f32 [Mk,D])."""
+    _need_cuda(q, k, anchor_idx, pos_idx, neg_idx)
+    assert q.dim() == 2 and k.dim() == 2 and q.shape[1] == k.shape[1] and q.dtype == k.dtype and q.stride(1) == 1 and k.stride(1) == 1
+    n = anchor_idx.numel()
+    assert n > 0 and pos_idx.numel() == n and neg_idx.numel() == n and anchor_idx.dtype == torch.long
+    D = q.shape[1]
+    out2 = torch.empty(2, dtype=torch.float32, device=q.device)
+    dq = torch.empty((q.shape[0], D), dtype=torch.float32, device=q.device) if need_grad else None
+    dk = torch.empty((k.shape[0], D), dtype=torch.float32, device=q.device) if need_grad else None
+    ws = _workspace(n * 12, q.device, 'triplet')
+    _check(lib().hvr_triplet_margin(_ptr(q), q.stride(0), _ptr(k), k.stride(0), D, q.shape[0], k.shape[0], _ptr(anchor_idx.contiguous()),
+                                    _ptr(pos_idx.contiguous()), _ptr(neg_idx.contiguous()), n, float(margin), _dt(q), _ptr(ws), n * 12,
+                                    _ptr(out2), _ptr(dq), _ptr(dk), _stream()), 'hvr_triplet_margin')
+    return out2, dq, dk
+
+
+def mining_argreduce(aff, labels, all_labels):
+    """aff f32 [Mq, Mk] (row stride >= Mk), labels int64 [Mq], all_labels int64 [Mk] -> int64 [Mq, 4]:
+    (argmax over different-label keys, argmin over same-label keys, top-2 over different-label keys)."""
+    _need_cuda(aff, labels, all_labels)
+    assert aff.dtype == torch.float32 and aff.dim() == 2 and aff.stride(1) == 1
+    assert labels.dtype == torch.long and all_labels.dtype == torch.long
+    Mq, Mk = aff.shape
+    assert labels.numel() == Mq and all_labels.numel() == Mk
+    out = torch.empty((Mq, 4), dtype=torch.long, device=aff.device)
+    _check(lib().hvr_mining_argreduce(_ptr(aff), Mq, Mk, aff.stride(0), _ptr(labels.contiguous()), _ptr(all_labels.contiguous()), _ptr(out),
+                                      _stream()), 'hvr_mining_argreduce')
+    return out
 
 
 def det_loss_sampled(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, sel_counts, beta=1.0):

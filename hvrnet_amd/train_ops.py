@@ -165,6 +165,32 @@ def rpn_loss(o, A, labels, label_weights, bbox_targets, bbox_weights, counts, be
     return dict(total=total, loss_rpn_cls=lc, loss_rpn_bbox=lb)
 
 
+class TripletMarginFunction(Function):
+    """STAND-IN for `TripletNonLocalLoss(margin).compute_loss(q, k, labels, [anchors, pos, neg])` (hrnmp_bbox_head.py:555-561): the
+    fork of pytorch_metric_learning that defines it is not in the reference tree, so this is the library's published
+    TripletMarginLoss over the mined triples (anchors from q, positives / negatives from k; include/hvr_hip.h has the formula).
+    -> (loss 0-dim, active triples 0-dim); parity with the reference is unpinned by construction."""
+
+    @staticmethod
+    def forward(ctx, q, k, anchor_idx, pos_idx, neg_idx, margin):
+        out2, dq, dk = native.triplet_margin(q.contiguous(), k.contiguous(), anchor_idx, pos_idx, neg_idx, margin)
+        ctx.save_for_backward(dq, dk)
+        ctx.dtypes = (q.dtype, k.dtype)
+        active = out2[1]
+        ctx.mark_non_differentiable(active)
+        return out2[0].clone(), active
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loss, g_active):
+        dq, dk = ctx.saved_tensors
+        return native.cast(dq * g_loss, ctx.dtypes[0]), native.cast(dk * g_loss, ctx.dtypes[1]), None, None, None, None
+
+
+def triplet_margin(q, k, anchor_idx, pos_idx, neg_idx, margin):
+    return TripletMarginFunction.apply(q, k, anchor_idx, pos_idx, neg_idx, float(margin))
+
+
 class ConvFunction(Function):
     """y = act(conv(x, w * s) + t (+ resid)) on physical NHWC tensors: an nn.Conv2d (no bias) followed by a frozen
     BatchNorm (scale s, shift t per output channel; pass s = ones / t = bias for a plain conv with bias) and optionally the

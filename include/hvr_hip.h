@@ -266,6 +266,22 @@ int hvr_box_targets(const float* boxes, int ldb, int n, const float* gts, const 
 int hvr_rpn_loss(const float* o, int ldo, int A, int rows, const int64_t* labels, const float* label_weights, const float* bbox_targets,
                  const float* bbox_weights, const int32_t* counts, float beta, float* out2, float* d_o, void* stream);
 int hvr_ce_rows(const float* logits, int ldl, int cls_off, int ncls, const int64_t* labels, int R, float* loss, void* stream);
+/* Hard-proposal mining of the HVR head (mmdet/models/bbox_heads/hrnmp_bbox_head.py:357-414 `hardest_proposal_mining`): for
+ * every query row of the scaled affinity matrix aff [Mq][ld] (f32), with row label labels[r] and key labels all_labels[k]:
+ *   out4[r][0] argmax over keys with a different label  (the reference's masked_fill(-inf) + topk(1), `inds_for_pos_sm`)
+ *   out4[r][1] argmin over keys with the same label     (masked_fill(+inf) + topk(1, largest=False), `inds_for_pos_nsm`)
+ *   out4[r][2], out4[r][3] the two largest among keys with a different label (topk(2), `inds_for_bg`, used for label-0 rows)
+ * ties to the lower index; a row without candidates gets index 0 (0, 1). */
+/* STAND-IN for the triplet loss over the mined triples: the reference calls TripletNonLocalLoss(margin).compute_loss(q, k, labels,
+ * [anchor_idx, pos_idx, neg_idx]) (hrnmp_bbox_head.py:555-561) from a pytorch_metric_learning fork that is NOT in the reference tree.
+ * This is the library's published TripletMarginLoss with anchors from q and positives / negatives from k:
+ * d(x,y) = ||x - y + 1e-6||_2, l_i = max(d(q_a,k_p) - d(q_a,k_n) + margin, 0), loss = sum l_i / max(#{l_i > 0}, 1).
+ * out2 = (loss, number of active triples); dq [Mq][D] / dk [Mk][D] (f32, nullable) = d loss / d q, d k.  ws: 3 n floats. */
+int hvr_triplet_margin(const void* q, int64_t ldq, const void* k, int64_t ldk, int D, int Mq, int Mk, const int64_t* anchor_idx,
+                       const int64_t* pos_idx, const int64_t* neg_idx, int n, float margin, int dtype, float* ws, size_t ws_bytes,
+                       float* out2, float* dq, float* dk, void* stream);
+int hvr_mining_argreduce(const float* aff, int Mq, int Mk, int64_t ld, const int64_t* labels, const int64_t* all_labels, int64_t* out4,
+                         void* stream);
 int hvr_det_loss_sampled(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels,
                          const float* label_weights, const float* bbox_targets, const float* bbox_weights, int R,
                          const int32_t* sel_counts, float beta, float* out3, float* dlogits, void* stream);

@@ -116,3 +116,18 @@ RPN_TRAIN_CFG = dict(assigner=dict(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou
 RCNN_TRAIN_CFG = dict(assigner=dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5), pos_weight=-1,
                       sampler=dict(num=300, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
                       ohem=dict(num=128, pos_fraction=0.25, neg_pos_ub=-1))
+
+
+def mining_case(mq=96, mk=288, d=64, ncls=6, seed=207):
+    """Scaled affinities of `mq` key-frame proposals against `mk` proposals of the video with class labels (0 = background,
+    a third of the rows), one class present only once among the keys and one query class absent from them."""
+    g = _gen(seed)
+    q, k = torch.randn((mq, d), generator=g), torch.randn((mk, d), generator=g)
+    labels = torch.randint(0, ncls, (mq,), generator=g)
+    labels[torch.rand(mq, generator=g) < 0.33] = 0
+    all_labels = torch.randint(0, ncls, (mk,), generator=g)
+    all_labels[all_labels == ncls - 1] = 1
+    all_labels[7] = ncls - 1          # a class with a single key
+    labels[3] = ncls + 3              # a query class no key carries: its "same label" set is empty
+    aff_scale = (q @ k.t()) * (1.0 / d ** 0.5)
+    return labels, all_labels, aff_scale

@@ -416,5 +416,11 @@ def main():
                  ohem_loss_bbox=lo['loss_bbox'].detach(), ohem_acc=lo['acc'].detach(), ohem_d_cls=cs12.grad, ohem_d_reg=bp12.grad)
     save('g12_targets', **out12)
 
+    # ---- G13 hard-proposal mining (hrnmp_bbox_head.py:357-414), the reference's own method (it never touches `self`) ----
+    ml, mal, maff = C.mining_case()
+    a_idx, pos_idx, neg_idx = ref.HRNMPBBoxHead.hardest_proposal_mining(None, ml, mal, maff[None].clone(), None)
+    top2 = maff.topk(3, dim=1).values
+    save('g13_mining', anchor_idx=a_idx, hardest_pos_idx=pos_idx, hardest_neg_idx=neg_idx, min_gap=(top2[:, 0] - top2[:, 1]).min())
+
 if __name__ == '__main__':
     main()

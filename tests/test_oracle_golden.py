@@ -247,6 +247,18 @@ def test_sampler_keys_pick_the_smallest_with_index_ties(O):
     assert pos.tolist() == [0, 6] and neg.tolist() == [2, 5, 7]
 
 
+def test_g13_hard_proposal_mining(O):
+    """The oracle's masked arg-reductions against the reference's own hardest_proposal_mining (G13), on a case with a
+    single-key class and a query class without keys; the best-vs-second gap of the case is far above f32 round-off."""
+    g = gold('g13_mining')
+    labels, all_labels, aff = C.mining_case()
+    anchors, pos, neg, bg2 = O.hardest_proposal_mining(labels, all_labels, aff)
+    assert np.array_equal(anchors.numpy(), g['anchor_idx'])
+    assert np.array_equal(pos.numpy(), g['hardest_pos_idx']) and np.array_equal(neg.numpy(), g['hardest_neg_idx'])
+    assert float(g['min_gap']) > 1e-4
+    assert bg2.shape == (labels.numel(), 2) and bool((all_labels[bg2[labels == 0]] != 0).all())
+
+
 def test_g8_det_readout(O):
     g = gold('g8_det')
     rois, cls, reg = C.det_case()

@@ -638,6 +638,57 @@ def test_selsa_rcnn_training_step_on_sampled_rois_matches_the_oracle(O):
         close(params[k].grad, w, 1e-2, 1e-2 * w.abs().max().item())
 
 
+def test_hvr_head_training_step_matches_the_oracle(O):
+    """HRNMPBBoxHead.forward_train + loss_train + backward (three videos of three frames; per-video stages 1-3, the
+    inter-video stage 4 with hard-proposal mining and the stand-in triplet term) against autograd over the oracle's
+    restatement of hrnmp_bbox_head.py:609-798: the six loss outputs + loss_trip, the mined triple, and every parameter
+    gradient by abs-sum and a strided sample.  (`loss_trip` itself is unpinned against the reference: see DESIGN.md.)"""
+    sd = S.synth_state_dict('hvr')
+    n, V, F_ = 8, 3, 3
+    head = hvrnet_amd.HRNMPBBoxHead(sampler_num=n, t_dim=V * F_, imgs_per_video=F_, in_channels=256, num_classes=31,
+                                    reg_class_agnostic=True)
+    head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
+    head = hvrnet_amd.enable_training(head.to(DEV))
+    hvrnet_amd.set_compute_dtype(head, torch.float32)
+    g = torch.Generator().manual_seed(97)
+    lens = [8, 6, 7]                                            # ragged key-frame row counts
+    feats = [torch.randn((l + 2 * n - v, 256, 7, 7), generator=g).abs() for v, l in enumerate(lens)]
+    curs = [dict(start=0, length=l) for l in lens]
+    R = sum(lens)
+    labels = torch.randint(0, 4, (R,), generator=g)
+    labels[::3] = 0
+    lw = torch.ones(R)
+    bt = torch.randn((R, 4), generator=g) * 0.8
+    bw = (labels > 0).float()[:, None].expand(-1, 4).contiguous()
+    names = [k for k in sd if k.startswith('bbox_head.')]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    cls_w, reg_w, extra = O.hvr_head_forward_train(feats, leaf, curs, labels, n, V * F_, F_)
+    want = O.hvr_head_loss(cls_w, reg_w, labels, lw, bt, bw)
+    want.update(extra)
+    sum(v for k, v in want.items() if 'loss' in k).backward()
+    logits, extra_g = head.forward_train([f.to(DEV) for f in feats], curs, labels.to(DEV))
+    got = head.loss_train(logits, labels.to(DEV), lw.to(DEV), bt.to(DEV), bw.to(DEV))
+    got.update(extra_g)
+    sum(v for k, v in got.items() if 'loss' in k).backward()
+    assert set(got) == set(want) and 'loss_trip' in got
+    for k in want:
+        close(got[k], want[k].detach(), 2e-4, 1e-5)
+    seen = 0
+    for name, prm in head.named_parameters():
+        w = leaf['bbox_head.' + name].grad
+        if w is None:
+            assert prm.grad is None or float(prm.grad.abs().sum()) == 0.0, name
+            continue
+        assert prm.grad is not None, name
+        want_abs = float(w.double().abs().sum())
+        if 'k_data_fc' in name and name.endswith('bias') and not name.startswith('selsa_4'):
+            continue                                             # analytically zero (softmax shift invariance); stage 4's is not: triplet
+        assert abs(float(prm.grad.double().abs().sum()) - want_abs) <= 2e-3 * want_abs + 1e-7, name
+        close(prm.grad.reshape(-1)[::4099], w.reshape(-1)[::4099], 5e-3, 5e-3 * want_abs / w.numel() + 1e-9)
+        seen += 1
+    assert seen >= 30
+
+
 def test_bf16_training_step_tracks_the_f32_oracle(O):
     """Throughput mode of the training step: bf16 activations and operands, f32 master weights / accumulation / weight
     gradients.  Same fixed-RoI step as the f32 test above; operands carry 2^-9 relative rounding through ~110 layers, so

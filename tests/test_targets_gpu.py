@@ -247,3 +247,65 @@ def test_unsupported_target_options_fail_loudly():
         asg.assign(b, b, gt_bboxes_ignore=b)
     with pytest.raises(native.HvrError):   # more ground-truth boxes than the kernel's LDS table
         native.max_iou_assign(torch.rand(8, 4, device=DEV), torch.rand(300, 4, device=DEV), 0.5, 0.5, 0.5)
+
+
+def test_hard_proposal_mining_matches_reference_and_oracle(O):
+    """HRNMPBBoxHead.hardest_proposal_mining on the device against G13 (the reference's own method) and, for the top-2 of the
+    background rows and larger random cases with ties, against the oracle."""
+    g13 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g13_mining.npz'))
+    labels, all_labels, aff = C.mining_case()
+    head = hvrnet_amd.HRNMPBBoxHead(sampler_num=8, t_dim=3, imgs_per_video=3, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    anchors, pos, neg = head.hardest_proposal_mining(labels.to(DEV), all_labels.to(DEV), aff[None].to(DEV), None)
+    assert _eq(anchors, g13['anchor_idx']) and _eq(pos, g13['hardest_pos_idx']) and _eq(neg, g13['hardest_neg_idx'])
+    picks = native.mining_argreduce(aff.to(DEV), labels.to(DEV), all_labels.to(DEV))
+    _, _, _, bg2 = O.hardest_proposal_mining(labels, all_labels, aff)
+    assert _eq(picks[:, 2:], bg2.numpy())
+    # coarse affinities (many exact ties -> the lower index), ragged sizes, a padded row stride
+    gen = torch.Generator().manual_seed(5)
+    for mq, mk in ((1, 1), (5, 2), (300, 900), (257, 4500)):
+        lab = torch.randint(0, 4, (mq,), generator=gen)
+        alab = torch.randint(0, 4, (mk,), generator=gen)
+        a = (torch.randn((mq, mk), generator=gen) * 4).round() / 4
+        buf = torch.zeros((mq, mk + 3))
+        buf[:, :mk] = a
+        got = native.mining_argreduce(buf.to(DEV)[:, :mk], lab.to(DEV), alab.to(DEV)).cpu()
+        diff = alab[None, :] != lab[:, None]
+        hi, lo = a.masked_fill(~diff, float('-inf')), a.masked_fill(diff, float('inf'))
+        first_max = (hi == hi.max(1, keepdim=True)[0]).float().argmax(1)      # lowest index among the maxima
+        first_min = (lo == lo.min(1, keepdim=True)[0]).float().argmax(1)
+        assert torch.equal(got[:, 0], first_max) and torch.equal(got[:, 1], first_min), (mq, mk)
+        if mk > 1:
+            hi2 = hi.clone()
+            hi2[torch.arange(mq), first_max] = float('-inf')
+            second = (hi2 == hi2.max(1, keepdim=True)[0]).float().argmax(1)
+            ok = torch.isfinite(hi2.max(1)[0]) | ~torch.isfinite(hi.max(1)[0])
+            # rows with exactly one candidate: the second pick is the lowest masked index other than the first
+            assert torch.equal(got[ok, 3], second[ok]), (mq, mk)
+
+
+@pytest.mark.parametrize('dtype,margin', [(torch.float32, 10.0), (torch.float32, 0.5), (torch.bfloat16, 10.0)])
+def test_triplet_margin_standin_matches_its_oracle(O, dtype, margin):
+    """The documented stand-in for the un-vendored TripletNonLocalLoss (parity with the reference is unpinned: the library is not
+    in its tree): forward value, active-triple count and both gradients against f64 autograd over the oracle's restatement of
+    the published TripletMarginLoss; repeated positives / negatives (gradient rows that collide) and inactive triples included."""
+    g = torch.Generator().manual_seed(int(margin * 10))
+    Mq, Mk, D, n = 40, 70, 1024, 33
+    q = (torch.randn((Mq, D), generator=g) * 0.3).to(dtype)
+    k = (torch.randn((Mk, D), generator=g) * 0.3).to(dtype)
+    a = torch.randint(0, Mq, (n,), generator=g)
+    p = torch.randint(0, 6, (n,), generator=g)          # few distinct rows: collisions
+    m = torch.randint(0, Mk, (n,), generator=g)
+    k[m[:5]] = k[m[:5]] * 6                             # far negatives: inactive triples when the margin is small
+    qd, kd = q.double().requires_grad_(True), k.double().requires_grad_(True)
+    want, want_active = O.triplet_margin_standin(qd, kd, a, p, m, margin)
+    want.backward()
+    qg, kg = q.to(DEV).requires_grad_(True), k.to(DEV).requires_grad_(True)
+    loss, active = TO.triplet_margin(qg, kg, a.to(DEV), p.to(DEV), m.to(DEV), margin)
+    loss.backward()
+    assert int(active) == int(want_active) and (margin > 1 or int(active) < n)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    close(loss, want.detach(), tol, tol)
+    scale = float(qd.grad.abs().max())
+    close(qg.grad, qd.grad, tol * 10, tol * scale)
+    close(kg.grad, kd.grad, tol * 10, tol * scale)
+    assert qg.grad.dtype == dtype

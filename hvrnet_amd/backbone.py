@@ -97,6 +97,15 @@ def enable_training(module):
             for f in frozen:
                 for p in f.parameters():
                     p.requires_grad = False
+    for m in module.modules():
+        if type(m).__name__ == 'HNMBRCNN':
+            # this detector's forward_train computes C4 under no_grad and never adds an RPN loss (hnmb_rcnn.py:269-283,318-325):
+            # backbone and RPN parameters never receive a gradient there, and torch.optim.SGD skips gradient-less parameters
+            # (no weight decay either) -- keep them out of the flat parameter set so the fused update leaves them alone too
+            for part in (m.backbone, getattr(m, 'rpn_head', None)):
+                if part is not None:
+                    for p in part.parameters():
+                        p.requires_grad = False
     return module
 
 

@@ -149,6 +149,18 @@ def selsa_train_config(nms_post=300, rcnn_sampler_num=128, t_dim=3, ohem=True):
     return Config(dict(model=model, train_cfg=_train_cfg(nms_post, rcnn_sampler_num, ohem), test_cfg=_test_cfg((t_dim - 1) // 2, nms_post)))
 
 
+def hvr_train_config(nms_post=300, rcnn_sampler_num=128, imgs_per_video=3, chosen_videos=3):
+    """HNMBRCNN with its training settings (configs/faster_rcnn_r101_hrnmp_c5.py:4-5,34-35,79-95,97-137): one RandomSampler of
+    `rcnn_sampler_num` per frame, head t_dim = imgs_per_video * chosen_videos."""
+    model = _model('HNMBRCNN', 'HRNMPBBoxHead', dict(sampler_num=rcnn_sampler_num, imgs_per_video=imgs_per_video,
+                                                     t_dim=imgs_per_video * chosen_videos))
+    train = _train_cfg(nms_post, rcnn_sampler_num, ohem=False)
+    train['rcnn']['sampler'] = dict(type='RandomSampler', num=rcnn_sampler_num, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    test = _test_cfg(1, nms_post)
+    test['bbox_head'].update(key_dim=0)
+    return Config(dict(model=model, train_cfg=train, test_cfg=test))
+
+
 def hvr_config(frame_interval=7, nms_post=300):
     """HNMBRCNN + HRNMPBBoxHead (configs/faster_rcnn_r101_hrnmp_c5.py), test-time settings."""
     model = _model('HNMBRCNN', 'HRNMPBBoxHead', dict(sampler_num=128, imgs_per_video=3, t_dim=9))

@@ -18,7 +18,8 @@ What differs from the reference is HOW a window executes, not what it computes:
     caller, which can enqueue the next window before collecting this one.
 The reference dump's defects are implemented as intended: SelsaRCNN takes
 `[:2]` of the head's 3-tuple (selsa_rcnn.py:306), `collections.Sequence` -> `collections.abc`.
-Training: SelsaRCNN.forward_train (selsa_rcnn.py:85-279) runs on the HIP path end to end; HNMBRCNN is inference only.
+Training: SelsaRCNN.forward_train (selsa_rcnn.py:85-279) and HNMBRCNN.forward_train (hnmb_rcnn.py:224-434; its triplet term
+through a documented stand-in) run on the HIP path end to end.
 """
 import collections.abc
 import os
@@ -70,9 +71,7 @@ class BaseDetector(nn.Module):
         return self.forward_test(img, img_meta, **kwargs)
 
     def forward_train(self, img, img_meta, **kwargs):
-        raise NotImplementedError('%s has no training step on the HIP path (SelsaRCNN does; HNMBRCNN.forward_train needs the '
-                                  'triplet loss of pytorch_metric_learning, which is not part of the reference tree)'
-                                  % type(self).__name__)
+        raise NotImplementedError('%s has no training step on the HIP path (SelsaRCNN and HNMBRCNN do)' % type(self).__name__)
 
     def forward_test(self, imgs, img_metas, **kwargs):
         for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
@@ -360,6 +359,8 @@ class SelsaRCNN(_WindowDetector):
         draws.  -> dict(loss_rpn_cls [1-list], loss_rpn_bbox [1-list], loss_cls, loss_bbox, acc); summing the 'loss' entries
         and calling backward() trains (the reference's parse_losses does the same sum)."""
         from . import native, ops, targets as T, train_ops as TO
+        if self.train_cfg is None:
+            raise ValueError('this detector was built without train_cfg (hvrnet_amd.config.selsa_train_config, or the reference config file)')
         key = self.key_dim
         if key != 0:
             raise NotImplementedError('training keeps the key frame first (train_cfg.rcnn.key_dim = 0 in both configs)')
@@ -463,6 +464,90 @@ class HNMBRCNN(_WindowDetector):
         pending = PendingWindow(branches, w['counts_dev'], w['full_count'], self.bbox_head.num_classes,
                                 lambda: self.forward_feat(x, img_meta, proposals, rescale, speculate=False))
         return pending if defer else pending.result()
+
+    # ---- training (hnmb_rcnn.py:54-102, 224-434) -------------------------------------------------------------------
+    IMGS_PER_VIDEO, VIDEO_PER_CLS = 3, 3      # hnmb_rcnn.py:265-267 (hard-coded there too)
+
+    def get_triplet_patches(self, c5_feats_all, key_video=0, imgs_per_video=3, extra_cls=2, video_per_cls=3):
+        """hnmb_rcnn.py:74-102: the three videos of an iteration -- the key video, the video of the SAME class least similar to
+        it and the video of ANOTHER class most similar to those two -- by softmax-normalised dot products of the videos'
+        descriptors (global average pool of each frame's res5 map, maximum over the video's frames).  A handful of
+        256-vectors: plain tensor arithmetic, one host read of the two chosen indices.
+        c5_feats_all: per video a logical [frames, C, h, w] map.  -> [key_video, same-class id, other-class id]."""
+        desc = [f.float().mean(dim=(2, 3)).max(dim=0).values[None] for f in c5_feats_all]        # [1, C] per video
+        key = torch.cat(desc[0:video_per_cls], dim=0)
+        scale = 1.0 / float(key.shape[-1]) ** 0.5
+        key_sim = torch.softmax(scale * (desc[0] @ key.t()), dim=1)
+        same_id = int(torch.argmin(key_sim[:, 1:], dim=1)[0]) + 1
+        chosen = torch.cat([desc[key_video], desc[same_id]], dim=0)
+        extra = torch.cat(desc[video_per_cls:], dim=0)
+        extra_sim = torch.softmax(scale * (chosen @ extra.t()), dim=1).sum(dim=0, keepdim=True)
+        other_id = int(torch.argmax(extra_sim, dim=1)[0]) + video_per_cls
+        return [key_video, same_id, other_id]
+
+    def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
+                      keys=None, generator=None):
+        """HNMBRCNN.forward_train (hnmb_rcnn.py:224-434, dynamic=False, single RandomSampler) on the HIP path.
+        img [V * 3, 3, H, W]: V videos of three frames, key frame first; videos 0..2 share the key video's class, the rest
+        are other classes.  As in the reference: the backbone and res5 run WITHOUT a graph over all V videos to pick the
+        triplet of videos (:269-277), the chosen videos' C4 maps are reused as constants (:280-283, so the backbone gets no
+        gradient in this detector's training step), the RPN only proposes (:318-325, no RPN loss), every frame of a chosen
+        video is assigned and sampled against its video's key-frame ground truth (:348-362), res5 (with a graph) + RoIAlign
+        feed the head (:333-336, 364-380), and the losses are HRNMPBBoxHead.loss on the three key frames' targets plus the
+        head's triplet term (:389-416; the latter through the documented stand-in).
+        keys: optional {'rcnn': [[f32 [num_gt + nms_post] per frame] per chosen video]} replacing the sampler's draws.
+        -> dict(loss_cls_1, acc_1, loss_bbox_1, loss_cls_2, acc_2, loss_bbox_2, loss_trip)."""
+        from . import ops, targets as T
+        if self.train_cfg is None:
+            raise ValueError('this detector was built without train_cfg (hvrnet_amd.config.hvr_train_config, or the reference config file)')
+        if self.key_dim != 0:
+            raise NotImplementedError('Key_dim has to be 0 in HNMBRCNN.forward_train (hnmb_rcnn.py:263)')
+        if gt_masks is not None or proposals is not None or gt_bboxes_ignore is not None:
+            raise NotImplementedError('masks / external proposals / ignore boxes are asserted away by the reference too (:260-261,:292)')
+        F_ = self.IMGS_PER_VIDEO
+        V = img.shape[0] // F_
+        rcnn_cfg = self.train_cfg.rcnn
+        if isinstance(rcnn_cfg.sampler, (list, tuple)):
+            raise NotImplementedError('the HVR config trains with a single RandomSampler (the head asserts post_sampler is None, :635)')
+        with torch.no_grad():                                   # extract_c4_c5_feat (:54-72)
+            c4_all = [self.extract_feat(img[v * F_:(v + 1) * F_])[0] for v in range(V)]
+            c5_all = [self.shared_head(c4) for c4 in c4_all]
+        chosen = self.get_triplet_patches(c5_all, 0, F_, V - self.VIDEO_PER_CLS, self.VIDEO_PER_CLS)
+        del c5_all
+        bbox_assigner = T.build_assigner(rcnn_cfg.assigner)
+        bbox_sampler = T.build_sampler(rcnn_cfg.sampler, context=self)
+        proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+        layer = self.bbox_roi_extractor.roi_layers[0]
+        feats, cur_ranges, key_results, key_gtb, key_gtl = [], [], [], [], []
+        for vi, v in enumerate(chosen):
+            c4 = c4_all[v]
+            metas = img_meta[v * F_:(v + 1) * F_]
+            gt_b, gt_l = gt_bboxes[v * F_ + self.key_dim], gt_labels[v * F_ + self.key_dim]
+            with torch.no_grad():
+                rpn_outs = self.rpn_head([c4])
+                proposal_list = self.rpn_head.get_bboxes(*(rpn_outs + (metas, proposal_cfg)))
+            results = []
+            for i in range(F_):
+                props = proposal_list[i].contiguous()
+                assign_result = bbox_assigner.assign(props, gt_b, None, gt_l)
+                k_i = None
+                if keys is not None and 'rcnn' in keys:
+                    k_i = keys['rcnn'][vi][i][:gt_b.shape[0] * int(bbox_sampler.add_gt_as_proposals) + props.shape[0]]
+                results.append(bbox_sampler.sample(assign_result, props, gt_b, gt_l, keys=k_i, generator=generator))
+            rois = torch.cat([torch.cat([r.bboxes.new_full((r.bboxes.shape[0], 1), float(i)), r.bboxes], 1)
+                              for i, r in enumerate(results)], 0)
+            c5 = self.shared_head.forward_train_nhwc(c4.permute(0, 2, 3, 1))          # res5 with a graph; C4 is a constant
+            feats.append(ops.roi_align(c5.permute(0, 3, 1, 2), rois, layer.out_size, layer.spatial_scale, layer.sample_num))
+            cur_ranges.append(dict(start=self.key_dim, length=results[self.key_dim].bboxes.shape[0]))
+            key_results.append(results[self.key_dim])
+            key_gtb.append(gt_b)
+            key_gtl.append(gt_l)
+        targets = T.bbox_target(key_results, key_gtb, key_gtl, rcnn_cfg, target_means=self.bbox_head.target_means,
+                                target_stds=self.bbox_head.target_stds)
+        logits, losses = self.bbox_head.forward_train(feats, cur_ranges, targets[0], key_dim=self.key_dim)
+        losses = dict(losses)
+        losses.update(self.bbox_head.loss_train(logits, *targets))
+        return losses
 
     def forward_feat_frames(self, entries, c4s=None, rescale=False, defer=False):
         """forward_feat from T cached `frame_tensors` entries (see _WindowDetector.frame_tensors)."""

@@ -93,8 +93,16 @@ def test_gpu_only_modules_fail_loudly_on_cpu():
         hvrnet_amd.ops.RoIAlign(7, 1 / 16, 2)(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5))
     with pytest.raises(NotImplementedError):
         hvrnet_amd.ops.nms(torch.rand(4, 5), 0.5)
-    with pytest.raises(NotImplementedError):
-        model(None, None, return_loss=True)
+    # the training step has no CPU path either: it dies in the first HIP op, not in a silent torch fallback
+    from hvrnet_amd.config import hvr_train_config, selsa_train_config
+    meta = dict(img_shape=(64, 64, 3), pad_shape=(64, 64, 3), scale_factor=1.0, flip=False)
+    for cfg, frames in ((hvr_train_config(nms_post=8, rcnn_sampler_num=4), 15), (selsa_train_config(nms_post=8, rcnn_sampler_num=4), 3)):
+        trainable = hvrnet_amd.enable_training(_build(cfg))
+        with pytest.raises(NotImplementedError):
+            trainable(torch.zeros(frames, 3, 64, 64), [meta] * frames, return_loss=True,
+                      gt_bboxes=[torch.tensor([[4., 4., 40., 40.]])] * frames, gt_labels=[torch.tensor([3])] * frames)
+    with pytest.raises(ValueError):       # a detector built without train_cfg says so
+        model(torch.zeros(15, 3, 64, 64), [meta] * 15, return_loss=True, gt_bboxes=[None] * 15, gt_labels=[None] * 15)
 
 
 class _FakeModel(object):

@@ -689,6 +689,63 @@ def test_hvr_head_training_step_matches_the_oracle(O):
     assert seen >= 30
 
 
+def test_hnmb_rcnn_forward_train_matches_the_oracle(O):
+    """HNMBRCNN.forward_train through the detector's dispatch on five videos of three 128x192 frames (three of the key class,
+    two others): video choice by res5 descriptors, proposals, per-frame sampling against each chosen video's key-frame ground
+    truth, res5 with a graph over constant C4 maps, RoIAlign, the HVR head with mining + the stand-in triplet term, the six
+    branch losses -- against the oracle's restatement of hnmb_rcnn.py:224-434 on the same sampler keys.  Chosen videos and
+    sampled sets exactly; losses to 1e-3; gradients of res5 / head weights to 1e-2 of their scale; the backbone and the RPN get
+    no gradient (the reference computes C4 under no_grad and never adds an RPN loss here)."""
+    from hvrnet_amd.config import hvr_train_config
+    sd = S.synth_state_dict('hvr')
+    n_post, n_sel, F_, V = 16, 8, 3, 5
+    cfg = hvr_train_config(nms_post=n_post, rcnn_sampler_num=n_sel)
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, sd, torch.float32, DEV))
+    g = torch.Generator().manual_seed(99)
+    hw = (128, 192)
+    imgs = torch.randn((V * F_, 3) + hw, generator=g) * 50.0
+    imgs = imgs + torch.arange(V).repeat_interleave(F_)[:, None, None, None].float() * 9.0      # videos differ in their descriptors
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(V * F_)]
+    gts = [torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]), torch.tensor([[40., 20., 120., 90.]]),
+           torch.tensor([[30., 40., 150., 120.], [10., 10., 60., 60.]]), torch.tensor([[60., 30., 140., 100.]]),
+           torch.tensor([[20., 50., 100., 120.]])]
+    gls = [torch.tensor([5, 12]), torch.tensor([5]), torch.tensor([5, 7]), torch.tensor([9]), torch.tensor([3])]
+    gt_b = [gts[v] for v in range(V) for _ in range(F_)]
+    gt_l = [gls[v] for v in range(V) for _ in range(F_)]
+    keys = dict(rcnn=[[torch.rand(2 + n_post, generator=g) for _ in range(F_)] for _ in range(3)])
+    watch = ['shared_head.layer4.0.conv1.weight', 'shared_head.layer4.2.conv3.weight', 'shared_head.new_layer_1.conv.weight',
+             'bbox_head.fc_new_1.bias', 'bbox_head.selsa_1.q_data_fc_1.weight', 'bbox_head.fc_new_3.weight',
+             'bbox_head.selsa_4.k_data_fc_4.weight', 'bbox_head.selsa_4.linear_out_4.weight', 'bbox_head.fc_cls.weight',
+             'bbox_head.fc_cls_2.weight', 'bbox_head.fc_reg_2.bias']
+    leaf = dict(sd)
+    for k in watch:
+        leaf[k] = sd[k].clone().requires_grad_(True)
+    tc = cfg.train_cfg
+    rcnn_o = dict(assigner=dict(tc.rcnn.assigner), sampler=dict(tc.rcnn.sampler), pos_weight=-1)
+    want, mid = O.hvr_forward_train(imgs, leaf, metas, gt_b, gt_l, keys, dict(tc.rpn_proposal), rcnn_o, n_sel)
+    sum(v for k, v in want.items() if 'loss' in k).backward()
+    assert 'loss_trip' in want and all(s_['pos_inds'].numel() > 0 and s_['neg_inds'].numel() > 0 for s_ in mid['samples'])
+
+    chosen = model.get_triplet_patches([O.shared_head(O.resnet_c4(imgs[v * F_:(v + 1) * F_], sd), sd).to(DEV) for v in range(V)],
+                                       0, F_, V - 3, 3)
+    assert chosen == mid['chosen'] and len(set(chosen)) == 3
+    dkeys = dict(rcnn=[[k_.to(DEV) for k_ in vk] for vk in keys['rcnn']])
+    got = model(imgs.to(DEV), metas, return_loss=True, gt_bboxes=[b.to(DEV) for b in gt_b], gt_labels=[l.to(DEV) for l in gt_l],
+                keys=dkeys)
+    sum(v for k, v in got.items() if 'loss' in k).backward()
+    assert set(got) == set(want)
+    for k in want:
+        close(got[k], want[k].detach(), 1e-3, 1e-5)
+    params = dict(model.named_parameters())
+    for k in watch:
+        w = leaf[k].grad
+        assert params[k].grad is not None, k
+        close(params[k].grad, w, 1e-2, 1e-2 * w.abs().max().item())
+    for k, p_ in params.items():
+        if k.startswith('backbone.') or k.startswith('rpn_head.'):
+            assert p_.grad is None or float(p_.grad.abs().sum()) == 0.0, k
+
+
 def test_bf16_training_step_tracks_the_f32_oracle(O):
     """Throughput mode of the training step: bf16 activations and operands, f32 master weights / accumulation / weight
     gradients.  Same fixed-RoI step as the f32 test above; operands carry 2^-9 relative rounding through ~110 layers, so

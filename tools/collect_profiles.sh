@@ -19,5 +19,6 @@ python tools/probe/blaslt_ref.py > $out/hipblaslt_calibration.txt 2>/dev/null
 # training step (SELSA, 1 key + 2 ref frames 600x1000, 300 proposals): throughput in both compute modes + kernel stats of the bf16 mode
 python tools/train_bench.py --steps 10 --warmup 2 > $out/train_bench.json 2>/dev/null
 python tools/train_bench.py --steps 5 --warmup 2 --dtype f32 > $out/train_bench_f32.json 2>/dev/null
+python tools/train_bench.py --steps 10 --warmup 2 --head hvr > $out/train_bench_hvr.json 2>/dev/null
 rm -rf /tmp/t_ks; rocprofv3 --kernel-trace --stats -d /tmp/t_ks -o train -- python tools/train_bench.py --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/rocpd_stats.py $(find /tmp/t_ks -name "*.db" | head -1) > $out/train_kernel_stats.txt

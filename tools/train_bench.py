@@ -19,7 +19,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hvrnet_amd  # noqa: E402
 from hvrnet_amd import synthetic as S  # noqa: E402
-from hvrnet_amd.config import selsa_train_config  # noqa: E402
+from hvrnet_amd.config import hvr_train_config, selsa_train_config  # noqa: E402
 from hvrnet_amd.dist_train import FlatParams, train_detector_iteration  # noqa: E402
 
 
@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--size', type=int, nargs=2, default=[600, 1000])
     ap.add_argument('--nms-post', type=int, default=300)
     ap.add_argument('--frames', type=int, default=3)
+    ap.add_argument('--head', choices=['selsa', 'hvr'], default='selsa', help='selsa: SelsaRCNN, 1 key + 2 ref frames; hvr: HNMBRCNN, '
+                    '5 videos x 3 frames in, 3 videos chosen (configs[4])')
     ap.add_argument('--detail', action='store_true', help='print the GEMM / conv calls of one iteration by shape (HIP-event times)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16', help='compute dtype (parameters, gradients and the update stay f32)')
     args = ap.parse_args()
@@ -38,19 +40,26 @@ def main():
     dev = 'cuda:%d' % local
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device(dev))
-    T = args.frames
     hw = tuple(args.size)
     pad = tuple((v + 15) // 16 * 16 for v in hw)
-    cfg = selsa_train_config(nms_post=args.nms_post, rcnn_sampler_num=128, t_dim=T)
-    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict('selsa'), torch.float32 if args.dtype == 'f32' else torch.bfloat16, dev))
-    flat = FlatParams(model)
-    imgs = torch.cat([S.synth_frame(1000 * rank + i, img_hw=hw, pad_hw=pad) for i in range(T)], 0).to(dev)
-    metas = [S.synth_meta(hw, pad) for _ in range(T)]
+    cdt = torch.float32 if args.dtype == 'f32' else torch.bfloat16
     sx, sy = hw[1] / 1000.0, hw[0] / 600.0
     gt_b = torch.tensor([[120., 80., 420., 330.], [296., 136., 359., 199.], [500., 100., 780., 300.], [820., 420., 865., 460.]])
     gt_b = (gt_b * torch.tensor([sx, sy, sx, sy])).to(dev)
     gt_l = torch.tensor([3, 17, 9, 22]).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    if args.head == 'selsa':
+        T = args.frames
+        cfg = selsa_train_config(nms_post=args.nms_post, rcnn_sampler_num=128, t_dim=T)
+        workload = '1 key + %d ref frames' % (T - 1)
+    else:
+        T = 15                                                  # 3 videos of the key class + 2 of other classes, 3 frames each
+        cfg = hvr_train_config(nms_post=args.nms_post, rcnn_sampler_num=128)
+        workload = '5 videos x 3 frames, 3 chosen'
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict(args.head), cdt, dev))
+    flat = FlatParams(model)
+    imgs = torch.cat([S.synth_frame(1000 * rank + i, img_hw=hw, pad_hw=pad) for i in range(T)], 0).to(dev)
+    metas = [S.synth_meta(hw, pad) for _ in range(T)]
     data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, generator=gen)
 
     def step():
@@ -83,7 +92,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
     if rank == 0:
-        print(json.dumps(dict(metric='SELSA training iterations/sec (1 key + %d ref frames %dx%d, %d proposals)' % (T - 1, hw[1], hw[0], args.nms_post),
+        print(json.dumps(dict(metric='%s training iterations/sec (%s, %dx%d, %d proposals)' % (args.head.upper(), workload, hw[1], hw[0], args.nms_post),
                               value=round(world * args.steps / dt, 3), unit='iterations/s', frames_per_s=round(world * args.steps * T / dt, 2),
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 2),
                               dtype=args.dtype, data='synthetic', params=int(flat.flat.numel()),

@@ -131,3 +131,35 @@ def mining_case(mq=96, mk=288, d=64, ncls=6, seed=207):
     labels[3] = ncls + 3              # a query class no key carries: its "same label" set is empty
     aff_scale = (q @ k.t()) * (1.0 / d ** 0.5)
     return labels, all_labels, aff_scale
+
+
+def eval_case(n_img=24, n_cls=5, seed=208):
+    """Per-class detection arrays + annotations for the mAP evaluation: detections are jittered copies of the ground truth
+    (some duplicated -> later claims of a covered box are false positives), background boxes, equal scores, images without
+    ground truth or without detections, a class without any ground truth, and ignore flags on a few boxes."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    dets, gtb, gtl, gti = [], [], [], []
+    for i in range(n_img):
+        k = 0 if i % 7 == 3 else rng.randint(1, 6)
+        xy = rng.rand(k, 2) * np.array([800.0, 450.0])
+        wh = rng.rand(k, 2) * 180 + 12
+        boxes = np.hstack([xy, xy + wh]).astype(np.float32)
+        labels = rng.randint(1, n_cls, size=k)          # class n_cls never occurs in the ground truth
+        gtb.append(boxes)
+        gtl.append(labels)
+        gti.append(rng.rand(k) < 0.15)
+        per_cls = []
+        for c in range(1, n_cls + 1):
+            mine = boxes[labels == c]
+            rows = []
+            for b in mine:
+                for _ in range(rng.randint(0, 3)):
+                    jit = (rng.rand(4) - 0.5) * (b[2] - b[0]) * rng.choice([0.1, 0.6])
+                    rows.append(np.append(b + jit, np.round(rng.rand(), 2)))       # two-decimal scores: ties occur
+            for _ in range(rng.randint(0, 3) if i % 5 else 0):
+                o = rng.rand(2) * np.array([800.0, 450.0])
+                rows.append(np.array([o[0], o[1], o[0] + 40, o[1] + 60, np.round(rng.rand(), 2)]))
+            per_cls.append(np.array(rows, dtype=np.float32).reshape(-1, 5))
+        dets.append(per_cls)
+    return dets, gtb, gtl, gti

@@ -422,5 +422,26 @@ def main():
     top2 = maff.topk(3, dim=1).values
     save('g13_mining', anchor_idx=a_idx, hardest_pos_idx=pos_idx, hardest_neg_idx=neg_idx, min_gap=(top2[:, 0] - top2[:, 1]).min())
 
+    # ---- G14 mAP evaluation through the reference's own eval_map (mean_ap.py:475-586; the tools/vid_eval.py path) ----
+    tt = _pkg('terminaltables')
+    tt.AsciiTable = type('AsciiTable', (), {'__init__': lambda self, *a, **k: None})
+    _pkg('mmdet.core.evaluation')
+    _load('mmdet.core.evaluation.bbox_overlaps', 'mmdet/core/evaluation/bbox_overlaps.py')
+    _load('mmdet.core.evaluation.class_names', 'mmdet/core/evaluation/class_names.py')
+    mean_ap_mod = _load('mmdet.core.evaluation.mean_ap', 'mmdet/core/evaluation/mean_ap.py')
+    dets14, gtb14, gtl14, gti14 = C.eval_case()
+    names14 = tuple('c%d' % i for i in range(len(dets14[0])))
+    out14 = {}
+    for tag, kw in (('plain', dict()), ('ignore', dict(gt_ignore=gti14)), ('thr75', dict(iou_thr=0.75)),
+                    ('scales', dict(gt_ignore=gti14, scale_ranges=[(0, 64), (64, 128), (128, 1e5)]))):
+        m, res = mean_ap_mod.eval_map(dets14, gtb14, gtl14, dataset=names14, print_summary=False, **kw)
+        out14[tag + '_map'] = np.asarray(m, dtype=np.float64)
+        out14[tag + '_ap'] = np.stack([np.atleast_1d(r['ap']) for r in res])
+        out14[tag + '_num_gts'] = np.stack([np.atleast_1d(r['num_gts']) for r in res])
+        out14[tag + '_num_dets'] = np.asarray([r['num_dets'] for r in res])
+        out14[tag + '_recall_c0'] = np.asarray(res[0]['recall'])
+        out14[tag + '_precision_c0'] = np.asarray(res[0]['precision'])
+    save('g14_eval_map', **out14)
+
 if __name__ == '__main__':
     main()

@@ -39,6 +39,7 @@ hipError_t run_rpn_loss(const float*, int, int, int, const long long*, const flo
 hipError_t run_ce_rows(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 hipError_t run_triplet_margin(const void*, long, const void*, long, int, int, int, const long long*, const long long*, const long long*, int,
                               float, int, float*, float*, float*, float*, hipStream_t);
+hipError_t run_ingest(const uint8_t*, int, int, long, float*, int, int, int, int, const float*, const float*, int, hipStream_t);
 hipError_t run_mining_argreduce(const float*, int, int, long, const long long*, const long long*, long long*, hipStream_t);
 hipError_t run_relation_dscore(const void*, const void*, const void*, const void*, void*, int, long, int, long, long, float, int, hipStream_t);
 hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -457,6 +458,17 @@ int hvr_triplet_margin(const void* q, int64_t ldq, const void* k, int64_t ldk, i
   return check_launch(run_triplet_margin(q, ldq, k, ldk, D, Mq, Mk, (const long long*)anchor_idx, (const long long*)pos_idx,
                                          (const long long*)neg_idx, n, margin, dtype == HVR_BF16, ws, out2, dq, dk, (hipStream_t)stream),
                       "hvr_triplet_margin");
+}
+
+int hvr_ingest_frame(const uint8_t* src, int src_h, int src_w, int64_t src_pitch, float* dst, int new_h, int new_w, int pad_h, int pad_w,
+                     const float* mean3, const float* std3, int to_rgb, void* stream) {
+  if (!src || !dst || !mean3 || !std3) return fail(HVR_EINVAL, "null pointer");
+  if (src_h <= 0 || src_w <= 0 || new_h <= 0 || new_w <= 0 || pad_h < new_h || pad_w < new_w || src_pitch < 3L * src_w)
+    return fail(HVR_EINVAL, "bad ingest shape");
+  for (int c = 0; c < 3; ++c)
+    if (std3[c] == 0.f) return fail(HVR_EINVAL, "std must be non-zero");
+  return check_launch(run_ingest(src, src_h, src_w, src_pitch, dst, new_h, new_w, pad_h, pad_w, mean3, std3, to_rgb, (hipStream_t)stream),
+                      "hvr_ingest_frame");
 }
 
 int hvr_ce_rows(const float* logits, int ldl, int cls_off, int ncls, const int64_t* labels, int R, float* loss, void* stream) {

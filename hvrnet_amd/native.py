@@ -98,6 +98,7 @@ SYMBOLS = {
     'hvr_rpn_loss': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     'hvr_ce_rows': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     'hvr_triplet_margin': (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'hvr_ingest_frame': (_i, [_vp, _i, _i, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'hvr_mining_argreduce': (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
@@ -577,6 +578,18 @@ def triplet_margin(q, k, anchor_idx, pos_idx, neg_idx, margin, need_grad=True):
                                     _ptr(pos_idx.contiguous()), _ptr(neg_idx.contiguous()), n, float(margin), _dt(q), _ptr(ws), n * 12,
                                     _ptr(out2), _ptr(dq), _ptr(dk), _stream()), 'hvr_triplet_margin')
     return out2, dq, dk
+
+
+def ingest_frame(frame, new_hw, pad_hw, mean, std, to_rgb=False):
+    """frame uint8 [H, W, 3] (cuda, rows contiguous) -> f32 [1, 3, pad_h, pad_w]: resize + normalise + pad in one kernel."""
+    _need_cuda(frame)
+    assert frame.dtype == torch.uint8 and frame.dim() == 3 and frame.shape[2] == 3 and frame.stride(2) == 1 and frame.stride(1) == 3
+    out = torch.empty((1, 3, int(pad_hw[0]), int(pad_hw[1])), dtype=torch.float32, device=frame.device)
+    m3, s3 = (ctypes.c_float * 3)(*[float(v) for v in mean]), (ctypes.c_float * 3)(*[float(v) for v in std])
+    _check(lib().hvr_ingest_frame(_ptr(frame), frame.shape[0], frame.shape[1], frame.stride(0), _ptr(out), int(new_hw[0]), int(new_hw[1]),
+                                  int(pad_hw[0]), int(pad_hw[1]), ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p),
+                                  int(bool(to_rgb)), _stream()), 'hvr_ingest_frame')
+    return out
 
 
 def mining_argreduce(aff, labels, all_labels):

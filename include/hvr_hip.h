@@ -286,6 +286,13 @@ int hvr_det_loss_sampled(const float* logits, int ldl, int cls_off, int reg_off,
                          const float* label_weights, const float* bbox_targets, const float* bbox_weights, int R,
                          const int32_t* sel_counts, float beta, float* out3, float* dlogits, void* stream);
 
+/* Frame ingest: decoded BGR uint8 frame src [src_h][src_pitch bytes] (3 bytes per pixel) -> dst f32 [3][pad_h][pad_w]:
+ * bilinear resize to new_w x new_h (OpenCV's 8-bit INTER_LINEAR fixed-point arithmetic, which mmcv.imrescale calls), optional
+ * BGR->RGB, (x - mean) / std, zero padding -- the reference's Resize -> Normalize -> Pad -> ImageToTensor
+ * (mmdet/datasets/pipelines/transforms.py:111-124,260-269,308-313) in one kernel instead of three CPU passes per frame. */
+int hvr_ingest_frame(const uint8_t* src, int src_h, int src_w, int64_t src_pitch, float* dst, int new_h, int new_w, int pad_h, int pad_w,
+                     const float* mean3, const float* std3, int to_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,6 +259,35 @@ def test_g13_hard_proposal_mining(O):
     assert bg2.shape == (labels.numel(), 2) and bool((all_labels[bg2[labels == 0]] != 0).all())
 
 
+def test_ingest_oracle_closed_form_cases(O):
+    """OpenCV is not in the image, so the resize restatement is pinned by cases with known answers: identity, an exact 2x
+    reduction (every output = the rounded mean of a 2x2 block), constants under any scale, border replication when
+    upscaling, and the pipeline's shapes / meta for the three VID frame sizes."""
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    assert np.array_equal(O.cv2_resize_linear_u8(img, (37, 53)), img)
+    even = rng.randint(0, 256, (40, 64, 3)).astype(np.uint8)
+    half = O.cv2_resize_linear_u8(even, (20, 32))
+    blocks = even.reshape(20, 2, 32, 2, 3).astype(np.int64)
+    s = blocks.sum(axis=(1, 3))
+    assert np.abs(half.astype(np.int64) * 4 - s).max() <= 2 and np.array_equal(half, ((s + 2) >> 2).astype(np.uint8))
+    const = np.full((23, 31, 3), 137, dtype=np.uint8)
+    for hw in ((46, 62), (11, 17), (23, 100)):
+        assert (O.cv2_resize_linear_u8(const, hw) == 137).all()
+    up = O.cv2_resize_linear_u8(img, (74, 106))
+    assert np.array_equal(up[0, 0], img[0, 0]) and np.array_equal(up[-1, -1], img[-1, -1])     # (0.5 * 0.5 - 0.5 < 0: clamped tap)
+    assert up.min() >= img.min() and up.max() <= img.max()
+    for (h, w), want in (((720, 1280), (563, 1000, 576, 1008)), ((360, 480), (600, 800, 608, 800)), ((600, 1000), (600, 1000, 608, 1008))):
+        out, meta = O.ingest_frame(rng.randint(0, 256, (h, w, 3)).astype(np.uint8))
+        assert meta['img_shape'][:2] == want[:2] and meta['pad_shape'][:2] == want[2:] and tuple(out.shape) == (1, 3) + want[2:]
+        assert float(out[0, :, want[0]:, :].abs().sum()) == 0 and float(out[0, :, :, want[1]:].abs().sum()) == 0
+    frame = rng.randint(0, 256, (600, 1000, 3)).astype(np.uint8)
+    out, meta = O.ingest_frame(frame)
+    assert meta['scale_factor'] == 1.0
+    want = frame.astype(np.float32) - np.array([103.06, 115.90, 123.15], dtype=np.float32)
+    assert np.array_equal(out[0, :, :600, :1000].numpy(), want.transpose(2, 0, 1))
+
+
 def test_g8_det_readout(O):
     g = gold('g8_det')
     rois, cls, reg = C.det_case()

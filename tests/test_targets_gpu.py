@@ -309,3 +309,21 @@ def test_triplet_margin_standin_matches_its_oracle(O, dtype, margin):
     close(qg.grad, qd.grad, tol * 10, tol * scale)
     close(kg.grad, kd.grad, tol * 10, tol * scale)
     assert qg.grad.dtype == dtype
+
+
+@pytest.mark.parametrize('hw', [(720, 1280), (360, 480), (600, 1000), (1080, 1920), (37, 53), (480, 270)])
+@pytest.mark.parametrize('to_rgb', [False, True])
+def test_frame_ingest_matches_the_oracle_bit_for_bit(O, hw, to_rgb):
+    """hvr_ingest_frame (resize + normalise + pad in one kernel) against the oracle's restatement of the reference's test
+    pipeline: integer resize arithmetic and an exact f32 subtraction -> identical bits; img_meta identical too."""
+    from hvrnet_amd.pipelines import FrameIngest
+    rng = np.random.RandomState(hw[0])
+    frame = rng.randint(0, 256, hw + (3,)).astype(np.uint8)
+    std = (1.0, 1.0, 1.0) if not to_rgb else (58.395, 57.12, 57.375)
+    want, meta = O.ingest_frame(frame, to_rgb=to_rgb, std=std)
+    got = FrameIngest(to_rgb=to_rgb, std=std, device=DEV)(frame)
+    assert torch.equal(got['img'].cpu(), want)
+    for k in ('ori_shape', 'img_shape', 'pad_shape', 'scale_factor', 'flip'):
+        assert got['img_meta'][k] == meta[k], k
+    again = FrameIngest(to_rgb=to_rgb, std=std, device=DEV)(torch.from_numpy(frame).to(DEV))    # frame already on the device
+    assert torch.equal(again['img'], got['img'])

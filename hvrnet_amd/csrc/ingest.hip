@@ -4,7 +4,7 @@
 // workers through mmcv / OpenCV (neither is part of the reference tree).  The resize restates OpenCV's published
 // INTER_LINEAR algorithm for 8-bit images (modules/imgproc/src/resize.cpp: coordinates (d + 0.5) * scale - 0.5 computed in
 // double and narrowed to float, 11-bit fixed-point coefficients, horizontal pass in int, vertical pass
-// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2): integer arithmetic, so the oracle and this kernel agree bit
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2): integer arithmetic, so the CPU checker and this kernel agree bit
 // for bit; against a real OpenCV build the parity is unpinned (no cv2 in the image).
 // HBM traffic: 3 source bytes per source pixel touched + 12 output bytes per padded pixel; every output pixel is independent.
 #include <hip/hip_runtime.h>

@@ -22,3 +22,4 @@ python tools/train_bench.py --steps 5 --warmup 2 --dtype f32 > $out/train_bench_
 python tools/train_bench.py --steps 10 --warmup 2 --head hvr > $out/train_bench_hvr.json 2>/dev/null
 rm -rf /tmp/t_ks; rocprofv3 --kernel-trace --stats -d /tmp/t_ks -o train -- python tools/train_bench.py --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/rocpd_stats.py $(find /tmp/t_ks -name "*.db" | head -1) > $out/train_kernel_stats.txt
+python tools/ingest_bench.py > $out/ingest_bench.json 2>/dev/null

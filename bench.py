@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--proposals', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train-step', action='store_true', help='skip the training-step side measurement (tools/train_bench.py)')
     ap.add_argument('--inflight', type=int, default=int(os.environ.get('HVR_INFLIGHT', '1')),
                     help='independent windows enqueued on that many HIP streams in turn (throughput mode)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
@@ -107,6 +108,23 @@ def cpu_baseline(head, T, n_prop, sd):
                 sample='%d of %d frames through backbone+res5+RPN+proposals+RoIAlign (%.2f s, scaled x%.1f) + full relation head '
                        'M=%d and read-out (%.2f s); torch %d threads' % (ns, T, t_frames, T / float(ns), M, t_head, cores),
                 window_seconds=window_s)
+
+
+def train_step_side_measurement(head):
+    """configs[4] beside the headline, never as `value`: one training iteration of the same detector family (HNMBRCNN: 5 videos x 3
+    frames in, 3 chosen; SelsaRCNN: 1 key + 2 reference frames) at 600x1000 / 300 proposals, bf16 operands with f32 master weights,
+    measured by tools/train_bench.py in its own process after the timed region.  None if that run fails."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_bench.py'), '--head', head, '--steps', '5', '--warmup', '2'],
+                           capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+        d = json.loads(line)
+        return dict(iterations_per_s=d['value'], ms_per_iteration=d['ms_per_step'], input_frames_per_s=d['frames_per_s'], dtype=d['dtype'],
+                    trainable_params=d['params'], what=d['metric'])
+    except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the headline down
+        sys.stderr.write('train_step side measurement skipped: %r\n' % (exc,))
+        return None
 
 
 def main():
@@ -300,6 +318,10 @@ def main():
                                         what='clip mode, two independent windows in flight on two HIP streams (--inflight 2)')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.head, T, n_prop, sd)
+        if world == 1 and not args.no_train_step:
+            ts = train_step_side_measurement(args.head)
+            if ts is not None:
+                out['train_step'] = ts
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

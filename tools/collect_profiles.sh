@@ -4,11 +4,11 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; mkdir -p $out
 python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
-rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_prof.json 2>/dev/null
+rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step > $out/bench_prof.json 2>/dev/null
 python tools/rocpd_stats.py $(find /tmp/p_ks -name "*.db" | head -1) > $out/bench_kernel_stats.txt
 python tools/rocpd_phases.py $(find /tmp/p_ks -name "*.db" | head -1) 4 > $out/bench_window_phases.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/p_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rm -rf /tmp/p_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/p_$c -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1
   python tools/rocpd_pmc.py $(find /tmp/p_$c -name "*.db" | head -1) $c > $out/pmc_$(echo $c | tr A-Z a-z).txt
   rm -rf /tmp/r_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/r_$c -o rel -- python tools/rel_bench.py --iters 5 > /dev/null 2>&1
   python tools/rocpd_pmc.py $(find /tmp/r_$c -name "*.db" | head -1) $c > $out/rel_pmc_$(echo $c | tr A-Z a-z).txt

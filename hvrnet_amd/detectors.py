@@ -509,39 +509,49 @@ class HNMBRCNN(_WindowDetector):
         rcnn_cfg = self.train_cfg.rcnn
         if isinstance(rcnn_cfg.sampler, (list, tuple)):
             raise NotImplementedError('the HVR config trains with a single RandomSampler (the head asserts post_sampler is None, :635)')
+        # Frames are independent through the backbone, res5 and the RPN, so where the reference loops over videos of three
+        # frames (:57-65, :305-336) the whole batch goes through each of them once: same numbers, 5x / 3x the rows per launch.
         with torch.no_grad():                                   # extract_c4_c5_feat (:54-72)
-            c4_all = [self.extract_feat(img[v * F_:(v + 1) * F_])[0] for v in range(V)]
-            c5_all = [self.shared_head(c4) for c4 in c4_all]
-        chosen = self.get_triplet_patches(c5_all, 0, F_, V - self.VIDEO_PER_CLS, self.VIDEO_PER_CLS)
-        del c5_all
+            c4 = self.extract_feat(img)[0]                      # [V * F, 1024, h, w] logical, NHWC in memory
+            c5_sel = self.shared_head(c4)
+        chosen = self.get_triplet_patches([c5_sel[v * F_:(v + 1) * F_] for v in range(V)], 0, F_, V - self.VIDEO_PER_CLS,
+                                          self.VIDEO_PER_CLS)
+        del c5_sel
         bbox_assigner = T.build_assigner(rcnn_cfg.assigner)
         bbox_sampler = T.build_sampler(rcnn_cfg.sampler, context=self)
         proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
         layer = self.bbox_roi_extractor.roi_layers[0]
-        feats, cur_ranges, key_results, key_gtb, key_gtl = [], [], [], [], []
+        c4k = torch.cat([c4.permute(0, 2, 3, 1)[v * F_:(v + 1) * F_] for v in chosen], 0)          # the chosen videos' frames
+        metas_k = [m for v in chosen for m in img_meta[v * F_:(v + 1) * F_]]
+        with torch.no_grad():
+            rpn_outs = self.rpn_head([c4k.permute(0, 3, 1, 2)])
+            if len({tuple(m['img_shape'][:2]) for m in metas_k}) == 1:
+                proposal_list = self.rpn_head.get_bboxes(*(rpn_outs + (metas_k, proposal_cfg)))
+            else:   # videos of different resolutions in one batch: the proposal pipeline clips per video
+                proposal_list = []
+                for vi in range(len(chosen)):
+                    sl = slice(vi * F_, (vi + 1) * F_)
+                    proposal_list += self.rpn_head.get_bboxes([rpn_outs[0][0][sl]], [rpn_outs[1][0][sl]], metas_k[sl], proposal_cfg)
+        rois, cur_ranges, key_results, key_gtb, key_gtl, rows = [], [], [], [], [], []
         for vi, v in enumerate(chosen):
-            c4 = c4_all[v]
-            metas = img_meta[v * F_:(v + 1) * F_]
             gt_b, gt_l = gt_bboxes[v * F_ + self.key_dim], gt_labels[v * F_ + self.key_dim]
-            with torch.no_grad():
-                rpn_outs = self.rpn_head([c4])
-                proposal_list = self.rpn_head.get_bboxes(*(rpn_outs + (metas, proposal_cfg)))
             results = []
             for i in range(F_):
-                props = proposal_list[i].contiguous()
+                props = proposal_list[vi * F_ + i].contiguous()
                 assign_result = bbox_assigner.assign(props, gt_b, None, gt_l)
                 k_i = None
                 if keys is not None and 'rcnn' in keys:
                     k_i = keys['rcnn'][vi][i][:gt_b.shape[0] * int(bbox_sampler.add_gt_as_proposals) + props.shape[0]]
                 results.append(bbox_sampler.sample(assign_result, props, gt_b, gt_l, keys=k_i, generator=generator))
-            rois = torch.cat([torch.cat([r.bboxes.new_full((r.bboxes.shape[0], 1), float(i)), r.bboxes], 1)
-                              for i, r in enumerate(results)], 0)
-            c5 = self.shared_head.forward_train_nhwc(c4.permute(0, 2, 3, 1))          # res5 with a graph; C4 is a constant
-            feats.append(ops.roi_align(c5.permute(0, 3, 1, 2), rois, layer.out_size, layer.spatial_scale, layer.sample_num))
+            rois += [torch.cat([r.bboxes.new_full((r.bboxes.shape[0], 1), float(vi * F_ + i)), r.bboxes], 1) for i, r in enumerate(results)]
+            rows.append(sum(r.bboxes.shape[0] for r in results))
             cur_ranges.append(dict(start=self.key_dim, length=results[self.key_dim].bboxes.shape[0]))
             key_results.append(results[self.key_dim])
             key_gtb.append(gt_b)
             key_gtl.append(gt_l)
+        c5 = self.shared_head.forward_train_nhwc(c4k)                                   # res5 with a graph; C4 is a constant
+        all_feats = ops.roi_align(c5.permute(0, 3, 1, 2), torch.cat(rois, 0), layer.out_size, layer.spatial_scale, layer.sample_num)
+        feats = list(torch.split(all_feats, rows, dim=0))
         targets = T.bbox_target(key_results, key_gtb, key_gtl, rcnn_cfg, target_means=self.bbox_head.target_means,
                                 target_stds=self.bbox_head.target_stds)
         logits, losses = self.bbox_head.forward_train(feats, cur_ranges, targets[0], key_dim=self.key_dim)

@@ -25,7 +25,7 @@ hipError_t run_colsum(const void*, float*, int, int, long, int, float*, hipStrea
 int colsum_slices(int M, int N);
 size_t sgd_workspace_bytes();
 hipError_t run_pack_conv_weight(const float*, const float*, void*, int, int, int, int, hipStream_t);
-hipError_t run_unpack_conv_wgrad(const float*, const float*, float*, int, int, int, hipStream_t);
+hipError_t run_unpack_conv_wgrad(const float*, const float*, float*, int, int, int, int, hipStream_t);
 hipError_t run_det_loss(const float*, int, int, int, int, const long long*, const float*, const float*, const float*, int, float, float,
                         float, float*, float*, const int*, hipStream_t);
 size_t assign_workspace_bytes(int n, int k);
@@ -364,9 +364,9 @@ int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout
   return check_launch(run_pack_conv_weight(w, scale, out, Cout, Cin, KH * KW, out_dtype, (hipStream_t)stream), "hvr_pack_conv_weight");
 }
 
-int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, void* stream) {
+int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, int accumulate, void* stream) {
   if (!dw || !scale || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return fail(HVR_EINVAL, "bad unpack_conv_wgrad arguments");
-  return check_launch(run_unpack_conv_wgrad(dw, scale, out, Cout, Cin, KH * KW, (hipStream_t)stream), "hvr_unpack_conv_wgrad");
+  return check_launch(run_unpack_conv_wgrad(dw, scale, out, Cout, Cin, KH * KW, accumulate, (hipStream_t)stream), "hvr_unpack_conv_wgrad");
 }
 
 int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const int64_t* labels, const float* label_weights,

@@ -423,13 +423,14 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
 
 // the way back for the gradient: dW_eff [Cout][KH*KW][Cin] (f32) * s[Cout] -> [Cout][Cin][KH][KW]
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ dw, const float* __restrict__ s, float* __restrict__ out, int Cout,
-                                         int Cin, int KK) {
+                                         int Cin, int KK, int accumulate) {
   const long total = (long)Cout * KK * Cin;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int t = (int)(idx % KK);
     const long r = idx / KK;
     const int c = (int)(r % Cin), o = (int)(r / Cin);
-    out[idx] = dw[((long)o * KK + t) * Cin + c] * s[o];
+    const float v = dw[((long)o * KK + t) * Cin + c] * s[o];
+    out[idx] = accumulate ? out[idx] + v : v;   // accumulate: straight into the parameter's .grad (weight gradients computed off the main stream)
   }
 }
 
@@ -442,9 +443,9 @@ hipError_t run_pack_conv_weight(const float* w, const float* sc, void* out, int 
   return hipGetLastError();
 }
 
-hipError_t run_unpack_conv_wgrad(const float* dw, const float* sc, float* out, int Cout, int Cin, int KK, hipStream_t s) {
+hipError_t run_unpack_conv_wgrad(const float* dw, const float* sc, float* out, int Cout, int Cin, int KK, int accumulate, hipStream_t s) {
   const long total = (long)Cout * Cin * KK;
-  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, dw, sc, out, Cout, Cin, KK);
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, dw, sc, out, Cout, Cin, KK, accumulate);
   return hipGetLastError();
 }
 

@@ -54,12 +54,21 @@ class FlatParams(object):
         self.steps += 1
 
 
-def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0):
+def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False):
     """One iteration in the reference's order (dist_utils.py:52-58): zero_grad, backward, all-reduce, clip, step.
-    loss_fn() builds the graph and returns the scalar to differentiate."""
+    loss_fn() builds the graph and returns the scalar to differentiate.  overlap_wgrad: conv weight gradients run on a
+    second HIP stream and land directly in the flat gradient buffer (train_ops.wgrad_overlap); joined before the exchange.
+    Off by default: at three frames per iteration the step is bound by the host's enqueue rate, and the extra events / stream
+    switches cost more than the overlap returns (22.1 vs 20.5 ms measured); it pays once the per-rank batch grows."""
+    from . import train_ops
     flat.zero_grad()
     loss = loss_fn()
-    loss.backward()
+    prev = train_ops.wgrad_overlap(overlap_wgrad)
+    try:
+        loss.backward()
+    finally:
+        train_ops.wgrad_overlap(prev)
+        train_ops.join_wgrad()
     world = flat.allreduce_grads()
     flat.sgd_step(lr, momentum, weight_decay, max_norm, world)
     return loss
@@ -81,7 +90,7 @@ def parse_losses(losses):
     return loss, {k: v.detach() for k, v in log_vars.items()}
 
 
-def train_detector_iteration(model, flat, data, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0):
+def train_detector_iteration(model, flat, data, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False):
     """batch_processor + the optimizer hook (mmdet/apis/train.py:37-54, mmdet/core/utils/dist_utils.py:52-58) for one rank's
     batch: model(**data) -> parse_losses -> backward -> one flat all-reduce over RCCL -> fused clip + SGD.  -> log_vars."""
     box = {}
@@ -90,5 +99,5 @@ def train_detector_iteration(model, flat, data, lr, momentum=0.9, weight_decay=1
         loss, box['log'] = parse_losses(model(**data))
         return loss
 
-    train_iteration(flat, loss_fn, lr, momentum, weight_decay, max_norm)
+    train_iteration(flat, loss_fn, lr, momentum, weight_decay, max_norm, overlap_wgrad)
     return box['log']

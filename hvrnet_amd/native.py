@@ -88,7 +88,7 @@ SYMBOLS = {
     'hvr_colsum_workspace_bytes': (_sz, [_i, _i]),
     'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
     'hvr_pack_conv_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'hvr_unpack_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'hvr_unpack_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_det_loss_sampled': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     'hvr_max_iou_assign_workspace_bytes': (_sz, [_i, _i]),
@@ -149,8 +149,15 @@ def _check(rc, what):
         raise HvrError('%s failed (%d): %s' % (what, rc, lib().hvr_last_error().decode()))
 
 
+def _raw_stream(device=None):
+    """hipStream_t of torch's current stream as an int.  torch.cuda.current_stream() builds a Stream object (and re-checks
+    availability) on every call, ~3-9 us; a training iteration asks ~1 700 times, so go to the raw getter."""
+    idx = torch._C._cuda_getDevice() if device is None or device.index is None else device.index
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _dt(t):
@@ -343,7 +350,7 @@ _ws_cache = {}
 
 def _workspace(nbytes, device, tag):
     # one buffer per (use, stream): windows enqueued on different HIP streams run concurrently and must not share scratch
-    key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (tag, device.index if isinstance(device, torch.device) else str(device), _raw_stream(device if isinstance(device, torch.device) else None))
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -459,13 +466,19 @@ def pack_conv_weight(w, scale, dtype):
     return out
 
 
-def unpack_conv_wgrad(dw, scale, shape):
-    """dW_eff [Cout, KH*KW*Cin] f32 * scale[Cout] -> [Cout,Cin,KH,KW] f32 (the nn.Conv2d parameter's layout)."""
+def unpack_conv_wgrad(dw, scale, shape, accumulate_into=None):
+    """dW_eff [Cout, KH*KW*Cin] f32 * scale[Cout] -> [Cout,Cin,KH,KW] f32 (the nn.Conv2d parameter's layout); with
+    `accumulate_into` (a contiguous f32 tensor of that shape, e.g. the parameter's .grad) the result is added to it in place."""
     _need_cuda(dw, scale)
     Cout, Cin, KH, KW = shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == Cout * Cin * KH * KW
-    out = torch.empty(shape, dtype=torch.float32, device=dw.device)
-    _check(lib().hvr_unpack_conv_wgrad(_ptr(dw), _ptr(scale), _ptr(out), Cout, Cin, KH, KW, _stream()), 'hvr_unpack_conv_wgrad')
+    if accumulate_into is not None:
+        out = accumulate_into
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(shape)
+    else:
+        out = torch.empty(shape, dtype=torch.float32, device=dw.device)
+    _check(lib().hvr_unpack_conv_wgrad(_ptr(dw), _ptr(scale), _ptr(out), Cout, Cin, KH, KW, int(accumulate_into is not None), _stream()),
+           'hvr_unpack_conv_wgrad')
     return out
 
 

@@ -22,6 +22,34 @@ from torch.autograd.function import once_differentiable
 from . import native
 
 
+# ---- weight gradients off the critical path --------------------------------------------------------------------------
+# In a backward pass only the data gradients form a chain; a conv's weight gradient (two transposes, a split-K GEMM, the
+# unpack) is a leaf that nothing waits for until the all-reduce.  With `wgrad_overlap(True)` ConvFunction.backward enqueues
+# that leaf on a second HIP stream and adds the result straight into the parameter's .grad (which FlatParams pre-allocates
+# as a view of the flat gradient buffer), returning None to autograd for it; the main stream goes on with the previous
+# layer's data gradient, whose kernels are small enough (57 row tiles for 256 CUs at three frames) to leave room.
+# `join_wgrad()` makes the main stream wait for the side stream: call it before the gradients are read (dist_train does).
+_overlap = dict(on=False, streams={})
+
+
+def wgrad_overlap(flag):
+    prev = _overlap['on']
+    _overlap['on'] = bool(flag)
+    return prev
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _overlap['streams']:
+        _overlap['streams'][key] = torch.cuda.Stream(device=device)
+    return _overlap['streams'][key]
+
+
+def join_wgrad():
+    for st in _overlap['streams'].values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
 def _pad_cols(t, n):
     """[M, N] -> [M, n] with zero columns appended (K-step padding of a GEMM operand)."""
     if t.shape[1] == n and t.is_contiguous():
@@ -213,6 +241,7 @@ class ConvFunction(Function):
         y = native.conv2d_nhwc(xs, w_eff, t, resid.contiguous() if resid is not None else None, relu=bool(relu), pad=pad, dil=dil,
                                out_f32=bool(out_f32))
         ctx.cfg = (bool(relu), int(stride), int(pad), int(dil), resid is not None, tuple(x.shape))
+        ctx.w_param = w if (w.is_leaf and w.requires_grad) else None       # where an off-stream weight gradient may land
         ctx.save_for_backward(xs, w_eff, s, y if relu else None)
         return y
 
@@ -243,9 +272,23 @@ class ConvFunction(Function):
             else:
                 dx = dxs
         if ctx.needs_input_grad[1]:
-            cols = xs.view(P, Cin) if (KH, KW) == (1, 1) else native.im2col_nhwc(xs, KH, KW, pad, dil)   # [P, KH*KW*Cin]
-            dw_eff = native.gemm_splitk(native.transpose_pad(dz2, ldp), native.transpose_pad(cols, ldp))   # [Cout, KH*KW*Cin], f32
-            dw = native.unpack_conv_wgrad(dw_eff, s, (Cout, Cin, KH, KW))                # * s, back in the parameter's layout
+            def weight_gradient(into=None):
+                cols = xs.view(P, Cin) if (KH, KW) == (1, 1) else native.im2col_nhwc(xs, KH, KW, pad, dil)   # [P, KH*KW*Cin]
+                dw_eff = native.gemm_splitk(native.transpose_pad(dz2, ldp), native.transpose_pad(cols, ldp))   # [Cout, KH*KW*Cin], f32
+                return native.unpack_conv_wgrad(dw_eff, s, (Cout, Cin, KH, KW), accumulate_into=into)   # * s, parameter layout
+
+            wp = ctx.w_param
+            if _overlap['on'] and wp is not None and wp.grad is not None and wp.grad.is_contiguous() and wp.grad.dtype == torch.float32:
+                main, side = torch.cuda.current_stream(dz.device), _side_stream(dz.device)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    weight_gradient(into=wp.grad)
+                for t_ in (dz, xs, s):
+                    t_.record_stream(side)
+            else:
+                dw = weight_gradient()
         dt = native.colsum(dz2) if ctx.needs_input_grad[3] else None   # a trainable bias passed as the shift (RPN / 1x1 heads)
         dr = dz if (has_resid and ctx.needs_input_grad[4]) else None
         return dx, dw, None, dt, dr, None, None, None, None, None

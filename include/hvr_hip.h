@@ -144,9 +144,9 @@ int hvr_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int
 int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t C, int dtype, void* stream);
 /* The two layout + scale passes of a trainable conv in one kernel each: the f32 master weight [Cout][Cin][KH][KW] times the
  * frozen BatchNorm scale, permuted to the conv kernel's [Cout][KH][KW][Cin] and rounded to the compute dtype; and the way back
- * for the f32 weight gradient. */
+ * for the f32 weight gradient (accumulate != 0: added to `out`, i.e. written straight into the parameter's gradient buffer). */
 int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout, int Cin, int KH, int KW, int out_dtype, void* stream);
-int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, void* stream);
+int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, int accumulate, void* stream);
 
 /* Optimizer step on a flat f32 buffer (the training configs: SGD lr 5e-4, momentum 0.9, weight decay 1e-4, gradient
  * clipping max_norm 35, configs/faster_rcnn_r101_selsa_c5.py:215-222; torch.optim.SGD semantics, dampening 0).  The two

@@ -840,6 +840,43 @@ def test_selsa_rcnn_forward_train_matches_the_oracle(O, ohem):
 
 
 
+def test_off_stream_weight_gradients_equal_the_autograd_order():
+    """train_ops.wgrad_overlap: conv weight gradients enqueued on a second HIP stream and added straight into the flat
+    gradient buffer must give the buffer autograd's own accumulation gives (same kernels, same order per parameter; the only
+    run-to-run noise in either mode is RoIAlign backward's atomic adds, hence a 1e-5 relative bar instead of bit equality)."""
+    from hvrnet_amd import train_ops as TO
+    from hvrnet_amd.config import selsa_train_config
+    from hvrnet_amd.dist_train import FlatParams, parse_losses
+    cfg = selsa_train_config(nms_post=24, rcnn_sampler_num=16, t_dim=3)
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict('selsa'), torch.float32, DEV))
+    g = torch.Generator().manual_seed(95)
+    hw = (128, 192)
+    imgs = (torch.randn((3, 3) + hw, generator=g) * 50.0).to(DEV)
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(3)]
+    gt_b, gt_l = torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]).to(DEV), torch.tensor([5, 12]).to(DEV)
+    keys = dict(rpn=torch.rand(8 * 12 * 12, generator=g).to(DEV), rcnn=[torch.rand(2 + 24, generator=g).to(DEV) for _ in range(3)])
+    data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * 3, gt_labels=[gt_l] * 3, keys=keys)
+    flat = FlatParams(model)
+    grads = []
+    for overlap in (False, True, True):
+        flat.zero_grad()
+        loss, _ = parse_losses(model(**data))
+        prev = TO.wgrad_overlap(overlap)
+        loss.backward()
+        TO.wgrad_overlap(prev)
+        TO.join_wgrad()
+        torch.cuda.synchronize()
+        grads.append(flat.grad.clone())
+    scale = float(grads[0].abs().max())
+    assert scale > 0
+    for other in grads[1:]:
+        assert float((other - grads[0]).abs().max()) <= 1e-5 * scale
+    # every trainable conv weight really got its gradient through the side stream (none was dropped)
+    for name, p_ in model.named_parameters():
+        if p_.requires_grad and p_.dim() == 4:
+            assert float(p_.grad.abs().sum()) > 0, name
+
+
 def test_full_detector_training_iterations_descend():
     """dist_train.train_detector_iteration on the whole SelsaRCNN (the reference's batch_processor + optimizer hook): with the
     sampler keys held fixed, three SGD iterations lower the summed loss, every trainable parameter moves, frozen ones

@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--head', choices=['selsa', 'hvr'], default='selsa', help='selsa: SelsaRCNN, 1 key + 2 ref frames; hvr: HNMBRCNN, '
                     '5 videos x 3 frames in, 3 videos chosen (configs[4])')
+    ap.add_argument('--overlap', action='store_true', help='conv weight gradients on a second HIP stream (train_ops.wgrad_overlap)')
+    ap.add_argument('--cprofile', action='store_true', help='host-side cProfile of 5 iterations (stderr)')
     ap.add_argument('--detail', action='store_true', help='print the GEMM / conv calls of one iteration by shape (HIP-event times)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16', help='compute dtype (parameters, gradients and the update stay f32)')
     args = ap.parse_args()
@@ -63,7 +65,7 @@ def main():
     data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, generator=gen)
 
     def step():
-        return train_detector_iteration(model, flat, data, lr=1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+        return train_detector_iteration(model, flat, data, lr=1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=args.overlap)
 
     for _ in range(args.warmup):
         log = step()
@@ -78,6 +80,16 @@ def main():
                                                                                    sum(d['work'] for d in prof.values()) / tot / 1e9), file=sys.stderr)
         for tag, d in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:45]:
             print('# %-44s calls %3d  %8.3f ms  %7.1f TF/s' % (tag, d['calls'], d['ms'], d['work'] / d['ms'] / 1e9), file=sys.stderr)
+    if args.cprofile and rank == 0:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(45)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()

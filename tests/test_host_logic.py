@@ -62,6 +62,29 @@ def test_reference_config_files_load_unchanged(name, builtin):
     assert type(model).__name__ == cfg.model.type
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference tree not present')
+@pytest.mark.parametrize('name,builtin', [('faster_rcnn_r101_selsa_c5.py', 'selsa_train_config'), ('faster_rcnn_r101_hrnmp_c5.py', 'hvr_train_config')])
+def test_reference_train_cfg_builds_the_same_target_objects(name, builtin):
+    """The shipped configs' train_cfg sections equal the built-in training configs and build assigners / samplers through
+    hvrnet_amd.targets exactly as the reference's build_assigner / build_sampler would (same classes, same arguments)."""
+    from hvrnet_amd import config as CFG, targets as T
+    cfg = Config.fromfile(os.path.join(REF_CFG, name))
+    mine = getattr(CFG, builtin)()
+    assert cfg.train_cfg.to_dict() == mine.train_cfg.to_dict() and cfg.model.to_dict() == mine.model.to_dict()
+    model = _build(Config(dict(model=cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)))
+    assert model.key_dim == 0                                        # train_cfg.rcnn.key_dim
+    for part in ('rpn', 'rcnn'):
+        asg = T.build_assigner(cfg.train_cfg[part].assigner)
+        assert isinstance(asg, T.MaxIoUAssigner) and asg.pos_iou_thr == cfg.train_cfg[part].assigner.pos_iou_thr
+    smp = T.build_sampler(cfg.train_cfg.rcnn.sampler, context=model)
+    if isinstance(cfg.train_cfg.rcnn.sampler, (list, tuple)):
+        assert [type(x).__name__ for x in smp] == ['RandomSampler', 'OHEMHNLSampler'] and (smp[0].num, smp[1].num) == (300, 128)
+    else:
+        assert type(smp).__name__ == 'RandomSampler' and smp.num == 128 and smp.add_gt_as_proposals
+    rpn_smp = T.build_sampler(cfg.train_cfg.rpn.sampler)
+    assert (rpn_smp.num, rpn_smp.pos_fraction, rpn_smp.add_gt_as_proposals) == (256, 0.5, False)
+
+
 def test_configdict_access_patterns_used_by_the_path():
     c = ConfigDict(score_thr=0.001, nms=dict(type='nms', iou_thr=0.3), max_per_img=300)
     assert hasattr(c, 'nms') and not hasattr(c, 'nope') and c.nms.iou_thr == 0.3 and c.get('x', 5) == 5

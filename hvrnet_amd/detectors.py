@@ -303,7 +303,14 @@ class _WindowDetector(TwoStageDetector):
         raise NotImplementedError
 
     def simple_test(self, img, img_meta, proposals=None, rescale=False):
-        raise NotImplementedError('single-image testing bypasses the relation head; use the window path (forward_feat)')
+        """Clip-mode test as the reference's simple_test INTENDS it (hnmb_rcnn.py:615-638, selsa_rcnn.py:319-338): img
+        [T,3,H,W] = the frames of one window -> extract_feat -> the window path.  As written the reference hands the C4 maps
+        (1024 channels) to simple_test_bboxes, whose RoI features then have the wrong width for fc_new_1 when
+        feat_from_shared_head=True (both configs), and HNMBRCNN passes its two-branch lists to bbox2result: the method cannot
+        run there; tools/test.py never calls it (it drives backbone_feat / forward_feat).  This is forward_feat on the
+        extracted features -- the clip mode bench.py times."""
+        x = self.extract_feat(img)
+        return self.forward_feat(x=x[0], img_meta=img_meta, proposals=proposals, rescale=rescale)
 
 
 @DETECTORS.register_module

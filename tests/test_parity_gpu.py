@@ -938,6 +938,28 @@ def test_cached_frame_loop_matches_clip_mode(kind):
     assert n_det > 0
 
 
+@pytest.mark.parametrize('kind', ['selsa', 'hvr'])
+def test_simple_test_is_the_clip_mode_window(kind):
+    """detector.simple_test(clip, metas) = extract_feat + forward_feat (what the reference's simple_test intends; see its
+    docstring for why the reference's own cannot run with these configs): identical per-class arrays."""
+    cfgf = selsa_config if kind == 'selsa' else hvr_config
+    hw, pad, n_prop, fi = (150, 250), (160, 256), 24, 1
+    model = hvrnet_amd.build_model(cfgf(frame_interval=fi, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    clip = torch.cat([S.synth_frame(40 + i, img_hw=hw, pad_hw=pad) for i in range(3)], 0).to(DEV)
+    metas = [S.synth_meta(hw, pad) for _ in range(3)]
+    with torch.no_grad():
+        a = model.simple_test(clip, metas, rescale=True)
+        c4 = model(img=clip, img_meta=metas, backbone_feat=True)[0]
+        b = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+    pairs = zip(a, b) if kind == 'hvr' else [(a, b)]
+    n = 0
+    for ra, rb in pairs:
+        for ca, cb in zip(ra, rb):
+            assert np.array_equal(np.asarray(ca), np.asarray(cb))
+            n += len(ca)
+    assert n > 0
+
+
 def test_two_windows_in_flight_on_two_streams_match_sequential():
     """bench.py --inflight 2 enqueues independent windows on two HIP streams: scratch buffers and helper streams are
     per stream, so the interleaved windows must reproduce their sequential results bit for bit."""

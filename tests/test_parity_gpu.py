@@ -840,6 +840,57 @@ def test_selsa_rcnn_forward_train_matches_the_oracle(O, ohem):
 
 
 
+@pytest.mark.parametrize('kind', ['selsa', 'hvr'])
+def test_full_size_training_step_properties(kind):
+    """The training step at BASELINE's size (600x1000 frames, 300 proposals; SELSA: 1 key + 2 reference frames, HVR: 5 videos x 3
+    frames) where the oracle's backward would take minutes: size-independent properties instead -- the f32 and bf16 modes see
+    the same sampled sets (same keys, same f32 proposals are NOT guaranteed, so only the sizes are compared) and agree on every
+    loss to 5 %; every parameter that should train gets a finite, non-zero f32 gradient in both modes; frozen ones get none;
+    the step is repeatable on fixed keys up to RoIAlign-backward's atomic order (1e-4 of the gradient scale)."""
+    from hvrnet_amd.config import hvr_train_config, selsa_train_config
+    from hvrnet_amd.dist_train import FlatParams, parse_losses
+    T = 3 if kind == 'selsa' else 15
+    cfg = selsa_train_config() if kind == 'selsa' else hvr_train_config()
+    sd = S.synth_state_dict(kind)
+    imgs = torch.cat([S.synth_frame(300 + i) for i in range(T)], 0).to(DEV)
+    metas = [S.synth_meta() for _ in range(T)]
+    gt_b = torch.tensor([[120., 80., 420., 330.], [296., 136., 359., 199.], [500., 100., 780., 300.], [820., 420., 865., 460.]]).to(DEV)
+    gt_l = torch.tensor([3, 17, 9, 22]).to(DEV)
+    g = torch.Generator().manual_seed(101)
+    if kind == 'selsa':
+        keys = dict(rpn=torch.rand(38 * 63 * 12, generator=g).to(DEV), rcnn=[torch.rand(4 + 300, generator=g).to(DEV) for _ in range(3)])
+    else:
+        keys = dict(rcnn=[[torch.rand(4 + 300, generator=g).to(DEV) for _ in range(3)] for _ in range(3)])
+    data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, keys=keys)
+    logs, flats = {}, {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, sd, dt, DEV))
+        flat = FlatParams(model)
+        runs = []
+        for _ in range(2):
+            flat.zero_grad()
+            out = model(**data)
+            out.pop('loss_trip', None)      # the mined triple is an argmax over affinities: bf16 and f32 may pick different rows,
+            loss, log = parse_losses(out)   # which is a different (equally valid) term, not a rounding difference
+            loss.backward()
+            runs.append(flat.grad.clone())
+        assert bool(torch.isfinite(runs[0]).all()) and bool(torch.isfinite(loss.detach()))
+        scale = float(runs[0].abs().max())
+        assert float((runs[1] - runs[0]).abs().max()) <= 1e-4 * scale + (0 if dt == torch.float32 else 2e-3 * scale)
+        for name, p_ in model.named_parameters():
+            if p_.requires_grad:
+                assert p_.grad is not None and p_.grad.dtype == torch.float32 and float(p_.grad.abs().sum()) > 0, (name, dt)
+            else:
+                assert p_.grad is None, name
+        logs[dt], flats[dt] = {k: float(v) for k, v in log.items()}, runs[0]
+        del model, flat
+    for k, v in logs[torch.float32].items():
+        if 'loss' in k:
+            assert abs(logs[torch.bfloat16][k] - v) <= 0.05 * abs(v) + 1e-3, (k, logs)
+    a, b = flats[torch.float32].double(), flats[torch.bfloat16].double()
+    assert float((a * b).sum() / (a.norm() * b.norm())) >= 0.95      # whole-model gradient direction, bf16 vs f32
+
+
 def test_off_stream_weight_gradients_equal_the_autograd_order():
     """train_ops.wgrad_overlap: conv weight gradients enqueued on a second HIP stream and added straight into the flat
     gradient buffer must give the buffer autograd's own accumulation gives (same kernels, same order per parameter; the only

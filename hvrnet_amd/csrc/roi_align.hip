@@ -102,6 +102,65 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ 
   }
 }
 
+// The path's own configuration (sample_num = 2, bf16, 16 B of channels per lane): the same arithmetic in the same
+// order, with the four sample points of a bin resolved first and their 16 gathers issued back to back -- the generic
+// kernel's data-dependent `continue` keeps the compiler from overlapping one sample's loads with the next sample's
+// (the kernel is latency-bound: 4 500 workgroups of short dependent gather chains).  A sample outside the map keeps
+// the reference's "skip" (roi_align_kernel.cu:29-35): its taps read pixel (0, 0) and are not accumulated.
+__device__ __forceinline__ void unpack8(const uint4& v, float f[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_s2(const bf16_t* __restrict__ feat, const float* __restrict__ rois,
+                                                                  bf16_t* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                                  float spatial_scale) {
+  const int k = blockIdx.x;
+  const int lanes_c = C / 8;
+  const int groups = blockDim.x / lanes_c;
+  const int cl = threadIdx.x % lanes_c, grp = threadIdx.x / lanes_c;
+  if (grp >= groups) return;
+  const RoiGeom g = roi_geom(rois + (long)k * 5, spatial_scale, 2, PH, PW);
+  const bf16_t* fb = feat + (long)g.batch * H * W * C + cl * 8;
+  for (int bin = grp; bin < PH * PW; bin += groups) {
+    const int ph = bin / PW, pw = bin - ph * PW;
+    BilinearTap t[4];
+    uint4 v[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int iy = s >> 1, ix = s & 1;
+      const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / 2.f;
+      const float x = g.start_w + pw * g.bin_w + (ix + .5f) * g.bin_w / 2.f;
+      t[s] = make_tap(H, W, y, x);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      v[s][0] = *reinterpret_cast<const uint4*>(fb + ((long)t[s].y_low * W + t[s].x_low) * C);
+      v[s][1] = *reinterpret_cast<const uint4*>(fb + ((long)t[s].y_low * W + t[s].x_high) * C);
+      v[s][2] = *reinterpret_cast<const uint4*>(fb + ((long)t[s].y_high * W + t[s].x_low) * C);
+      v[s][3] = *reinterpret_cast<const uint4*>(fb + ((long)t[s].y_high * W + t[s].x_high) * C);
+    }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float lt[8], rt[8], lb[8], rb[8];
+      unpack8(v[s][0], lt); unpack8(v[s][1], rt); unpack8(v[s][2], lb); unpack8(v[s][3], rb);
+      if (t[s].inside) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (t[s].w1 * lt[e] + t[s].w2 * rt[e] + t[s].w3 * lb[e] + t[s].w4 * rb[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] /= 4.f;
+    bf16_t* dst = out + ((long)k * PH * PW + bin) * C + cl * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+  }
+}
+
 // layout 0: features [B][C][H][W], output [K][C][PH][PW] -- the reference's own layout
 // (kept for drop-in callers that hand NCHW tensors; one thread per output element).
 template <typename T>
@@ -176,7 +235,10 @@ hipError_t run_roi_align_fwd(const void* feat, const float* rois, void* out, int
   if (K == 0) return hipSuccess;
   if (layout == 1) {
     if (dtype == DT_BF16) {
-      if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
+      const bool al16 = ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+      if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && sample_num == 2 && al16) {
+        hipLaunchKernelGGL(roi_align_fwd_nhwc_bf16_s2, dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale);
+      } else if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
         hipLaunchKernelGGL((roi_align_fwd_nhwc<bf16_t, 8>), dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale, sample_num);
       } else if (C % 4 == 0 && C / 4 <= 256) {
         hipLaunchKernelGGL((roi_align_fwd_nhwc<bf16_t, 4>), dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale, sample_num);

@@ -259,6 +259,7 @@ class ConvFunction(Function):
         ldp = (P + step - 1) // step * step
         dz2 = dz.view(P, Cout)
         dx = dw = None
+        side_reads_dz = False
         if ctx.needs_input_grad[0]:
             if (KH, KW) == (1, 1):
                 ldn = (Cout + step - 1) // step * step
@@ -287,10 +288,14 @@ class ConvFunction(Function):
                     weight_gradient(into=wp.grad)
                 for t_ in (dz, xs, s):
                     t_.record_stream(side)
+                side_reads_dz = True
             else:
                 dw = weight_gradient()
         dt = native.colsum(dz2) if ctx.needs_input_grad[3] else None   # a trainable bias passed as the shift (RPN / 1x1 heads)
-        dr = dz if (has_resid and ctx.needs_input_grad[4]) else None
+        # dz doubles as the residual's gradient.  Autograd may later add another branch's gradient INTO the tensor it is
+        # handed (InputBuffer accumulates in place when it holds the only reference), on the main stream -- while the side
+        # stream is still reading dz for the weight gradient.  Off-stream mode therefore hands autograd its own copy.
+        dr = (dz.clone() if side_reads_dz else dz) if (has_resid and ctx.needs_input_grad[4]) else None
         return dx, dw, None, dt, dr, None, None, None, None, None
 
 

@@ -921,7 +921,7 @@ def test_off_stream_weight_gradients_equal_the_autograd_order():
     scale = float(grads[0].abs().max())
     assert scale > 0
     for other in grads[1:]:
-        assert float((other - grads[0]).abs().max()) <= 1e-5 * scale
+        assert float((other - grads[0]).abs().max()) <= 1e-5 * scale, (float((other - grads[0]).abs().max()), scale)
     # every trainable conv weight really got its gradient through the side stream (none was dropped)
     for name, p_ in model.named_parameters():
         if p_.requires_grad and p_.dim() == 4:

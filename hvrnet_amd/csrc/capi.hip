@@ -190,6 +190,13 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   }
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->Cout; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
+  if (pointwise) p.zero = d->zero;  // (expand.hip reads it in place of a missing shift)
+  // the expand convs of a Bottleneck (1x1, K <= 512, + residual) are HBM-bound: row-panel kernel (expand.hip)
+  static const int use_expand = std::getenv("HVR_EXPAND") ? std::atoi(std::getenv("HVR_EXPAND")) : 1;
+  if (pointwise && expand_supported(p) &&
+      (p.tile_hint == kExpandHint || (p.tile_hint == 0 && use_expand && p.resid && p.N >= 2 * p.K)))
+    return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
+  if (p.tile_hint == kExpandHint) p.tile_hint = 0;
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
 }
 

@@ -53,4 +53,9 @@ int choose_tile(const GemmParams& p, int epi);
 
 hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream);
 
+// Row-panel kernel for the channel-expanding 1x1 convs with a residual (expand.hip); tile_hint kExpandHint forces it
+constexpr int kExpandHint = kNumTileShapes + 1;
+bool expand_supported(const GemmParams& p);
+hipError_t run_expand(const GemmParams& p, hipStream_t stream);
+
 }  // namespace hvr

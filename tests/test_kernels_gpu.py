@@ -69,6 +69,39 @@ def test_conv_matches_torch(cfg, dtype, staging):
     torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, **_tol(dtype))
 
 
+@pytest.mark.parametrize('relu,with_res', [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize('Cin,Cout,H,W,B', [(64, 256, 19, 23, 2), (128, 512, 13, 31, 3), (256, 1024, 38, 63, 2), (512, 2048, 11, 13, 3),
+                                            (256, 1024, 8, 16, 1), (64, 128, 12, 11, 1)])
+def test_expand_conv_panel_kernel(Cin, Cout, H, W, B, relu, with_res):
+    """expand.hip (row-panel kernel for the Bottleneck's 1x1 expand + residual, resnet.py:248-264): forced through tile
+    hint 13 and as the automatic choice; against the f32 statement of the op and against the tile engine (hint 1) on the
+    same operands.  Shapes: every K the kernel instantiates (64 / 128 / 256 / 512), a ragged last row panel (M % 128 != 0),
+    exactly one panel (M = 128), the narrowest output it accepts (N = 2 chunks), no residual / no ReLU."""
+    x = _rand((B, H, W, Cin), torch.bfloat16, 61)
+    w = _rand((Cout, 1, 1, Cin), torch.bfloat16, 62, 0.05)
+    bias = _rand((Cout,), torch.float32, 63)
+    resid = _rand((B, H, W, Cout), torch.bfloat16, 64) if with_res else None
+    ref = x.float().view(-1, Cin) @ w.float().view(Cout, Cin).t() + bias
+    if with_res:
+        ref = ref + resid.float().view(-1, Cout)
+    if relu:
+        ref = torch.relu(ref)
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV) if with_res else None
+    forced = native.conv2d_nhwc(xd, wd, bd, rd, relu=relu, tile=13)
+    engine = native.conv2d_nhwc(xd, wd, bd, rd, relu=relu, tile=1)
+    auto = native.conv2d_nhwc(xd, wd, bd, rd, relu=relu)
+    assert forced.dtype == torch.bfloat16 and forced.shape == (B, H, W, Cout)
+    torch.testing.assert_close(forced.float().cpu().view(-1, Cout), ref, **_tol(torch.bfloat16))
+    # same products, same f32 accumulation up to order, one bf16 rounding: the two kernels agree to an output ulp
+    torch.testing.assert_close(forced.float(), engine.float(), rtol=2 ** -7, atol=2 ** -7)
+    torch.testing.assert_close(auto.float().cpu().view(-1, Cout), ref, **_tol(torch.bfloat16))
+    # transposition / permutation detector: one-hot input rows pick single weight columns exactly
+    eye = torch.zeros((1, 1, 128, Cin), dtype=torch.bfloat16)
+    eye[0, 0, torch.arange(128), torch.arange(128) % Cin] = 1
+    got = native.conv2d_nhwc(eye.to(DEV), wd, None, None, relu=False, tile=13).view(128, Cout).cpu()
+    assert torch.equal(got, w.view(Cout, Cin).t()[torch.arange(128) % Cin])
+
+
 def _relation_ref(q, k, v, scale):
     p = torch.softmax(scale * (q.double() @ k.double().t()), dim=1)
     return (p @ v.double()).float()

@@ -8,8 +8,8 @@ mkdir -p build
 pids=()
 for f in gemm expand misc roi_align nms stem relation_bt targets ingest capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_params.h -nt build/$f.o ] || [ relation_bt.h -nt build/$f.o ] || [ ../../include/hvr_hip.h -nt build/$f.o ]; then
-    if [ $f = gemm ]; then
-      hipcc $FLAGS -Rpass-analysis=kernel-resource-usage -c $f.hip -o build/$f.o 2> build/gemm.remarks &
+    if [ $f = gemm ] || [ $f = expand ]; then
+      hipcc $FLAGS -Rpass-analysis=kernel-resource-usage -c $f.hip -o build/$f.o 2> build/$f.remarks &
     elif [ $f = targets ] || [ $f = ingest ]; then  # thresholds / equality tests on IoUs: keep the reference's rounding (no fused multiply-add)
       hipcc $FLAGS -ffp-contract=off -c $f.hip -o build/$f.o &
     else
@@ -19,7 +19,9 @@ for f in gemm expand misc roi_align nms stem relation_bt targets ingest capi; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-if grep -q "error:" build/gemm.remarks 2>/dev/null; then grep -A3 "error:" build/gemm.remarks; rm -f build/gemm.o; exit 1; fi
-python3 check_regs.py build/gemm.remarks
+for f in gemm expand; do
+  if grep -q "error:" build/$f.remarks 2>/dev/null; then grep -A3 "error:" build/$f.remarks; rm -f build/$f.o; exit 1; fi
+done
+python3 check_regs.py build/gemm.remarks build/expand.remarks
 hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/expand.o build/misc.o build/roi_align.o build/nms.o build/stem.o build/relation_bt.o build/targets.o build/ingest.o build/capi.o -o $OUT
 echo "built $(realpath $OUT)"

@@ -10,12 +10,19 @@ import re
 import sys
 
 
-def main(path):
-    text = open(path).read()
+def main(*paths):
+    text = ''.join(open(p).read() for p in paths)
     blocks = re.split(r'remark: Function Name: ', text)[1:]
     bad, seen = [], 0
     for b in blocks:
         name = b.split()[0]
+        if name.startswith('_ZN3hvr17expand_res_kernel'):   # expand.hip: sized for two workgroups per CU, a spill means it no longer fits
+            seen += 1
+            spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
+            scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b).group(1))
+            if spill or scratch:
+                bad.append('%s: %d VGPRs spilled, %d bytes of scratch' % (name, spill, scratch))
+            continue
         m = re.match(r'_ZN3hvr11tile_kernelI[tf]Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)E', name)
         if not m:
             continue
@@ -33,4 +40,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(*sys.argv[1:])

@@ -75,8 +75,10 @@ def test_conv_matches_torch(cfg, dtype, staging):
 def test_expand_conv_panel_kernel(Cin, Cout, H, W, B, relu, with_res):
     """expand.hip (row-panel kernel for the Bottleneck's 1x1 expand + residual, resnet.py:248-264): forced through tile
     hint 13 and as the automatic choice; against the f32 statement of the op and against the tile engine (hint 1) on the
-    same operands.  Shapes: every K the kernel instantiates (64 / 128 / 256 / 512), a ragged last row panel (M % 128 != 0),
-    exactly one panel (M = 128), the narrowest output it accepts (N = 2 chunks), no residual / no ReLU."""
+    same operands.  Shapes: every K the kernel instantiates (64 / 128 / 256) with 2, 4 and 8 chunks per workgroup, a
+    ragged last row panel (M % 128 != 0: rows past M are clamped, not predicated), exactly one panel (M = 128), the
+    narrowest output it accepts (N = 2 chunks), no residual / no ReLU; K = 512 (res5) is declined by the kernel and
+    must come back from the tile engine unchanged."""
     x = _rand((B, H, W, Cin), torch.bfloat16, 61)
     w = _rand((Cout, 1, 1, Cin), torch.bfloat16, 62, 0.05)
     bias = _rand((Cout,), torch.float32, 63)

@@ -18,6 +18,8 @@ triplet loss) is not part of this round.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn.modules.utils import _pair
@@ -406,16 +408,40 @@ class HRNMPBBoxHead(_RelationHead):
     def forward(self, *args, **kwargs):
         raise NotImplementedError('HRNMPBBoxHead.forward: use forward_test (inference) or forward_train (training, dynamic=False)')
 
+    readout_streams = os.environ.get('HVR_READOUT_STREAMS', '1') != '0'
+
     def get_det_bboxes(self, rois, cls_scores, bbox_preds, img_shape, scale_factor, rescale=False, cfg=None, defer=False):
         """Per-branch read-out -> (list of det_bboxes, list of det_labels), hrnmp_bbox_head.py:1009-1052."""
-        boxes_c, scores_c = [], []
-        for cls_score, bbox_pred in zip(cls_scores, bbox_preds):
+        def branch(cls_score, bbox_pred):
             scores, bboxes = self._decode(rois, cls_score, bbox_pred, img_shape, scale_factor, rescale)
             if cfg is None or not hasattr(cfg, 'nms'):
-                boxes_c.append(bboxes)
-                scores_c.append(scores)
-            else:
-                d, lab = self._nms(bboxes, scores, cfg, defer)
-                boxes_c.append(d)
-                scores_c.append(lab)
-        return boxes_c, scores_c
+                return bboxes, scores
+            return self._nms(bboxes, scores, cfg, defer)
+
+        pairs = list(zip(cls_scores, bbox_preds))
+        # The two branches' read-outs are independent chains of small, latency-bound launches (decode, 30 one-workgroup
+        # class sweeps, a one-workgroup merge: ~150 us each on an otherwise idle chip): with deferred results the second
+        # runs on a side stream beside the first.  Same kernels on the same inputs: identical results.
+        if defer and self.readout_streams and len(pairs) == 2 and rois.is_cuda and cfg is not None and hasattr(cfg, 'nms'):
+            main = torch.cuda.current_stream(rois.device)
+            pool = self.__dict__.setdefault('_readout_side', {})
+            key = (str(rois.device), main.cuda_stream)   # a side stream belongs to one main stream (windows in flight)
+            if key not in pool:
+                pool[key] = torch.cuda.Stream(device=rois.device)
+            side = pool[key]
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                out1 = branch(*pairs[1])
+            out0 = branch(*pairs[0])
+            main.wait_stream(side)
+            for t in out1[0]:
+                t.record_stream(main)
+            for t in pairs[1] + (rois,):
+                if torch.is_tensor(t):
+                    t.record_stream(side)
+            outs = [out0, out1]
+        else:
+            outs = [branch(c, b) for c, b in pairs]
+        return [o[0] for o in outs], [o[1] for o in outs]

@@ -9,6 +9,6 @@ B=hvrnet_amd/csrc/build
 if [ -n "${GEMM_SAME:-}" ]; then cp $B/gemm.o dbg/$name/gemm.o; fi
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $defs -c hvrnet_amd/csrc/relation_bt.hip -o dbg/$name/relation_bt.o
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DHVR_DEBUG_KNOBS $defs -c hvrnet_amd/csrc/capi.hip -o dbg/$name/capi.o
-hipcc --offload-arch=gfx950 -shared -fPIC dbg/$name/gemm.o $B/misc.o $B/roi_align.o $B/nms.o $B/stem.o dbg/$name/relation_bt.o dbg/$name/capi.o -o dbg/libhvr_$name.so
+hipcc --offload-arch=gfx950 -shared -fPIC dbg/$name/gemm.o $B/expand.o $B/misc.o $B/roi_align.o $B/nms.o $B/stem.o $B/targets.o $B/ingest.o dbg/$name/relation_bt.o dbg/$name/capi.o -o dbg/libhvr_$name.so
 rm -rf dbg/$name
 echo built dbg/libhvr_$name.so

@@ -16,7 +16,13 @@
 
 namespace hvr {
 
-constexpr int ST_PH = 4, ST_PW = 16;                       // pooled tile
+#ifndef HVR_ST_PH
+#define HVR_ST_PH 3
+#endif
+#ifndef HVR_ST_PW
+#define HVR_ST_PW 16
+#endif
+constexpr int ST_PH = HVR_ST_PH, ST_PW = HVR_ST_PW;        // pooled tile
 constexpr int ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1;  // conv region 9 x 33
 constexpr int ST_NCONV = ST_CH * ST_CW;                    // 297
 constexpr int ST_FRAGS = (ST_NCONV + 15) / 16;             // 19
@@ -46,17 +52,29 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 
   // input patch -> LDS [row][col][4] bf16
   const float* ib = img + (long)b * 3 * H * W;
-  for (int i = tid; i < (ST_IR + 3) * ST_PCOLS; i += 256) {
+  // branch-free: out-of-image / padding items read a clamped (valid) address and are zeroed afterwards, so that the
+  // unrolled loop puts all of a thread's loads in flight before the first LDS write (the phase is latency-bound)
+  constexpr int ST_ITEMS = (ST_IR + 3) * ST_PCOLS, ST_ITERS = (ST_ITEMS + 255) / 256;
+  float pv[ST_ITERS][3];
+#pragma unroll
+  for (int it = 0; it < ST_ITERS; ++it) {
+    const int i = it * 256 + tid;
     const int r = i / ST_PCOLS, c = i - r * ST_PCOLS;
     const int iy = iy0 + r, ix = ix0 + c;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    if (r < ST_IR && c < ST_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-      const long o = (long)iy * W + ix;
-      v0 = ib[o];
-      v1 = ib[o + (long)H * W];
-      v2 = ib[o + 2L * H * W];
-    }
-    *reinterpret_cast<uint2*>(patch + (long)i * 4) = make_uint2(pack2bf(v0, v1), pack2bf(v2, 0.f));
+    const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+    const long o = (long)cy * W + cx;
+    pv[it][0] = ib[o];
+    pv[it][1] = ib[o + (long)H * W];
+    pv[it][2] = ib[o + 2L * H * W];
+  }
+#pragma unroll
+  for (int it = 0; it < ST_ITERS; ++it) {
+    const int i = it * 256 + tid;
+    const int r = i / ST_PCOLS, c = i - r * ST_PCOLS;
+    const int iy = iy0 + r, ix = ix0 + c;
+    const bool ok = r < ST_IR && c < ST_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const float v0 = ok ? pv[it][0] : 0.f, v1 = ok ? pv[it][1] : 0.f, v2 = ok ? pv[it][2] : 0.f;
+    if (i < ST_ITEMS) *reinterpret_cast<uint2*>(patch + (long)i * 4) = make_uint2(pack2bf(v0, v1), pack2bf(v2, 0.f));
   }
   __syncthreads();
 

@@ -167,14 +167,14 @@ int hvr_gemm_splitk(const hvr_gemm_desc* d, void* ws, size_t ws_bytes, void* str
   return check_launch(e, "hvr_gemm_splitk");
 }
 
-int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
+// descriptor -> kernel parameters + the path it takes (0 tile engine, 1 expand.hip); a negative return is the error
+static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   if (!d) return fail(HVR_EINVAL, "null descriptor");
   const int OH = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const int OW = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   if (OH <= 0 || OW <= 0) return fail(HVR_EINVAL, "empty conv output %dx%d", OH, OW);
   const int bke = 128 / elem_size(d->dtype);
   if (d->Cin % bke) return fail(HVR_EINVAL, "Cin=%d is not a multiple of %d", d->Cin, bke);
-  GemmParams p;
   const long M = (long)d->B * OH * OW;
   if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
   if ((long)d->B * d->H * d->W * d->Cin * (long)elem_size(d->dtype) >= (1L << 31))
@@ -191,13 +191,28 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->Cout; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
   if (pointwise) p.zero = d->zero;  // (expand.hip reads it in place of a missing shift)
-  // the expand convs of a Bottleneck (1x1, K <= 512, + residual) are HBM-bound: row-panel kernel (expand.hip)
+  // the expand convs of a Bottleneck (1x1, K <= 256, + residual) are HBM-bound: row-panel kernel (expand.hip)
   static const int use_expand = std::getenv("HVR_EXPAND") ? std::atoi(std::getenv("HVR_EXPAND")) : 1;
-  if (pointwise && expand_supported(p) &&
-      (p.tile_hint == kExpandHint || (p.tile_hint == 0 && use_expand && p.resid && p.N >= 2 * p.K)))
-    return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
+  path = (pointwise && expand_supported(p) &&
+          (p.tile_hint == kExpandHint || (p.tile_hint == 0 && use_expand && p.resid && p.N >= 2 * p.K))) ? 1 : 0;
   if (p.tile_hint == kExpandHint) p.tile_hint = 0;
+  return 0;
+}
+
+int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
+  GemmParams p;
+  int path = 0;
+  const int rc = conv_params(d, p, path);
+  if (rc) return rc;
+  if (path == 1) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
+}
+
+int hvr_conv2d_path(const hvr_conv_desc* d) {
+  GemmParams p;
+  int path = 0;
+  const int rc = conv_params(d, p, path);
+  return rc ? rc : path;
 }
 
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream) {

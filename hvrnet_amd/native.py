@@ -72,6 +72,7 @@ SYMBOLS = {
     'hvr_gemm_splitk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_gemm_splitk': (_i, [ctypes.POINTER(GemmDesc), _vp, _sz, _vp]),
     'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    'hvr_conv2d_path': (_i, [ctypes.POINTER(ConvDesc)]),
     'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_stem_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -310,6 +311,16 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                2.0 * B * OH * OW * Cout * KH * KW * Cin):
         _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
     return y
+
+
+def conv2d_path(B, H, W, Cin, Cout, k=1, stride=1, pad=0, dil=1, dtype=torch.bfloat16, resid=True, bias=True, out_f32=False, tile=0):
+    """Which kernel hvr_conv2d_nhwc would run for a conv of this shape (0 tile engine, 1 expand.hip panel kernel, < 0 rejected).
+    Nothing is launched and no memory is touched: the descriptor carries placeholder (16-byte aligned) addresses."""
+    fake = 1 << 20
+    d = ConvDesc(x=fake, w=fake, y=fake, B=B, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=stride, pad=pad, dil=dil,
+                 bias=fake if bias else None, resid=fake if resid else None, relu=1, out_f32=int(out_f32),
+                 dtype=HVR_BF16 if dtype == torch.bfloat16 else HVR_F32, staging=STAGING, tile_hint=tile, zero=fake)
+    return int(lib().hvr_conv2d_path(ctypes.byref(d)))
 
 
 def im2col_stem(img, dtype, kp=192):

@@ -85,6 +85,12 @@ typedef struct hvr_conv_desc {
   const void* zero;
 } hvr_conv_desc;
 int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
+/* Which kernel hvr_conv2d_nhwc would run for this descriptor, without launching anything (pointers are only inspected
+ * for alignment): 0 = MFMA tile engine (gemm.hip), 1 = row-panel kernel for the Bottleneck's channel-expanding 1x1 conv
+ * + residual (expand.hip: bf16, 1x1 stride 1, Cin = 64 / 128 / 256, a residual, Cout >= 2 Cin in whole 64-channel chunks,
+ * >= 128 output pixels; tile_hint 13 forces it where it applies, HVR_EXPAND=0 in the environment turns the automatic
+ * choice off); negative = the descriptor would be rejected. */
+int hvr_conv2d_path(const hvr_conv_desc* d);
 
 /* 7x7/2 stem: gathers img (NCHW f32, the reference's input layout, resnet.py:522-524) into
  * patch rows [B*OH*OW][KP] with k = (ky*7+kx)*3 + c and zeros for k >= 147 (KP = 192). */

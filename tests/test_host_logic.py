@@ -165,6 +165,31 @@ def test_c_abi_exports_every_declared_symbol():
     assert native.lib().hvr_abi_version() == 1
 
 
+def test_bottleneck_expand_convs_take_the_panel_kernel():
+    """hvr_conv2d_path (no launch, no GPU): the channel-expanding 1x1 + residual convs of layers 1-3 (resnet.py:248-264) go to
+    expand.hip at every batch size the window uses (15 frames, the 8 / 7-frame groups, one cached frame); everything else --
+    res5's K = 512, convs without a residual, 3x3 convs, the f32 parity mode, fewer than 128 pixels -- stays on the tile
+    engine; tile hint 13 forces the panel kernel where it applies (no residual needed) and is ignored where it does not."""
+    if not os.path.exists(native.LIB_PATH):
+        native.build()
+    layers = [(152, 252, 64), (76, 126, 128), (38, 63, 256)]
+    for frames in (15, 8, 7, 1):
+        for H, W, c in layers:
+            assert native.conv2d_path(frames, H, W, c, 4 * c) == 1, (frames, c)
+    assert native.conv2d_path(15, 38, 63, 512, 2048) == 0                       # res5: tile engine
+    assert native.conv2d_path(15, 38, 63, 256, 1024, resid=False) == 0          # automatic choice wants the residual
+    assert native.conv2d_path(15, 38, 63, 256, 1024, resid=False, tile=13) == 1
+    assert native.conv2d_path(15, 38, 63, 512, 2048, tile=13) == 0
+    assert native.conv2d_path(15, 38, 63, 1024, 256) == 0                       # the reducing 1x1
+    assert native.conv2d_path(15, 38, 63, 256, 256, k=3, pad=1) == 0
+    assert native.conv2d_path(15, 38, 63, 256, 1024, dtype=torch.float32) == 0
+    assert native.conv2d_path(15, 38, 63, 256, 1024, out_f32=True) == 0
+    assert native.conv2d_path(1, 9, 14, 64, 256) == 0                           # 126 pixels < one 128-row panel
+    assert native.conv2d_path(1, 8, 16, 64, 256) == 1
+    assert native.conv2d_path(15, 38, 63, 256, 1024 + 32) == 0                  # not whole 64-channel chunks
+    assert native.conv2d_path(15, 38, 63, 48, 192) < 0                          # Cin not a K-step multiple: rejected
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'hvrnet_amd')):

@@ -1040,6 +1040,38 @@ def test_two_windows_in_flight_on_two_streams_match_sequential():
                 assert np.array_equal(np.asarray(ca), np.asarray(cb)), 'clip %d differs under concurrency' % i
 
 
+def test_second_branch_read_out_on_a_side_stream_changes_nothing():
+    """HRNMPBBoxHead.get_det_bboxes runs the second branch's decode / 30-class NMS / merge on a side stream beside the
+    first (deferred results only): the same kernels on the same inputs, so the window's detections are bit for bit those
+    of the one-stream read-out -- over several rounds, so that the side stream's buffers are reused while the main one runs."""
+    hw, pad, n_prop, fi = (150, 250), (160, 256), 24, 2
+    T = 2 * fi + 1
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=fi, nms_post=n_prop), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    clips = [torch.cat([S.synth_frame(300 * c + i, img_hw=hw, pad_hw=pad) for i in range(T)], 0).to(DEV) for c in range(3)]
+    metas = [S.synth_meta(hw, pad) for _ in range(T)]
+
+    def run(side):
+        model.bbox_head.readout_streams = side
+        out = []
+        with torch.no_grad():
+            for rep in range(3):
+                pend = []
+                for c in clips:
+                    c4 = model(img=c, img_meta=metas, backbone_feat=True)[0]
+                    pend.append(model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, defer=True))
+                out.append([p.result() for p in pend])
+        return out
+
+    assert type(model.bbox_head).readout_streams is True       # the default: the side stream is what the bench measures
+    one, two = run(False), run(True)
+    assert any(len(cls) for clip in one[0] for branch in clip for cls in branch)
+    for ra, rb in zip(one, two):
+        for ca, cb in zip(ra, rb):
+            for ba, bb in zip(ca, cb):
+                for xa, xb in zip(ba, bb):
+                    assert np.array_equal(np.asarray(xa), np.asarray(xb))
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_T15_N300():
     """BASELINE sizes (M = 4500, D = 1024): size-independent properties of the relation kernel."""

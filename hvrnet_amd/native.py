@@ -307,8 +307,14 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
                  staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile,
                  zero=zero_page(x.device).data_ptr())
-    with _span('conv' if not (_prof and _prof['detail']) else 'conv %dx%d %d->%d k%d s%d d%d%s' % (H, W, Cin, Cout, KH, stride, dil, '+res' if resid is not None else ''),
-               2.0 * B * OH * OW * Cout * KH * KW * Cin):
+    tag, work = 'conv', 2.0 * B * OH * OW * Cout * KH * KW * Cin
+    if _prof is not None and ('*' in _prof['tags'] or 'conv' in _prof['tags'] or 'conv_expand' in _prof['tags']):
+        if lib().hvr_conv2d_path(ctypes.byref(d)) == 1:
+            # the HBM-bound expand + residual convs (expand.hip) are accounted in bytes: X, residual and output once, W once
+            tag, work = 'conv_expand', float((B * OH * OW * (Cin + (2 if resid is not None else 1) * Cout) + Cout * Cin) * x.element_size())
+        if _prof['detail']:
+            tag = '%s %dx%d %d->%d k%d s%d d%d%s' % (tag, H, W, Cin, Cout, KH, stride, dil, '+res' if resid is not None else '')
+    with _span(tag, work):
         _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
     return y
 

@@ -123,6 +123,36 @@ def test_roi_align_hand_derived_geometry(O):
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
+def test_roi_align_against_an_independent_interpolator(O):
+    """Second pin for the CUDA-only RoIAlign: on RANDOM (non-linear) features the restatement must equal the average of
+    torch.nn.functional.grid_sample's bilinear values (align_corners=True, an interpolator this build did not write) at the
+    2 x 2 sample points of every bin (roi_align_kernel.cu:78-116: start + (p + (i + .5) / 2) * bin, end = (x2 + 1) * scale).
+    Interior boxes exercise the plain 4-tap rule; boxes that stick out exercise its border rule (:29-53): a point in
+    [-1, 0) or (H - 1, H] is clamped onto the edge pixel -- grid_sample's padding_mode='border' -- and a point beyond
+    [-1, H] x [-1, W] contributes 0 but still counts in the mean."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 2, 5, 19, 27
+    feat = torch.randn((B, C, H, W), generator=g)
+    rois = torch.tensor([[0, 33., 21., 250., 170.], [1, 100.5, 40.25, 180.75, 260.5], [0, 5., 7., 60., 44.],
+                         [1, -30., -20., 120., 90.], [0, 300., 200., 470., 330.], [1, -300., 10., -100., 80.]])
+    ph = pw = 7
+    got = O.roi_align(feat, rois, ph, 1 / 16, 2)
+    for k in range(rois.shape[0]):
+        b, x1, y1, x2, y2 = rois[k].tolist()
+        sw, sh = x1 / 16, y1 / 16
+        bw, bh = max((x2 + 1) / 16 - sw, 0.) / pw, max((y2 + 1) / 16 - sh, 0.) / ph
+        ys = torch.tensor([sh + p * bh + (i + .5) * bh / 2 for p in range(ph) for i in range(2)])       # [14]
+        xs = torch.tensor([sw + p * bw + (i + .5) * bw / 2 for p in range(pw) for i in range(2)])
+        yy, xx = torch.meshgrid(ys, xs, indexing='ij')
+        inside = ((yy >= -1) & (yy <= H) & (xx >= -1) & (xx <= W)).float()
+        grid = torch.stack([xx / (W - 1) * 2 - 1, yy / (H - 1) * 2 - 1], dim=-1)[None]                    # x first, in [-1, 1]
+        vals = F.grid_sample(feat[int(b)][None], grid.float(), mode='bilinear', padding_mode='border', align_corners=True)[0]
+        want = (vals * inside).view(C, ph, 2, pw, 2).mean(dim=(2, 4))
+        close(got[k], want, 1e-5, 1e-5)
+    assert got[5].abs().max() == 0                                              # entirely left of x = -1
+
+
 def test_g5_relation_stage(O):
     g = gold('g5_relation')
     sd_s, sd_h = S.synth_state_dict('selsa'), S.synth_state_dict('hvr')

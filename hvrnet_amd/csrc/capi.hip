@@ -196,6 +196,9 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   path = (pointwise && expand_supported(p) &&
           (p.tile_hint == kExpandHint || (p.tile_hint == 0 && use_expand && p.resid && p.N >= 2 * p.K))) ? 1 : 0;
   if (p.tile_hint == kExpandHint) p.tile_hint = 0;
+  // layer 1's 3x3 (64 -> 64): persistent kernel with the weights resident in the LDS (conv3x3.hip)
+  static const int use_c3 = std::getenv("HVR_CONV3") ? std::atoi(std::getenv("HVR_CONV3")) : 1;
+  if (path == 0 && p.tile_hint == 0 && use_c3 && conv3x3_c64_supported(p)) path = 2;
   return 0;
 }
 
@@ -205,6 +208,7 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   const int rc = conv_params(d, p, path);
   if (rc) return rc;
   if (path == 1) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
+  if (path == 2) return check_launch(run_conv3x3_c64(p, (hipStream_t)stream), "hvr_conv2d_nhwc(conv3x3_c64)");
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
 }
 

@@ -56,6 +56,9 @@ hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream);
 // Row-panel kernel for the channel-expanding 1x1 convs with a residual (expand.hip); tile_hint kExpandHint forces it
 constexpr int kExpandHint = kNumTileShapes + 1;
 bool expand_supported(const GemmParams& p);
+// Persistent 3x3 / 64 -> 64 channel kernel with LDS-resident weights (conv3x3.hip: the layer-1 conv2)
+bool conv3x3_c64_supported(const GemmParams& p);
+hipError_t run_conv3x3_c64(const GemmParams& p, hipStream_t stream);
 hipError_t run_expand(const GemmParams& p, hipStream_t stream);
 
 }  // namespace hvr

@@ -89,7 +89,9 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
  * for alignment): 0 = MFMA tile engine (gemm.hip), 1 = row-panel kernel for the Bottleneck's channel-expanding 1x1 conv
  * + residual (expand.hip: bf16, 1x1 stride 1, Cin = 64 / 128 / 256, a residual, Cout >= 2 Cin in whole 64-channel chunks,
  * >= 128 output pixels; tile_hint 13 forces it where it applies, HVR_EXPAND=0 in the environment turns the automatic
- * choice off); negative = the descriptor would be rejected. */
+ * choice off), 2 = persistent 3x3 kernel with LDS-resident weights for bf16 64 -> 64 channels, stride 1, pad 1, no
+ * residual (conv3x3.hip: layer 1's conv2; HVR_CONV3=0 turns it off; any tile_hint keeps the tile engine);
+ * negative = the descriptor would be rejected. */
 int hvr_conv2d_path(const hvr_conv_desc* d);
 
 /* 7x7/2 stem: gathers img (NCHW f32, the reference's input layout, resnet.py:522-524) into

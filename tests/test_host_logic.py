@@ -182,6 +182,14 @@ def test_bottleneck_expand_convs_take_the_panel_kernel():
     assert native.conv2d_path(15, 38, 63, 512, 2048, tile=13) == 0
     assert native.conv2d_path(15, 38, 63, 1024, 256) == 0                       # the reducing 1x1
     assert native.conv2d_path(15, 38, 63, 256, 256, k=3, pad=1) == 0
+    # layer 1's conv2 (3x3, 64 -> 64, no residual) has its own persistent kernel (conv3x3.hip); nothing else does
+    for frames in (15, 8, 7, 1):
+        assert native.conv2d_path(frames, 152, 252, 64, 64, k=3, pad=1, resid=False) == 2
+    assert native.conv2d_path(15, 152, 252, 64, 64, k=3, pad=1, resid=False, tile=1) == 0
+    assert native.conv2d_path(15, 152, 252, 64, 64, k=3, pad=1, resid=True) == 0
+    assert native.conv2d_path(15, 76, 126, 128, 128, k=3, pad=1, resid=False) == 0
+    assert native.conv2d_path(15, 152, 252, 64, 64, k=3, pad=2, dil=2, resid=False) == 0
+    assert native.conv2d_path(1, 19, 23, 64, 64, k=3, pad=1, resid=False) == 0           # fewer than four tiles
     assert native.conv2d_path(15, 38, 63, 256, 1024, dtype=torch.float32) == 0
     assert native.conv2d_path(15, 38, 63, 256, 1024, out_f32=True) == 0
     assert native.conv2d_path(1, 9, 14, 64, 256) == 0                           # 126 pixels < one 128-row panel

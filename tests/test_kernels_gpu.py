@@ -104,6 +104,37 @@ def test_expand_conv_panel_kernel(Cin, Cout, H, W, B, relu, with_res):
     assert torch.equal(got, w.view(Cout, Cin).t()[torch.arange(128) % Cin])
 
 
+@pytest.mark.parametrize('relu,with_bias', [(True, True), (False, False)])
+@pytest.mark.parametrize('B,H,W', [(2, 37, 53), (1, 32, 32), (3, 16, 80), (1, 152, 252)])
+def test_conv3x3_c64_persistent_kernel(B, H, W, relu, with_bias):
+    """conv3x3.hip (layer 1's conv2: 3x3, 64 -> 64, LDS-resident weights, 16 x 16 output tiles from an 18 x 18 halo): against
+    F.conv2d and, bit for bit, against the tile engine (same MFMA sequence per output element: tap-major, two 32-channel
+    halves per tap).  Shapes: ragged tiles on both axes, exactly one tile per workgroup, a tile row cut by the image's
+    bottom edge, several frames (the halo must not leak across frame boundaries), the path's own 152 x 252 map."""
+    x = _rand((B, 64, H, W), torch.bfloat16, 71)
+    w = _rand((64, 64, 3, 3), torch.bfloat16, 72, 0.05)
+    bias = _rand((64,), torch.float32, 73) if with_bias else None
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wn = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bd = bias.to(DEV) if with_bias else None
+    assert native.conv2d_path(B, H, W, 64, 64, k=3, pad=1, resid=False, bias=with_bias) == 2
+    got = native.conv2d_nhwc(xn, wn, bd, None, relu=relu, pad=1)
+    engine = native.conv2d_nhwc(xn, wn, bd, None, relu=relu, pad=1, tile=1)
+    torch.testing.assert_close(got.float().cpu().permute(0, 3, 1, 2), ref, **_tol(torch.bfloat16))
+    assert torch.equal(got, engine)
+    # a one-hot input pixel reproduces the (flipped) filter around it exactly: transposition / tap-order detector
+    one = torch.zeros((1, 40, 40, 64), dtype=torch.bfloat16)
+    one[0, 17, 23, 5] = 1
+    out = native.conv2d_nhwc(one.to(DEV), wn, None, None, relu=False, pad=1).cpu()
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            assert torch.equal(out[0, 17 + dy, 23 + dx], w[:, 5, 1 - dy, 1 - dx])
+    assert float(out.float().abs().sum()) == float(w[:, 5].float().abs().sum())
+
+
 def _relation_ref(q, k, v, scale):
     p = torch.softmax(scale * (q.double() @ k.double().t()), dim=1)
     return (p @ v.double()).float()

@@ -125,31 +125,37 @@ __global__ __launch_bounds__(C3_NT, 1) void conv3x3_c64_kernel(const Conv3x3Para
     __builtin_amdgcn_sched_barrier(0);
 
     f32x4 acc[2][4];
+    // 18 steps (tap, 32-channel half); step s + 1's six fragments are requested before step s's eight MFMAs
+    uint4 xf[2][2], wf[2][4];
+    auto read_step = [&](int s, uint4 (&xd)[2], uint4 (&wd)[4]) {
+      const int tap = s >> 1, kk = s & 1, ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
+      for (int i = 0; i < 2; ++i) {
+        const int hp = (2 * wave + i + ky) * C3_HW + kx + q;  // halo pixel of output (row 2 wave + i, x = q) under this tap
+        xd[i] = c3_lds_read128(hb + hp * 128 + (((kk * 4 + g) ^ (hp & 7)) << 4));
+      }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint4 xf[2], wf[4];
+      for (int j = 0; j < 4; ++j) wd[j] = c3_lds_read128((w_lane + tap * (64 * 128) + j * 4 * 128) ^ (kk ? 64u : 0u));
+    };
+    read_step(0, xf[0], wf[0]);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      if (s + 1 < 18) {
+        read_step(s + 1, xf[(s + 1) & 1], wf[(s + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int hp = (2 * wave + i + ky) * C3_HW + kx + q;  // halo pixel of output (row 2 wave + i, x = q) under this tap
-          xf[i] = c3_lds_read128(hb + hp * 128 + (((kk * 4 + g) ^ (hp & 7)) << 4));
+          const f32x4 cin = s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s & 1][j]),
+                                                              __builtin_bit_cast(bf16x8, xf[s & 1][i]), cin, 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = c3_lds_read128((w_lane + tap * (64 * 128) + j * 4 * 128) ^ (kk ? 64u : 0u));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const f32x4 cin = (tap == 0 && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]),
-                                                                cin, 0, 0, 0);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // the next halo has landed (it had the MFMA phase); the previous tile's stores are long gone

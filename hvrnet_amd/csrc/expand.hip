@@ -1,7 +1,7 @@
 // Channel-expanding 1x1 convolution with the block's residual:  out = act(X W^T + shift + R)   (bf16, gfx950)
-//   X [M][K] (K = 64 / 128 / 256), W [N][K] with N = 4 K in a Bottleneck, R / out [M][N].
-// Replaces conv3 + bn3 + `out += identity` + ReLU of mmdet/models/backbones/resnet.py:248-264 -- 30 launches per frame
-// batch (the res5 blocks' K = 512 stays on the tile engine: it is compute-heavy enough to lose nothing there).
+//   X [M][K] (K = 64 / 128 / 256 / 512), W [N][K] with N = 4 K in a Bottleneck, R / out [M][N].
+// Replaces conv3 + bn3 + `out += identity` + ReLU of mmdet/models/backbones/resnet.py:248-264 and of the res5 blocks
+// (shared_heads/res_layer.py:67-74) -- 33 launches per frame batch.
 //
 // Why not the tile engine (gemm.hip): this product is HBM-bound (l3: 18.8 GF over 165 MB; the engine's output tiles
 // run 53 us = 3.1 TB/s where an elementwise add over the same tensors streams at 6-7 TB/s on this box).  A K of 1-4
@@ -34,9 +34,12 @@ namespace {
 __device__ __forceinline__ uint32_t x_lds_off(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
-__device__ __forceinline__ uint4 x_lds_read128(uint32_t addr) {
+// the fragment's distance from the lane's base goes into the instruction's 16-bit offset field: with one address
+// register per read the unrolled chunks' (identical) address values are kept live across chunks -- 100+ registers
+template <int OFF> __device__ __forceinline__ uint4 x_lds_read128(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
   uint4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
 // s_waitcnt vmcnt(N) through the builtin, not inline asm: the compiler's own wait-count pass reads it and learns that
@@ -61,20 +64,22 @@ __device__ __forceinline__ int swz_key(int row) { return (((row >> 4) & 3) << 1)
 
 // KF: K / 32 (MFMA K-steps), RES: a residual is added, NC: chunks of 64 output channels per workgroup (blockIdx.y
 // selects the range: panels alone leave most CUs with one workgroup when M / 128 is close to the CU count)
-template <int KF, bool RES, int NC>
-__global__ __launch_bounds__(256, 2) void expand_res_kernel(const GemmParams p) {
-  constexpr int K = KF * 32, FJ = X_FJ, BN = X_BN, BM = X_BM, NT = X_NT;
+// RF: 16-row fragments per wave -- 2 with 4 waves (two workgroups per CU), 1 with 8 waves (K = 512: X alone is 64
+// registers per row fragment, and two 64 KB W buffers leave room for one workgroup per CU, so it brings its own 8 waves)
+template <int KF, bool RES, int NC, int RF>
+__global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand_res_kernel(const GemmParams p) {
+  constexpr int K = KF * 32, FJ = X_FJ, BN = X_BN, BM = X_BM, NT = 64 * (X_BM / 16 / RF);
   constexpr int CHUNK = BN * K * 2;               // bytes of one W chunk
   constexpr int SLOTS = CHUNK / 16 / NT;          // DMA pieces per thread per chunk
   static_assert(KF % 2 == 0 && CHUNK % (16 * NT) == 0, "shape");
   constexpr int NV = FJ / 2;                      // 16-byte pieces of a lane's 16 channels (bf16)
-  constexpr int NRES = RES ? 2 * NV : 0, NST = 2 * NV;  // residual loads / output stores per thread and chunk
+  constexpr int NRES = RES ? RF * NV : 0, NST = RF * NV;  // residual loads / output stores per thread and chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM + wave * 32;
+  const int m0 = blockIdx.x * BM + wave * 16 * RF;
   const int cb = blockIdx.y * NC;                 // first chunk of this workgroup
 
   // ---- W chunk loader: slot s = i * NT + tid -> (ks, row, pos); LDS image [ks][row][128 B], linear destination ----
@@ -95,10 +100,10 @@ __global__ __launch_bounds__(256, 2) void expand_res_kernel(const GemmParams p) 
   for (int n = tid; n < NC * BN; n += NT) shl[n] = p.bias ? p.bias[cb * BN + n] : 0.f;
 
   // ---- X fragments: rows m0 + 16 i + q, k = 32 kf + 8 g .. + 8 ----
-  xu32x4 x[2][KF];
-  int mrow[2];
+  xu32x4 x[RF][KF];
+  int mrow[RF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < RF; ++i) {
     const int m = m0 + i * 16 + q;
     mrow[i] = m < p.M ? m : p.M - 1;
     const char* xr = (const char*)p.A + (long)mrow[i] * p.lda * 2 + g * 16;
@@ -108,12 +113,12 @@ __global__ __launch_bounds__(256, 2) void expand_res_kernel(const GemmParams p) 
 
   // residual rows of a chunk: lane's channels n = c BN + 16 g .. + 16 of rows mrow[0], mrow[1]
   // ring of RD chunks' residual rows, fetched RD - 1 chunks ahead (K = 256 has registers for one chunk ahead only)
-  constexpr int RD = KF >= 8 ? 2 : 3, AHEAD = RD - 1;
-  xu32x4 res[RD][2][NV];  // [ring slot][row fragment][piece]
-  auto load_res = [&](int c, xu32x4 (&r)[2][NV]) {
+  constexpr int RD = 3, AHEAD = RD - 1;
+  xu32x4 res[RD][RF][NV];  // [ring slot][row fragment][piece]
+  auto load_res = [&](int c, xu32x4 (&r)[RF][NV]) {
     if constexpr (RES) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < RF; ++i) {
         const char* rr = (const char*)p.resid + ((long)mrow[i] * p.ldr + c * BN + g * 4 * FJ) * 2;
 #pragma unroll
         for (int v = 0; v < NV; ++v) r[i][v] = *reinterpret_cast<const xu32x4*>(rr + v * 16);
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void expand_res_kernel(const GemmParams p) 
   static_for<NC>([&](auto U) {
     constexpr int u = decltype(U)::value;
     const int c = cb + u;
-    xu32x4 (&rcur)[2][NV] = res[u % RD];
+    xu32x4 (&rcur)[RF][NV] = res[u % RD];
     // Top of chunk u.  In flight behind DMA(u), oldest first: res(u + 1) (if there is one) and the previous chunk's NST
     // stores; DMA(u) must have landed.  Vector memory operations retire in order and every wave issues every one of
     // them (rows past M are clamped, not predicated: see the stores), so the count is exact and branch-free -- a
@@ -147,49 +152,53 @@ __global__ __launch_bounds__(256, 2) void expand_res_kernel(const GemmParams p) 
     if constexpr (u + 1 < NC) dma_chunk(c + 1, smem + ((u + 1) & 1) * CHUNK);
     if constexpr (u + AHEAD < NC) load_res(c + AHEAD, res[(u + AHEAD) % RD]);
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t base = w_lane + (uint32_t)(u & 1) * CHUNK;
+    // two base addresses per buffer (the 32-channel half kk = 1 is the same address with bit 6 flipped); everything else
+    // is an immediate offset
+    const uint32_t base0 = w_lane + (uint32_t)(u & 1) * CHUNK, base1 = base0 ^ 64u;
     const int nb = c * BN + g * 4 * FJ;
-    f32x4 acc[2][FJ];
+    f32x4 acc[RF][FJ];
     // software pipeline over the KF MFMA K-steps in half-steps of FJ / 2 fragments: while one half's MFMAs run, the
     // other half's fragments (and then the next step's) are on their way -- one step's worth of fragment registers
     constexpr int H = FJ / 2;
     uint4 wf[2][H];  // [half][fragment]
-    auto read_half = [&](int t, int hf, uint4 (&dst)[H]) {
-      const uint32_t a = (base + (uint32_t)(t >> 1) * (BN * 128)) ^ ((t & 1) ? 64u : 0u);
-#pragma unroll
-      for (int j = 0; j < H; ++j) dst[j] = x_lds_read128(a + (hf * H + j) * 4 * 128);
+    auto read_half = [&](auto T, auto HF) {
+      constexpr int t = decltype(T)::value, hf = decltype(HF)::value;
+      static_for<H>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        wf[hf][j] = x_lds_read128<(t >> 1) * (BN * 128) + (hf * H + j) * 4 * 128>((t & 1) ? base1 : base0);
+      });
     };
-    read_half(0, 0, wf[0]);
-    read_half(0, 1, wf[1]);
-#pragma unroll
-    for (int t = 0; t < KF; ++t) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
+    read_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    read_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    static_for<KF>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      static_for<2>([&](auto HF) {
+        constexpr int hf = decltype(HF)::value;
         // outstanding here: this half, then the other half (of this step for hf = 0, of the next for hf = 1)
-        if (t + 1 < KF || hf == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(H) : "memory");
+        if constexpr (t + 1 < KF || hf == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(H) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < H; ++j)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < RF; ++i) {
             const f32x4 cin = t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][hf * H + j];
             acc[i][hf * H + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[hf][j]),
                                                                           __builtin_bit_cast(bf16x8, x[i][t]), cin, 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < KF) read_half(t + 1, hf, wf[hf]);
+        if constexpr (t + 1 < KF) read_half(std::integral_constant<int, t + 1>{}, HF);
         __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+      });
+    });
     // ---- epilogue: lane holds out[m0 + 16 i + q][c BN + 16 g + 4 j + r] = acc[i][j][r] ----
     uint4 sh[FJ];
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) sh[j] = x_lds_read128(sh_lane + (u * BN + 4 * j) * 4);
+    for (int j = 0; j < FJ; ++j) sh[j] = x_lds_read128<0>(sh_lane + (u * BN + 4 * j) * 4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RF; ++i) {
       // a lane whose row is past M was given row M - 1's X and residual: it holds row M - 1's outputs bit for bit and
       // stores them where row M - 1 goes (same bytes from several lanes), so no store is ever skipped
       char* dst = (char*)p.C + ((long)mrow[i] * p.ldc + nb) * 2;
@@ -228,10 +237,10 @@ static int expand_nc(int M, int N) {
 }
 
 // The panel kernel applies when the product is a plain bf16 GEMM with a short K, whole 16-byte rows, and an output of
-// an even number of 64-channel chunks (the expand convs of layers 1-3: K = 64 / 128 / 256, N = 4 K).
+// an even number of 64-channel chunks (the expand convs of layers 1-3 and res5: K = 64 / 128 / 256 / 512, N = 4 K).
 bool expand_supported(const GemmParams& p) {
   if (p.dtype != DT_BF16 || p.conv || p.out_f32 || p.ksplit_steps > 0) return false;
-  if (!(p.K == 64 || p.K == 128 || p.K == 256)) return false;
+  if (!(p.K == 64 || p.K == 128 || p.K == 256 || p.K == 512)) return false;
   if (p.N % X_BN || p.M < X_BM || expand_nc(p.M, p.N) == 0) return false;
   if (p.lda % 8 || p.ldb % 8 || p.ldc % 8 || (p.resid && p.ldr % 8)) return false;
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
@@ -243,15 +252,16 @@ bool expand_supported(const GemmParams& p) {
 
 template <int KF, bool RES, int NC>
 static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
+  constexpr int RF = KF > 8 ? 1 : 2;
   constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4;  // two W chunks + this workgroup's shifts
-  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  static_assert(lds <= (RF == 2 ? 80 : 160) * 1024, "two workgroups per CU (one with 8 waves at K = 512)");
   static bool attr_set = false;
-  auto kern = expand_res_kernel<KF, RES, NC>;
+  auto kern = expand_res_kernel<KF, RES, NC, RF>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((p.M + X_BM - 1) / X_BM, p.N / X_BN / NC), dim3(X_NT), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((p.M + X_BM - 1) / X_BM, p.N / X_BN / NC), dim3(64 * (X_BM / 16 / RF)), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -275,6 +285,7 @@ hipError_t run_expand(const GemmParams& p, hipStream_t stream) {
     case 64: return launch_expand<2>(p, stream);
     case 128: return launch_expand<4>(p, stream);
     case 256: return launch_expand<8>(p, stream);
+    case 512: return launch_expand<16>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -167,8 +167,8 @@ def test_c_abi_exports_every_declared_symbol():
 
 def test_bottleneck_expand_convs_take_the_panel_kernel():
     """hvr_conv2d_path (no launch, no GPU): the channel-expanding 1x1 + residual convs of layers 1-3 (resnet.py:248-264) go to
-    expand.hip at every batch size the window uses (15 frames, the 8 / 7-frame groups, one cached frame); everything else --
-    res5's K = 512, convs without a residual, 3x3 convs, the f32 parity mode, fewer than 128 pixels -- stays on the tile
+    expand.hip at every batch size the window uses (15 frames, the 8 / 7-frame groups, one cached frame), and so do res5's
+    (K = 512); everything else -- convs without a residual, 3x3 convs, the f32 parity mode, fewer than 128 pixels -- stays on the tile
     engine; tile hint 13 forces the panel kernel where it applies (no residual needed) and is ignored where it does not."""
     if not os.path.exists(native.LIB_PATH):
         native.build()
@@ -176,10 +176,10 @@ def test_bottleneck_expand_convs_take_the_panel_kernel():
     for frames in (15, 8, 7, 1):
         for H, W, c in layers:
             assert native.conv2d_path(frames, H, W, c, 4 * c) == 1, (frames, c)
-    assert native.conv2d_path(15, 38, 63, 512, 2048) == 0                       # res5: tile engine
+    assert native.conv2d_path(15, 38, 63, 512, 2048) == 1                       # res5's expand convs too (8 waves x 16 rows)
     assert native.conv2d_path(15, 38, 63, 256, 1024, resid=False) == 0          # automatic choice wants the residual
     assert native.conv2d_path(15, 38, 63, 256, 1024, resid=False, tile=13) == 1
-    assert native.conv2d_path(15, 38, 63, 512, 2048, tile=13) == 0
+    assert native.conv2d_path(15, 38, 63, 1024, 4096, tile=13) == 0             # K = 1024: not a shape the kernel has
     assert native.conv2d_path(15, 38, 63, 1024, 256) == 0                       # the reducing 1x1
     assert native.conv2d_path(15, 38, 63, 256, 256, k=3, pad=1) == 0
     # layer 1's conv2 (3x3, 64 -> 64, no residual) has its own persistent kernel (conv3x3.hip); nothing else does

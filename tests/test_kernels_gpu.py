@@ -77,8 +77,8 @@ def test_expand_conv_panel_kernel(Cin, Cout, H, W, B, relu, with_res):
     hint 13 and as the automatic choice; against the f32 statement of the op and against the tile engine (hint 1) on the
     same operands.  Shapes: every K the kernel instantiates (64 / 128 / 256) with 2, 4 and 8 chunks per workgroup, a
     ragged last row panel (M % 128 != 0: rows past M are clamped, not predicated), exactly one panel (M = 128), the
-    narrowest output it accepts (N = 2 chunks), no residual / no ReLU; K = 512 (res5) is declined by the kernel and
-    must come back from the tile engine unchanged."""
+    narrowest output it accepts (N = 2 chunks), no residual / no ReLU; K = 512 (res5) runs the 8-wave, one-row-fragment
+    form of the kernel."""
     x = _rand((B, H, W, Cin), torch.bfloat16, 61)
     w = _rand((Cout, 1, 1, Cin), torch.bfloat16, 62, 0.05)
     bias = _rand((Cout,), torch.float32, 63)

@@ -80,8 +80,17 @@ class BBoxHead(nn.Module, PackedMixin):
             cls_score = sum(cls_score) / float(len(cls_score))
         if not isinstance(scale_factor, (int, float)):
             raise NotImplementedError('per-axis scale_factor arrays are outside the HVR hot path')
-        logits = torch.cat([cls_score.float(), bbox_pred.float()], dim=1).contiguous()
         ncls = cls_score.shape[1]
+        # the heads' own read-out hands two column views of ONE f32 GEMM output (_readout): decode straight from it
+        # (row pitch and column offsets are arguments of hvr_det_decode) instead of concatenating a copy first
+        if (cls_score.dtype == torch.float32 and bbox_pred.dtype == torch.float32 and cls_score.stride(1) == 1 and bbox_pred.stride(1) == 1
+                and cls_score.stride(0) == bbox_pred.stride(0) and cls_score.shape[0] == bbox_pred.shape[0] > 1
+                and cls_score.untyped_storage().data_ptr() == bbox_pred.untyped_storage().data_ptr()):
+            reg_off = bbox_pred.storage_offset() - cls_score.storage_offset()
+            if ncls <= reg_off and reg_off + 4 <= cls_score.stride(0):
+                return native.det_decode(cls_score, 0, reg_off, ncls, rois, self.target_means, self.target_stds, img_shape,
+                                         float(scale_factor) if rescale else 0.0)
+        logits = torch.cat([cls_score.float(), bbox_pred.float()], dim=1).contiguous()
         return native.det_decode(logits, 0, ncls, ncls, rois, self.target_means, self.target_stds, img_shape,
                                  float(scale_factor) if rescale else 0.0)
 

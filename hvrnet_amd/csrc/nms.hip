@@ -553,6 +553,11 @@ __global__ __launch_bounds__(1024) void mc_nms_merge_kernel(const float* __restr
     dets[j * 5 + 4] = scores[(long)r * ncls + c + 1];
     labels[j] = c;
   }
+  // rows behind the count are zero (the caller hands uninitialised buffers)
+  for (int j = nout + threadIdx.x; j < max_num; j += blockDim.x) {
+    dets[j * 5 + 0] = dets[j * 5 + 1] = dets[j * 5 + 2] = dets[j * 5 + 3] = dets[j * 5 + 4] = 0.f;
+    labels[j] = 0;
+  }
   if (threadIdx.x == 0) *n_out = nout;
 }
 

@@ -745,9 +745,11 @@ def multiclass_nms(boxes, scores, score_thr, iou_thr, max_num):
     """boxes [R,4], scores [R,ncls] f32 -> (dets [max_num,5], labels [max_num] int64, n int32[1]) device tensors."""
     _need_cuda(boxes, scores)
     R, ncls = scores.shape
-    dets = torch.zeros((max_num, 5), dtype=torch.float32, device=boxes.device)
-    labels = torch.zeros(max_num, dtype=torch.long, device=boxes.device)
-    n_out = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    # (the merge kernel writes the count and zeroes the rows behind it: no fill launches in front of it)
+    alloc = torch.empty if R > 0 else torch.zeros
+    dets = alloc((max_num, 5), dtype=torch.float32, device=boxes.device)
+    labels = alloc(max_num, dtype=torch.long, device=boxes.device)
+    n_out = alloc(1, dtype=torch.int32, device=boxes.device)
     ws = _workspace(lib().hvr_multiclass_nms_workspace_bytes(R, ncls), boxes.device, 'mcnms')
     _check(lib().hvr_multiclass_nms(_ptr(boxes.contiguous()), _ptr(scores.contiguous()), R, ncls, float(score_thr),
                                     float(iou_thr), int(max_num), _ptr(dets), _ptr(labels), _ptr(n_out), _ptr(ws),

@@ -219,7 +219,8 @@ int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* st
  *   hvr_multiclass_nms: mmdet/core/post_processing/bbox_nms.py:6-66 (class-agnostic boxes)
  * logits [R][ldl] f32 with class logits at cls_off.. and 4 deltas at reg_off..;
  * rois [R][5]; scores [R][ncls]; boxes [R][4]; dets [max_num][5]; labels [max_num] int64
- * (0-based foreground class); *n_out device int32.  R <= 512.
+ * (0-based foreground class); *n_out device int32; rows [*n_out, max_num) of dets / labels come back zeroed (R > 0:
+ * the caller's buffers need no initialisation).  R <= 512.
  * scale_factor <= 0 means rescale=False.  img_w <= 0 means no clipping.
  * ---------------------------------------------------------------------------------- */
 int hvr_det_decode(const float* logits, int ldl, int cls_off, int reg_off, int ncls, const float* rois, int R,

@@ -135,15 +135,17 @@ class Bottleneck(nn.Module, PackedMixin):
             p['ds'] = fold_conv_bn(self.downsample[0], self.downsample[1], dtype)
         return p
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, out=None):
+        """out: where the block's output goes (a contiguous [B,OH,OW,4*planes] tensor), e.g. a frame group's slice of a map."""
         p = self.packed(x.device)
+        dst = out
         out = native.conv2d_nhwc(x, p['c1'][0], p['c1'][1], relu=True, stride=self.conv1_stride)
         out = native.conv2d_nhwc(out, p['c2'][0], p['c2'][1], relu=True, stride=self.conv2_stride, pad=self.dilation,
                                  dil=self.dilation)
         identity = x
         if self.downsample is not None:
             identity = native.conv2d_nhwc(x, p['ds'][0], p['ds'][1], relu=False, stride=self.stride)
-        return native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=identity, relu=True)
+        return native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=identity, relu=True, out=dst)
 
     def forward(self, x):
         return as_logical(self.forward_nhwc(as_nhwc(x, self.compute_dtype)))
@@ -243,8 +245,21 @@ class ResNet(nn.Module, PackedMixin):
         wf[:, :, :7, :3] = w
         return dict(stem=(wp.to(dtype), b), fused=wf.view(64, 7, 32).to(torch.bfloat16).contiguous())
 
-    def forward(self, x):
-        """x [B,3,H,W] f32 -> tuple of logical-NCHW feature maps (resnet.py:522-533)."""
+    def out_shape_nhwc(self, B, H, W):
+        """Physical [B,h,w,C] shape of the LAST returned map for a [B,3,H,W] input (stem 7x7/2 + pool 3x3/2, then one
+        stride per stage), or None when the net returns several maps."""
+        if len(self.out_indices) != 1:
+            return None
+        last = self.out_indices[0]
+        h, w = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        for i in range(last + 1):
+            h, w = (h - 1) // self.strides[i] + 1, (w - 1) // self.strides[i] + 1
+        return (B, h, w, 64 * 2 ** last * 4)
+
+    def forward(self, x, out=None):
+        """x [B,3,H,W] f32 -> tuple of logical-NCHW feature maps (resnet.py:522-533).  out: a contiguous NHWC tensor of
+        out_shape_nhwc(...) in the compute dtype that receives the (single) returned map, e.g. a slice of a larger batch."""
         if not x.is_cuda:
             raise NotImplementedError('ResNet runs on the GPU only (no CPU fallback)')
         p = self.packed(x.device)
@@ -256,11 +271,17 @@ class ResNet(nn.Module, PackedMixin):
             y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
             y = native.maxpool3x3s2_nhwc(y)
         outs = []
+        if out is not None:
+            assert len(self.out_indices) == 1, 'out= needs a single returned map'
         for i, name in enumerate(self.res_layers):
-            for blk in getattr(self, name):
-                y = blk.forward_nhwc(y)
+            blocks = list(getattr(self, name))
+            for j, blk in enumerate(blocks):
+                last = out is not None and i == self.out_indices[0] and j == len(blocks) - 1
+                y = blk.forward_nhwc(y, out=out) if last else blk.forward_nhwc(y)
             if i in self.out_indices:
                 outs.append(as_logical(y))
+            if out is not None and i == self.out_indices[0]:
+                break
         return tuple(outs)
 
     def forward_train_nhwc(self, x):

@@ -140,6 +140,11 @@ class TwoStageDetector(BaseDetector):
             return fn(x)
         main = torch.cuda.current_stream(x.device)
         sides = self._group_streams(x.device, G - 1)
+        whole = None
+        shape_of = getattr(fn, 'out_shape_nhwc', None)
+        if shape_of is not None and x.dim() == 4 and shape_of(x.shape[0], x.shape[2], x.shape[3]) is not None and os.environ.get('HVR_GROUP_CAT') != '1':
+            # every group writes its frames' slice of ONE map: no concatenation (a 147 MB copy at 15 frames) at the join
+            whole = torch.empty(shape_of(x.shape[0], x.shape[2], x.shape[3]), dtype=fn.compute_dtype, device=x.device)
         bounds = [round(i * x.shape[0] / G) for i in range(G + 1)]
         if G == 2 and x.shape[0] >= 5:
             # two UNEQUAL groups (9 + 6 of 15 frames): equal ones run the same kernel sequence in step and meet at every
@@ -153,12 +158,18 @@ class TwoStageDetector(BaseDetector):
         for g in range(1, G):
             with torch.cuda.stream(sides[g - 1]):
                 sides[g - 1].wait_event(start)
-                outs[g] = fn(x[bounds[g]:bounds[g + 1]])
-        outs[0] = fn(x[bounds[0]:bounds[1]])
+                if whole is not None:
+                    whole.record_stream(sides[g - 1])
+                    outs[g] = fn(x[bounds[g]:bounds[g + 1]], out=whole[bounds[g]:bounds[g + 1]])
+                else:
+                    outs[g] = fn(x[bounds[g]:bounds[g + 1]])
+        outs[0] = fn(x[bounds[0]:bounds[1]], out=whole[bounds[0]:bounds[1]]) if whole is not None else fn(x[bounds[0]:bounds[1]])
         for g in range(1, G):
             main.wait_stream(sides[g - 1])
             for t in outs[g]:
                 t.record_stream(main)
+        if whole is not None:
+            return (whole.permute(0, 3, 1, 2),)
         # concatenate in the physical (NHWC) layout, frames outermost
         return tuple(torch.cat([o[k].permute(0, 2, 3, 1) for o in outs], 0).permute(0, 3, 1, 2) for k in range(len(outs[0])))
 

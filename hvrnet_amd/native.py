@@ -292,14 +292,21 @@ def gemm_splitk(a, w, staging=None, tile=None):
     return out
 
 
-def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None, tile=None):
-    """x [B,H,W,Cin] (physical NHWC), w [Cout,KH,KW,Cin] -> [B,OH,OW,Cout]."""
+def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None, tile=None, out=None):
+    """x [B,H,W,Cin] (physical NHWC), w [Cout,KH,KW,Cin] -> [B,OH,OW,Cout]; out: a contiguous tensor of that shape and the
+    output dtype to write into (the caller-allocates contract of the C ABI) instead of a fresh one."""
     _need_cuda(x, w, bias, resid)
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-    y = torch.empty((B, OH, OW, Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    odt = torch.float32 if out_f32 else x.dtype
+    if out is not None:
+        assert tuple(out.shape) == (B, OH, OW, Cout) and out.dtype == odt and out.is_contiguous() and out.device == x.device, \
+            (tuple(out.shape), (B, OH, OW, Cout), out.dtype)
+        y = out
+    else:
+        y = torch.empty((B, OH, OW, Cout), dtype=odt, device=x.device)
     d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, KH=KH, KW=KW,
                  stride=stride, pad=pad, dil=dil,
                  bias=bias.data_ptr() if bias is not None else None,

@@ -2,6 +2,7 @@
 1000x600 frames (padded 608x1008), 300 proposals / frame, T = 15 frames / window.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 2                      # launches the two ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -11,14 +12,24 @@ steps, and one key-frame detection comes out (per-class arrays on the host, as t
 bbox2result returns them).  Frames are already resident in HBM when timing starts.  Ranks run
 independent clips (no data-path collective): weak scaling, value = N * steps / max-over-ranks time.
 
-Extra JSON keys: `roofline` (relation core, measured with HIP events inside the timed region),
-`kernel_classes` (per-class time / achieved rate from one extra instrumented window after the timed
-region) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (one process per
+GPU under torch.distributed.run, 127.0.0.1 rendezvous -- what tools/dist_test.sh:9-10 does for the reference) and refuses
+loudly when fewer than N devices are visible.
+
+Extra JSON keys: `roofline` (relation core, measured with HIP events inside the timed region), `kernel_classes`
+(per-class time / achieved rate from one extra instrumented window after the timed region), `f32_parity_mode` (the same
+window timed in the f32 compute mode, the mode whose outputs meet north_star's 1e-3), `parity` (this run's detections --
+headline dtype and f32 -- against the CPU oracle's on the same frames) and `cpu_baseline` (the CPU oracle timed on the
+whole window: 1 warm-up + median of 3, plus configs[0]; rank 0, N = 1); for N > 1 `per_rank`, `rccl_world_size` and
+`train_allreduce` (the training step's one exchange: a flat f32 gradient buffer of the detector's trainable size).
 """
 import argparse
 import contextlib
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,9 +41,12 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TF = {'bf16': 2500.0, 'f32': 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7           # per GPU, SURVEY.md section 5
+# trainable f32 parameters whose gradients one training step exchanges (176 MB HVR / 271 MB SELSA)
+TRAIN_GRAD_ELEMS = {'hvr': 44128768, 'selsa': 67700000}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -41,12 +55,18 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--proposals', type=int, default=300)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle leg (and with it the `parity` object)')
+    ap.add_argument('--quick', action='store_true', help='cpu_baseline on a 3-frame sample (scaled) instead of whole windows')
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the f32 parity-mode timing')
     ap.add_argument('--no-train-step', action='store_true', help='skip the training-step side measurement (tools/train_bench.py)')
+    ap.add_argument('--no-side-loops', action='store_true', help='skip ref_loop / cached_loop / two_in_flight (profiling runs)')
     ap.add_argument('--inflight', type=int, default=int(os.environ.get('HVR_INFLIGHT', '1')),
                     help='independent windows enqueued on that many HIP streams in turn (throughput mode)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
-    return ap.parse_args()
+    ap.add_argument('--stub', action='store_true',
+                    help='host-logic self-test of the launcher / barrier / max-over-ranks / JSON contract without a GPU: the window '
+                         'is a fixed sleep and the process group is gloo (tests/test_bench_launcher.py); never a measurement')
+    return ap.parse_args(argv)
 
 
 def host_cores():
@@ -62,10 +82,35 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(head, T, n_prop, sd):
-    """CPU oracle ("port": PyTorch-CPU restatement, oracle/hvr_oracle.py) on a bounded sample of one clip-mode window:
-    3 of the T frames through backbone/res5/RPN/proposals/RoIAlign (scaled by T/3) + the full-size relation head
-    (M = T * n_prop rows) + read-out, all host cores."""
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` without a torchrun environment: start the N ranks (one process per GPU, tools/dist_test.sh:9-10) and
+    return their exit code.  The children see WORLD_SIZE and run main() directly."""
+    if not args.stub:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d asked for but only %d GPU(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); '
+                             'refusing to run fewer ranks than asked for\n' % (args.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC only on this driver: RCCL needs it across processes
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------ CPU oracle leg
+def cpu_baseline_quick(head, T, n_prop, sd):
+    """--quick: the oracle on 3 of the T frames (scaled by T/3) + the full-size relation head and read-out."""
     from hvrnet_amd import synthetic as S
     from oracle import hvr_oracle as O
     cores = host_cores()
@@ -85,36 +130,84 @@ def cpu_baseline(head, T, n_prop, sd):
         cfg = dict(O.RPN_TEST_CFG, nms_post=n_prop, max_num=n_prop)
         props = [O.rpn_get_bboxes_single(cls[i], reg[i], anchors, metas[i]['img_shape'], cfg) for i in range(ns)]
         rois = [O.bbox2roi([p]) for p in props]
-        feats = torch.cat([O.roi_align(c5[i:i + 1], rois[i], 7, 1.0 / 16, 2) for i in range(ns)], 0)
+        torch.cat([O.roi_align(c5[i:i + 1], rois[i], 7, 1.0 / 16, 2) for i in range(ns)], 0)
         t_frames = time.time() - t0
         M = T * n_prop
         g = torch.Generator().manual_seed(0)
         roi_feats = torch.rand((M, 256, 7, 7), generator=g)
-        key = T // 2
-        cur = dict(start=key * n_prop, length=n_prop)
+        cur = dict(start=(T // 2) * n_prop, length=n_prop)
         t0 = time.time()
         if head == 'hvr':
             cs, rs = O.hvr_head_forward_test(roi_feats, sd, cur, n_prop, T)
         else:
             c, r = O.selsa_head_forward(roi_feats, sd, cur, n_prop, T)
             cs, rs = [c], [r]
-        key_rois = torch.cat([torch.zeros(n_prop, 1), props[0][:n_prop, :4]], 1) if props[0].shape[0] >= n_prop else \
-            torch.cat([torch.zeros(n_prop, 1), torch.rand(n_prop, 4) * 500], 1)
+        key_rois = torch.cat([torch.zeros(n_prop, 1), torch.rand(n_prop, 4) * 500], 1)
         for c, r in zip(cs, rs):
             O.get_det_bboxes(key_rois, c, r, (600, 1000, 3), 1.0, True, O.RCNN_TEST_CFG)
         t_head = time.time() - t0
     window_s = t_frames * (T / float(ns)) + t_head
     return dict(value=1.0 / window_s, unit='frames/s', cores=cores, kind='port',
-                sample='%d of %d frames through backbone+res5+RPN+proposals+RoIAlign (%.2f s, scaled x%.1f) + full relation head '
-                       'M=%d and read-out (%.2f s); torch %d threads' % (ns, T, t_frames, T / float(ns), M, t_head, cores),
-                window_seconds=window_s)
+                sample='--quick: %d of %d frames through backbone+res5+RPN+proposals+RoIAlign (%.2f s, scaled x%.1f) + full relation '
+                       'head M=%d and read-out (%.2f s); torch %d threads' % (ns, T, t_frames, T / float(ns), M, t_head, cores),
+                window_seconds=window_s), None
+
+
+def cpu_baseline_full(head, T, n_prop, sd, frame_ids):
+    """SURVEY.md 8(d) "CPU baseline": the CPU oracle ("port": the PyTorch-CPU restatement oracle/hvr_oracle.py, pinned to the
+    reference's modules by tests/golden) on the SAME synthetic clip, clip mode, whole windows: 1 warm-up + median of 3, all
+    usable host cores; plus configs[0] (1 key + 2 reference frames, 32 proposals).  -> (cpu_baseline dict, last window's result)."""
+    from hvrnet_amd import synthetic as S
+    from oracle import hvr_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    imgs = [S.synth_frame(i) for i in frame_ids]
+    metas = [S.synth_meta() for _ in frame_ids]
+    rpn_cfg = dict(O.RPN_TEST_CFG, nms_post=n_prop, max_num=n_prop)
+    times, res = [], None
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.time()
+            res = O.clip_forward(imgs, metas, sd, head, T // 2, n_prop, T, rpn_cfg=rpn_cfg)
+            times.append(time.time() - t0)
+        # configs[0]: the reference's own CPU-runnable case
+        t1 = []
+        for it in range(3):
+            t0 = time.time()
+            O.clip_forward(imgs[:3], metas[:3], sd, head, 1, 32, 3, rpn_cfg=dict(O.RPN_TEST_CFG, nms_post=32, max_num=32))
+            t1.append(time.time() - t0)
+    runs = sorted(times[1:])
+    window_s = runs[len(runs) // 2]
+    c1 = sorted(t1[1:])[0]
+    out = dict(value=1.0 / window_s, unit='frames/s', cores=cores, kind='port',
+               sample='whole %d-frame clip-mode windows of the same synthetic clip (600x1000, %d proposals/frame, %s head) through '
+                      'oracle.clip_forward: 1 warm-up + median of 3 (%.2f / %.2f / %.2f s); torch %d threads'
+                      % (T, n_prop, head, runs[0], runs[1], runs[2], cores),
+               window_seconds=window_s, warmup_window_seconds=times[0],
+               config1=dict(what='configs[0]: 1 key + 2 reference frames, 32 proposals, one window (1 warm-up, best of 2)',
+                            window_seconds=c1, frames_per_s=1.0 / c1))
+    return out, (res if head == 'hvr' else res[0])
+
+
+def parity_object(head, dtype_name, got, want):
+    """This run's detections against the CPU oracle's (same frames, same weights): position-by-position (class indices exact?)
+    and, for results that keep different boxes at the discontinuous steps, box-to-box matching."""
+    from hvrnet_amd import parity
+    g, w = (got[-1], want[-1]) if head == 'hvr' else (got, want)
+    st, tr = parity.strict(g, w), parity.track(g, w)
+    return dict(dtype=dtype_name, against='oracle.clip_forward (CPU, f32) on the same %s window, final branch' % head,
+                class_flips=st['class_flips'], max_score_err=round(st['max_score_err'], 6), max_box_err=round(st['max_box_err'], 5),
+                detections=st['n'],
+                matched=dict(what='oracle detections with score >= 0.05 that reappear with the same class and IoU > 0.9',
+                             n_ref=tr['n_ref'], same_class_frac=round(tr['same_class_frac'], 4),
+                             max_score_err=round(tr['max_score_err'], 5), mean_score_err=round(tr['mean_score_err'], 5),
+                             max_box_err=round(tr['max_box_err'], 4)))
 
 
 def train_step_side_measurement(head):
     """configs[4] beside the headline, never as `value`: one training iteration of the same detector family (HNMBRCNN: 5 videos x 3
     frames in, 3 chosen; SelsaRCNN: 1 key + 2 reference frames) at 600x1000 / 300 proposals, bf16 operands with f32 master weights,
     measured by tools/train_bench.py in its own process after the timed region.  None if that run fails."""
-    import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_bench.py'), '--head', head, '--steps', '5', '--warmup', '2'],
                            capture_output=True, text=True, timeout=300)
@@ -127,14 +220,117 @@ def train_step_side_measurement(head):
         return None
 
 
-def main():
-    args = parse()
+def allreduce_leg(dist, world, head, device, iters=5):
+    """The training step's one exchange (mmdet/core/utils/dist_utils.py:9-28: one flat f32 all-reduce of every gradient)
+    timed alone on a buffer of the detector's trainable size -- RCCL over xGMI on GPUs (gloo in --stub runs)."""
+    n = TRAIN_GRAD_ELEMS[head]
+    buf = torch.ones(n if device.type == 'cuda' else min(n, 1 << 20), dtype=torch.float32, device=device)
+    nbytes = buf.numel() * 4
+
+    def sync():
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
+    for _ in range(2):
+        dist.all_reduce(buf)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    sync()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    t = torch.tensor([ms], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    algbw = nbytes / (ms * 1e-3) / 1e9
+    frac = 2.0 * (world - 1) / world
+    return dict(what='one flat f32 gradient all-reduce, %s training step (%.1f MB)' % (head.upper(), nbytes / 1e6), bytes=nbytes,
+                ms=round(ms, 4), algbw_gbs=round(algbw, 2), busbw_gbs=round(algbw * frac, 2),
+                est_ring_one_link_ms=round(frac * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3, 3),
+                est_direct_all_links_ms=round(frac * nbytes / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS * 1e9) * 1e3, 3),
+                backend=dist.get_backend())
+
+
+def lib_sha16():
+    from hvrnet_amd import native
+    return hashlib.sha256(open(native.LIB_PATH, 'rb').read()).hexdigest()[:16]
+
+
+def relation_traffic():
+    """HBM-side bytes per relation-core launch from the committed PMC passes (bench.py cannot collect PMC itself): the newest
+    profiles/r*_relation_traffic.json whose `lib_sha16` names THIS build of libhvr_hip.so; None (stale) otherwise."""
+    import glob
+    sha = lib_sha16()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_relation_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+        except ValueError:
+            continue
+        if d.get('lib_sha16') == sha:
+            return d.get('traffic_bytes_per_launch'), os.path.basename(path)
+    return None, 'no profiles/r*_relation_traffic.json was collected for this build (lib %s): tools/collect_profiles.sh' % sha
+
+
+# ------------------------------------------------------------------------------------------ stub (CPU host-logic self-test)
+def stub_main(args, rank, local_rank, world):
+    import torch.distributed as dist
+    dev = torch.device('cpu')
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.002)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))      # rank r is (1 + r)x slower: the reported time must be the slowest rank's
+    sync()
+    mine = time.perf_counter() - t0
+    elapsed, per_rank, ar = mine, [mine], None
+    if world > 1:
+        t = torch.tensor([mine], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([mine], dtype=torch.float64))
+        per_rank = [float(x.item()) for x in allt]
+        ar = allreduce_leg(dist, world, args.head, dev, iters=2)
+    if rank == 0:
+        out = dict(metric='STUB (launcher self-test, not a measurement)', value=round(world * args.steps / elapsed, 3), unit='frames/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='none', data='none',
+                   config=dict(workload='stub'), per_rank=[dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)],
+                   rccl_world_size=(dist.get_world_size() if world > 1 else 1), gpus_requested=args.gpus)
+        if ar is not None:
+            out['train_allreduce'] = ar
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ the benchmark
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s); the JSON line reports the ranks that ran\n' % (args.gpus, world))
+    if args.stub:
+        return stub_main(args, rank, local_rank, world)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit('bench.py: rank %d has no GPU %d (%d visible)' % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world)
     dev = torch.device('cuda', local_rank if world > 1 else 0)
@@ -151,9 +347,9 @@ def main():
     sd = S.synth_state_dict(args.head)
     model = hvrnet_amd.build_model(cfg, sd, dt, dev)
     # each rank works on its own clip: different synthetic frames per rank
-    frames = torch.cat([S.synth_frame(rank * 1000 + i) for i in range(T)], 0).to(dev)  # [T,3,608,1008] resident in HBM
+    frame_ids = [rank * 1000 + i for i in range(T)]
+    frames = torch.cat([S.synth_frame(i) for i in frame_ids], 0).to(dev)  # [T,3,608,1008] resident in HBM
     metas = [S.synth_meta() for _ in range(T)]
-    n_keys = []
 
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 else [None]
     if args.inflight > 1 and 'HVR_FRAME_GROUPS' not in os.environ:
@@ -180,86 +376,97 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    pend = None
-    for _ in range(args.warmup):
-        pend = step(pend)
-    if pend is not None:
-        pend.result()
-    sync()
-    native.profile_begin(tags=('relation_full', 'relation_key'))
-    t0 = time.perf_counter()
-    pend = None
-    for _ in range(args.steps):
-        pend = step(pend)
-    res = pend.result()
-    sync()
-    elapsed = time.perf_counter() - t0
-    rel = native.profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # the reference's own steady-state loop (tools/test.py:214-250): ONE new frame through the backbone per output
-    # frame, the other T-1 C4 maps come from the deque; reported next to the clip-mode headline, never as `value`
-    with torch.no_grad():
-        c4_all = model(img=frames, img_meta=metas, backbone_feat=True)[0]
-        window = [c4_all[i:i + 1] for i in range(T)]
-    n_loop = max(3, min(args.steps, 10))
-    sync()
-    t1 = time.perf_counter()
-    for i in range(n_loop):
-        with torch.no_grad():
-            new = model(img=frames[i % T:i % T + 1], img_meta=[metas[0]], backbone_feat=True)[0]
-            window = window[1:] + [new]
-            model(x=window, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
-    sync()
-    ref_loop_fps = n_loop / (time.perf_counter() - t1)
-
-    # the same loop with the per-frame cache: res5 / RPN / RoIAlign / fc_new_1 run once per incoming frame
-    # (model.frame_tensors), a window runs the relation stages and the read-out on the T cached entries; the results
-    # are bit-identical to the two loops above (tests/test_parity_gpu.py::test_cached_frame_loop_matches_clip_mode)
-    with torch.no_grad():
-        entries = [model.frame_tensors(c, m) for c, m in zip(window, metas)]
-    sync()
-    t2 = time.perf_counter()
-    pend = None
-    for i in range(n_loop):
-        with torch.no_grad():
-            new = model(img=frames[i % T:i % T + 1], img_meta=[metas[0]], backbone_feat=True)[0]
-            window = window[1:] + [new]
-            entries = entries[1:] + [model.frame_tensors(new, metas[0])]
-            nxt = model.forward_feat_frames(entries, c4s=window, rescale=True, defer=True)
+    def timed(steps, warmup, tags=None):
+        pend = None
+        for _ in range(warmup):
+            pend = step(pend)
         if pend is not None:
             pend.result()
-        pend = nxt
-    pend.result()
-    sync()
-    cached_loop_fps = n_loop / (time.perf_counter() - t2)
+        sync()
+        if tags:
+            native.profile_begin(tags=tags)
+        t0 = time.perf_counter()
+        pend = None
+        for _ in range(steps):
+            pend = step(pend)
+        res = pend.result()
+        sync()
+        el = time.perf_counter() - t0
+        spans = native.profile_end() if tags else None
+        return el, res, spans
 
-    # clip mode again with TWO independent windows in flight on two HIP streams (frame groups off): the latency-bound
-    # phases of one window (proposals, read-out) run under the dense phases of the other.  Reported beside the headline:
-    # the headline run stays single-lane so that the HIP-event times around the relation core are that kernel's own
-    overlap2_fps = None
-    if args.inflight == 1 and world == 1:
-        lanes[:] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        groups0 = type(model).frame_groups
-        type(model).frame_groups = 1
+    mine, res, rel = timed(args.steps, args.warmup, tags=('relation_full', 'relation_key'))
+    elapsed, per_rank = mine, [mine]
+    if world > 1:
+        t = torch.tensor([mine], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([mine], dtype=torch.float64, device=dev))
+        per_rank = [float(x.item()) for x in allt]
+
+    # ---- the same window in the f32 compute mode (exact-f32 MFMA): the mode whose outputs meet north_star's 1e-3 ----
+    f32_leg = res_f32 = None
+    if args.dtype == 'bf16' and not args.no_f32_leg and world == 1:
+        hvrnet_amd.set_compute_dtype(model, torch.float32)
+        n32 = max(2, min(args.steps, 5))
+        el32, res_f32, _ = timed(n32, 1)
+        f32_leg = dict(frames_per_s=round(n32 / el32, 3), ms_per_step=round(el32 / n32 * 1e3, 3), steps=n32, dtype='f32',
+                       what='the same clip-mode window with f32 operands on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 '
+                            'rate): the compute mode whose detections match the CPU reference path to 1e-3')
+        hvrnet_amd.set_compute_dtype(model, dt)
+
+    ref_loop_fps = cached_loop_fps = overlap2_fps = None
+    n_loop = max(3, min(args.steps, 10))
+    if not args.no_side_loops:
+        # the reference's own steady-state loop (tools/test.py:214-250): ONE new frame through the backbone per output
+        # frame, the other T-1 C4 maps come from the deque; reported next to the clip-mode headline, never as `value`
+        with torch.no_grad():
+            c4_all = model(img=frames, img_meta=metas, backbone_feat=True)[0]
+            window = [c4_all[i:i + 1] for i in range(T)]
+        sync()
+        t1 = time.perf_counter()
+        for i in range(n_loop):
+            with torch.no_grad():
+                new = model(img=frames[i % T:i % T + 1], img_meta=[metas[0]], backbone_feat=True)[0]
+                window = window[1:] + [new]
+                model(x=window, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+        sync()
+        ref_loop_fps = n_loop / (time.perf_counter() - t1)
+
+        # the same loop with the per-frame cache: res5 / RPN / RoIAlign / fc_new_1 run once per incoming frame
+        # (model.frame_tensors), a window runs the relation stages and the read-out on the T cached entries; the results
+        # are bit-identical to the two loops above (tests/test_parity_gpu.py::test_cached_frame_loop_matches_clip_mode)
+        with torch.no_grad():
+            entries = [model.frame_tensors(c, m) for c, m in zip(window, metas)]
+        sync()
+        t2 = time.perf_counter()
         pend = None
-        for _ in range(2):
-            pend = step(pend)
+        for i in range(n_loop):
+            with torch.no_grad():
+                new = model(img=frames[i % T:i % T + 1], img_meta=[metas[0]], backbone_feat=True)[0]
+                window = window[1:] + [new]
+                entries = entries[1:] + [model.frame_tensors(new, metas[0])]
+                nxt = model.forward_feat_frames(entries, c4s=window, rescale=True, defer=True)
+            if pend is not None:
+                pend.result()
+            pend = nxt
         pend.result()
         sync()
-        n2 = max(4, min(args.steps, 12))
-        t3 = time.perf_counter()
-        pend = None
-        for _ in range(n2):
-            pend = step(pend)
-        pend.result()
-        sync()
-        overlap2_fps = n2 / (time.perf_counter() - t3)
-        lanes[:] = [None]
-        type(model).frame_groups = groups0
+        cached_loop_fps = n_loop / (time.perf_counter() - t2)
+
+        # clip mode again with TWO independent windows in flight on two HIP streams (frame groups off): the latency-bound
+        # phases of one window (proposals, read-out) run under the dense phases of the other.  Reported beside the headline:
+        # the headline run stays single-lane so that the HIP-event times around the relation core are that kernel's own
+        if args.inflight == 1 and world == 1:
+            lanes[:] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            groups0 = type(model).frame_groups
+            type(model).frame_groups = 1
+            n2 = max(4, min(args.steps, 12))
+            el2, _, _ = timed(n2, 2)
+            overlap2_fps = n2 / el2
+            lanes[:] = [None]
+            type(model).frame_groups = groups0
 
     # per-class breakdown from one extra, fully instrumented window (outside the timed region)
     native.profile_begin(tags=('*',))
@@ -272,21 +479,21 @@ def main():
             rate = d['work'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
             sys.stderr.write('%-44s calls %3d  %8.3f ms  %8.1f T(FLOP|B)/s\n' % (tag, d['calls'], d['ms'], rate))
 
+    ar = allreduce_leg(dist, world, args.head, dev) if world > 1 else None
+
     if rank == 0:
         branch = res[-1] if args.head == 'hvr' else res
         n_det = int(sum(len(r) for r in branch))
         full = rel.get('relation_full', dict(calls=0, ms=0.0, work=0.0))
         peak = MFMA_PEAK_TF[args.dtype]
         roofline = None
-        traffic = None  # HBM-side bytes per launch come from the committed PMC passes (bench.py cannot collect PMC itself)
-        tpath = os.path.join(ROOT, 'profiles', 'r01_relation_traffic.json')
-        if os.path.exists(tpath) and T * n_prop == 4500 and args.dtype == 'bf16':
-            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+        traffic, traffic_src = (relation_traffic() if T * n_prop == 4500 and args.dtype == 'bf16'
+                                else (None, 'collected for the 4500-row bf16 problem only'))
         if full['calls']:
             ach = full['work'] / (full['ms'] * 1e-3) / 1e12
-            roofline = dict(kernel='relation core (scores incl. V^T copy + apply: 2 launches), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
+            roofline = dict(kernel='relation core (the launches of hvr_relation_fwd: scores + apply), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
-                            launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
+                            traffic_source=traffic_src, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
                             flops_per_launch=full['work'] / full['calls'])
         kc = {}
         for tag, d in classes.items():
@@ -308,16 +515,34 @@ def main():
                                mode='clip (all T frames through backbone+res5+RPN+RoIAlign+head every step)',
                                parallelism='dp%d independent clips, no collectives' % world, windows_in_flight=args.inflight,
                                key_frame_detections=n_det),
-                   roofline=roofline, kernel_classes=kc,
-                   ref_loop=dict(frames_per_s_per_gpu=round(ref_loop_fps, 2), steps=n_loop,
-                                 what='tools/test.py steady state: 1 new backbone frame + res5/RPN/RoIAlign/head on all T per output frame'),
-                   cached_loop=dict(frames_per_s_per_gpu=round(cached_loop_fps, 2), steps=n_loop,
-                                    what='the same loop with per-frame caching of res5/RPN/RoIAlign/fc_new_1 (identical detections)'))
+                   roofline=roofline, kernel_classes=kc, gpus_requested=args.gpus,
+                   per_rank=[dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)],
+                   rccl_world_size=(dist.get_world_size() if world > 1 else 1))
+        if f32_leg is not None:
+            out['f32_parity_mode'] = f32_leg
+        if ref_loop_fps is not None:
+            out['ref_loop'] = dict(frames_per_s_per_gpu=round(ref_loop_fps, 2), steps=n_loop,
+                                   what='tools/test.py steady state: 1 new backbone frame + res5/RPN/RoIAlign/head on all T per output frame')
+            # ~650 GF (HVR) / 504 GF (SELSA) per output frame with the per-frame cache (SURVEY.md 8d "stream mode")
+            gf = 650.0 if args.head == 'hvr' else 504.0
+            out['cached_loop'] = dict(frames_per_s_per_gpu=round(cached_loop_fps, 2), steps=n_loop,
+                                      tflops=round(cached_loop_fps * gf / 1e3, 1), frac_mfma_peak=round(cached_loop_fps * gf / 1e3 / peak, 4),
+                                      what='the same loop with per-frame caching of res5/RPN/RoIAlign/fc_new_1 (identical detections); '
+                                           '%.0f GF per output frame' % gf)
         if overlap2_fps is not None:
             out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2),
                                         what='clip mode, two independent windows in flight on two HIP streams (--inflight 2)')
+        if ar is not None:
+            out['train_allreduce'] = ar
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.head, T, n_prop, sd)
+            if args.quick:
+                out['cpu_baseline'], want = cpu_baseline_quick(args.head, T, n_prop, sd)
+            else:
+                out['cpu_baseline'], want = cpu_baseline_full(args.head, T, n_prop, sd, frame_ids)
+            if want is not None:
+                out['parity'] = parity_object(args.head, args.dtype, res, want)
+                if res_f32 is not None:
+                    out['f32_parity_mode']['parity'] = parity_object(args.head, 'f32', res_f32, want)
         if world == 1 and not args.no_train_step:
             ts = train_step_side_measurement(args.head)
             if ts is not None:

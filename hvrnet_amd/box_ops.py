@@ -92,8 +92,18 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, s
     if nms_cfg_.pop('type', 'nms') != 'nms':
         raise NotImplementedError('only greedy nms is on the HVR hot path (configs use type="nms")')
     iou_thr = nms_cfg_.pop('iou_thr')
-    if max_num is None or max_num < 0:
-        max_num = multi_bboxes.shape[0] * (multi_scores.shape[1] - 1)
-    dets, labels, n = native.multiclass_nms(multi_bboxes.float(), multi_scores.float(), score_thr, iou_thr, max(int(max_num), 1))
+    R, nfg = multi_bboxes.shape[0], multi_scores.shape[1] - 1
+    boxes, scores = multi_bboxes.float(), multi_scores.float()
+    if max_num < 0:
+        # The reference's default max_num = -1 is not "no cap": `bboxes.shape[0] > max_num` is always true, so the survivors are
+        # sorted by score and `inds[:max_num]` drops the last |max_num| of them (bbox_nms.py:55-59).  Reproduced as written:
+        # count the survivors first (uncapped pass, class order), then cut to count + max_num in score order.
+        dets, labels, n = native.multiclass_nms(boxes, scores, score_thr, iou_thr, max(R * nfg, 1))
+        k = int(n.item()) + int(max_num)
+        if k <= 0:
+            return dets[:0], labels[:0]
+        dets, labels, n = native.multiclass_nms(boxes, scores, score_thr, iou_thr, k)
+        return dets[:k], labels[:k]
+    dets, labels, n = native.multiclass_nms(boxes, scores, score_thr, iou_thr, max(int(max_num), 1))
     k = int(n.item())
     return dets[:k], labels[:k]

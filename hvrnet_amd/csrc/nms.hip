@@ -407,16 +407,19 @@ __global__ __launch_bounds__(1024) void mc_nms_class_kernel(const float* __restr
     const int lane = threadIdx.x;
     unsigned long long supp = 0ull;
     int kept = 0;
-    for (int base = 0; base < ncand; base += 64) {
-      const int mine = base + lane < ncand ? (int)idx[base + lane] : 0;
-      unsigned long long rows[64];
+    // (chunks of 32: 64 prefetched 64-bit rows are 128 VGPRs, the whole budget of a 1024-thread workgroup -- the
+    // compiler spilled; nms.hip is in build.sh's -Rpass-analysis / check_regs gate now)
+    constexpr int CH = 32;
+    for (int base = 0; base < ncand; base += CH) {
+      const int mine = (lane < CH && base + lane < ncand) ? (int)idx[base + lane] : 0;
+      unsigned long long rows[CH];
 #pragma unroll
-      for (int j = 0; j < 64; ++j) {
+      for (int j = 0; j < CH; ++j) {
         const int r = __builtin_amdgcn_readlane(mine, j);
         rows[j] = lane < words ? iou[r][lane] : 0ull;
       }
 #pragma unroll
-      for (int j = 0; j < 64; ++j) {
+      for (int j = 0; j < CH; ++j) {
         if (base + j < ncand) {  // wave-uniform
           const int r = __builtin_amdgcn_readlane(mine, j);
           const unsigned long long wv = readlane64(supp, r >> 6);
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(1024) void mc_nms_class_kernel(const float* __restr
 // keeps the max_num highest scores in descending order (bbox_nms.py:54-61)
 __global__ __launch_bounds__(1024) void mc_nms_merge_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                             int R, int ncls, const unsigned char* __restrict__ keepflag,
-                                                            const int* __restrict__ kcount, int max_num,
+                                                            const int* __restrict__ kcount, int max_num, int sp2,
                                                             float* __restrict__ dets, long long* __restrict__ labels,
                                                             int* __restrict__ n_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -475,14 +478,18 @@ __global__ __launch_bounds__(1024) void mc_nms_merge_kernel(const float* __restr
   }
   __syncthreads();
   int nout = total;
-  if (total > max_num) {
+  if (total > max_num && sp2 == 0) {
+    // no LDS for the select stage (max_num close to the list length, e.g. the reference's max_num = -1 quirk): sort the
+    // whole list in place -- same order (score desc, list position asc), the padding entries (key 0) go last
+    bitonic_sort_pairs(key, idx, np2);
+    nout = max_num;
+  } else if (total > max_num) {
     // top max_num by (score desc, list position asc): radix-select the max_num-th key (4 passes over the LDS list),
     // gather the entries above it plus the first ties, and sort only those (bbox_nms.py:54-61 sorts everything and
     // cuts; the survivors and their order are the same)
     __shared__ int hist[256];
     __shared__ uint32_t sh_prefix, sh_remaining;
     __shared__ int sh_count;
-    const int sp2 = next_pow2(max_num);
     uint32_t* skey = idx + np2;
     uint32_t* sidx = skey + sp2;
     uint32_t prefix = 0u, remaining = (uint32_t)max_num;
@@ -632,8 +639,12 @@ hipError_t run_multiclass_nms(const float* boxes, const float* scores, int R, in
   hipLaunchKernelGGL(mc_nms_class_kernel, dim3(ncls - 1), dim3(1024), 0, s, boxes, scores, R, ncls, score_thr, iou_thr, keepflag, kcount);
   int np2 = 1;
   while (np2 < (ncls - 1) * R) np2 <<= 1;
+  // the select stage (radix-select the max_num-th score, sort only the entries above it) needs a second LDS list of
+  // next_pow2(max_num) entries; when that does not fit beside the survivor list -- max_num close to the list length -- or can
+  // never run (max_num >= every possible survivor count) the kernel sorts the survivor list in place instead (sp2 = 0)
   int sp2 = 1;
   while (sp2 < max_num) sp2 <<= 1;
+  if (max_num >= (ncls - 1) * R || (size_t)np2 * 8 + (size_t)sp2 * 8 > 160 * 1024 - 3072) sp2 = 0;
   const size_t lds = (size_t)np2 * 8 + (size_t)sp2 * 8;
   if (lds > 160 * 1024 - 3072) return hipErrorInvalidValue;
   static bool attr = false;
@@ -641,7 +652,7 @@ hipError_t run_multiclass_nms(const float* boxes, const float* scores, int R, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mc_nms_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 3072);
     attr = true;
   }
-  hipLaunchKernelGGL(mc_nms_merge_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, R, ncls, keepflag, kcount, max_num, dets, labels, n_out);
+  hipLaunchKernelGGL(mc_nms_merge_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, R, ncls, keepflag, kcount, max_num, sp2, dets, labels, n_out);
   return hipGetLastError();
 }
 

@@ -20,6 +20,17 @@ class FlatParams(object):
     """Re-homes the trainable parameters of `module` into one flat f32 buffer (parameters keep their shapes as views)."""
 
     def __init__(self, module):
+        from .backbone import PackedMixin
+        # inference-layout weight caches (BN folded, packed per dtype) of the modules whose parameters this object updates:
+        # they are functions of the parameters and must be rebuilt after every update (see sgd_step)
+        def owned(m):  # the parameters a packed module folds into its cache: its subtree minus nested packed modules
+            for p in m.parameters(recurse=False):
+                yield p
+            for c in m.children():
+                if not isinstance(c, PackedMixin):
+                    for p in owned(c):
+                        yield p
+        self._packed_modules = [m for m in module.modules() if isinstance(m, PackedMixin) and any(p.requires_grad for p in owned(m))]
         self.params = [p for p in module.parameters() if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params), 'f32 parameters only'
         dev = self.params[0].device
@@ -52,6 +63,11 @@ class FlatParams(object):
         native.sgd_step(self.flat, self.grad, self.momentum, lr, momentum, weight_decay, grad_scale=1.0 / world_size,
                         max_norm=max_norm, first_step=self.steps == 0)
         self.steps += 1
+        # The update wrote the parameters in place through the flat buffer: every packed (graph-free) forward -- res5 in
+        # HNMBRCNN.get_triplet_patches, the RPN's proposal pass, an evaluation after training -- must see the new weights,
+        # as the reference's modules do (they hold no second copy).
+        for m in self._packed_modules:
+            m._drop_packed()
 
 
 def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False):

@@ -93,3 +93,30 @@ class VideoWindowRunner(object):
             for off, res in self.step(frames[0], metas[0], LAST, 0, seg_len=1):
                 results[off] = res
         return results
+
+
+def window_frames(num_frames, window):
+    """{emitted frame offset: the `window` frame indices its deque holds, oldest first} for a video of `num_frames` frames --
+    the loop above run on frame indices instead of tensors (tools/test.py:201-212,214-250,257-300): the first frame is
+    repeated until the deque holds (T+1)/2 entries, the last one is repeated while the remaining centres are emitted."""
+    class _Ids(object):
+        frame_tensors = None
+
+        def __call__(self, **kw):
+            return [kw['img']] if kw.get('backbone_feat') else list(kw['x'])
+
+    runner = VideoWindowRunner(_Ids(), window)
+    out = {}
+    flags = frame_flags(num_frames)
+    for i, flag in enumerate(flags):
+        for off, ids in runner.step(i, None, flag, i, seg_len=num_frames):
+            out[off] = ids
+    if num_frames == 1:
+        for off, ids in runner.step(0, None, LAST, 0, seg_len=1):
+            out[off] = ids
+    return out
+
+
+def window_indices(offset, num_frames, window):
+    """The deque content (frame indices, oldest first) when frame `offset` of a `num_frames`-frame video is emitted."""
+    return window_frames(num_frames, window)[offset]

@@ -123,6 +123,26 @@ def test_roi_align_hand_derived_geometry(O):
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
+def test_roi_align_restatement_reproduces_g4(O):
+    """G4 pins the C restatement of ROIAlignForward against drift (the expected outputs were produced by it, the fixture says
+    so: the reference's kernel has no CPU path, roi_align.py:27-28).  Bit for bit; NaN where the reference's arithmetic gives
+    0 / 0 (adaptive sample count of a zero-size box)."""
+    g = gold('g4_roi_align')
+    assert str(g['roi_align_source']) == 'oracle'
+    for name, scale, out in (('m15', 1 / 16, 7), ('m38', 1 / 16, 7), ('gc', 1 / 8, 3)):
+        feat, rois = torch.from_numpy(g[name + '_feat']), torch.from_numpy(g[name + '_rois'])
+        for sn in (2, 0):
+            got = O.roi_align(feat, rois, out, scale, sn).numpy()
+            assert np.array_equal(got, g['%s_out_s%d' % (name, sn)], equal_nan=True)
+    # the special boxes of the fixture behave as roi_align_kernel.cu:16-45,78-116 says they must
+    feat, rois = torch.from_numpy(g['m15_feat']), torch.from_numpy(g['m15_rois'])
+    o2 = g['m15_out_s2']
+    assert np.all(o2[5] == 0)                                         # fully outside: every sample out of bounds -> 0
+    b = int(rois[6, 0])
+    assert np.allclose(o2[6], feat[b, :, 0, 0].numpy()[:, None, None])  # samples in (-1, 0) clamp to pixel (0, 0)
+    assert np.isnan(g['m15_out_s0'][2]).all()                         # malformed box, adaptive sampling: 0 samples -> 0 / 0
+
+
 def test_roi_align_against_an_independent_interpolator(O):
     """Second pin for the CUDA-only RoIAlign: on RANDOM (non-linear) features the restatement must equal the average of
     torch.nn.functional.grid_sample's bilinear values (align_corners=True, an interpolator this build did not write) at the

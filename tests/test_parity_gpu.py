@@ -107,6 +107,42 @@ def test_roi_align_backward_and_errors(O):
     assert ops.roi_align(feat.to(DEV), torch.zeros((0, 5), device=DEV), 3, 1 / 16, 2).shape == (0, 8, 3, 3)
 
 
+def test_roi_align_matches_g4_fixtures():
+    """G4 (tests/golden/make_g4.py; expected outputs = this build's C restatement of ROIAlignForward, the file is flagged
+    roi_align_source = "oracle": the reference kernel cannot run here): the HIP op in both layouts on SURVEY's cases."""
+    g = gold('g4_roi_align')
+    assert str(g['roi_align_source']) == 'oracle'
+    for name in ('m15', 'm38'):
+        feat, rois = torch.from_numpy(g[name + '_feat']).to(DEV), torch.from_numpy(g[name + '_rois']).to(DEV)
+        for sn in (2, 0):
+            want = g['%s_out_s%d' % (name, sn)]
+            close(ops.roi_align(feat, rois, 7, 1 / 16, sn), want, 1e-5, 1e-5, equal_nan=True)
+            close(ops.roi_align(feat.contiguous(memory_format=torch.channels_last), rois, 7, 1 / 16, sn), want, 1e-5, 1e-5, equal_nan=True)
+    feat, rois = torch.from_numpy(g['gc_feat']).to(DEV), torch.from_numpy(g['gc_rois']).to(DEV)
+    for sn in (0, 2):
+        close(ops.RoIAlign(3, 1.0 / 8, sn)(feat, rois), g['gc_out_s%d' % sn], 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize('sample_num', [0, 2])
+def test_roi_align_reference_gradcheck_recipe(sample_num):
+    """The reference's only RoIAlign test, its gradcheck script (mmdet/ops/roi_align/gradcheck.py:11-30), run on
+    hvrnet_amd.ops.RoIAlign: 15x15 map, 16 channels, 2 images, 20 RoIs in the lower-right half of the image, out 3,
+    spatial_scale 1/8, `gradcheck(RoIAlign(3, scale[, 2]), (feat, rois), atol=1e-3, eps=1e-3)` -- f32 as there.
+    nondet_tol: the backward accumulates with f32 atomics (as ROIAlignBackward does, roi_align_kernel.cu:241-250), so two
+    runs may differ in the last bits; the script's torch predates gradcheck's re-run comparison."""
+    from torch.autograd import gradcheck
+    feat_size, spatial_scale, num_imgs, num_rois = 15, 1.0 / 8, 2, 20
+    img_size = feat_size / spatial_scale
+    rs = np.random.RandomState(7 + sample_num)
+    batch_ind = rs.randint(num_imgs, size=(num_rois, 1))
+    rois = rs.rand(num_rois, 4) * img_size * 0.5
+    rois[:, 2:] += img_size * 0.5
+    rois = torch.from_numpy(np.hstack((batch_ind, rois))).float().to(DEV)
+    feat = torch.randn(num_imgs, 16, feat_size, feat_size, requires_grad=True, device=DEV)
+    layer = ops.RoIAlign(3, spatial_scale, sample_num) if sample_num else ops.RoIAlign(3, spatial_scale)
+    assert gradcheck(layer, (feat, rois), atol=1e-3, eps=1e-3, nondet_tol=1e-4)
+
+
 # ------------------------------------------------------------------------------- NMS
 def test_nms_matches_reference_golden_vectors():
     g = gold('g3_nms')
@@ -215,6 +251,24 @@ def test_multiclass_nms_full_size_with_ties(O, max_num):
     db, dl = multiclass_nms(boxes.to(DEV), scores.to(DEV), 0.001, dict(type='nms', iou_thr=0.3), max_num)
     assert dl.cpu().tolist() == want_l.tolist()
     close(db, want_b.numpy(), 0, 1e-6)
+
+
+def test_multiclass_nms_default_max_num_as_the_reference_computes_it(O):
+    """max_num = -1, the reference's default, is not "no cap": `bboxes.shape[0] > -1` always holds, the survivors are sorted
+    by score and `inds[:-1]` drops the last one (bbox_nms.py:55-59; the oracle restates those lines literally).  R = 300 x 30
+    classes: thousands of survivors, far more than the select stage's LDS list holds -- the merge kernel's in-place sort."""
+    g = torch.Generator().manual_seed(78)
+    R, ncls = 300, 31
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([900.0, 500.0])
+    wh = torch.rand((R, 2), generator=g) * 120 + 8
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.softmax(torch.randn((R, ncls), generator=g) * 2, 1)
+    for mx in (-1, -7, 6000):
+        want_b, want_l = O.multiclass_nms(boxes, scores, 0.001, 0.3, mx)
+        assert want_b.shape[0] > 300
+        db, dl = multiclass_nms(boxes.to(DEV), scores.to(DEV), 0.001, dict(type='nms', iou_thr=0.3), mx)
+        assert dl.cpu().tolist() == want_l.tolist()
+        close(db, want_b.numpy(), 0, 1e-6)
 
 
 # ------------------------------------------------------------------------------- relation + heads
@@ -962,7 +1016,83 @@ def test_full_detector_training_iterations_descend():
         assert bool(torch.isfinite(after[k].float()).all()), k
 
 
+def test_packed_weights_follow_the_optimizer_step():
+    """The graph-free (packed: BN folded, per-dtype) forwards must use the CURRENT parameters after an SGD step, as the
+    reference's modules do -- HNMBRCNN.forward_train picks its video triplet with `shared_head(c4)` under no_grad every
+    iteration (hnmb_rcnn.py:54-72), and a model is evaluated after it was trained.  One training iteration, then the packed
+    forward of the trained model must equal that of a FRESH model built from the updated state dict."""
+    from hvrnet_amd.config import selsa_train_config
+    from hvrnet_amd.dist_train import FlatParams, train_detector_iteration
+    n_post, n_sel, T = 24, 16, 3
+    cfg = selsa_train_config(nms_post=n_post, rcnn_sampler_num=n_sel, t_dim=T)
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict('selsa'), torch.float32, DEV))
+    g = torch.Generator().manual_seed(94)
+    hw = (128, 192)
+    imgs = (torch.randn((T, 3) + hw, generator=g) * 50.0).to(DEV)
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(T)]
+    gt_b = torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]).to(DEV)
+    gt_l = torch.tensor([5, 12]).to(DEV)
+    keys = dict(rpn=torch.rand((hw[0] // 16) * (hw[1] // 16) * 12, generator=g).to(DEV),
+                rcnn=[torch.rand(2 + n_post, generator=g).to(DEV) for _ in range(T)])
+    data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, keys=keys)
+    with torch.no_grad():   # packs every module with the pre-training weights
+        c4_0 = model(img=imgs, img_meta=metas, backbone_feat=True)[0]
+        c5_0 = model.shared_head(c4_0).float().clone()
+    flat = FlatParams(model)
+    train_detector_iteration(model, flat, data, lr=5e-3, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+    with torch.no_grad():
+        c4_1 = model(img=imgs, img_meta=metas, backbone_feat=True)[0]
+        c5_1 = model.shared_head(c4_1).float()
+        rpn_1 = [t.float() for t in model.rpn_head([c4_1])[0]]
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    fresh = hvrnet_amd.build_model(cfg, sd, torch.float32, DEV)
+    with torch.no_grad():
+        c4_f = fresh(img=imgs, img_meta=metas, backbone_feat=True)[0]
+        c5_f = fresh.shared_head(c4_f).float()
+        rpn_f = [t.float() for t in fresh.rpn_head([c4_f])[0]]
+    assert not torch.equal(c5_1, c5_0)                       # the step moved res5's weights and the packed path saw it
+    torch.testing.assert_close(c4_1.float(), c4_f.float(), rtol=0, atol=0)
+    torch.testing.assert_close(c5_1, c5_f, rtol=0, atol=0)
+    for a, b in zip(rpn_1, rpn_f):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
 # ------------------------------------------------------------------------------- per-frame cache
+@pytest.mark.parametrize('kind', ['selsa', 'hvr'])
+def test_cached_frame_loop_matches_the_oracle(O, kind):
+    """The per-frame cache against the CPU oracle directly, f32, smoke-size frames: every output frame of a
+    short video through VideoWindowRunner(cache_frames=True) -- padded first / last windows included (tools/test.py:201-212,
+    257-300) -- must equal oracle.clip_forward on the same window of frames: classes exact, boxes / scores within 1e-3."""
+    from hvrnet_amd.window import VideoWindowRunner, window_indices
+    cfgf = selsa_config if kind == 'selsa' else hvr_config
+    hw, pad, n_prop, fi = (150, 250), (160, 256), 16, 1
+    T = 2 * fi + 1
+    sd = S.synth_state_dict(kind)
+    model = hvrnet_amd.build_model(cfgf(frame_interval=fi, nms_post=n_prop), sd, torch.float32, DEV)
+    frames = [S.synth_frame(i, img_hw=hw, pad_hw=pad) for i in range(5)]
+    metas = [S.synth_meta(hw, pad) for _ in frames]
+    with torch.no_grad():
+        cached = VideoWindowRunner(model, T, cache_frames=True).run_video([f.to(DEV) for f in frames], metas)
+        c4 = [O.resnet_c4(f, sd) for f in frames]
+    assert sorted(cached) == list(range(len(frames)))
+    n_det = 0
+    for off in range(len(frames)):
+        idx = window_indices(off, len(frames), T)
+        with torch.no_grad():
+            want = O.window_forward([c4[i] for i in idx], [metas[i] for i in idx], sd, kind, fi, n_prop, T,
+                                    rpn_cfg=dict(O.RPN_TEST_CFG, nms_post=n_prop, max_num=n_prop))
+        got = cached[off]
+        pairs = zip(got, want) if kind == 'hvr' else [(got, want[0])]
+        for g_, w_ in pairs:
+            for c, (gc, wc) in enumerate(zip(g_, w_)):
+                gc, wc = np.asarray(gc), np.asarray(wc)
+                assert gc.shape == wc.shape, 'frame %d class %d: %s vs %s' % (off, c, gc.shape, wc.shape)
+                if len(wc):
+                    assert np.abs(gc - wc).max() < 1e-3, 'frame %d class %d differs by %g' % (off, c, np.abs(gc - wc).max())
+                n_det += len(wc)
+    assert n_det > 0
+
+
 @pytest.mark.parametrize('kind', ['selsa', 'hvr'])
 def test_cached_frame_loop_matches_clip_mode(kind):
     """VideoWindowRunner(cache_frames=True) computes res5 / RPN / RoIAlign / fc_new_1 once per frame and runs a window

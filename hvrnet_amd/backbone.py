@@ -61,13 +61,31 @@ class PackedMixin(object):
 
     def _drop_packed(self):
         self._packed = None
+        self._packed_ready = None
+
+    _packed_ready = None
 
     def packed(self, device):
+        """The packed weights, built on first use.  The pack kernels run on the stream that first asks (with frame groups that
+        is a SIDE stream: the host enqueues the side groups first); any other stream that uses the same tensors afterwards
+        -- the main stream's group, a second window lane -- must be ordered behind them, or it reads weights that are still
+        being written: an event recorded behind the pack, awaited once per consuming stream."""
         key = (self.compute_dtype, str(device))
         if self._packed is None or self._packed_key != key:
             with torch.no_grad():
                 self._packed = self._pack(self.compute_dtype)
             self._packed_key = key
+            self._packed_ready = None
+            if getattr(device, 'type', None) == 'cuda':
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+                self._packed_ready = (ev, {native._raw_stream(device)})
+        elif self._packed_ready is not None:
+            ev, seen = self._packed_ready
+            rs = native._raw_stream(device)
+            if rs not in seen:
+                torch.cuda.current_stream(device).wait_event(ev)
+                seen.add(rs)
         return self._packed
 
 

@@ -243,6 +243,7 @@ def zero_page(device):
     z = _zero_pages.get(device)
     if z is None:
         z = torch.zeros(256, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()  # once per device: every stream reads this page afterwards
         _zero_pages[device] = z
     return z
 

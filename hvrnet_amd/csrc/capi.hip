@@ -120,6 +120,17 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   if ((d->ldc * (d->out_f32 ? 4 : es)) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
+  if (d->tile_hint == kPcHint128 || d->tile_hint == kPcHint256) {
+    if (!pc_supported(p, EPI_LINEAR)) return fail(HVR_EUNSUPPORTED, "the producer / consumer tile kernel takes aligned bf16 operands with N %% 8 == 0");
+    return check_launch(run_pc(p, EPI_LINEAR, d->tile_hint == kPcHint256 ? 256 : 128, (hipStream_t)stream), "hvr_gemm (pc)");
+  }
+  // Long-K products whose 144 x 128 tile grid is one round of the chip (fc_new_1: 4500 x 1024 x 12544 -> 256 tiles of 196
+  // K-steps): the producer / consumer kernel, 1.00-1.03 PF/s against the tile engine's 0.90 (tools/pc_bench.py).  Shorter K
+  // loops do not amortise its one-wave-per-SIMD compute stream's prologue; there the tile engine stays ahead.
+  if (d->tile_hint == 0 && d->K >= 8192 && pc_supported(p, EPI_LINEAR)) {
+    const long tiles = (long)((d->M + 143) / 144) * ((d->N + 127) / 128);
+    if (tiles > 192 && tiles <= 256) return check_launch(run_pc(p, EPI_LINEAR, 128, (hipStream_t)stream), "hvr_gemm (pc)");
+  }
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm");
 }
 
@@ -276,6 +287,8 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   static const int gm_scores = std::getenv("HVR_GM_SCORES") ? std::atoi(std::getenv("HVR_GM_SCORES")) : 8;
   static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
   static const int no_bt = env_tile("HVR_NO_BT");  // force the tile-engine scores pass
+  static const int no_pc = env_tile("HVR_NO_PC");  // force the tile-engine apply pass
+  static const int pc_apply = env_tile("HVR_PC_APPLY");
 #ifdef HVR_DEBUG_KNOBS  // tuning builds only (tools/build_dbg.sh): alias every operand row to row 0 (no memory-system cost)
   static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
 #endif
@@ -311,6 +324,11 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 #ifdef HVR_DEBUG_KNOBS
   if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
 #endif
+  // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table): correct
+  // and tested, but 60 us against the tile engine's 57 on the 4 500-row window (DESIGN.md section 3 has the elimination
+  // builds: its DMA-only path runs at 26 B/clk/CU of the 52 the same pieces reach in isolation) -- opt-in, HVR_PC_APPLY=1.
+  if (pc_apply && !no_pc && tile_apply == 0 && Mq >= 1024 && pc_supported(p, EPI_APPLY))
+    return check_launch(run_pc(p, EPI_APPLY, 128, s), "relation: apply (pc)");
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
 }
 

@@ -23,13 +23,18 @@ def main(*paths):
             if spill or scratch:
                 bad.append('%s: %d VGPRs spilled, %d bytes of scratch' % (name, spill, scratch))
             continue
-        if name.startswith(('_ZN3hvr19mc_nms_', '_ZN3hvr15nms_', '_ZN3hvr16nms_', '_ZN3hvr17rpn_', '_ZN3hvr25relation_scores_bt')):
+        if name.startswith(('_ZN3hvr19mc_nms_', '_ZN3hvr15nms_', '_ZN3hvr16nms_', '_ZN3hvr17rpn_', '_ZN3hvr25relation_scores_bt', '_ZN3hvr14pc_tile_kernel')):
             # the serial read-out / proposal kernels and the one-round scores kernel: scratch traffic inside their dependency
             # chains (the greedy sweep's prefetched IoU rows, the 176 accumulators) is a silent slowdown -- fail the build
             seen += 1
             spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
             scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b).group(1))
-            if spill or scratch:
+            # The producer / consumer kernels with the fattest compute waves park values in scratch OUTSIDE the K loop only
+            # (checked in the .s, `-save-temps`: no scratch access between the loop's barriers): pc_tile_kernel<4, LINEAR, 3>
+            # a few epilogue addresses before the loop (<= 32 B), pc_tile_kernel<2, APPLY, 4> the folded accumulators between
+            # the last block and the epilogue's LDS staging (<= 256 B).  Anything beyond that fails the build.
+            allow = 32 if name.startswith('_ZN3hvr14pc_tile_kernelILi4ELi0E') else (256 if name.startswith('_ZN3hvr14pc_tile_kernelILi2ELi2E') else 0)
+            if scratch > allow or (spill and not allow):
                 bad.append('%s: %d VGPRs spilled, %d bytes of scratch' % (name, spill, scratch))
             continue
         m = re.match(r'_ZN3hvr11tile_kernelI[tf]Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)E', name)

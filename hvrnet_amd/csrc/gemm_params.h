@@ -60,5 +60,10 @@ bool expand_supported(const GemmParams& p);
 bool conv3x3_c64_supported(const GemmParams& p);
 hipError_t run_conv3x3_c64(const GemmParams& p, hipStream_t stream);
 hipError_t run_expand(const GemmParams& p, hipStream_t stream);
+// Producer / consumer tile kernel (pc_gemm.hip): 144 x 128 / 144 x 256 tiles, 4 compute + 4 DMA waves; EPI_LINEAR (plain
+// GEMM) and EPI_APPLY.  tile_hint kPcHint128 / kPcHint256 force it for a plain GEMM (tuning / tests)
+constexpr int kPcHint128 = kNumTileShapes + 2, kPcHint256 = kNumTileShapes + 3;
+bool pc_supported(const GemmParams& p, int epi);
+hipError_t run_pc(const GemmParams& p, int epi, int bn, hipStream_t stream);
 
 }  // namespace hvr

@@ -60,6 +60,7 @@ def parse(argv=None):
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the f32 parity-mode timing')
     ap.add_argument('--no-train-step', action='store_true', help='skip the training-step side measurement (tools/train_bench.py)')
     ap.add_argument('--no-side-loops', action='store_true', help='skip ref_loop / cached_loop / two_in_flight (profiling runs)')
+    ap.add_argument('--no-graphs', action='store_true', help='skip the hipGraph legs (graphed_clip / graphed_stream)')
     ap.add_argument('--inflight', type=int, default=int(os.environ.get('HVR_INFLIGHT', '1')),
                     help='independent windows enqueued on that many HIP streams in turn (throughput mode)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
@@ -468,6 +469,88 @@ def main(argv=None):
             lanes[:] = [None]
             type(model).frame_groups = groups0
 
+    # ---- the same work replayed from hipGraphs (hvrnet_amd/graphs.py): the window / the per-frame and per-window chains are
+    # captured once, with their side streams, and replayed with one host call each.  Reported beside the eager headline (whose
+    # per-kernel HIP-event spans cannot be taken inside a replay); bit-identical detections (tests/test_graphs_gpu.py).
+    graphed_clip = graphed_stream = None
+    if not args.no_graphs and args.inflight == 1:
+        from hvrnet_amd.graphs import GraphedClip, GraphedStream
+        groups0 = type(model).frame_groups
+        gc = GraphedClip(model, frames, metas, rescale=True)
+        pend = gc.run()
+        pend.result()
+        sync()
+        ng = max(4, args.steps)
+        tg = time.perf_counter()
+        pend = None
+        for _ in range(ng):
+            nxt = gc.run()
+            if pend is not None:
+                pend.result()
+            pend = nxt
+        res_graph = pend.result()
+        sync()
+        el = time.perf_counter() - tg
+        graphed_clip = dict(frames_per_s_per_gpu=round(ng / el, 3), ms_per_step=round(el / ng * 1e3, 3), steps=ng,
+                            same_detections=bool(all(len(a) == len(b) for a, b in zip(res_graph[-1] if args.head == 'hvr' else res_graph,
+                                                                                      res[-1] if args.head == 'hvr' else res))),
+                            what='the headline window (clip mode, all T frames) replayed as ONE hipGraph per window, two graphs in turn '
+                                 'so that window i + 1 is enqueued before window i is read')
+        del gc
+        # stream mode: one new frame per output frame, per-frame cache, graph F (frame arrives) + graph W (window emitted)
+        gs = GraphedStream(model, frames[0:1], metas[0], rescale=True)
+        for i in range(T):
+            gs.push(frames[i:i + 1])
+        gs.emit().result()
+        sync()
+        nsg = max(10, args.steps)
+        tg = time.perf_counter()
+        pend = None
+        for i in range(nsg):
+            gs.push(frames[i % T:i % T + 1])
+            nxt = gs.emit()
+            if pend is not None:
+                pend.result()
+            pend = nxt
+        pend.result()
+        sync()
+        el = time.perf_counter() - tg
+        gf = 650.0 if args.head == 'hvr' else 504.0
+        graphed_stream = dict(frames_per_s_per_gpu=round(nsg / el, 2), ms_per_frame=round(el / nsg * 1e3, 3), steps=nsg,
+                              tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
+                              what='tools/test.py steady state with the per-frame cache as two hipGraphs: one new frame through backbone / '
+                                   'res5 / RPN / RoIAlign / fc_new_1 per output frame + relation stages and read-out on the T cached entries')
+        del gs
+        # the same loop with look-ahead batches (offline video: T frames through the per-frame part at once, then one output frame
+        # at a time): what a single 600x1000 frame cannot give the chip -- 2 394 stride-16 rows are 17-19 row tiles for 256 CUs
+        gl = GraphedStream(model, frames[0:1], metas[0], rescale=True, lookahead=T)
+        gl.push_batch(frames)
+        for i in range(T):
+            gl.advance(i)
+        gl.emit().result()
+        sync()
+        nb = max(2, args.steps // 5)
+        tg = time.perf_counter()
+        pend = None
+        for b in range(nb):
+            gl.push_batch(frames)
+            for i in range(T):
+                gl.advance(i)
+                nxt = gl.emit()
+                if pend is not None:
+                    pend.result()
+                pend = nxt
+        pend.result()
+        sync()
+        el = time.perf_counter() - tg
+        graphed_stream['lookahead'] = dict(frames_per_s_per_gpu=round(nb * T / el, 2), ms_per_frame=round(el / (nb * T) * 1e3, 3), batch=T,
+                                           steps=nb * T, tflops=round(nb * T / el * gf / 1e3, 1),
+                                           frac_mfma_peak=round(nb * T / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
+                                           what='the same loop with the per-frame part run on look-ahead batches of T frames (identical '
+                                                'detections, tests/test_graphs_gpu.py); one window emitted per frame')
+        del gl
+        type(model).frame_groups = groups0
+
     # per-class breakdown from one extra, fully instrumented window (outside the timed region)
     native.profile_begin(tags=('*',))
     step()
@@ -532,6 +615,9 @@ def main(argv=None):
         if overlap2_fps is not None:
             out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2),
                                         what='clip mode, two independent windows in flight on two HIP streams (--inflight 2)')
+        if graphed_clip is not None:
+            out['graphed_clip'] = graphed_clip
+            out['graphed_stream'] = graphed_stream
         if ar is not None:
             out['train_allreduce'] = ar
         if world == 1 and not args.no_cpu_baseline:

@@ -16,6 +16,7 @@
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
+hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
 hipError_t run_im2col_nhwc(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -256,10 +257,25 @@ static int env_tile(const char* name) {  // tuning override, read once
 }
 static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
 
+// Key-slices of the apply pass when there are few query rows (the key-frame-only stage: Mq = 300 against Mk = 4 500 gives a
+// 3 x 8 output tile grid with a 72-step K loop -- 24 workgroups on 256 CUs): the 128-key blocks are dealt to `slices` workgroups
+// per output tile (at least 2 blocks each), every slice writes an f32 partial, one reduce launch sums and rounds them.  The
+// block weights g = 2^(m_t - m*) / L are global per row, so the partials simply add.  1 = no split.
+static int apply_slices(int Mq, int Mk, int D) {
+  const long tiles = (long)((Mq + 127) / 128) * ((D + 127) / 128);
+  const int nblk = (int)(rel_ldp(Mk) / 128);
+  if (tiles >= 96 || nblk < 8 || D % 8) return 1;
+  // a FIXED four blocks (512 keys) per slice: the partition -- and with it the order of the f32 sum -- depends on Mk only,
+  // so a query row's result does not depend on how many other rows are in the call
+  return (nblk + 3) / 4;
+}
+
 size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
   const long ldp = rel_ldp(Mk), nt = ldp / 128;
   const size_t es = elem_size(dtype);
-  return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 2 * align256((size_t)Mq * nt * 4);
+  const int slices = apply_slices(Mq, Mk, D);
+  return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 2 * align256((size_t)Mq * nt * 4) +
+         (slices > 1 ? align256((size_t)slices * Mq * D * 4) : 0);
 }
 
 int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
@@ -277,7 +293,8 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   void* P = w;                w += align256((size_t)Mq * ldp * es);
   void* Vt = w;               w += align256((size_t)D * ldp * es);
   float* mstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
-  float* lstat = (float*)w;
+  float* lstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
+  float* partial = (float*)w;  // apply_slices(...) > 1: the slices' f32 partial outputs
   hipStream_t s = (hipStream_t)stream;
 
   GemmParams p;
@@ -324,6 +341,21 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 #ifdef HVR_DEBUG_KNOBS
   if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
 #endif
+  static const int no_split = env_tile("HVR_NO_APPLY_SPLIT");
+  const int slices = no_split ? 1 : apply_slices(Mq, Mk, D);
+  if (slices > 1 && tile_apply == 0 && (dtype != HVR_BF16 || (ldo % 8 == 0 && aligned16(O)))) {
+    const int steps_per_blk = dtype == HVR_BF16 ? 2 : 4;
+    const int per = 4;  // apply_slices: four 128-key blocks per slice
+    p.ksplit_steps = per * steps_per_blk;
+    p.ksplit_count = slices;
+    p.csplit_bytes = (long)Mq * D * 4;
+    p.C = partial; p.ldc = D; p.out_f32 = dtype == HVR_BF16 ? 1 : 0;
+    p.tile_hint = 1;  // 128 x 128 tiles (two workgroups per CU): the slices' K loops are a handful of steps
+    hipError_t e = run_tile_op(p, EPI_APPLY, s);
+    if (e == hipSuccess)
+      e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
+    return check_launch(e, "relation: apply (key slices)");
+  }
   // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table): correct
   // and tested, but 60 us against the tile engine's 57 on the 4 500-row window (DESIGN.md section 3 has the elimination
   // builds: its DMA-only path runs at 26 B/clk/CU of the 52 the same pieces reach in isolation) -- opt-in, HVR_PC_APPLY=1.

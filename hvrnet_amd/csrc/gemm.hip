@@ -129,20 +129,23 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   }
   const int m0 = pid_m * BM, n0 = pid_n * BN;
 
-  // split-K (EPI_LINEAR, plain GEMM only): gridDim.y slices of `ksplit_steps` K-steps each write their own f32 partial
+  // split-K (EPI_LINEAR plain GEMMs; EPI_APPLY with few query rows, whose block weights g are global per row so that the
+  // slices' partials simply add): gridDim.y slices of `ksplit_steps` K-steps each write their own f32 partial
   // [M][N] at C + blockIdx.y * csplit_bytes; a weight-gradient GEMM has a few output tiles and a K of 10^4..10^5, which
   // one workgroup per tile would walk alone while most of the chip idles.  The slice is folded into the base pointers.
   const char* Ab = (const char*)p.A;
   const char* Bb = (const char*)p.B;
   char* Cb = (char*)p.C;
   int nk_slice = p.K / BKE;
-  if constexpr (EPI == EPI_LINEAR) {
+  int blk0 = 0;  // EPI_APPLY: first 128-key block of this workgroup's K slice (slices are whole blocks)
+  if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
     if (p.ksplit_steps > 0) {
       const int kt0 = blockIdx.y * p.ksplit_steps;
       Ab += (long)kt0 * 128;
       Bb += (long)kt0 * 128;
       Cb += (long)blockIdx.y * p.csplit_bytes;
       nk_slice = nk_slice - kt0 < p.ksplit_steps ? nk_slice - kt0 : p.ksplit_steps;
+      blk0 = kt0 / (128 / BKE);
     }
   }
 
@@ -256,7 +259,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     return (m < p.M ? m : p.M - 1) * p.ntile;
   };
   if constexpr (EPI == EPI_APPLY) {
-    // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*):
+    // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*)
+    // (v_exp_f32 / v_log_f32 directly: one instruction each, 1 ulp; exp2f / log2f wrap them in denormal handling these
+    // weights never need -- the prologue is serial work in front of every tile's first MFMA):
     // the four lanes that share a row split the key tiles, then merge their (max, sum) pairs.
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -265,18 +270,18 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       for (int t = lane >> 4; t < p.ntile; t += 4) {
         const float mt = p.mstat[row + t], lt = p.lstat[row + t];
         const float mn = fmaxf(mx, mt);
-        l = l * exp2f(mx - mn) + lt * exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
+        l = l * __builtin_amdgcn_exp2f(mx - mn) + lt * __builtin_amdgcn_exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
         mx = mn;
       }
 #pragma unroll
       for (int o = 16; o < 64; o <<= 1) {
         const float mo = __shfl_xor(mx, o), lo = __shfl_xor(l, o);
         const float mn = fmaxf(mx, mo);  // a lane without tiles carries (-inf, 0); some lane has a finite max
-        l = (mx == mn ? l : l * exp2f(mx - mn)) + (mo == mn ? lo : lo * exp2f(mo - mn));
+        l = (mx == mn ? l : l * __builtin_amdgcn_exp2f(mx - mn)) + (mo == mn ? lo : lo * __builtin_amdgcn_exp2f(mo - mn));
         mx = mn;
       }
-      gref[i] = mx + log2f(l);
-      gcur[i] = exp2f(p.mstat[row] - gref[i]);
+      gref[i] = mx + __builtin_amdgcn_logf(l);
+      gcur[i] = __builtin_amdgcn_exp2f(p.mstat[row + blk0] - gref[i]);
       landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
       gnext[i] = 0.f;
     }
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         if (first) {
           if (kt + STEPS_PER_BLOCK < nk) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + kt / STEPS_PER_BLOCK + 1);
+            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + kt / STEPS_PER_BLOCK + 1);
           }
           __builtin_amdgcn_sched_barrier(0);  // the g loads stay ahead of this step's DMA in the vmcnt queue
         }
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       if constexpr (EPI == EPI_APPLY && first) {
         if (kt + STEPS_PER_BLOCK < nk) {
 #pragma unroll
-          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + kt / STEPS_PER_BLOCK + 1);
+          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + kt / STEPS_PER_BLOCK + 1);
         }
       }
       if (load) tap_of(kt + NS - 1);
@@ -840,7 +845,7 @@ static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, EPI == EPI_LINEAR && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
 }
 

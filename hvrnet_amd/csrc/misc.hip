@@ -584,6 +584,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
 }
 
+// the same sum rounded once to bf16 (the relation apply pass's split-K form); N % 8 == 0, 16-byte aligned rows
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, bf16_t* __restrict__ C, int M, int N, long ldc,
+                                                                 int S) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x, per_row = N / 8, total = (long)M * per_row;
+  if (q >= total) return;
+  const long m = q / per_row, n = (q - m * per_row) * 8, stride = (long)M * N;
+  const float* src = ws + m * N + n;
+  float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  for (int s = 1; s < S; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(src + s * stride), v = *reinterpret_cast<const float4*>(src + s * stride + 4);
+    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+  }
+  *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+}
+
+hipError_t run_splitk_reduce_bf16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
+  const long total = (long)M * (N / 8);
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S);
+  return hipGetLastError();
+}
+
 hipError_t run_splitk_reduce(const float* ws, float* C, int M, int N, long ldc, int S, hipStream_t s) {
   const long total = (long)M * (N / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, C, M, N, ldc, S);

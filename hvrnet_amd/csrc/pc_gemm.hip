@@ -150,11 +150,11 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
         for (int t = 0; t < p.ntile; ++t) {
           const float mt = p.mstat[row + t], lt = p.lstat[row + t];
           const float mn = fmaxf(mx, mt);
-          l = l * exp2f(mx - mn) + lt * exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
+          l = l * __builtin_amdgcn_exp2f(mx - mn) + lt * __builtin_amdgcn_exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
           mx = mn;
         }
-        const float gref = mx + log2f(l);
-        for (int t = 0; t < p.ntile; ++t) g_lds[t * PC_BM + ptid] = exp2f(p.mstat[row + t] - gref);
+        const float gref = mx + __builtin_amdgcn_logf(l);
+        for (int t = 0; t < p.ntile; ++t) g_lds[t * PC_BM + ptid] = __builtin_amdgcn_exp2f(p.mstat[row + t] - gref);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table is written before B_0 releases its readers
     }

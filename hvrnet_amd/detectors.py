@@ -308,6 +308,13 @@ class _WindowDetector(TwoStageDetector):
         f1 = self.bbox_head.fc1_rows(self.get_roi_feat(feats, rois.contiguous()))
         return dict(props=proposal_list[0], count=counts_dev, f1=f1, meta=img_meta)
 
+    def frames_tensors(self, c4, img_metas):
+        """frame_tensors for a BATCH of B frames (frames are independent up to fc_new_1: one launch sequence for all of them):
+        -> dict(props [B,mx,5], count [B] int32 device, f1 [B * mx, 1024]); frame i's rows are f1[i * mx:(i + 1) * mx]."""
+        feats, proposal_list, rois, counts_dev, _ = self._c5_and_rois(c4, list(img_metas), None, speculate=True)
+        f1 = self.bbox_head.fc1_rows(self.get_roi_feat(feats, rois.contiguous()))
+        return dict(props=torch.stack(proposal_list, 0), count=counts_dev, f1=f1, meta=img_metas[0])
+
     def _frames_window(self, entries):
         mx = entries[0]['props'].shape[0]
         key = self.key_dim
@@ -316,6 +323,32 @@ class _WindowDetector(TwoStageDetector):
         key_rois = torch.cat([entries[key]['props'].new_zeros((mx, 1)), entries[key]['props'][:, :4]], dim=1)
         counts_dev = torch.cat([e['count'] for e in entries])
         return f1, cur_range, key_rois, counts_dev, mx
+
+    # ---- device-only forms (no host read, no PendingWindow): what graphs.py captures into a hipGraph ----
+    def _head_branches(self, feats, from_f1, cur_range, key_rois, meta0, rescale):
+        """relation head + read-out -> list of (dets [max,5], labels [max], n [1]) device tensors, one per output branch."""
+        if type(self).__name__ == 'HNMBRCNN':
+            head = self.bbox_head.forward_from_f1 if from_f1 else self.bbox_head.forward_test
+            cls_score, bbox_pred = head(feats, [cur_range], key_dim=self.key_dim, all_res=False)
+            branches, _ = self.bbox_head.get_det_bboxes(key_rois, cls_score, bbox_pred, meta0['img_shape'], meta0['scale_factor'],
+                                                        rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
+            return list(branches)
+        head = self.bbox_head.forward_from_f1 if from_f1 else self.bbox_head
+        cls_score, bbox_pred = head(feats, cur_range, key_dim=self.key_dim, all_res=False)[:2]
+        branch, _ = self.bbox_head.get_det_bboxes(key_rois, cls_score, bbox_pred, meta0['img_shape'], meta0['scale_factor'],
+                                                  rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
+        return [branch]
+
+    def window_device_outputs(self, x, img_meta, rescale=False):
+        """One speculative window (every frame assumed to keep nms_post proposals) up to its device-side results:
+        -> (branches, counts_dev [T] int32, full_count); the caller checks counts == full_count when it reads the results."""
+        w = self.window_tensors(x, img_meta, None, rescale, speculate=True)
+        return self._head_branches(w['roi_feats'], False, w['cur_range'], w['key_rois'], img_meta[0], rescale), w['counts_dev'], w['full_count']
+
+    def head_device_outputs(self, f1, cur_range, key_rois, counts_dev, meta0, rescale=False):
+        """The window part of the per-frame-cache loop on assembled rows: f1 [T * n, 1024] (fc_new_1 rows of the T frames in
+        window order), key_rois [n, 5] -> (branches, counts_dev, n)."""
+        return self._head_branches(f1, True, cur_range, key_rois, meta0, rescale), counts_dev, int(cur_range['length'])
 
     def simple_test_bboxes(self, x, img_meta, proposals, rcnn_test_cfg, rescale=False):
         raise NotImplementedError

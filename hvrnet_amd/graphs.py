@@ -1,0 +1,290 @@
+"""hipGraph capture of the window (clip mode) and of the per-frame / per-window chains (stream mode).
+
+The reference's loop is launch-bound by construction: ~250 kernel launches per window from Python (tools/test.py:214-250 ->
+hnmb_rcnn.py:195-222), each a few microseconds of host time; the eager HIP path here enqueues a clip-mode window in ~2.8 ms
+of host time against 7.5 ms of GPU time, and a stream-mode output frame (one new frame through the backbone + the head on
+cached rows) is host-bound outright.  The kernels of a window are shape-static once every frame keeps its `nms_post`
+proposals (the speculative path of detectors.py; a short frame is detected from the counts read with the results and re-run
+through the exact eager path), so the whole chain -- frame groups on their side streams, the RPN side stream, the second
+branch's read-out stream included -- is captured ONCE into a hipGraph and replayed: one host call per window, dependencies
+resolved on the device.
+
+  GraphedClip(model, frames, metas)          clip mode: T frames -> key-frame detections, one graph
+  GraphedStream(model, frame_shape, meta)    stream mode (the reference's loop with the per-frame cache): one
+                                             graph for "a frame arrives" (backbone, res5, RPN, proposals, RoIAlign, fc_new_1
+                                             -> the frame's cached rows), one for "a window is emitted" (relation stages and
+                                             read-out on the T cached entries)
+
+torch.cuda.CUDAGraph is the capture mechanism (hipStreamBeginCapture / hipGraphLaunch underneath); every kernel inside is this
+build's own, launched through the C ABI on the capturing streams.  Results are identical to the eager path (same kernels,
+same order per stream): tests/test_graphs_gpu.py.
+"""
+import torch
+
+from .box_ops import bbox2result
+
+
+class _HostOut(object):
+    """Pinned host mirrors of a window's device outputs; the D2H copies are graph nodes."""
+
+    def __init__(self, branches, counts_dev):
+        self.dev = [tuple(b) for b in branches]
+        self.counts_dev = counts_dev
+        self.host = [tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in b) for b in self.dev]
+        self.counts_host = torch.empty(counts_dev.shape, dtype=counts_dev.dtype, pin_memory=True) if counts_dev is not None else None
+
+    def enqueue_copies(self):
+        for hb, db in zip(self.host, self.dev):
+            for h, d in zip(hb, db):
+                h.copy_(d, non_blocking=True)
+        if self.counts_host is not None:
+            self.counts_host.copy_(self.counts_dev, non_blocking=True)
+
+
+class PendingGraphWindow(object):
+    """A replayed window whose results have not been read; result() is its single host synchronisation."""
+
+    def __init__(self, owner, out, event, exact):
+        self._owner, self._out, self._event, self._exact, self._result = owner, out, event, exact, None
+        self.respeculated = False
+
+    def result(self):
+        if self._result is None:
+            self._event.synchronize()
+            o = self._owner
+            out = self._out
+            if out.counts_host is not None and any(int(c) != o._full for c in out.counts_host.tolist()):
+                self.respeculated = True
+                self._result = self._exact()
+            else:
+                res = []
+                for dets, labels, n in out.host:
+                    k = int(n[0])
+                    res.append(bbox2result(dets[:k].clone(), labels[:k].clone(), o._num_classes))
+                self._result = res[0] if o._single else res
+        return self._result
+
+
+class GraphedClip(object):
+    """One clip-mode window (all T frames through backbone, res5, RPN, proposals, RoIAlign, head, read-out) as a hipGraph.
+
+    frames: [T,3,H,W] f32 on the device -- the graph reads THIS buffer; write the next clip's frames into `self.frames`
+    (or pass them to `run`) before replaying.  A replay must have been read (`result()`) before the next one is launched:
+    the outputs are static buffers."""
+
+    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2):
+        assert frames.is_cuda and frames.dim() == 4 and frames.shape[0] == len(metas)
+        self.model, self.metas, self.rescale = model, list(metas), rescale
+        self.frames = frames.clone()
+        self._num_classes = model.bbox_head.num_classes
+        self._single = type(model).__name__ == 'SelsaRCNN'
+        dev = frames.device
+        self._stream = torch.cuda.Stream(device=dev)
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        self._graphs, self._outs, self._turn, self._generation = [], [], 0, 0
+        with torch.no_grad(), torch.cuda.stream(self._stream):
+            for _ in range(max(1, warmup)):   # builds every lazily created object: packed weights, workspaces, side streams
+                branches, counts, full = self._enqueue()
+            self._stream.synchronize()
+            self._full = full
+            # n_out graphs of the same window, each with its own output buffers (replayed in turn: window i + 1 can be
+            # enqueued before window i's results are read); they share one memory pool -- same stream, never concurrent
+            for k in range(max(1, n_out)):
+                out = _HostOut(branches, counts)   # pinned buffers exist before the capture (no host allocation inside it)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self._stream, **(dict(pool=self._graphs[0].pool()) if self._graphs else {})):
+                    b2, c2, _ = self._enqueue()
+                    out.dev, out.counts_dev = [tuple(b) for b in b2], c2
+                    out.enqueue_copies()
+                self._graphs.append(graph)
+                self._outs.append(out)
+        torch.cuda.current_stream(dev).wait_stream(self._stream)
+
+    def _enqueue(self):
+        m = self.model
+        c4 = m(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
+        return m.window_device_outputs(c4, self.metas, rescale=self.rescale)
+
+    def _exact(self):
+        with torch.no_grad():
+            c4 = self.model(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
+            return self.model.forward_feat(x=c4, img_meta=self.metas, rescale=self.rescale, speculate=False)
+
+    def run(self, frames=None):
+        """Replays the window on the current stream; -> PendingGraphWindow.  With n_out graphs at most n_out - 1 earlier
+        windows may still be unread."""
+        if frames is not None:
+            self.frames.copy_(frames, non_blocking=True)
+        if frames is not None:
+            self._generation += 1
+        gen = self._generation
+        k = self._turn % len(self._graphs)
+        self._turn += 1
+        self._graphs[k].replay()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.frames.device))
+
+        def exact():
+            if gen != self._generation:
+                raise RuntimeError('a frame of this window kept fewer than nms_post proposals, but its input buffer has been overwritten by a '
+                                   'later run(frames=...): read result() before handing over the next clip')
+            return self._exact()
+        return PendingGraphWindow(self, self._outs[k], ev, exact)
+
+
+class GraphedStream(object):
+    """The reference's steady-state loop (tools/test.py:214-250) with the per-frame cache, as two hipGraphs.
+
+      push(frame)   graph F: backbone -> res5 / RPN / proposals / RoIAlign / fc_new_1 of ONE frame; its rows are appended to
+                    the window buffers (the oldest frame's rows drop out: a device-side shift, part of the graph)
+      emit()        graph W: the relation stages and the read-out on the T frames in the window buffers -> PendingGraphWindow
+
+    Window buffers hold T entries in arrival order: fc_new_1 rows [T * n, 1024], proposals [T, n, 5], counts [T]; n = nms_post.
+    A frame may be pushed several times without recomputing it (`repeat_last()`): the reference pads the first and last
+    windows of a video with copies of a frame (test.py:201-212, 257-300)."""
+
+    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1):
+        assert frame.is_cuda and frame.dim() == 4 and frame.shape[0] == 1
+        self.model, self.meta, self.rescale = model, meta, rescale
+        self.lookahead = int(lookahead)
+        dev = frame.device
+        self.T = int(model.bbox_head.t_dim)
+        self.key = int(model.key_dim)
+        self.frame = frame.clone()
+        self._num_classes = model.bbox_head.num_classes
+        self._single = type(model).__name__ == 'SelsaRCNN'
+        self._stream = torch.cuda.Stream(device=dev)
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        T = self.T
+        with torch.no_grad(), torch.cuda.stream(self._stream):
+            e = None
+            for _ in range(max(1, warmup)):
+                e = self._frame_entry()
+            n, D = e['f1'].shape
+            self.n = n
+            self.f1 = torch.zeros((T * n, D), dtype=e['f1'].dtype, device=dev)
+            self.f1_tmp = torch.empty(((T - 1) * n, D), dtype=e['f1'].dtype, device=dev)
+            self.props = torch.zeros((T, n, 5), dtype=e['props'].dtype, device=dev)
+            self.props_tmp = torch.empty((T - 1, n, 5), dtype=e['props'].dtype, device=dev)
+            self.counts = torch.full((T,), n, dtype=torch.int32, device=dev)
+            self.counts_tmp = torch.empty((T - 1,), dtype=torch.int32, device=dev)
+            self.last = dict(f1=torch.zeros_like(e['f1']), props=torch.zeros_like(e['props']), count=torch.zeros_like(e['count']))
+            for _ in range(max(1, warmup)):
+                self._push_from(e)
+                branches, counts, full = self._window()
+            self._stream.synchronize()
+            self._full = n
+            self.graph_f = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_f, stream=self._stream):
+                e = self._frame_entry()
+                self.last['f1'].copy_(e['f1'])
+                self.last['props'].copy_(e['props'])
+                self.last['count'].copy_(e['count'])
+                self._push_from(self.last)
+            self.graph_p = torch.cuda.CUDAGraph()          # push the last computed frame again (padding)
+            with torch.cuda.graph(self.graph_p, stream=self._stream, pool=self.graph_f.pool()):
+                self._push_from(self.last)
+            # Look-ahead (offline video: the frames of a clip are all there): `lookahead` frames go through backbone / res5 / RPN /
+            # RoIAlign / fc_new_1 in ONE batch -- a single 600x1000 frame gives the stride-16 stages 2 394 rows, 17-19 row tiles
+            # for 256 CUs -- into a staging area; frame i of the batch then enters the window buffers (graph S_i + graph P)
+            # when its turn comes.  Same rows as one frame at a time (every kernel of the per-frame part is row-independent).
+            self.graph_fb, self._stage_graphs = None, []
+            if self.lookahead > 1:
+                B = self.lookahead
+                self.batch = self.frame.new_zeros((B,) + tuple(self.frame.shape[1:]))
+                metas = [self.meta] * B
+                for _ in range(max(1, warmup)):
+                    c4 = self.model(img=self.batch, img_meta=metas, backbone_feat=True)[0]
+                    eb = self.model.frames_tensors(c4, metas)
+                self._stream.synchronize()
+                self.graph_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_fb, stream=self._stream, pool=self.graph_f.pool()):
+                    c4 = self.model(img=self.batch, img_meta=metas, backbone_feat=True)[0]
+                    eb = self.model.frames_tensors(c4, metas)
+                self._staged = eb   # static buffers of the batch graph: props [B,n,5], count [B], f1 [B * n, D]
+                for i in range(B):
+                    gi = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gi, stream=self._stream, pool=self.graph_f.pool()):
+                        self.last['f1'].copy_(eb['f1'][i * n:(i + 1) * n])
+                        self.last['props'].copy_(eb['props'][i])
+                        self.last['count'].copy_(eb['count'][i:i + 1])
+                        self._push_from(self.last)
+                    self._stage_graphs.append(gi)
+            # n_out window graphs with their own output buffers, replayed in turn (see GraphedClip)
+            self._graphs_w, self._outs, self._turn = [], [], 0
+            for k in range(max(1, n_out)):
+                out = _HostOut(branches, counts)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self._stream, pool=self.graph_f.pool()):
+                    b2, c2, _ = self._window()
+                    out.dev, out.counts_dev = [tuple(b) for b in b2], c2
+                    out.enqueue_copies()
+                self._graphs_w.append(graph)
+                self._outs.append(out)
+        torch.cuda.current_stream(dev).wait_stream(self._stream)
+        self._hist = []  # the window's input frames (copies), for the exact re-run of a window that holds a short frame
+
+    # ---- pieces (each runs eagerly during warm-up and inside a capture afterwards) ----
+    def _frame_entry(self):
+        m = self.model
+        c4 = m(img=self.frame, img_meta=[self.meta], backbone_feat=True)[0]
+        return m.frame_tensors(c4, self.meta)
+
+    def _push_from(self, e):
+        n, T = self.n, self.T
+        # shift by one frame through a scratch copy (source and destination overlap), then append
+        self.f1_tmp.copy_(self.f1[n:])
+        self.f1[:(T - 1) * n].copy_(self.f1_tmp)
+        self.f1[(T - 1) * n:].copy_(e['f1'])
+        self.props_tmp.copy_(self.props[1:])
+        self.props[:T - 1].copy_(self.props_tmp)
+        self.props[T - 1].copy_(e['props'])
+        self.counts_tmp.copy_(self.counts[1:])
+        self.counts[:T - 1].copy_(self.counts_tmp)
+        self.counts[T - 1:].copy_(e['count'])
+
+    def _window(self):
+        m, n = self.model, self.n
+        cur_range = dict(start=self.key * n, length=n)
+        key_rois = torch.cat([self.props.new_zeros((n, 1)), self.props[self.key, :, :4]], dim=1)
+        return m.head_device_outputs(self.f1, cur_range, key_rois, self.counts, self.meta, rescale=self.rescale)
+
+    def _exact(self, hist):
+        with torch.no_grad():
+            frames = torch.cat(hist, 0)
+            metas = [self.meta] * frames.shape[0]
+            c4 = self.model(img=frames, img_meta=metas, backbone_feat=True)[0]
+            return self.model.forward_feat(x=c4, img_meta=metas, rescale=self.rescale, speculate=False)
+
+    # ---- the loop ----
+    def push(self, frame=None):
+        """A new frame arrives: graph F (its rows enter the window buffers)."""
+        if frame is not None:
+            self.frame.copy_(frame, non_blocking=True)
+        self.graph_f.replay()
+        self._hist = (self._hist + [self.frame.clone()])[-self.T:]
+
+    def push_batch(self, frames):
+        """`lookahead` frames arrive together: their per-frame rows are computed in one batch (graph FB) and staged; call
+        `advance(i)` to move frame i of the batch into the window buffers."""
+        assert self.graph_fb is not None and frames.shape[0] == self.lookahead
+        self.batch.copy_(frames, non_blocking=True)
+        self.graph_fb.replay()
+        self._batch_frames = frames
+
+    def advance(self, i):
+        self._stage_graphs[i].replay()
+        self._hist = (self._hist + [self._batch_frames[i:i + 1]])[-self.T:]
+
+    def repeat_last(self):
+        self.graph_p.replay()
+        self._hist = (self._hist + [self._hist[-1]])[-self.T:]
+
+    def emit(self):
+        k = self._turn % len(self._graphs_w)
+        self._turn += 1
+        self._graphs_w[k].replay()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.frame.device))
+        hist = list(self._hist[-self.T:])   # this window's frames: later pushes must not change what a re-run sees
+        return PendingGraphWindow(self, self._outs[k], ev, lambda: self._exact(hist))

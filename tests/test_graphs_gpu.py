@@ -1,0 +1,145 @@
+"""hipGraph replays (hvrnet_amd/graphs.py) against the eager path they were captured from: the same kernels in the same
+per-stream order, so the per-class detection arrays must be bit-identical -- clip mode (frame groups, RPN side stream and
+read-out side stream inside the capture) and stream mode (per-frame cache, padded first / last windows), both heads, several
+replays with changing inputs; and a window with a short frame must come back through the exact eager path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hvrnet_amd  # noqa: E402
+from hvrnet_amd import synthetic as S  # noqa: E402
+from hvrnet_amd.config import hvr_config, selsa_config  # noqa: E402
+from hvrnet_amd.graphs import GraphedClip, GraphedStream  # noqa: E402
+
+DEV = 'cuda:0'
+HW, PAD = (150, 250), (160, 256)
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+
+def _check(kind, got, want):
+    if kind == 'hvr':
+        assert len(got) == len(want) == 2 and all(_same(g, w) for g, w in zip(got, want))
+    else:
+        assert _same(got, want)
+
+
+@pytest.mark.parametrize('kind', ['hvr', 'selsa'])
+def test_graphed_clip_equals_the_eager_window(kind):
+    T, n_prop = 5, 24
+    make = hvr_config if kind == 'hvr' else selsa_config
+    model = hvrnet_amd.build_model(make(frame_interval=T // 2, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    metas = [S.synth_meta(HW, PAD) for _ in range(T)]
+    clips = [torch.cat([S.synth_frame(10 * c + i, img_hw=HW, pad_hw=PAD) for i in range(T)], 0).to(DEV) for c in range(3)]
+    g = GraphedClip(model, clips[0], metas, rescale=True)
+    n_det = 0
+    for rep in range(2):
+        for clip in clips:
+            pend = g.run(clip)
+            got = pend.result()
+            assert not pend.respeculated
+            with torch.no_grad():
+                c4 = model(img=clip, img_meta=metas, backbone_feat=True)[0]
+                want = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
+            _check(kind, got, want)
+            n_det += sum(len(r) for r in (got[-1] if kind == 'hvr' else got))
+    assert n_det > 0
+
+
+def test_graphed_clip_with_a_short_frame_takes_the_exact_path():
+    """A harsh RPN NMS leaves some frame with fewer than nms_post proposals: the replay's speculative result is discarded and
+    the window is re-run through the exact (ragged) eager path -- same answer as eager forward_feat(speculate=False)."""
+    T = 3
+    cfg = hvr_config(frame_interval=1, nms_post=400)
+    cfg.test_cfg.rpn.nms_thr = 0.02
+    model = hvrnet_amd.build_model(cfg, S.synth_state_dict('hvr'), torch.float32, DEV)
+    metas = [S.synth_meta() for _ in range(T)]
+    clip = torch.cat([S.synth_frame(i) for i in range(T)], 0).to(DEV)
+    g = GraphedClip(model, clip, metas, rescale=True, warmup=1)
+    pend = g.run()
+    got = pend.result()
+    assert pend.respeculated
+    with torch.no_grad():
+        c4 = model(img=clip, img_meta=metas, backbone_feat=True)[0]
+        want = model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True, speculate=False)
+    _check('hvr', got, want)
+
+
+@pytest.mark.parametrize('kind', ['hvr', 'selsa'])
+def test_graphed_stream_equals_the_cached_frame_loop(kind):
+    """GraphedStream (graph F per arriving frame, graph W per emitted window) driven in the reference loop's shape --
+    the first frame pushed (T+1)/2 times, the last one repeated while the remaining centres are emitted
+    (tools/test.py:201-212,257-300) -- against VideoWindowRunner(cache_frames=True) on the same video."""
+    from hvrnet_amd.window import VideoWindowRunner
+    fi, n_prop = 2, 24
+    T = 2 * fi + 1
+    make = hvr_config if kind == 'hvr' else selsa_config
+    model = hvrnet_amd.build_model(make(frame_interval=fi, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    frames = [S.synth_frame(i, img_hw=HW, pad_hw=PAD).to(DEV) for i in range(8)]
+    meta = S.synth_meta(HW, PAD)
+    with torch.no_grad():
+        want = VideoWindowRunner(model, T, cache_frames=True).run_video(frames, [meta] * len(frames))
+    gs = GraphedStream(model, frames[0], meta, rescale=True)
+    got = {}
+    # first frame: the deque is padded with copies until it holds (T + 1) / 2 entries
+    gs.push(frames[0])
+    for _ in range((T + 1) // 2 - 1):
+        gs.repeat_last()
+    filled = (T + 1) // 2
+    emitted = 0
+    for i in range(1, len(frames) - 1):
+        gs.push(frames[i])
+        filled += 1
+        if filled >= T:
+            got[emitted] = gs.emit().result()
+            emitted += 1
+    # last frame: pad to T - 1, then append + emit the remaining centres
+    gs.push(frames[-1])
+    filled += 1
+    while filled < T:
+        gs.repeat_last()
+        filled += 1
+    got[emitted] = gs.emit().result()
+    emitted += 1
+    while emitted < len(frames):
+        gs.repeat_last()
+        got[emitted] = gs.emit().result()
+        emitted += 1
+    assert sorted(got) == sorted(want) == list(range(len(frames)))
+    for off in want:
+        _check(kind, got[off], want[off])
+
+
+@pytest.mark.parametrize('kind', ['hvr', 'selsa'])
+def test_graphed_stream_with_look_ahead_batches_gives_the_same_frames(kind):
+    """`lookahead` frames through the per-frame part in one batch (graph FB), then one `advance(i)` + `emit()` per output
+    frame: the rows of a frame do not depend on what else is in its batch, so every emitted window equals the
+    one-frame-at-a-time stream's bit for bit."""
+    fi, n_prop, B = 1, 24, 4
+    T = 2 * fi + 1
+    make = hvr_config if kind == 'hvr' else selsa_config
+    model = hvrnet_amd.build_model(make(frame_interval=fi, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    frames = torch.cat([S.synth_frame(i, img_hw=HW, pad_hw=PAD) for i in range(2 * B)], 0).to(DEV)
+    meta = S.synth_meta(HW, PAD)
+    one = GraphedStream(model, frames[0:1], meta, rescale=True)
+    want = []
+    for i in range(frames.shape[0]):
+        one.push(frames[i:i + 1])
+        if i >= T - 1:
+            want.append(one.emit().result())
+    look = GraphedStream(model, frames[0:1], meta, rescale=True, lookahead=B)
+    got, seen = [], 0
+    for b0 in range(0, frames.shape[0], B):
+        look.push_batch(frames[b0:b0 + B])
+        for i in range(B):
+            look.advance(i)
+            seen += 1
+            if seen >= T:
+                got.append(look.emit().result())
+    assert len(got) == len(want) == frames.shape[0] - T + 1
+    for g, w in zip(got, want):
+        _check(kind, g, w)

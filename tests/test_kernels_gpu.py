@@ -6,6 +6,7 @@ Tolerances: bf16 operands are rounded before both sides see them, so the only er
 f32 accumulation order (+ bf16 rounding of stored outputs, 2^-9 relative).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -403,3 +404,70 @@ def test_gemm_splitk_matches_the_single_pass_product(dtype, M, N, K):
         assert float((got - want).abs().max()) <= 1e-5 * scale + 1e-6
         ref = a.double() @ w.double().t()
         assert float((got.double() - ref).abs().max()) <= float((want.double() - ref).abs().max()) * 2 + 1e-4 * scale
+
+
+# ------------------------------------------------------------------------------- producer / consumer tile kernel
+PC128, PC256 = 14, 15   # gemm_params.h: kPcHint128 / kPcHint256
+
+
+@pytest.mark.parametrize('tile', [PC128, PC256])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 512, 320), (700, 264, 192), (513, 128, 1280), (2394, 256, 128), (4500, 1024, 256)])
+def test_producer_consumer_kernel_equals_the_tile_engine(M, N, K, tile):
+    """pc_gemm.hip (4 compute + 4 DMA waves, 144 x 128 / 144 x 256 tiles): the MFMA sequence of an output element is the
+    tile engine's (K-steps in order, two 32-wide halves each), so the results are bit-identical -- ragged M / N tiles,
+    K loops shorter (2 K-steps) and longer (20) than the LDS ring, bias + residual + ReLU and the f32 output included."""
+    dtype = torch.bfloat16
+    a, w = _rand((M, K), dtype, 71), _rand((N, K), dtype, 72, 0.1)
+    bias, resid = _rand((N,), torch.float32, 73), _rand((M, N), dtype, 74)
+    ref = torch.relu(a.float() @ w.float().t() + bias + resid.float())
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV)
+    out = native.gemm(ad, wd, bd, rd, relu=True, staging=1, tile=tile)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(dtype))
+    assert torch.equal(out, native.gemm(ad, wd, bd, rd, relu=True, staging=1, tile=1))
+    out32 = native.gemm(ad, wd, bd, out_f32=True, staging=1, tile=tile)
+    assert torch.equal(out32, native.gemm(ad, wd, bd, out_f32=True, staging=1, tile=1))
+
+
+def test_producer_consumer_kernel_rejects_what_it_cannot_run():
+    a, w = _rand((145, 64), torch.bfloat16, 75).to(DEV), _rand((36, 64), torch.bfloat16, 76).to(DEV)
+    with pytest.raises(native.HvrError):
+        native.gemm(a, w, tile=PC128)          # N % 8 != 0 and a one-K-step loop: no silent fallback behind a forced shape
+    out = native.gemm(a, w)                    # the default dispatch takes the tile engine
+    torch.testing.assert_close(out.float().cpu(), a.float().cpu() @ w.float().cpu().t(), **_tol(torch.bfloat16))
+
+
+def test_producer_consumer_apply_pass_opt_in():
+    """HVR_PC_APPLY=1 routes the window-sized apply pass through pc_gemm.hip (block weights from an LDS table written by the
+    DMA waves, the previous block's fold riding between the next block's MFMAs).  The switch is read once per process, so the
+    check runs in a child: against an f64 statement of softmax(q k^T / 32) v, with a key whose score jumps the row maximum by
+    2^40 between blocks (the fold's weights must follow), and against the default (tile engine) apply pass of the parent."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from hvrnet_amd import native
+g = torch.Generator().manual_seed(5)
+M, D = 2200, 1024
+q = (torch.randn((M, D), generator=g) * 1.2).to(torch.bfloat16)
+k = (torch.randn((M, D), generator=g) * 1.2).to(torch.bfloat16)
+v = torch.randn((M, D), generator=g).to(torch.bfloat16)
+k[1500] = q[7] * 4.0        # a spike: row 7's maximum jumps far above the earlier blocks' at block 11
+o = native.relation_fwd(q.cuda(), k.cuda(), v.cuda(), 1 / 32).float().cpu()
+ref = (torch.softmax((q.double() @ k.double().t()) / 32, 1) @ v.double()).float()
+err = (o - ref).abs().max().item()
+assert err < 2e-2 * v.float().abs().max().item(), err
+torch.save(o, sys.argv[1])
+print('ok', err)
+'''
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ('1', '0'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            env = dict(os.environ, HVR_PC_APPLY=flag)
+            r = subprocess.run([sys.executable, '-c', code % root, f.name], capture_output=True, text=True, timeout=300, env=env)
+            assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-1500:]
+            outs.append(torch.load(f.name))
+    # same P~, same block statistics, same per-block products; only the weights' rounding path differs (table vs in-loop exp2)
+    assert (outs[0] - outs[1]).abs().max().item() < 8e-3

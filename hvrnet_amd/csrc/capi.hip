@@ -350,7 +350,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     p.ksplit_count = slices;
     p.csplit_bytes = (long)Mq * D * 4;
     p.C = partial; p.ldc = D; p.out_f32 = dtype == HVR_BF16 ? 1 : 0;
-    p.tile_hint = 1;  // 128 x 128 tiles (two workgroups per CU): the slices' K loops are a handful of steps
+    p.tile_hint = 1;  // 128 x 128 tiles; the slices are latency chains of 8 K-steps (the pipelined shapes measure the same)
     hipError_t e = run_tile_op(p, EPI_APPLY, s);
     if (e == hipSuccess)
       e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);

@@ -258,34 +258,57 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     const int m = m0 + (wm * FM + i) * 16 + (lane & 15);
     return (m < p.M ? m : p.M - 1) * p.ntile;
   };
-  if constexpr (EPI == EPI_APPLY) {
-    // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*)
-    // (v_exp_f32 / v_log_f32 directly: one instruction each, 1 ulp; exp2f / log2f wrap them in denormal handling these
-    // weights never need -- the prologue is serial work in front of every tile's first MFMA):
-    // the four lanes that share a row split the key tiles, then merge their (max, sum) pairs.
+  // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*)
+  // (v_exp_f32 / v_log_f32 directly: one instruction each, 1 ulp; exp2f / log2f wrap them in denormal handling these
+  // weights never need): the four lanes that share a row split the key tiles, then merge their (max, sum) pairs.  It is
+  // serial work in front of the tile's first MFMA, so (a) it runs AFTER the pipeline's first K-steps have been requested
+  // and (b) its loads go out in batches of 8 tiles x FM rows -- one memory round trip per batch instead of one per tile.
+  auto apply_prologue = [&]() {
+    if constexpr (EPI == EPI_APPLY) {
+      constexpr int TB = 8;
+      float mx[FM], l[FM];
+      int rowo[FM];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int row = stat_row(i);
-      float mx = -INFINITY, l = 0.f;
-      for (int t = lane >> 4; t < p.ntile; t += 4) {
-        const float mt = p.mstat[row + t], lt = p.lstat[row + t];
-        const float mn = fmaxf(mx, mt);
-        l = l * __builtin_amdgcn_exp2f(mx - mn) + lt * __builtin_amdgcn_exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
-        mx = mn;
+      for (int i = 0; i < FM; ++i) { mx[i] = -INFINITY; l[i] = 0.f; rowo[i] = stat_row(i); }
+      for (int t0 = lane >> 4; t0 < p.ntile; t0 += 4 * TB) {
+        float mt[FM][TB], lt[FM][TB];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const int t = t0 + 4 * u;
+            const bool ok = t < p.ntile;
+            const int tt = ok ? t : p.ntile - 1;
+            const float a = p.mstat[rowo[i] + tt], b = p.lstat[rowo[i] + tt];
+            mt[i][u] = ok ? a : -INFINITY;   // a tile past the end: weight 0 (mx stays finite: t0 itself is a real tile)
+            lt[i][u] = ok ? b : 0.f;
+          }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const float mn = fmaxf(mx[i], mt[i][u]);
+            l[i] = l[i] * __builtin_amdgcn_exp2f(mx[i] - mn) + lt[i][u] * __builtin_amdgcn_exp2f(mt[i][u] - mn);  // 0 * exp2(-inf) = 0
+            mx[i] = mn;
+          }
       }
 #pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
-        const float mo = __shfl_xor(mx, o), lo = __shfl_xor(l, o);
-        const float mn = fmaxf(mx, mo);  // a lane without tiles carries (-inf, 0); some lane has a finite max
-        l = (mx == mn ? l : l * __builtin_amdgcn_exp2f(mx - mn)) + (mo == mn ? lo : lo * __builtin_amdgcn_exp2f(mo - mn));
-        mx = mn;
+      for (int i = 0; i < FM; ++i) {
+        float m_ = mx[i], l_ = l[i];
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float mo = __shfl_xor(m_, o), lo = __shfl_xor(l_, o);
+          const float mn = fmaxf(m_, mo);  // a lane without tiles carries (-inf, 0); some lane has a finite max
+          l_ = (m_ == mn ? l_ : l_ * __builtin_amdgcn_exp2f(m_ - mn)) + (mo == mn ? lo : lo * __builtin_amdgcn_exp2f(mo - mn));
+          m_ = mn;
+        }
+        gref[i] = m_ + __builtin_amdgcn_logf(l_);
+        gcur[i] = __builtin_amdgcn_exp2f(p.mstat[rowo[i] + blk0] - gref[i]);
+        landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
+        gnext[i] = 0.f;
       }
-      gref[i] = mx + __builtin_amdgcn_logf(l);
-      gcur[i] = __builtin_amdgcn_exp2f(p.mstat[row + blk0] - gref[i]);
-      landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
-      gnext[i] = 0.f;
     }
-  }
+  };
 
   const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
   // per-lane part of the fragment read addresses (kk = 1 is the same address with bit 6 flipped)
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     // Double buffer, one barrier per K-step: the next step's loads are issued at the top of a step and drained at
     // its bottom (the compiler waits for them in front of the barrier).
     issue_loads(0, smem);
+    apply_prologue();
     commit_stage(smem);
     __syncthreads();
 
@@ -483,6 +507,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) issue_loads(s, smem + s * STAGE_BYTES);
+    apply_prologue();
     if constexpr (RES_EARLY) {
 #pragma unroll
       for (int pass = 0; pass < WM; ++pass)

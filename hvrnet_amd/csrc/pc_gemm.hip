@@ -132,6 +132,15 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base[i] + (long)kt * 128),
                                          (__attribute__((address_space(3))) void*)(stage + dst[i]), 16, 0, 0);
     };
+#ifdef HVR_DBG_PC_FREERUN
+    // tuning build: the producers stream the whole K loop into the ring on their own counted waits, no barriers, nobody reads
+    for (int kt = 0; kt < nk; ++kt) {
+      issue(kt);
+      pc_wait_vm<HVR_DBG_PC_FREERUN * PPW>();
+    }
+    pc_wait_vm<0>();
+    return;
+#endif
     // steps 0 .. NS - 3 ahead of B_0; after B_j: step j + NS - 2 (the slot of step j - 2, consumed before B_j)
 #pragma unroll
     for (int s = 0; s < NS - 2; ++s)
@@ -147,14 +156,33 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
         const int m = m0 + ptid;
         const long row = (long)(m < p.M ? m : p.M - 1) * p.ntile;
         float mx = -INFINITY, l = 0.f;
-        for (int t = 0; t < p.ntile; ++t) {
-          const float mt = p.mstat[row + t], lt = p.lstat[row + t];
-          const float mn = fmaxf(mx, mt);
-          l = l * __builtin_amdgcn_exp2f(mx - mn) + lt * __builtin_amdgcn_exp2f(mt - mn);  // first term: 0 * exp2(-inf) = 0
-          mx = mn;
+        constexpr int TB = 12;   // loads go out in batches: one memory round trip per 12 tiles, not per tile
+        for (int t0 = 0; t0 < p.ntile; t0 += TB) {
+          float mt[TB], lt[TB];
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const bool ok = t0 + u < p.ntile;
+            const int tt = ok ? t0 + u : p.ntile - 1;
+            const float a = p.mstat[row + tt], b = p.lstat[row + tt];
+            mt[u] = ok ? a : -INFINITY;
+            lt[u] = ok ? b : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const float mn = fmaxf(mx, mt[u]);
+            l = l * __builtin_amdgcn_exp2f(mx - mn) + lt[u] * __builtin_amdgcn_exp2f(mt[u] - mn);  // 0 * exp2(-inf) = 0
+            mx = mn;
+          }
         }
         const float gref = mx + __builtin_amdgcn_logf(l);
-        for (int t = 0; t < p.ntile; ++t) g_lds[t * PC_BM + ptid] = __builtin_amdgcn_exp2f(p.mstat[row + t] - gref);
+        for (int t0 = 0; t0 < p.ntile; t0 += TB) {
+          float mt[TB];
+#pragma unroll
+          for (int u = 0; u < TB; ++u) mt[u] = p.mstat[row + (t0 + u < p.ntile ? t0 + u : p.ntile - 1)];
+#pragma unroll
+          for (int u = 0; u < TB; ++u)
+            if (t0 + u < p.ntile) g_lds[(t0 + u) * PC_BM + ptid] = __builtin_amdgcn_exp2f(mt[u] - gref);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table is written before B_0 releases its readers
     }
@@ -169,6 +197,9 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
   }
 
   // ========================================= consumer =========================================
+#ifdef HVR_DBG_PC_FREERUN
+  return;
+#endif
   const int wn = wave;
   const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
   const uint32_t a_lane = pc_lds_off(smem) + frag_row * 128 + ((frag_grp ^ swz) * 16);

@@ -16,6 +16,7 @@ struct ScoresBTParams {
   int Mq, Mk, D, ntile;
   long ldq, ldk, ldv, ldp;
   float sl2;        // scale * log2(e)
+  int tile0, tiles_here;  // set by run_scores_bt per launch: this launch's slice of the tile grid
 };
 
 // true when the one-round 352 x 256 tiling applies (bf16, aligned operands, a tile grid that fills most of the chip)

@@ -81,9 +81,11 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   const int tiles_n = (int)((p.ldp + BT_BN - 1) / BT_BN);
   const int tiles_m = (p.Mq + BT_BM - 1) / BT_BM;
   const int ntiles = tiles_m * tiles_n;
-  const bool has_tile = (int)blockIdx.x < ntiles;
+  // Rounds of up to 256 tiles, one LAUNCH per round (one for the 4 500-row window: 234 tiles; two for the shipped T = 21
+  // window's 6 300 rows: 450 tiles): this launch holds tiles p.tile0 .. p.tile0 + p.tiles_here - 1
+  const bool has_tile = (int)blockIdx.x < p.tiles_here;
   // n fastest inside an XCD's contiguous range: the 352-row query panel is shared by neighbouring tiles
-  const int tile = has_tile ? xcd_remap(blockIdx.x, ntiles) : 0;
+  const int tile = has_tile ? p.tile0 + xcd_remap(blockIdx.x, p.tiles_here) : 0;
   const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;
   const int m0 = pid_m * BT_BM, n0 = pid_n * BT_BN;
 
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   // ---------------- V^T[D][ldp] = V[Mk][ldv]^T, zero-filled for keys Mk .. ldp - 1 ----------------
   // 64 x 64 tiles, one per half workgroup (256 threads) and pass; 16-byte global accesses on both sides
 #ifndef HVR_DBG_BT_NOTRANSPOSE
-  {
+  if (p.tile0 == 0) {   // the first round's launch carries the V^T copy
     constexpr int PITCH = 64 * 2 + 16;
     const int half = tid >> 8, ht = tid & 255;
     char* tbuf = smem + BT_STAGE + half * (64 * PITCH);
@@ -304,7 +306,8 @@ bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, lo
   if ((long)Mq * ldq * 2 >= (1L << 31) || (long)Mk * ldk * 2 >= (1L << 31)) return false;
   // the single-round shape only pays once the tile grid fills most of the chip
   const long tiles = (long)((Mq + BT_BM - 1) / BT_BM) * ((ldp + BT_BN - 1) / BT_BN);
-  return tiles >= 160 && tiles <= 256 && Mk >= 128;
+  // one round on most of the chip, or two rounds whose second is at least half full (the shipped T = 21 window: 450 tiles)
+  return ((tiles >= 160 && tiles <= 256) || (tiles >= 384 && tiles <= 512)) && Mk >= 128;
 }
 
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
@@ -313,7 +316,14 @@ hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(relation_scores_bt_kernel, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
+  const int ntiles = ((p.Mq + BT_BM - 1) / BT_BM) * (int)((p.ldp + BT_BN - 1) / BT_BN);
+  ScoresBTParams q = p;
+  for (int t0 = 0; t0 < ntiles; t0 += 256) {
+    q.tile0 = t0;
+    q.tiles_here = ntiles - t0 < 256 ? ntiles - t0 : 256;
+    // the first launch is a full grid: the workgroups without a tile still carry their share of the V^T copy
+    hipLaunchKernelGGL(relation_scores_bt_kernel, dim3(t0 == 0 ? 256 : q.tiles_here), dim3(BT_NT), BT_LDS, stream, q);
+  }
   return hipGetLastError();
 }
 

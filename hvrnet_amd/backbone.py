@@ -13,6 +13,8 @@ forward pass runs on packed device buffers:
 Inference only: BN layers are always treated as frozen (both configs set norm_eval=True,
 requires_grad=False).  There is no CPU path (native.py raises on CPU tensors).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -151,6 +153,9 @@ class Bottleneck(nn.Module, PackedMixin):
                  c3=fold_conv_bn(self.conv3, self.bn3, dtype))
         if self.downsample is not None:
             p['ds'] = fold_conv_bn(self.downsample[0], self.downsample[1], dtype)
+            # the projection shortcut as a second K segment of the closing 1x1 (hvr_bottleneck_tail): rows [W3 | Wd]
+            p['tail'] = (torch.cat([p['c3'][0].reshape(p['c3'][0].shape[0], -1), p['ds'][0].reshape(p['ds'][0].shape[0], -1)], 1).contiguous(),
+                         (p['c3'][1] + p['ds'][1]).contiguous())
         return p
 
     def forward_nhwc(self, x, out=None):
@@ -162,8 +167,13 @@ class Bottleneck(nn.Module, PackedMixin):
                                  dil=self.dilation)
         identity = x
         if self.downsample is not None:
+            if self.fuse_tail and native.bottleneck_tail_supported(out, x, p['tail'][0], p['tail'][1], self.stride):
+                # relu(conv3(out) + downsample(x)) in one pass: the identity map is never written (resnet.py:248-264)
+                return native.bottleneck_tail(out, x, p['tail'][0], p['tail'][1], stride2=self.stride, relu=True, out=dst)
             identity = native.conv2d_nhwc(x, p['ds'][0], p['ds'][1], relu=False, stride=self.stride)
         return native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=identity, relu=True, out=dst)
+
+    fuse_tail = os.environ.get('HVR_FUSE_TAIL', '1') != '0'
 
     def forward(self, x):
         return as_logical(self.forward_nhwc(as_nhwc(x, self.compute_dtype)))

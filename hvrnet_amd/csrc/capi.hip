@@ -224,6 +224,37 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
 }
 
+static int tail_params(const hvr_tail_desc* d, GemmParams& p) {
+  if (!d) return fail(HVR_EINVAL, "null descriptor");
+  if (d->dtype != HVR_BF16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail is bf16 only");
+  if (d->B <= 0 || d->OH <= 0 || d->OW <= 0 || d->stride2 <= 0) return fail(HVR_EINVAL, "empty tail problem");
+  if ((d->OH - 1) * d->stride2 >= d->H2 || (d->OW - 1) * d->stride2 >= d->W2) return fail(HVR_EINVAL, "the sampled pixels fall outside x");
+  const long M = (long)d->B * d->OH * d->OW;
+  if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
+  const int K = d->C1 + d->C2;
+  int rc = fill_linear(p, d->h, d->w, d->y, (int)M, d->Cout, K, d->C1, K, d->Cout, d->dtype, 1);
+  if (rc) return rc;
+  if (!d->x || !aligned16(d->x)) return fail(HVR_EINVAL, "x must be a 16-byte aligned device pointer");
+  if ((long)d->B * d->H2 * d->W2 * d->C2 * 2 >= (1L << 31)) return fail(HVR_EUNSUPPORTED, "block input of 2 GiB or more");
+  p.bias = d->bias; p.relu = d->relu;
+  p.A2 = d->x; p.K1 = d->C1; p.H2 = d->H2; p.W2 = d->W2; p.s2 = d->stride2; p.OH = d->OH; p.OW = d->OW;
+  return 0;
+}
+
+int hvr_bottleneck_tail_supported(const hvr_tail_desc* d) {
+  GemmParams p;
+  if (tail_params(d, p)) return 0;
+  return expand_supported(p) ? 1 : 0;
+}
+
+int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream) {
+  GemmParams p;
+  const int rc = tail_params(d, p);
+  if (rc) return rc;
+  if (!expand_supported(p)) return fail(HVR_EUNSUPPORTED, "no fused tail kernel for C1=%d C2=%d Cout=%d", d->C1, d->C2, d->Cout);
+  return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail");
+}
+
 int hvr_conv2d_path(const hvr_conv_desc* d) {
   GemmParams p;
   int path = 0;

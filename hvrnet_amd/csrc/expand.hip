@@ -107,8 +107,16 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
     const int m = m0 + i * 16 + q;
     mrow[i] = m < p.M ? m : p.M - 1;
     const char* xr = (const char*)p.A + (long)mrow[i] * p.lda * 2 + g * 16;
+    // second K segment (p.s2 > 0: the block's projection shortcut): the row's pixel of the block INPUT, sampled at stride s2
+    const char* x2r = xr;
+    const int kf1 = p.s2 > 0 ? p.K1 / 32 : KF;
+    if (p.s2 > 0) {
+      const int ox = mrow[i] % p.OW, t = mrow[i] / p.OW, oy = t % p.OH, b = t / p.OH;
+      x2r = (const char*)p.A2 + (((long)b * p.H2 + oy * p.s2) * p.W2 + ox * p.s2) * (long)(K - p.K1) * 2 + g * 16;
+    }
 #pragma unroll
-    for (int kf = 0; kf < KF; ++kf) x[i][kf] = *reinterpret_cast<const xu32x4*>(xr + kf * 64);
+    for (int kf = 0; kf < KF; ++kf)
+      x[i][kf] = *reinterpret_cast<const xu32x4*>(kf < kf1 ? xr + kf * 64 : x2r + (kf - kf1) * 64);
   }
 
   // residual rows of a chunk: lane's channels n = c BN + 16 g .. + 16 of rows mrow[0], mrow[1]
@@ -237,10 +245,12 @@ static int expand_nc(int M, int N) {
 }
 
 // The panel kernel applies when the product is a plain bf16 GEMM with a short K, whole 16-byte rows, and an output of
-// an even number of 64-channel chunks (the expand convs of layers 1-3 and res5: K = 64 / 128 / 256 / 512, N = 4 K).
+// an even number of 64-channel chunks (the expand convs of layers 1-3 and res5: K = 64 / 128 / 256 / 512, N = 4 K), or the
+// first block of a stage with its projection shortcut as a second K segment (K = 64 + 64, 128 + 256: hvr_bottleneck_tail).
 bool expand_supported(const GemmParams& p) {
   if (p.dtype != DT_BF16 || p.conv || p.out_f32 || p.ksplit_steps > 0) return false;
-  if (!(p.K == 64 || p.K == 128 || p.K == 256 || p.K == 512)) return false;
+  if (!(p.K == 64 || p.K == 128 || p.K == 256 || p.K == 512 || (p.K == 384 && p.s2 > 0))) return false;
+  if (p.s2 > 0 && (p.K1 % 32 || p.K1 <= 0 || p.K1 >= p.K || (p.K - p.K1) % 8 || (reinterpret_cast<uintptr_t>(p.A2) & 15) || p.resid)) return false;
   if (p.N % X_BN || p.M < X_BM || expand_nc(p.M, p.N) == 0) return false;
   if (p.lda % 8 || p.ldb % 8 || p.ldc % 8 || (p.resid && p.ldr % 8)) return false;
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
@@ -285,6 +295,7 @@ hipError_t run_expand(const GemmParams& p, hipStream_t stream) {
     case 64: return launch_expand<2>(p, stream);
     case 128: return launch_expand<4>(p, stream);
     case 256: return launch_expand<8>(p, stream);
+    case 384: return launch_expand<12>(p, stream);
     case 512: return launch_expand<16>(p, stream);
     default: return hipErrorInvalidValue;
   }

@@ -40,6 +40,10 @@ struct GemmParams {
   float* lstat;    // [M][ntile] tile sum
   int ntile;
   int group_m;  // > 1: tile order walks `group_m` row tiles per B panel (see tile_kernel)
+  // second K segment of the expand kernel (expand.hip, a Bottleneck's projection shortcut folded into its closing 1x1):
+  // columns K1 .. K - 1 of a row come from A2, an NHWC map [.][H2][W2][K - K1] sampled at stride s2 (0 = no second segment)
+  const void* A2;
+  int K1, H2, W2, s2;
   // split-K (EPI_LINEAR, no conv): ksplit_count slices of ksplit_steps K-steps, partial s at C + s * csplit_bytes (0 = off)
   int ksplit_steps, ksplit_count;
   long csplit_bytes;

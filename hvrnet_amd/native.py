@@ -51,6 +51,13 @@ class ConvDesc(ctypes.Structure):
                 ('zero', ctypes.c_void_p)]
 
 
+class TailDesc(ctypes.Structure):
+    _fields_ = [('h', ctypes.c_void_p), ('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('B', ctypes.c_int32), ('OH', ctypes.c_int32), ('OW', ctypes.c_int32), ('C1', ctypes.c_int32),
+                ('H2', ctypes.c_int32), ('W2', ctypes.c_int32), ('C2', ctypes.c_int32), ('stride2', ctypes.c_int32),
+                ('Cout', ctypes.c_int32), ('bias', ctypes.c_void_p), ('relu', ctypes.c_int32), ('dtype', ctypes.c_int32)]
+
+
 class RpnDesc(ctypes.Structure):
     _fields_ = [('cls', ctypes.c_void_p), ('reg', ctypes.c_void_p),
                 ('T', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
@@ -73,6 +80,8 @@ SYMBOLS = {
     'hvr_gemm_splitk': (_i, [ctypes.POINTER(GemmDesc), _vp, _sz, _vp]),
     'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'hvr_conv2d_path': (_i, [ctypes.POINTER(ConvDesc)]),
+    'hvr_bottleneck_tail': (_i, [ctypes.POINTER(TailDesc), _vp]),
+    'hvr_bottleneck_tail_supported': (_i, [ctypes.POINTER(TailDesc)]),
     'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_stem_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -324,6 +333,40 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
             tag = '%s %dx%d %d->%d k%d s%d d%d%s' % (tag, H, W, Cin, Cout, KH, stride, dil, '+res' if resid is not None else '')
     with _span(tag, work):
         _check(lib().hvr_conv2d_nhwc(ctypes.byref(d), _stream()), 'hvr_conv2d_nhwc')
+    return y
+
+
+def _tail_desc(h, x, w, bias, stride2, relu, y):
+    B, OH, OW, C1 = h.shape
+    _, H2, W2, C2 = x.shape
+    return TailDesc(h=h.data_ptr(), x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr() if y is not None else 1 << 20, B=B, OH=OH, OW=OW, C1=C1,
+                    H2=H2, W2=W2, C2=C2, stride2=int(stride2), Cout=w.shape[0], bias=bias.data_ptr(), relu=int(relu), dtype=_dt(h))
+
+
+def bottleneck_tail_supported(h, x, w, bias, stride2):
+    """True when hvr_bottleneck_tail has a fused kernel for these shapes (bf16, C1 + C2 in {128, 384}, ...)."""
+    if not (h.is_cuda and h.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and h.is_contiguous() and x.is_contiguous()):
+        return False
+    return bool(lib().hvr_bottleneck_tail_supported(ctypes.byref(_tail_desc(h, x, w, bias, stride2, True, None))))
+
+
+def bottleneck_tail(h, x, w, bias, stride2=1, relu=True, out=None):
+    """relu(h W3^T + x_s Wd^T + bias): the closing 1x1 of a Bottleneck with its projection shortcut as a second K segment.
+    h [B,OH,OW,C1], x [B,H2,W2,C2] physical NHWC, w [Cout, C1 + C2], bias f32 [Cout] -> [B,OH,OW,Cout]."""
+    _need_cuda(h, x, w, bias)
+    B, OH, OW, C1 = h.shape
+    Cout = w.shape[0]
+    if out is not None:
+        assert tuple(out.shape) == (B, OH, OW, Cout) and out.dtype == h.dtype and out.is_contiguous()
+        y = out
+    else:
+        y = torch.empty((B, OH, OW, Cout), dtype=h.dtype, device=h.device)
+    d = _tail_desc(h, x, w, bias, stride2, relu, y)
+    tag, work = 'conv_expand', float((h.numel() + B * OH * OW * x.shape[3] + y.numel() + w.numel()) * h.element_size())
+    if _prof is not None and _prof['detail']:
+        tag = 'conv_expand tail %dx%d %d+%d->%d s%d' % (OH, OW, C1, x.shape[3], Cout, stride2)
+    with _span(tag, work):
+        _check(lib().hvr_bottleneck_tail(ctypes.byref(d), _stream()), 'hvr_bottleneck_tail')
     return y
 
 

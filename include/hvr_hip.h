@@ -94,6 +94,24 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
  * negative = the descriptor would be rejected. */
 int hvr_conv2d_path(const hvr_conv_desc* d);
 
+/* Closing 1x1 conv of a Bottleneck whose identity path is a projection -- the first block of every stage
+ * (mmdet/models/backbones/resnet.py:248-264 with `downsample`, built at resnet.py:283-296):
+ *     y = relu( h W3^T + x_s Wd^T + bias )
+ * in ONE pass: the downsample conv (1x1, stride s) becomes a second K segment of the expand product, so its [B][OH][OW][Cout]
+ * output is neither written nor re-read as a residual.  h [B][OH][OW][C1] = conv2's output, x [B][H2][W2][C2] = the block
+ * input, x_s its pixels (oy * s, ox * s); w [Cout][C1 + C2] = [W3 | Wd] rows with both BatchNorm scales folded in;
+ * bias [Cout] = shift3 + shiftd (f32).  bf16, C1 + C2 in {128, 384} (stages 1 and 2 of the R-101: 64 + 64, 128 + 256),
+ * Cout a multiple of 128.  hvr_bottleneck_tail_supported: 1 when this descriptor runs, 0 otherwise (the caller then issues the
+ * two convs separately through hvr_conv2d_nhwc). */
+typedef struct hvr_tail_desc {
+  const void* h; const void* x; const void* w; void* y;
+  int32_t B, OH, OW, C1, H2, W2, C2, stride2, Cout;
+  const float* bias;
+  int32_t relu, dtype;
+} hvr_tail_desc;
+int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream);
+int hvr_bottleneck_tail_supported(const hvr_tail_desc* d);
+
 /* 7x7/2 stem: gathers img (NCHW f32, the reference's input layout, resnet.py:522-524) into
  * patch rows [B*OH*OW][KP] with k = (ky*7+kx)*3 + c and zeros for k >= 147 (KP = 192). */
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream);

@@ -471,3 +471,42 @@ print('ok', err)
             outs.append(torch.load(f.name))
     # same P~, same block statistics, same per-block products; only the weights' rounding path differs (table vs in-loop exp2)
     assert (outs[0] - outs[1]).abs().max().item() < 8e-3
+
+
+# ------------------------------------------------------------------------------- Bottleneck tail (projection shortcut as a second K segment)
+@pytest.mark.parametrize('C1,C2,Cout,stride,B,OH,OW', [(64, 64, 256, 1, 2, 38, 63), (128, 256, 512, 2, 3, 19, 32), (64, 64, 256, 1, 1, 152, 252)])
+def test_bottleneck_tail_fuses_the_projection_shortcut(C1, C2, Cout, stride, B, OH, OW):
+    """hvr_bottleneck_tail: relu(h W3^T + x_s Wd^T + bias) with x_s = the block input sampled at the downsample conv's stride
+    (resnet.py:248-264, first block of a stage) against the same expression in f32 -- and against the two-conv path it
+    replaces (downsample conv -> bf16 identity -> expand conv + residual), which differs only by the identity's rounding."""
+    g = torch.Generator().manual_seed(C1 + Cout)
+    H2, W2 = (OH - 1) * stride + 1 + (stride - 1), (OW - 1) * stride + 1   # a row / column beyond the last sampled pixel too
+    h = (torch.randn((B, OH, OW, C1), generator=g)).to(torch.bfloat16)
+    x = (torch.randn((B, H2, W2, C2), generator=g)).to(torch.bfloat16)
+    w3 = (torch.randn((Cout, C1), generator=g) * 0.1).to(torch.bfloat16)
+    wd = (torch.randn((Cout, C2), generator=g) * 0.1).to(torch.bfloat16)
+    b3, bd = torch.randn(Cout, generator=g) * 0.1, torch.randn(Cout, generator=g) * 0.1
+    xs = x[:, ::stride, ::stride][:, :OH, :OW]
+    ref = torch.relu(h.float() @ w3.float().t() + xs.float() @ wd.float().t() + b3 + bd)
+    w = torch.cat([w3, wd], 1).contiguous().to(DEV)
+    hd, xd = h.to(DEV), x.to(DEV)
+    bias = (b3 + bd).to(DEV)
+    assert native.bottleneck_tail_supported(hd, xd, w, bias, stride)
+    out = native.bottleneck_tail(hd, xd, w, bias, stride2=stride, relu=True)
+    torch.testing.assert_close(out.float().cpu(), ref, **_tol(torch.bfloat16))
+    ident = native.conv2d_nhwc(xd, wd.view(Cout, 1, 1, C2).to(DEV), bd.to(DEV), relu=False, stride=stride)
+    two = native.conv2d_nhwc(hd, w3.view(Cout, 1, 1, C1).to(DEV), b3.to(DEV), resid=ident[:, :OH, :OW].contiguous(), relu=True)
+    torch.testing.assert_close(out.float(), two.float(), rtol=2e-2, atol=6e-2)
+    # writing into a caller-owned slice (frame groups)
+    whole = torch.zeros((B + 1, OH, OW, Cout), dtype=torch.bfloat16, device=DEV)
+    native.bottleneck_tail(hd, xd, w, bias, stride2=stride, relu=True, out=whole[1:])
+    assert torch.equal(whole[1:], out) and not whole[0].any()
+
+
+def test_bottleneck_tail_says_when_it_does_not_apply():
+    h = torch.zeros((1, 8, 16, 64), device=DEV)                     # f32: the parity mode keeps the two-conv path
+    x = torch.zeros((1, 8, 16, 64), device=DEV)
+    w, b = torch.zeros((256, 128), device=DEV), torch.zeros(256, device=DEV)
+    assert not native.bottleneck_tail_supported(h, x, w, b, 1)
+    hb, xb = h.bfloat16(), torch.zeros((1, 8, 16, 512), device=DEV, dtype=torch.bfloat16)
+    assert not native.bottleneck_tail_supported(hb, xb, torch.zeros((256, 576), device=DEV, dtype=torch.bfloat16), b, 1)  # 64 + 512: no kernel

@@ -158,13 +158,29 @@ class Bottleneck(nn.Module, PackedMixin):
                          (p['c3'][1] + p['ds'][1]).contiguous())
         return p
 
-    def forward_nhwc(self, x, out=None):
-        """out: where the block's output goes (a contiguous [B,OH,OW,4*planes] tensor), e.g. a frame group's slice of a map."""
+    def forward_nhwc(self, x, out=None, h1=None, nxt=None):
+        """out: where the block's output goes (a contiguous [B,OH,OW,4*planes] tensor), e.g. a frame group's slice of a map.
+        h1: this block's conv1 output, when the previous block's tail already computed it.  nxt: the block that consumes
+        this one's output; the return value is then (y, h1 of nxt or None) -- nxt's conv1 rides on this block's tail when
+        hvr_bottleneck_tail_next has a kernel for the shapes."""
         p = self.packed(x.device)
         dst = out
-        out = native.conv2d_nhwc(x, p['c1'][0], p['c1'][1], relu=True, stride=self.conv1_stride)
+        out = h1 if h1 is not None else native.conv2d_nhwc(x, p['c1'][0], p['c1'][1], relu=True, stride=self.conv1_stride)
         out = native.conv2d_nhwc(out, p['c2'][0], p['c2'][1], relu=True, stride=self.conv2_stride, pad=self.dilation,
                                  dil=self.dilation)
+        if nxt is not None and self.fuse_next and nxt.conv1_stride == 1:
+            pn = nxt.packed(x.device)
+            wn, bn = pn['c1'][0].reshape(pn['c1'][0].shape[0], -1), pn['c1'][1]
+            if self.downsample is not None:
+                args = (out, x, None, p['tail'][0], p['tail'][1], self.stride) if self.fuse_tail else None
+            else:
+                args = (out, None, x, p['c3'][0].reshape(p['c3'][0].shape[0], -1), p['c3'][1], 1)
+            if args is not None and native.bottleneck_tail_next_supported(*args, wn, bn):
+                return native.bottleneck_tail_next(args[0], args[1], args[2], args[3], args[4], wn, bn, stride2=args[5], out=dst)
+        y = self._tail(x, out, p, dst)
+        return y if nxt is None else (y, None)
+
+    def _tail(self, x, out, p, dst):
         identity = x
         if self.downsample is not None:
             if self.fuse_tail and native.bottleneck_tail_supported(out, x, p['tail'][0], p['tail'][1], self.stride):
@@ -173,6 +189,7 @@ class Bottleneck(nn.Module, PackedMixin):
             identity = native.conv2d_nhwc(x, p['ds'][0], p['ds'][1], relu=False, stride=self.stride)
         return native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=identity, relu=True, out=dst)
 
+    fuse_next = os.environ.get('HVR_FUSE_NEXT', '1') != '0'
     fuse_tail = os.environ.get('HVR_FUSE_TAIL', '1') != '0'
 
     def forward(self, x):
@@ -303,9 +320,13 @@ class ResNet(nn.Module, PackedMixin):
             assert len(self.out_indices) == 1, 'out= needs a single returned map'
         for i, name in enumerate(self.res_layers):
             blocks = list(getattr(self, name))
+            h1 = None
             for j, blk in enumerate(blocks):
                 last = out is not None and i == self.out_indices[0] and j == len(blocks) - 1
-                y = blk.forward_nhwc(y, out=out) if last else blk.forward_nhwc(y)
+                if j + 1 < len(blocks):  # the next block's conv1 rides on this block's tail where a kernel exists
+                    y, h1 = blk.forward_nhwc(y, h1=h1, nxt=blocks[j + 1])
+                else:
+                    y = blk.forward_nhwc(y, out=out if last else None, h1=h1)
             if i in self.out_indices:
                 outs.append(as_logical(y))
             if out is not None and i == self.out_indices[0]:

@@ -255,6 +255,43 @@ int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream) {
   return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail");
 }
 
+// closing 1x1 (+ projection shortcut or identity residual) + the next block's reducing 1x1 (expand.hip, NX > 0)
+static int tail_next_params(const hvr_tail_next_desc* d, GemmParams& p) {
+  if (!d) return fail(HVR_EINVAL, "null descriptor");
+  const hvr_tail_desc& t = d->tail;
+  if (t.C2 > 0) {
+    const int rc = tail_params(&t, p);
+    if (rc) return rc;
+  } else {
+    if (t.dtype != HVR_BF16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail_next is bf16 only");
+    if (t.B <= 0 || t.OH <= 0 || t.OW <= 0) return fail(HVR_EINVAL, "empty tail problem");
+    const long M = (long)t.B * t.OH * t.OW;
+    if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
+    const int rc = fill_linear(p, t.h, t.w, t.y, (int)M, t.Cout, t.C1, t.C1, t.C1, t.Cout, t.dtype, 1);
+    if (rc) return rc;
+    if (!d->resid || !aligned16(d->resid)) return fail(HVR_EINVAL, "an identity block needs its (16-byte aligned) residual map");
+    p.bias = t.bias; p.relu = t.relu; p.resid = d->resid; p.ldr = t.Cout;
+  }
+  if (!t.relu) return fail(HVR_EUNSUPPORTED, "the next block reads the activated output (relu = 1)");
+  p.Wn = d->wn; p.bias_n = d->bias_n; p.Hn = d->hn; p.Cn = d->Cn;
+  return 0;
+}
+
+int hvr_bottleneck_tail_next_supported(const hvr_tail_next_desc* d) {
+  GemmParams p;
+  if (tail_next_params(d, p)) return 0;
+  return expand_next_supported(p) ? 1 : 0;
+}
+
+int hvr_bottleneck_tail_next(const hvr_tail_next_desc* d, void* stream) {
+  GemmParams p;
+  const int rc = tail_next_params(d, p);
+  if (rc) return rc;
+  if (!expand_next_supported(p))
+    return fail(HVR_EUNSUPPORTED, "no fused tail + next conv kernel for C1=%d C2=%d Cout=%d Cn=%d", d->tail.C1, d->tail.C2, d->tail.Cout, d->Cn);
+  return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail_next");
+}
+
 int hvr_conv2d_path(const hvr_conv_desc* d) {
   GemmParams p;
   int path = 0;

@@ -66,13 +66,21 @@ __device__ __forceinline__ int swz_key(int row) { return (((row >> 4) & 3) << 1)
 // selects the range: panels alone leave most CUs with one workgroup when M / 128 is close to the CU count)
 // RF: 16-row fragments per wave -- 2 with 4 waves (two workgroups per CU), 1 with 8 waves (K = 512: X alone is 64
 // registers per row fragment, and two 64 KB W buffers leave room for one workgroup per CU, so it brings its own 8 waves)
-template <int KF, bool RES, int NC, int RF>
+// NX > 0: the workgroup owns ALL N output channels of its 128 pixels (NC = N / 64, gridDim.y = 1) and also computes the next
+// block's reducing 1x1 on them, Hn = relu(out Wn^T + bias_n) with Cn = 16 NX output channels (resnet.py:224-232 of block
+// i + 1): after a chunk's epilogue the lane's packed bf16 outputs -- 16 consecutive channels of one pixel -- ARE the MFMA
+// B fragments of that product (k-slot e of lane group g <-> channel 16 g + e, + 8 for the second MFMA); Wn streams
+// through the LDS in 64-input-channel chunks beside W.  The next block then never reads this block's output for its conv1.
+template <int KF, bool RES, int NC, int RF, int NX>
 __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand_res_kernel(const GemmParams p) {
   constexpr int K = KF * 32, FJ = X_FJ, BN = X_BN, BM = X_BM, NT = 64 * (X_BM / 16 / RF);
   constexpr int CHUNK = BN * K * 2;               // bytes of one W chunk
   constexpr int SLOTS = CHUNK / 16 / NT;          // DMA pieces per thread per chunk
   static_assert(KF % 2 == 0 && CHUNK % (16 * NT) == 0, "shape");
   constexpr int NV = FJ / 2;                      // 16-byte pieces of a lane's 16 channels (bf16)
+  constexpr int CN = NX * 16, NCHUNK = CN * 128;  // next conv: output channels, bytes of one Wn chunk ([Cn][64 inputs])
+  constexpr int NSLOTS = NX > 0 ? NCHUNK / 16 / NT : 0;
+  static_assert(NX == 0 || (NX % 4 == 0 && NCHUNK % (16 * NT) == 0), "next-conv shape");
   constexpr int NRES = RES ? RF * NV : 0, NST = RF * NV;  // residual loads / output stores per thread and chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -91,6 +99,18 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
       const char* src = (const char*)p.B + (((long)(c * BN + row) * p.ldb) * 2 + ks * 128 + ch * 16);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(buf + (i * NT + wave * 64) * 16), 16, 0, 0);
+    }
+    if constexpr (NX > 0) {
+      // Wn chunk c: rows = the Cn output channels, 128 B (this chunk's 64 input channels) each; same row-keyed slot swizzle
+      char* nbuf = smem + 2 * CHUNK + NC * BN * 4 + (buf == smem ? 0 : NCHUNK);
+#pragma unroll
+      for (int i = 0; i < NSLOTS; ++i) {
+        const int s = i * NT + tid, row = s >> 3, pos = s & 7;
+        const int ch = pos ^ swz_key(row);
+        const char* src = (const char*)p.Wn + ((long)row * p.N * 2 + (long)c * 128 + ch * 16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(nbuf + (i * NT + wave * 64) * 16), 16, 0, 0);
+      }
     }
   };
   dma_chunk(cb, smem);
@@ -141,6 +161,16 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
   const int key = ((q >> 2) << 1) | ((q >> 1) & 1);
   const uint32_t w_lane = x_lds_off(smem) + ((q >> 2) * 4 * FJ + (q & 3)) * 128 + ((g ^ key) << 4);
   const uint32_t sh_lane = x_lds_off(shl) + g * 4 * FJ * 4;
+
+  f32x4 hacc[NX > 0 ? RF : 1][NX > 0 ? NX : 1];
+  if constexpr (NX > 0) {
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) hacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // Wn fragment of this lane: row 64 (jo >> 2) + 16 (q >> 2) + 4 (jo & 3) + (q & 3), 16-byte slot (2 g + v) ^ key
+  const uint32_t n_lane = x_lds_off(smem) + 2 * CHUNK + NC * BN * 4 + ((q >> 2) * 16 + (q & 3)) * 128;
 
   static_for<NC>([&](auto U) {
     constexpr int u = decltype(U)::value;
@@ -200,6 +230,7 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
       });
     });
     // ---- epilogue: lane holds out[m0 + 16 i + q][c BN + 16 g + 4 j + r] = acc[i][j][r] ----
+    uint4 yv[NX > 0 ? RF : 1][NV];  // (NX > 0) the chunk's packed outputs: the next conv's B fragments
     uint4 sh[FJ];
 #pragma unroll
     for (int j = 0; j < FJ; ++j) sh[j] = x_lds_read128<0>(sh_lane + (u * BN + 4 * j) * 4);
@@ -227,10 +258,52 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
           o[h] = pack2bf(lo, hi);
         }
         *reinterpret_cast<uint4*>(dst + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        if constexpr (NX > 0) yv[i][v] = make_uint4(o[0], o[1], o[2], o[3]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NX > 0) {
+      // next block's conv1 on this chunk: 2 K = 32 MFMAs (v = 0 / 1) per (row fragment, output fragment)
+      const uint32_t nb0 = n_lane + (uint32_t)(u & 1) * NCHUNK;
+      static_for<NX>([&](auto JO) {
+        constexpr int jo = decltype(JO)::value;
+        constexpr int roff = (64 * (jo >> 2) + 4 * (jo & 3)) * 128;
+        const uint4 w0 = x_lds_read128<roff>(nb0 + ((((g << 1) | 0) ^ key) << 4));
+        const uint4 w1 = x_lds_read128<roff>(nb0 + ((((g << 1) | 1) ^ key) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < RF; ++i) {
+          hacc[i][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, yv[i][0]), hacc[i][jo], 0, 0, 0);
+          hacc[i][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, yv[i][1]), hacc[i][jo], 0, 0, 0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
   });
+  if constexpr (NX > 0) {
+    // ---- next conv epilogue: lane holds Hn[m0 + 16 i + q][64 hg + 16 g + 4 j + r] = hacc[i][4 hg + j][r] ----
+#pragma unroll
+    for (int i = 0; i < RF; ++i) {
+      char* dst = (char*)p.Hn + ((long)mrow[i] * CN + g * 16) * 2;
+#pragma unroll
+      for (int hg = 0; hg < NX / 4; ++hg) {
+        const float* bn = p.bias_n + hg * 64 + g * 16;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          uint32_t o[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int j = 2 * v + (h >> 1), r = 2 * (h & 1);
+            const float lo = fmaxf(hacc[i][4 * hg + j][r] + bn[4 * j + r], 0.f);
+            const float hi = fmaxf(hacc[i][4 * hg + j][r + 1] + bn[4 * j + r + 1], 0.f);
+            o[h] = pack2bf(lo, hi);
+          }
+          *reinterpret_cast<uint4*>(dst + hg * 128 + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+  }
 }
 
 // chunks per workgroup: 8 when that still gives the chip two workgroups per CU, else 4, else 2
@@ -260,13 +333,13 @@ bool expand_supported(const GemmParams& p) {
   return true;
 }
 
-template <int KF, bool RES, int NC>
+template <int KF, bool RES, int NC, int NX = 0>
 static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
   constexpr int RF = KF > 8 ? 1 : 2;
-  constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4;  // two W chunks + this workgroup's shifts
+  constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4 + 2 * NX * 16 * 128;  // two W chunks + shifts (+ two Wn chunks)
   static_assert(lds <= (RF == 2 ? 80 : 160) * 1024, "two workgroups per CU (one with 8 waves at K = 512)");
   static bool attr_set = false;
-  auto kern = expand_res_kernel<KF, RES, NC, RF>;
+  auto kern = expand_res_kernel<KF, RES, NC, RF, NX>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
@@ -290,7 +363,30 @@ static hipError_t launch_expand(const GemmParams& p, hipStream_t stream) {
   return p.resid ? launch_expand_res<KF, true>(p, stream) : launch_expand_res<KF, false>(p, stream);
 }
 
+// with the next block's conv1: the workgroup owns all N channels (NC = N / 64); stage 1 (N = 256, Cn = 64) and stage 2
+// (N = 512, Cn = 128) of the R-101, with or without the projection-shortcut segment
+static hipError_t run_expand_next(const GemmParams& p, hipStream_t stream) {
+  if (p.N == 256 && p.Cn == 64) {
+    if (p.K == 64 && p.resid) return launch_expand_nc<2, true, 4, 4>(p, stream);
+    if (p.K == 128 && !p.resid) return launch_expand_nc<4, false, 4, 4>(p, stream);
+  }
+  if (p.N == 512 && p.Cn == 128) {
+    if (p.K == 128 && p.resid) return launch_expand_nc<4, true, 8, 8>(p, stream);
+    if (p.K == 384 && !p.resid) return launch_expand_nc<12, false, 8, 8>(p, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+bool expand_next_supported(const GemmParams& p) {
+  if (!p.Wn || !p.Hn || !p.bias_n || !expand_supported(p)) return false;
+  if ((reinterpret_cast<uintptr_t>(p.Wn) | reinterpret_cast<uintptr_t>(p.Hn) | reinterpret_cast<uintptr_t>(p.bias_n)) & 15) return false;
+  if (p.N == 256 && p.Cn == 64) return (p.K == 64 && p.resid) || (p.K == 128 && !p.resid && p.s2 > 0);
+  if (p.N == 512 && p.Cn == 128) return (p.K == 128 && p.resid) || (p.K == 384 && !p.resid && p.s2 > 0);
+  return false;
+}
+
 hipError_t run_expand(const GemmParams& p, hipStream_t stream) {
+  if (p.Wn) return run_expand_next(p, stream);
   switch (p.K) {
     case 64: return launch_expand<2>(p, stream);
     case 128: return launch_expand<4>(p, stream);

@@ -44,6 +44,12 @@ struct GemmParams {
   // columns K1 .. K - 1 of a row come from A2, an NHWC map [.][H2][W2][K - K1] sampled at stride s2 (0 = no second segment)
   const void* A2;
   int K1, H2, W2, s2;
+  // the NEXT block's reducing 1x1 computed on the expand kernel's output while it is still in registers (expand.hip, NX > 0):
+  // Hn [M][Cn] = relu(out Wn^T + bias_n), Wn [Cn][N] (K contiguous), Cn = 64 / 128; null = off
+  const void* Wn;
+  const float* bias_n;
+  void* Hn;
+  int Cn;
   // split-K (EPI_LINEAR, no conv): ksplit_count slices of ksplit_steps K-steps, partial s at C + s * csplit_bytes (0 = off)
   int ksplit_steps, ksplit_count;
   long csplit_bytes;
@@ -64,6 +70,7 @@ bool expand_supported(const GemmParams& p);
 bool conv3x3_c64_supported(const GemmParams& p);
 hipError_t run_conv3x3_c64(const GemmParams& p, hipStream_t stream);
 hipError_t run_expand(const GemmParams& p, hipStream_t stream);
+bool expand_next_supported(const GemmParams& p);
 // Producer / consumer tile kernel (pc_gemm.hip): 144 x 128 / 144 x 256 tiles, 4 compute + 4 DMA waves; EPI_LINEAR (plain
 // GEMM) and EPI_APPLY.  tile_hint kPcHint128 / kPcHint256 force it for a plain GEMM (tuning / tests)
 constexpr int kPcHint128 = kNumTileShapes + 2, kPcHint256 = kNumTileShapes + 3;

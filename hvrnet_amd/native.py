@@ -58,6 +58,11 @@ class TailDesc(ctypes.Structure):
                 ('Cout', ctypes.c_int32), ('bias', ctypes.c_void_p), ('relu', ctypes.c_int32), ('dtype', ctypes.c_int32)]
 
 
+class TailNextDesc(ctypes.Structure):
+    _fields_ = [('tail', TailDesc), ('resid', ctypes.c_void_p), ('wn', ctypes.c_void_p), ('bias_n', ctypes.c_void_p),
+                ('hn', ctypes.c_void_p), ('Cn', ctypes.c_int32)]
+
+
 class RpnDesc(ctypes.Structure):
     _fields_ = [('cls', ctypes.c_void_p), ('reg', ctypes.c_void_p),
                 ('T', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
@@ -82,6 +87,8 @@ SYMBOLS = {
     'hvr_conv2d_path': (_i, [ctypes.POINTER(ConvDesc)]),
     'hvr_bottleneck_tail': (_i, [ctypes.POINTER(TailDesc), _vp]),
     'hvr_bottleneck_tail_supported': (_i, [ctypes.POINTER(TailDesc)]),
+    'hvr_bottleneck_tail_next': (_i, [ctypes.POINTER(TailNextDesc), _vp]),
+    'hvr_bottleneck_tail_next_supported': (_i, [ctypes.POINTER(TailNextDesc)]),
     'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_stem_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -368,6 +375,51 @@ def bottleneck_tail(h, x, w, bias, stride2=1, relu=True, out=None):
     with _span(tag, work):
         _check(lib().hvr_bottleneck_tail(ctypes.byref(d), _stream()), 'hvr_bottleneck_tail')
     return y
+
+
+def _tail_next_desc(h, x, resid, w, bias, stride2, wn, bias_n, y, hn):
+    B, OH, OW, C1 = h.shape
+    ph = 1 << 20  # placeholder address for the support query
+    if x is not None:
+        t = _tail_desc(h, x, w, bias, stride2, True, y)
+    else:
+        t = TailDesc(h=h.data_ptr(), x=None, w=w.data_ptr(), y=y.data_ptr() if y is not None else ph, B=B, OH=OH, OW=OW, C1=C1,
+                     H2=OH, W2=OW, C2=0, stride2=1, Cout=w.shape[0], bias=bias.data_ptr(), relu=1, dtype=_dt(h))
+    return TailNextDesc(tail=t, resid=resid.data_ptr() if resid is not None else None, wn=wn.data_ptr(), bias_n=bias_n.data_ptr(),
+                        hn=hn.data_ptr() if hn is not None else ph, Cn=wn.shape[0])
+
+
+def bottleneck_tail_next_supported(h, x, resid, w, bias, stride2, wn, bias_n):
+    """True when hvr_bottleneck_tail_next runs these shapes: (Cout, Cn) = (256, 64) / (512, 128), bf16, contiguous maps."""
+    ts = [t for t in (h, x, resid) if t is not None]
+    if not all(t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() for t in ts):
+        return False
+    if (x is None) == (resid is None) or wn.dim() != 2 or wn.shape[1] != w.shape[0] or not wn.is_contiguous():
+        return False
+    return bool(lib().hvr_bottleneck_tail_next_supported(ctypes.byref(_tail_next_desc(h, x, resid, w, bias, stride2, wn, bias_n, None, None))))
+
+
+def bottleneck_tail_next(h, x, resid, w, bias, wn, bias_n, stride2=1, out=None):
+    """y = relu(h W3^T [+ x_s Wd^T] + bias [+ resid]) and hn = relu(y wn^T + bias_n), the next block's conv1, in one pass.
+    Exactly one of x (projection block: its input map) and resid (identity block) is given.  -> (y, hn)"""
+    _need_cuda(h, w, bias, wn, bias_n)
+    B, OH, OW, C1 = h.shape
+    Cout, Cn = w.shape[0], wn.shape[0]
+    if out is not None:
+        assert tuple(out.shape) == (B, OH, OW, Cout) and out.dtype == h.dtype and out.is_contiguous()
+        y = out
+    else:
+        y = torch.empty((B, OH, OW, Cout), dtype=h.dtype, device=h.device)
+    hn = torch.empty((B, OH, OW, Cn), dtype=h.dtype, device=h.device)
+    d = _tail_next_desc(h, x, resid, w, bias, stride2, wn, bias_n, y, hn)
+    side = x if x is not None else resid
+    tag = 'conv_expand'
+    work = float((h.numel() + B * OH * OW * side.shape[3] + y.numel() + hn.numel() + w.numel() + wn.numel()) * h.element_size())
+    if _prof is not None and _prof['detail']:
+        tag = 'conv_expand tail+next %dx%d %d+%d->%d->%d' % (OH, OW, C1, x.shape[3] if x is not None else 0, Cout, Cn)
+    with _span(tag, work):
+        _check(lib().hvr_bottleneck_tail_next(ctypes.byref(d), _stream()), 'hvr_bottleneck_tail_next')
+    return y, hn
 
 
 def conv2d_path(B, H, W, Cin, Cout, k=1, stride=1, pad=0, dil=1, dtype=torch.bfloat16, resid=True, bias=True, out_f32=False, tile=0):

@@ -112,6 +112,23 @@ typedef struct hvr_tail_desc {
 int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream);
 int hvr_bottleneck_tail_supported(const hvr_tail_desc* d);
 
+/* The same closing 1x1 AND the next block's opening (reducing) 1x1 + bn1 + ReLU (resnet.py:224-232 of block i + 1) in one
+ * pass over the pixels: the workgroup that produced all Cout channels of a pixel multiplies them by wn while they are still
+ * in registers, so the next block's conv1 never re-reads y.
+ *   y  = relu(h W3^T [+ x_s Wd^T] + bias [+ resid])          written as before (the next block's residual / shortcut input)
+ *   hn = relu(y wn^T + bias_n)                                [B][OH][OW][Cn]
+ * tail.C2 == 0 (tail.x ignored): an identity block, resid [B][OH][OW][Cout] is its input map; tail.C2 > 0: resid must be
+ * NULL.  wn [Cn][Cout] bf16, bias_n f32 [Cn].  (Cout, Cn) in {(256, 64), (512, 128)}: stages 1 and 2 of the R-101;
+ * hn is computed from the bf16-rounded y, exactly as a separate conv would read it. */
+typedef struct hvr_tail_next_desc {
+  hvr_tail_desc tail;
+  const void* resid;
+  const void* wn; const float* bias_n; void* hn;
+  int32_t Cn;
+} hvr_tail_next_desc;
+int hvr_bottleneck_tail_next(const hvr_tail_next_desc* d, void* stream);
+int hvr_bottleneck_tail_next_supported(const hvr_tail_next_desc* d);
+
 /* 7x7/2 stem: gathers img (NCHW f32, the reference's input layout, resnet.py:522-524) into
  * patch rows [B*OH*OW][KP] with k = (ky*7+kx)*3 + c and zeros for k >= 147 (KP = 192). */
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream);

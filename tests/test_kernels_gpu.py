@@ -503,6 +503,58 @@ def test_bottleneck_tail_fuses_the_projection_shortcut(C1, C2, Cout, stride, B, 
     assert torch.equal(whole[1:], out) and not whole[0].any()
 
 
+@pytest.mark.parametrize('C1,C2,Cout,Cn,stride,B,OH,OW', [
+    (64, 64, 256, 64, 1, 2, 38, 63),      # layer1.0: projection block + layer1.1's conv1
+    (64, 0, 256, 64, 1, 2, 38, 63),       # layer1.1: identity block + layer1.2's conv1
+    (128, 256, 512, 128, 2, 3, 19, 32),   # layer2.0 (stride-2 shortcut) + layer2.1's conv1
+    (128, 0, 512, 128, 1, 1, 76, 126),    # layer2.x at the bench frame size (a ragged last panel: 9576 = 74 * 128 + 104)
+])
+def test_bottleneck_tail_next_also_computes_the_next_conv1(C1, C2, Cout, Cn, stride, B, OH, OW):
+    """hvr_bottleneck_tail_next: the block output y is BIT-identical to the tail / expand kernel's, and hn is the next block's
+    conv1 + bn1 + ReLU (resnet.py:224-232) of that bf16 y -- against f32 arithmetic on the same bf16 operands, and against the
+    separate conv launch it replaces."""
+    g = torch.Generator().manual_seed(C1 + Cout + C2)
+    h = torch.randn((B, OH, OW, C1), generator=g).to(torch.bfloat16).to(DEV)
+    w3 = (torch.randn((Cout, C1), generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    b3 = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    wn = (torch.randn((Cn, Cout), generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    bn = (torch.randn(Cn, generator=g) * 0.1).to(DEV)
+    if C2:
+        H2, W2 = (OH - 1) * stride + 1 + (stride - 1), (OW - 1) * stride + 1
+        x = torch.randn((B, H2, W2, C2), generator=g).to(torch.bfloat16).to(DEV)
+        wd = (torch.randn((Cout, C2), generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+        w, resid = torch.cat([w3, wd], 1).contiguous(), None
+        want_y = native.bottleneck_tail(h, x, w, b3, stride2=stride, relu=True)
+    else:
+        x, w = None, w3
+        resid = torch.randn((B, OH, OW, Cout), generator=g).to(torch.bfloat16).to(DEV)
+        want_y = native.conv2d_nhwc(h, w3.view(Cout, 1, 1, C1), b3, resid=resid, relu=True)
+    assert native.bottleneck_tail_next_supported(h, x, resid, w, b3, stride, wn, bn)
+    y, hn = native.bottleneck_tail_next(h, x, resid, w, b3, wn, bn, stride2=stride)
+    assert torch.equal(y, want_y)
+    ref = torch.relu(y.float().reshape(-1, Cout) @ wn.float().t() + bn).reshape(B, OH, OW, Cn)
+    torch.testing.assert_close(hn.float(), ref, **_tol(torch.bfloat16))
+    sep = native.conv2d_nhwc(y, wn.view(Cn, 1, 1, Cout), bn, relu=True)
+    torch.testing.assert_close(hn.float(), sep.float(), rtol=2e-2, atol=3e-2)
+    whole = torch.zeros((B + 1, OH, OW, Cout), dtype=torch.bfloat16, device=DEV)
+    y2, hn2 = native.bottleneck_tail_next(h, x, resid, w, b3, wn, bn, stride2=stride, out=whole[1:])
+    assert torch.equal(whole[1:], y) and torch.equal(hn2, hn) and not whole[0].any()
+
+
+def test_bottleneck_tail_next_says_when_it_does_not_apply():
+    bf = dict(device=DEV, dtype=torch.bfloat16)
+    h, r = torch.zeros((1, 16, 16, 256), **bf), torch.zeros((1, 16, 16, 1024), **bf)
+    w, b = torch.zeros((1024, 256), **bf), torch.zeros(1024, device=DEV)
+    wn, bn = torch.zeros((256, 1024), **bf), torch.zeros(256, device=DEV)
+    assert not native.bottleneck_tail_next_supported(h, None, r, w, b, 1, wn, bn)      # stage 3: no kernel (Cn = 256 accumulators)
+    h1, r1 = torch.zeros((1, 16, 16, 64), **bf), torch.zeros((1, 16, 16, 256), **bf)
+    w1, b1 = torch.zeros((256, 64), **bf), torch.zeros(256, device=DEV)
+    wn1, bn1 = torch.zeros((64, 256), **bf), torch.zeros(64, device=DEV)
+    assert native.bottleneck_tail_next_supported(h1, None, r1, w1, b1, 1, wn1, bn1)
+    assert not native.bottleneck_tail_next_supported(h1, None, None, w1, b1, 1, wn1, bn1)  # neither shortcut input nor residual
+    assert not native.bottleneck_tail_next_supported(h1.float(), None, r1.float(), w1.float(), b1, 1, wn1.float(), bn1)  # f32 parity mode
+
+
 def test_bottleneck_tail_says_when_it_does_not_apply():
     h = torch.zeros((1, 8, 16, 64), device=DEV)                     # f32: the parity mode keeps the two-conv path
     x = torch.zeros((1, 8, 16, 64), device=DEV)

@@ -670,6 +670,21 @@ int hvr_nms(const float* dets, int n, float thr, int ge_semantics, int64_t* keep
                       "hvr_nms");
 }
 
+int hvr_nms_first(const float* dets, int n, float thr, int ge_semantics, int max_keep, int64_t* keep, int32_t* n_keep, void* ws,
+                  size_t ws_bytes, void* stream) {
+  if (max_keep <= 0) return fail(HVR_EINVAL, "hvr_nms_first needs max_keep > 0 (hvr_nms keeps every survivor)");
+  if (!n_keep) return fail(HVR_EINVAL, "null n_keep");
+  if (n == 0) {
+    (void)hipMemsetAsync(n_keep, 0, sizeof(int32_t), (hipStream_t)stream);
+    return HVR_OK;
+  }
+  if (!dets || !keep || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (n < 0 || n > 8192) return fail(HVR_EUNSUPPORTED, "hvr_nms_first supports 0 <= n <= 8192, got %d", n);
+  if (ws_bytes < hvr_nms_workspace_bytes(n)) return fail(HVR_EWORKSPACE, "nms workspace too small");
+  return check_launch(run_nms_batched(dets, 1, n, thr, ge_semantics, 0, max_keep, (long long*)keep, n_keep, ws, (hipStream_t)stream),
+                      "hvr_nms_first");
+}
+
 // ---- RPN ----
 static inline int rpn_npre(int H, int W, int A, int nms_pre) {
   const long n = (long)H * W * A;

@@ -92,6 +92,9 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
 
   // ---- W chunk loader: slot s = i * NT + tid -> (ks, row, pos); LDS image [ks][row][128 B], linear destination ----
   auto dma_chunk = [&](int c, char* buf) {
+#ifdef HVR_DBG_X_NODMA
+    if (c != cb) return;
+#endif
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int s = i * NT + tid, ks = s / (BN * 8), rem = s - ks * (BN * 8), row = rem >> 3, pos = rem & 7;
@@ -144,7 +147,11 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
   constexpr int RD = 3, AHEAD = RD - 1;
   xu32x4 res[RD][RF][NV];  // [ring slot][row fragment][piece]
   auto load_res = [&](int c, xu32x4 (&r)[RF][NV]) {
+#ifdef HVR_DBG_X_NORES
+    if constexpr (false) {
+#else
     if constexpr (RES) {
+#endif
 #pragma unroll
       for (int i = 0; i < RF; ++i) {
         const char* rr = (const char*)p.resid + ((long)mrow[i] * p.ldr + c * BN + g * 4 * FJ) * 2;
@@ -183,7 +190,11 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
     // barrier every wave's DMA pieces are in the LDS and every wave is done reading the buffer the next DMA overwrites.
     // (with one chunk of read-ahead res(u) itself sits between DMA(u) and the stores, and is waited for here too: the
     // compiler then knows it has landed and puts no wait of its own -- a vmcnt(0), while a DMA is pending -- in the epilogue)
+#if defined(HVR_DBG_X_NORES) || defined(HVR_DBG_X_NOSTORE)
+    constexpr int behind = 0;
+#else
     constexpr int behind = (AHEAD > 1 && u + 1 < NC ? NRES : 0) + (u > 0 ? NST : 0);
+#endif
     x_wait_vm<behind>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -213,19 +224,31 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
       static_for<2>([&](auto HF) {
         constexpr int hf = decltype(HF)::value;
         // outstanding here: this half, then the other half (of this step for hf = 0, of the next for hf = 1)
+#ifdef HVR_DBG_X_NOLDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         if constexpr (t + 1 < KF || hf == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(H) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < H; ++j)
 #pragma unroll
           for (int i = 0; i < RF; ++i) {
             const f32x4 cin = t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][hf * H + j];
+#ifdef HVR_DBG_X_NOMMA
+            if (t == 0) acc[i][hf * H + j] = __builtin_bit_cast(f32x4, wf[hf][j]); else acc[i][hf * H + j][0] += __uint_as_float(wf[hf][j].x ^ x[i][t][0]);
+#else
             acc[i][hf * H + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[hf][j]),
                                                                           __builtin_bit_cast(bf16x8, x[i][t]), cin, 0, 0, 0);
+#endif
           }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef HVR_DBG_X_NOLDS
+        if constexpr (false) read_half(std::integral_constant<int, t + 1>{}, HF);
+#else
         if constexpr (t + 1 < KF) read_half(std::integral_constant<int, t + 1>{}, HF);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     });
@@ -257,6 +280,9 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
           if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
           o[h] = pack2bf(lo, hi);
         }
+#ifdef HVR_DBG_X_NOSTORE
+        if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u)
+#endif
         *reinterpret_cast<uint4*>(dst + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         if constexpr (NX > 0) yv[i][v] = make_uint4(o[0], o[1], o[2], o[3]);
       }
@@ -310,7 +336,9 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
 static int expand_nc(int M, int N) {
   const int panels = (M + X_BM - 1) / X_BM, nchunks = N / X_BN;
   static const int env_nc = std::getenv("HVR_EXPAND_NC") ? std::atoi(std::getenv("HVR_EXPAND_NC")) : 0;
-  if ((env_nc == 2 || env_nc == 4 || env_nc == 8) && nchunks % env_nc == 0) return env_nc;
+  if ((env_nc == 2 || env_nc == 4 || env_nc == 8 || env_nc == 16) && nchunks % env_nc == 0) return env_nc;
+  // (16 = one workgroup per panel at N = 1024: measured SLOWER at layer 3 / 15 frames, 51 us against 42 -- 281 workgroups do
+  // not keep enough loads in flight; kept as an override for experiments)
   if (nchunks % 8 == 0 && (long)panels * (nchunks / 8) >= 512) return 8;
   if (nchunks % 4 == 0) return 4;
   if (nchunks % 2 == 0) return 2;
@@ -351,6 +379,9 @@ static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
 template <int KF, bool RES>
 static hipError_t launch_expand_res(const GemmParams& p, hipStream_t stream) {
   switch (expand_nc(p.M, p.N)) {
+    case 16:
+      if constexpr (KF == 8) return launch_expand_nc<KF, RES, 16>(p, stream);
+      else return hipErrorInvalidValue;
     case 8: return launch_expand_nc<KF, RES, 8>(p, stream);
     case 4: return launch_expand_nc<KF, RES, 4>(p, stream);
     case 2: return launch_expand_nc<KF, RES, 2>(p, stream);

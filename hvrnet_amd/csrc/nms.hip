@@ -9,6 +9,7 @@
 //
 // Integer / index work: bit-exact against the CPU reference semantics.  Tie rule (unspecified in the
 // reference, which relies on torch.sort/topk): higher score first, then lower index.
+#include <cstdlib>
 #include "common.h"
 #include "gemm_params.h"
 
@@ -41,6 +42,95 @@ __device__ void bitonic_sort_pairs(uint32_t* key, uint32_t* idx, int n_pow2) {
   }
 }
 
+// Descending sort of n_pow2 64-bit composites (key << 32 | 0xffffffff - index: higher key first, lower index on ties; pads
+// are 0 and sink to the end) by a 1024-thread workgroup, the same bitonic network as above with most of it off the LDS:
+// thread t holds elements m * 1024 + t (m < E) in registers, so partners at distance j >= 1024 are its own registers, at
+// j < 64 a lane of its own wave (shuffles, no barrier), and only 64 <= j < 1024 goes through the LDS (22 of the 91 stages at
+// n = 8192; the in-LDS version pays two array reads, a conditional write and a barrier in every one of the 91).
+template <int E>
+__device__ __forceinline__ void block_sort_desc_u64_regs(unsigned long long* buf) {
+  constexpr int B = 1024;
+  const int t = threadIdx.x;
+  unsigned long long v[E];
+#pragma unroll
+  for (int m = 0; m < E; ++m) v[m] = buf[m * B + t];
+  for (int k = 2; k <= E * B; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= B) {
+#pragma unroll
+        for (int jm = E / 2; jm > 0; jm >>= 1) {  // register indices stay compile-time constants
+          if (j != jm * B) continue;
+#pragma unroll
+          for (int m = 0; m < E; ++m) {
+            const int pm = m ^ jm;
+            if (pm > m) {
+              const bool up = ((m * B) & k) == 0;
+              const unsigned long long a = v[m], b = v[pm];
+              const unsigned long long hi = a > b ? a : b, lo = a > b ? b : a;
+              v[m] = up ? hi : lo;
+              v[pm] = up ? lo : hi;
+            }
+          }
+        }
+      } else if (j >= 64) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < E; ++m) buf[m * B + t] = v[m];
+        __syncthreads();
+        const bool lower = (t & j) == 0;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+          const unsigned long long o = buf[m * B + (t ^ j)];
+          const bool up = ((m * B + t) & k) == 0;
+          const bool keep_max = lower == up;
+          const unsigned long long a = v[m];
+          v[m] = keep_max ? (a > o ? a : o) : (a > o ? o : a);
+        }
+      } else {
+        const bool lower = (t & j) == 0;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+          const unsigned long long a = v[m];
+          const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)a, j), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(a >> 32), j);
+          const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+          const bool up = ((m * B + t) & k) == 0;
+          const bool keep_max = lower == up;
+          v[m] = keep_max ? (a > o ? a : o) : (a > o ? o : a);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < E; ++m) buf[m * B + t] = v[m];
+  __syncthreads();
+}
+
+// any workgroup size / length: the plain in-LDS network
+__device__ void block_sort_desc_u64(unsigned long long* buf, int n_pow2) {
+  if (blockDim.x == 1024 && n_pow2 >= 1024 && n_pow2 <= 8192) {
+    switch (n_pow2 >> 10) {
+      case 1: block_sort_desc_u64_regs<1>(buf); return;
+      case 2: block_sort_desc_u64_regs<2>(buf); return;
+      case 4: block_sort_desc_u64_regs<4>(buf); return;
+      case 8: block_sort_desc_u64_regs<8>(buf); return;
+    }
+  }
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n_pow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = buf[i], b = buf[ixj];
+          const bool up = (i & k) == 0;
+          if (up ? (b > a) : (a > b)) { buf[i] = b; buf[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __device__ __forceinline__ int next_pow2(int n) {
   int p = 1;
   while (p < n) p <<= 1;
@@ -55,6 +145,29 @@ __device__ __forceinline__ float box_iou_plus1(const float4 a, const float4 b) {
   const float aa = (a.z - a.x + 1.f) * (a.w - a.y + 1.f), ab = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
   return inter / (aa + ab - inter);
 }
+
+__device__ __forceinline__ float box_area_plus1(const float4 a) { return (a.z - a.x + 1.f) * (a.w - a.y + 1.f); }
+
+// The comparison  box_iou_plus1(a, b) >= thr  (ge) /  > thr  -- the same truth value as the rounded quotient gives, without
+// the division in all but a sliver of cases.  r = fma(-thr, uni, inter) is (inter - thr uni) rounded once, so it carries the
+// sign of (inter / uni - thr) whenever it is not zero.  The ROUNDED quotient can sit on the other side of thr than the real
+// one only when the real one is within an ulp of thr, i.e. |inter - thr uni| < 2^-22 thr uni; inside 2^-21 thr uni (and for
+// uni <= 0, NaNs, thr <= 0) the division is done as before.  aa / ab: box_area_plus1 of a / b (the same expressions
+// box_iou_plus1 evaluates, so `uni` is the same float).
+__device__ __forceinline__ bool box_iou_hits(const float4 a, const float aa, const float4 b, const float ab, const float thr,
+                                             const float band_k, const int ge) {
+  const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+  const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+  const float inter = w * h;
+  const float uni = aa + ab - inter;
+  const float r = __builtin_fmaf(-thr, uni, inter);
+  const float band = band_k * uni;  // band_k = 2^-21 thr (<= 0 switches the shortcut off)
+  if (band > 0.f && r > band) return true;
+  if (band > 0.f && r < -band) return false;
+  const float ovr = inter / uni;
+  return ge ? (ovr >= thr) : (ovr > thr);
+}
+__device__ __forceinline__ float iou_band_k(float thr) { return thr > 0.f ? thr * 4.76837158203125e-07f : 0.f; }
 
 // ---------------------------------------------------------------------------------
 // generic batched NMS: problem p has n boxes at dets + p * n * 5
@@ -111,6 +224,27 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l);
   const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
   return ((unsigned long long)hi << 32) | lo;
+}
+
+// survivors (flag[i] != 0, i = original index) -> ascending index list + count; whole workgroup, wsum [blockDim / 64 + 1]
+__device__ __forceinline__ void compact_flags(const unsigned char* flag, int* wsum, int n, long long* kp, int* n_out) {
+  const int per = (n + blockDim.x - 1) / blockDim.x;
+  const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += flag[i];
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if ((threadIdx.x & 63) >= o) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+  int pos = base + incl - c;
+  for (int i = lo; i < hi; ++i)
+    if (flag[i]) kp[pos++] = i;
+  if (threadIdx.x == blockDim.x - 1) *n_out = base + incl;
 }
 
 // (3) sequential sweep by wave 0 (stops after max_keep survivors when max_keep > 0), then the
@@ -181,25 +315,134 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long
     }
   }
   __syncthreads();
-  // ordered compaction: per-thread contiguous segment
-  const int per = (n + blockDim.x - 1) / blockDim.x;
-  const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
-  int c = 0;
-  for (int i = lo; i < hi; ++i) c += flag[i];
-  int incl = c;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o);
-    if ((threadIdx.x & 63) >= o) incl += v;
+  compact_flags(flag, wsum, n, keep + (long)p * keep_stride, n_keep + p);
+}
+
+// (2 + 3 in one, for a SMALL survivor cap) Greedy NMS that evaluates only the IoUs it needs.  The mask kernel above prices every
+// pair (n^2 / 2: 18 M IoUs per frame at the RPN's n = 6000) although only the rows of boxes that SURVIVE are ever read, the RPN
+// keeps at most nms_post = 300 of them (rpn_head.py:92-103), and nothing behind the box at which the 300th survivor is found
+// matters at all.  One workgroup per problem, the score-sorted boxes in the LDS, a suppression set that is kept up to date
+// only for a FRONT of `L` 64-box words which grows as the sweep reaches it; per chunk of 64 boxes:
+//   0. (chunk at the front) the next EXT words are brought up to date against every survivor so far;
+//   1. the chunk's 64 x 64 diagonal block: wave w takes rows 4 w .. 4 w + 3 -- row j's word is ONE ballot over the lanes'
+//      IoU(box j, box lane) (the block is symmetric, so the ballot over rows is the row over columns);
+//   2. the serial "survives / suppresses the rest of its chunk" chain, scalar code (ctz over the candidates, a readlane of
+//      the row word) run by ONE wave -- the CU has a single scalar unit, sixteen waves running it redundantly to save the
+//      broadcast took sixteen times as long;
+//   3. the chunk's new survivors against the later words inside the front.
+// Steps 0 and 3 are one routine over (word, block of 16 survivors) tasks dealt to the waves, four survivors per step (four
+// independent IoU chains per lane), results OR-ed into the word with an LDS atomic.  IoU work: survivors x boxes walked
+// (300 x ~1000 on typical RPN output) instead of n^2 / 2, and no more than survivors x n; fully suppressed words are skipped.
+// Same arithmetic and comparison as the mask kernel (box_iou_hits == the rounded quotient's verdict, row = the earlier box), so
+// the survivor set is the same bit for bit; 15 workgroups instead of a chip-filling mask launch: the chip stays with res5.
+__global__ __launch_bounds__(1024) void nms_greedy_kernel(const float* __restrict__ dets, const float4* __restrict__ boxes4,
+                                                          const int* __restrict__ order, int n, float thr, int ge, int max_keep,
+                                                          long long* __restrict__ keep, int* __restrict__ n_keep, int keep_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EXT = 4;  // words the front grows by
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
+  const int nb = (n + 63) >> 6;  // <= 128
+  float4* box = reinterpret_cast<float4*>(smem);                                        // [nb * 64], score order
+  unsigned long long* removed = reinterpret_cast<unsigned long long*>(box + nb * 64);  // [nb]
+  unsigned long long* diag = removed + nb;                                               // [64]
+  unsigned char* flag = reinterpret_cast<unsigned char*>(diag + 64);                     // [n] by original index
+  int* wsum = reinterpret_cast<int*>(flag + ((n + 15) & ~15));                           // [blockDim / 64 + 1]
+  unsigned short* kall = reinterpret_cast<unsigned short*>(wsum + 32);                   // [max_keep] survivors, score order
+  __shared__ unsigned long long sh_kept;
+  __shared__ int sh_nkept, sh_done;
+  const float band_k = iou_band_k(thr);
+  const float* d = dets ? dets + (long)p * n * 5 : nullptr;  // presorted: read in place
+  const float4* b4 = boxes4 ? boxes4 + (long)p * n : nullptr;
+  const int* ord = order ? order + (long)p * n : nullptr;
+  for (int i = tid; i < nb * 64; i += blockDim.x) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) v = b4 ? b4[i] : make_float4(d[i * 5 + 0], d[i * 5 + 1], d[i * 5 + 2], d[i * 5 + 3]);
+    box[i] = v;
   }
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  for (int i = tid; i < nb; i += blockDim.x) removed[i] = 0ull;
+  for (int i = tid; i < n; i += blockDim.x) flag[i] = 0;
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
-  int pos = base + incl - c;
-  long long* kp = keep + (long)p * keep_stride;
-  for (int i = lo; i < hi; ++i)
-    if (flag[i]) kp[pos++] = i;
-  if (threadIdx.x == blockDim.x - 1) n_keep[p] = base + incl;
+
+  // survivors kall[k0 .. k1) against the words [w0, w1)
+  auto apply = [&](int w0, int w1, int k0, int k1) {
+    const int nkb = (k1 - k0 + 15) >> 4, ntask = (w1 - w0) * nkb;
+    for (int t = wave; t < ntask; t += nwaves) {
+      const int cw = w0 + t / nkb, kb = k0 + (t % nkb) * 16, cnt = min(16, k1 - kb);
+      const unsigned long long gone = removed[cw];
+      if (__builtin_amdgcn_readfirstlane((int)(gone == ~0ull))) continue;  // nothing left to suppress in this word
+      const float4 col = box[cw * 64 + lane];
+      const float ca = box_area_plus1(col);
+      const int myk = (int)kall[kb + min(lane & 15, cnt - 1)];  // lanes 0..15: the block's survivors (the tail repeats the last)
+      bool hit = false;
+      for (int q = 0; q < cnt; q += 4) {
+        float4 bj[4];
+        float ba[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bj[e] = box[__builtin_amdgcn_readlane(myk, q + e)];
+          ba[e] = box_area_plus1(bj[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hit |= box_iou_hits(bj[e], ba[e], col, ca, thr, band_k, ge);
+      }
+      const unsigned long long m = __ballot(hit) & ~gone;
+      if (lane == 0 && m) atomicOr(&removed[cw], m);
+    }
+  };
+
+  int nkept = 0, L = min(nb, EXT);
+  for (int cb = 0; cb < nb; ++cb) {
+    if (cb >= L) {  // the sweep has reached the front: bring the next words up to date
+      const int L2 = min(nb, L + EXT);
+      if (nkept > 0) apply(L, L2, 0, nkept);
+      L = L2;
+      __syncthreads();
+    }
+    const int bi = cb * 64 + lane;
+    const float4 mine = box[bi];
+    const float mine_area = box_area_plus1(mine);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = 4 * wave + u;
+      const float4 bj = box[cb * 64 + j];
+      const bool hit = box_iou_hits(bj, box_area_plus1(bj), mine, mine_area, thr, band_k, ge) && lane > j && bi < n;
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) diag[j] = m;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const unsigned long long drow = diag[lane];
+      const unsigned long long rm = removed[cb];
+      unsigned long long cur = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rm >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rm);
+      const int cnt = min(64, n - cb * 64);
+      const unsigned long long valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+      unsigned long long kept_w = 0ull, cand = ~cur & valid;
+      int nk_w = nkept;
+      bool done_w = false;
+      while (cand) {
+        const int j = __builtin_ctzll(cand);
+        kept_w |= 1ull << j;
+        if (++nk_w == max_keep) { done_w = true; break; }
+        cur |= readlane64(drow, j);
+        cand = ~cur & valid & ~((2ull << j) - 1ull);
+      }
+      if ((kept_w >> lane) & 1ull) {
+        kall[nkept + (int)__popcll(kept_w & ((1ull << lane) - 1ull))] = (unsigned short)bi;
+        flag[ord ? ord[bi] : bi] = 1;
+      }
+      if (lane == 0) { sh_kept = kept_w; sh_nkept = nk_w; sh_done = done_w ? 1 : 0; }
+    }
+    __syncthreads();
+    const int nk0 = nkept;
+    nkept = sh_nkept;
+    if (sh_done) break;
+    if (nkept > nk0 && cb + 1 < L) apply(cb + 1, L, nk0, nkept);
+    __syncthreads();
+  }
+  __syncthreads();
+  compact_flags(flag, wsum, n, keep + (long)p * keep_stride, n_keep + p);
 }
 
 // ---------------------------------------------------------------------------------
@@ -216,12 +459,18 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
   const int f = blockIdx.x, n = rp.n_anchor, k = rp.npre;
   const T* c = cls + (long)f * cls_stride;
   const T* r = reg + (long)f * reg_stride;
-  uint32_t* key = reinterpret_cast<uint32_t*>(smem);
+  unsigned long long* comp = reinterpret_cast<unsigned long long*>(smem);  // [kp2] key << 32 | ~index
+#ifdef HVR_DBG_SEL_CLK
+  long long dbgc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   const int kp2 = next_pow2(k);
-  uint32_t* idx = key + kp2;
-  __shared__ int hist[256];
+  __shared__ int whist[16][256];  // one histogram per wave: no cross-wave contention
+  __shared__ int tot[256];
+  __shared__ int wsum[17];
+  __shared__ int tcnt[32 * 16];
   __shared__ uint32_t sh_prefix, sh_remaining;
   __shared__ int sh_count;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
   // anchor i = cell * A + a lives at pixel `cell`, channel a of a [H*W][cls_pitch] map (pitch >= A lets the
   // objectness and delta maps be channel slices of one fused conv output)
@@ -231,73 +480,210 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
     return 1.f / (1.f + expf(-ElemTraits<T>::load(c + (long)cell * cpitch + a)));  // torch.sigmoid
   };
 
+#ifdef HVR_DBG_SEL_CLK
+  dbgc[0] = clock64();
+#endif
   if (n > k) {
-    // radix select (MSB first) of the k-th largest (key, then smallest index) element
+    // radix select (MSB first) of the k-th largest (key, then smallest index) element.  The scores are sigmoids: the top
+    // byte of almost every key is one of a handful of values, and an atomicAdd per element serialises on those few LDS
+    // words (4 passes x 28 728 adds took 0.4 ms of this kernel's 0.53).  Here the lanes of a wave that hit the same bin are
+    // counted with a ballot and added once (up to 4 distinct bins per 64 elements; what is left -- the evenly spread lower
+    // bytes of the later passes -- goes to the wave's own histogram with plain LDS atomics, which then rarely collide).
+    // Up to CE * 1024 anchors (32 768; the C4 map of a 1000 x 600 frame has 28 728) the keys are computed ONCE and stay in
+    // registers for the seven scans (four histogram passes, the collection, two for the ties); longer inputs recompute them.
+    constexpr int CE = 32;
+    const bool cached = blockDim.x == 1024 && n <= CE * 1024;
+    const int mcount = (n + 1023) >> 10;
+    uint32_t uc[CE];
+    if (cached) {
+#pragma unroll
+      for (int m = 0; m < CE; ++m) {
+        const int i = m * 1024 + (int)threadIdx.x;
+        uc[m] = i < n ? float_key(score_of(i)) : 0u;
+      }
+    }
+    int* wh = whist[wave & 15];
+    auto hist_add = [&](bool valid, int bin) {
+      unsigned long long todo = __ballot(valid);
+      for (int it = 0; it < 4 && todo; ++it) {
+        const int leader = __builtin_ctzll(todo);
+        const int lb = __builtin_amdgcn_readlane(bin, leader);
+        const unsigned long long same = __ballot(valid && bin == lb);
+        if (lane == leader) atomicAdd(&wh[lb], (int)__popcll(same));
+        todo &= ~same;
+      }
+      if ((todo >> lane) & 1ull) atomicAdd(&wh[bin], 1);
+    };
+#ifdef HVR_DBG_SEL_CLK
+  dbgc[1] = clock64();
+#endif
     uint32_t prefix = 0u, remaining = (uint32_t)k;
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
-      for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+      for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) (&whist[0][0])[i] = 0;
       __syncthreads();
       const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-      for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t u = float_key(score_of(i));
-        if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+      if (cached) {
+#pragma unroll
+        for (int m = 0; m < CE; ++m) {
+          if (m < mcount) {
+            const int i = m * 1024 + (int)threadIdx.x;
+            const uint32_t u = uc[m];
+            hist_add(i < n && (u & himask) == prefix, (int)((u >> shift) & 255u));
+          }
+        }
+      } else {
+        for (int i0 = wave * 64; i0 < n; i0 += blockDim.x) {
+          const int i = i0 + lane;
+          uint32_t u = 0u;
+          if (i < n) u = float_key(score_of(i));
+          hist_add(i < n && (u & himask) == prefix, (int)((u >> shift) & 255u));
+        }
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t rem = remaining;
-        int b = 255;
-        for (; b > 0; --b) {
-          if ((uint32_t)hist[b] >= rem) break;
-          rem -= hist[b];
+      if (threadIdx.x < 256) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += whist[w][threadIdx.x];
+        tot[threadIdx.x] = t;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        // bins from 255 down until `remaining` elements are covered: lane l owns bins 4 l .. 4 l + 3, suffix sums by shuffles
+        const int t0 = tot[4 * lane], t1 = tot[4 * lane + 1], t2 = tot[4 * lane + 2], t3 = tot[4 * lane + 3];
+        int suf = t0 + t1 + t2 + t3;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_down(suf, o);
+          if (lane + o < 64) suf += v;
         }
-        sh_prefix = prefix | ((uint32_t)b << shift);
-        sh_remaining = rem;
+        const unsigned long long ge = __ballot((uint32_t)suf >= remaining);
+        const int ls = ge ? 63 - __builtin_clzll(ge) : 0;         // the highest lane whose suffix still covers `remaining`
+        const int above = __shfl(suf - (t0 + t1 + t2 + t3), ls);  // elements in the bins above lane ls's four
+        if (lane == ls) {
+          uint32_t rem = remaining - (uint32_t)above;
+          int b = 3;
+          if ((uint32_t)t3 < rem) {
+            rem -= (uint32_t)t3; b = 2;
+            if ((uint32_t)t2 < rem) {
+              rem -= (uint32_t)t2; b = 1;
+              if ((uint32_t)t1 < rem) { rem -= (uint32_t)t1; b = 0; }
+            }
+          }
+          sh_prefix = prefix | ((uint32_t)(4 * ls + b) << shift);
+          sh_remaining = rem;
+        }
       }
       __syncthreads();
       prefix = sh_prefix;
       remaining = sh_remaining;
       __syncthreads();
     }
+#ifdef HVR_DBG_SEL_CLK
+  dbgc[2] = clock64();
+#endif
     // prefix == key of the k-th element; `remaining` of the equal-key elements are taken, lowest index first
     const uint32_t thr_key = prefix;
     if (threadIdx.x == 0) sh_count = 0;
-    for (int i = threadIdx.x; i < kp2; i += blockDim.x) { key[i] = 0u; idx[i] = 0xffffffffu; }
+    for (int i = threadIdx.x; i < kp2; i += blockDim.x) comp[i] = 0ull;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint32_t u = float_key(score_of(i));
-      if (u > thr_key) {
-        const int pos = atomicAdd(&sh_count, 1);
-        key[pos] = u;
-        idx[pos] = (uint32_t)i;
+    auto collect = [&](int i, uint32_t u) {
+      const bool sel = i < n && u > thr_key;
+      const unsigned long long m = __ballot(sel);
+      if (m) {  // one slot reservation per wave and step (the order inside comp is irrelevant: it is sorted below)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&sh_count, (int)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (sel) comp[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)u << 32) | (0xffffffffu - (uint32_t)i);
+      }
+    };
+    if (cached) {
+#pragma unroll
+      for (int m = 0; m < CE; ++m)
+        if (m < mcount) collect(m * 1024 + (int)threadIdx.x, uc[m]);
+    } else {
+      for (int i0 = wave * 64; i0 < n; i0 += blockDim.x) {
+        const int i = i0 + lane;
+        collect(i, i < n ? float_key(score_of(i)) : 0u);
       }
     }
     __syncthreads();
-    // ties at the threshold: ordered pick by one wave (rare path: `remaining` is usually 1)
-    if (threadIdx.x < 64) {
-      int taken = 0, base = sh_count;
-      for (int i0 = 0; i0 < n && taken < (int)remaining; i0 += 64) {
-        const int i = i0 + threadIdx.x;
-        const bool eq = i < n && float_key(score_of(i)) == thr_key;
-        const unsigned long long m = __ballot(eq);
-        const int before = __popcll(m & ((1ull << threadIdx.x) - 1ull));
-        if (eq && taken + before < (int)remaining) {
-          key[base + taken + before] = thr_key;
-          idx[base + taken + before] = (uint32_t)i;
+#ifdef HVR_DBG_SEL_CLK
+  dbgc[3] = clock64();
+#endif
+    // ties at the threshold, lowest index first (bf16 logits tie often)
+    if (cached) {
+      // index order = (m, wave, lane): per-(m, wave) tie counts, one exclusive scan over the 512 of them, ranks by ballot
+#pragma unroll
+      for (int m = 0; m < CE; ++m) {
+        const int i = m * 1024 + (int)threadIdx.x;
+        const unsigned long long mm = __ballot(i < n && uc[m] == thr_key);
+        if (lane == 0) tcnt[m * 16 + wave] = (int)__popcll(mm);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        int c8[8], sum = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { c8[e] = tcnt[8 * lane + e]; sum += c8[e]; }
+        int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
         }
-        taken += __popcll(m);
+        int run = incl - sum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { tcnt[8 * lane + e] = run; run += c8[e]; }
+      }
+      __syncthreads();
+      const int base = sh_count;
+#pragma unroll
+      for (int m = 0; m < CE; ++m) {
+        if (m < mcount) {
+          const int i = m * 1024 + (int)threadIdx.x;
+          const bool eq = i < n && uc[m] == thr_key;
+          const unsigned long long mm = __ballot(eq);
+          const int rank = tcnt[m * 16 + wave] + (int)__popcll(mm & ((1ull << lane) - 1ull));
+          if (eq && rank < (int)remaining) comp[base + rank] = ((unsigned long long)thr_key << 32) | (0xffffffffu - (uint32_t)i);
+        }
+      }
+    } else {  // every thread ranks a contiguous index segment
+      const int per = (n + blockDim.x - 1) / blockDim.x;
+      const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+      int cnt = 0;
+      for (int i = lo; i < hi; ++i) cnt += float_key(score_of(i)) == thr_key;
+      int incl = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int rank = incl - cnt;
+      for (int w = 0; w < wave; ++w) rank += wsum[w];
+      const int base = sh_count;
+      if (cnt > 0 && rank < (int)remaining) {
+        for (int i = lo; i < hi && rank < (int)remaining; ++i)
+          if (float_key(score_of(i)) == thr_key) {
+            comp[base + rank] = ((unsigned long long)thr_key << 32) | (0xffffffffu - (uint32_t)i);
+            ++rank;
+          }
       }
     }
+#ifdef HVR_DBG_SEL_CLK
+  dbgc[4] = clock64();
+#endif
     __syncthreads();
-    bitonic_sort_pairs(key, idx, kp2);
+    block_sort_desc_u64(comp, kp2);
   } else {
-    for (int i = threadIdx.x; i < k; i += blockDim.x) idx[i] = (uint32_t)i;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) comp[i] = 0xffffffffu - (uint32_t)i;
     __syncthreads();
   }
+#ifdef HVR_DBG_SEL_CLK
+  dbgc[5] = clock64();
+#endif
   // decode (delta2bbox, mmdet/core/bbox/transforms.py:78-110) in sorted order
   const int cnt = n > k ? k : n;
   for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-    const int i = (int)idx[j];
+    const int i = (int)(0xffffffffu - (uint32_t)comp[j]);
     const int a = i % rp.A, cell = i / rp.A, x = cell % rp.W, y = cell / rp.W;
     const float ax1 = rp.base[a][0] + x * rp.stride, ay1 = rp.base[a][1] + y * rp.stride;
     const float ax2 = rp.base[a][2] + x * rp.stride, ay2 = rp.base[a][3] + y * rp.stride;
@@ -317,6 +703,11 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
     float* o = out + ((long)f * k + j) * 5;
     o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = score_of(i);
   }
+#ifdef HVR_DBG_SEL_CLK
+  if (threadIdx.x == 0 && f == 0 && n > k)
+    printf("rpn_select clocks: keys %lld  hist %lld  collect %lld  ties %lld  sort %lld  decode %lld\n", dbgc[1] - dbgc[0], dbgc[2] - dbgc[1],
+           dbgc[3] - dbgc[2], dbgc[4] - dbgc[3], dbgc[5] - dbgc[4], (long long)clock64() - dbgc[5]);
+#endif
 }
 
 // first nms_post survivors (ascending index), then topk(min(max_num, count)) by score
@@ -595,6 +986,20 @@ hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, i
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
     attr = true;
+  }
+  // a small survivor cap (the RPN's nms_post): the greedy kernel prices max_keep x n IoUs instead of n^2 / 2
+  static const bool no_greedy = std::getenv("HVR_NMS_MASK") != nullptr;
+  if (max_keep > 0 && max_keep <= 1024 && !no_greedy) {
+    static bool gattr = false;
+    if (!gattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      gattr = true;
+    }
+    if (!presorted) hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(1024), (size_t)np2 * 8, s, dets, n, 0, order, boxes4);
+    const size_t lds = (size_t)nb * 64 * 16 + (size_t)nb * 8 + 64 * 8 + ((n + 15) & ~15) + 128 + 2 * 1024;
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(P), dim3(1024), lds, s, presorted ? dets : nullptr, presorted ? nullptr : boxes4,
+                       presorted ? nullptr : order, n, thr, ge, max_keep, keep, n_keep, n);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(1024), (size_t)np2 * 8, s, dets, n, presorted, order, boxes4);
   const size_t sweep_lds = ((n + 15) & ~15) + 64;

@@ -119,10 +119,14 @@ class TwoStageDetector(BaseDetector):
             self.bbox_head.init_weights()
 
     # Frames are independent through the backbone.  With `frame_groups` = G > 1 a batch of frames is cut into G
-    # contiguous groups that run on G HIP streams: a bottleneck alternates compute-bound (3x3) and HBM-bound
-    # (1x1 + residual) convolutions, and two groups that are out of step overlap one kind with the other -- the
-    # memory-bound kernel of one group then has the whole chip's bandwidth while the other group computes.
-    frame_groups = int(os.environ.get('HVR_FRAME_GROUPS', '2'))
+    # contiguous groups that run on G HIP streams.  The idea -- a bottleneck alternates MFMA-bound (3x3) and HBM-bound
+    # (1x1 + residual) convolutions, so two groups out of step would overlap one kind with the other -- does NOT pay on
+    # this chip: two hipGraph chains of layer-3 blocks on two streams (8 + 7, 9 + 6, 10 + 5 frames) take exactly the time
+    # of one 15-frame chain (114.6 vs 114.7 us per block, tools/probe/two_stream_l3.py), the work is conserved, not
+    # overlapped; and in eager mode the second group's launches queue behind the first's on the host.  One group (the
+    # default since round 2) keeps every launch at the full 15-frame size, where the 3x3 tile grid is one round of the
+    # chip (250 tiles of 144 x 256 on 256 CUs), and halves the launch count.  G > 1 stays as a knob.
+    frame_groups = int(os.environ.get('HVR_FRAME_GROUPS', '1'))
     group_first = int(os.environ.get('HVR_GROUP_FIRST', '0'))
 
     def _group_streams(self, device, n):

@@ -120,6 +120,7 @@ SYMBOLS = {
     'hvr_roi_align_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     'hvr_roi_align_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'hvr_nms_workspace_bytes': (_sz, [_i]),
+    'hvr_nms_first': (_i, [_vp, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'hvr_nms': (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     'hvr_rpn_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'hvr_rpn_proposals': (_i, [ctypes.POINTER(RpnDesc), _vp, _sz, _vp]),
@@ -784,6 +785,22 @@ def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sample_num, layout)
     _check(lib().hvr_roi_align_bwd(_ptr(grad_out), _ptr(rois), _ptr(grad_in), B, C, H, W, K, PH, PW, float(spatial_scale),
                                    int(sample_num), layout, _stream()), 'hvr_roi_align_bwd')
     return grad_in
+
+
+def nms_first(dets, iou_thr, max_keep, ge_semantics=True):
+    """The first max_keep survivors (in score order) of greedy NMS: nms(dets, thr)[:max_keep] of rpn_head.py:95-97, as
+    ascending input indices.  dets [n,5] f32 cuda."""
+    _need_cuda(dets)
+    dets = dets.contiguous().float()
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long, device=dets.device)
+    keep = torch.empty(n, dtype=torch.long, device=dets.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dets.device)
+    ws = _workspace(lib().hvr_nms_workspace_bytes(n), dets.device, 'nms')
+    _check(lib().hvr_nms_first(_ptr(dets), n, float(iou_thr), int(ge_semantics), int(max_keep), _ptr(keep), _ptr(cnt), _ptr(ws),
+                               ws.numel(), _stream()), 'hvr_nms_first')
+    return keep[:int(cnt.item())]
 
 
 def nms(dets, iou_thr, ge_semantics=True):

@@ -223,6 +223,12 @@ int hvr_roi_align_bwd(const float* grad_out, const float* rois, float* grad_feat
 size_t hvr_nms_workspace_bytes(int n);
 int hvr_nms(const float* dets, int n, float thr, int ge_semantics, int64_t* keep, int32_t* n_keep,
             void* ws, size_t ws_bytes, void* stream);
+/* The same, stopping after the first max_keep survivors in score order: `nms(proposals, thr)[:nms_post]` of
+ * mmdet/models/anchor_heads/rpn_head.py:95-97 without pricing the IoUs of boxes behind the cut.  keep: ascending input
+ * order of those survivors.  One workgroup that evaluates only the rows of surviving boxes (max_keep x n IoUs, not n^2/2);
+ * max_keep <= 1024, larger caps take the mask + sweep path of hvr_nms and stop the sweep at the cap. */
+int hvr_nms_first(const float* dets, int n, float thr, int ge_semantics, int max_keep, int64_t* keep, int32_t* n_keep,
+                  void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * RPN proposal generation for T frames in one call.  Replaces RPNHead.get_bboxes_single

@@ -280,7 +280,7 @@ def test_layout_and_cast_round_trip():
     assert torch.equal(native.cast(b, torch.float32).cpu(), x.cpu().to(torch.bfloat16).float())
 
 
-def _greedy_nms(dets, thr, ge=True):
+def _greedy_nms(dets, thr, ge=True, score_order=False):
     import numpy as np
     d = dets.numpy().astype(np.float32)
     n = len(d)
@@ -300,6 +300,8 @@ def _greedy_nms(dets, thr, ge=True):
         ovr = inter / (area[i] + area[rest] - inter)
         hit = (ovr >= np.float32(thr)) if ge else (ovr > np.float32(thr))
         dead[rest[hit]] = True
+    if score_order:
+        return [i for i in order if not dead[i]]
     return [i for i in range(n) if not dead[i]]
 
 
@@ -316,6 +318,32 @@ def test_nms_matches_greedy(n, thr):
     dets = _boxes(n, 50 + n)
     keep = native.nms(dets.to(DEV), thr).cpu().tolist()
     assert keep == _greedy_nms(dets, thr)
+
+
+@pytest.mark.parametrize('n,thr,max_keep', [(1, 0.5, 1), (65, 0.7, 3), (700, 0.5, 50), (700, 0.3, 1024), (6000, 0.7, 300),
+                                            (6000, 0.3, 300), (8192, 0.7, 1000)])
+def test_nms_first_keeps_the_first_survivors(n, thr, max_keep):
+    """hvr_nms_first == nms(dets, thr)[:max_keep] of rpn_head.py:95-97 (the survivors in score order, cut, reported as
+    ascending input indices): the greedy kernel that only prices the surviving rows finds the same set as the full sweep."""
+    dets = _boxes(n, 90 + n, span=200.0 if n < 2000 else 900.0)
+    want = sorted(_greedy_nms(dets, thr, score_order=True)[:max_keep])
+    assert native.nms_first(dets.to(DEV), thr, max_keep).cpu().tolist() == want
+
+
+@pytest.mark.parametrize('ge', [True, False])
+@pytest.mark.parametrize('thr', [0.5, 1.0 / 3.0, 2.0 / 3.0, 0.6, 0.25])
+def test_nms_first_on_boxes_whose_ious_sit_on_the_threshold(thr, ge):
+    """Small integer boxes: many pairs have an IoU of exactly 1/2, 1/3, 2/3, 3/5 ... -- the real quotient equals (or is within
+    an ulp of) the threshold, where the kernel's division-free comparison has to fall back to the rounded division to agree
+    with nms_cpu.cpp:46-54 (`>=`) / nms_kernel.cu (`>`) bit for bit."""
+    g = torch.Generator().manual_seed(int(thr * 1000) + ge)
+    n = 1500
+    xy = torch.randint(0, 24, (n, 2), generator=g).float()
+    wh = torch.randint(1, 12, (n, 2), generator=g).float()
+    dets = torch.cat([xy, xy + wh - 1, torch.rand((n, 1), generator=g)], 1)
+    for max_keep in (40, 1024):
+        want = sorted(_greedy_nms(dets, thr, ge=ge, score_order=True)[:max_keep])
+        assert native.nms_first(dets.to(DEV), thr, max_keep, ge_semantics=ge).cpu().tolist() == want
 
 
 def test_nms_docstring_case_and_empty():

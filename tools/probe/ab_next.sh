@@ -1,9 +1,3 @@
-mkdir -p gpurun_out/r2
-python -m pytest tests/test_kernels_gpu.py -x -q -k "tail" 2>&1 | tail -15
-python -m pytest tests/test_parity_gpu.py -x -q -k "backbone or config1 or cached" 2>&1 | tail -5
-for v in 1 0; do HVR_FUSE_NEXT=$v python bench.py --steps 20 --warmup 5 --no-side-loops --no-graphs --no-f32-leg --quick 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('FUSE_NEXT=$v', d['value'], d['ms_per_step'])
-"; done
+for e in "A=1" "HVR_FRAME_GROUPS=2" "HVR_FUSE_NEXT=0" "HVR_FUSE_TAIL=0 HVR_FUSE_NEXT=0"; do
+echo "== $e"; env $e python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "bf16_training_step" 2>&1 | grep -o "q_data_fc_1.weight', [0-9.]*, [0-9.]*\|passed\|failed" | head -3
+done

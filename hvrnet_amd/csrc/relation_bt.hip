@@ -84,6 +84,10 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   // Rounds of up to 256 tiles, one LAUNCH per round (one for the 4 500-row window: 234 tiles; two for the shipped T = 21
   // window's 6 300 rows: 450 tiles): this launch holds tiles p.tile0 .. p.tile0 + p.tiles_here - 1
   const bool has_tile = (int)blockIdx.x < p.tiles_here;
+#ifdef HVR_DBG_BT_CLK
+  long long dbg_t[5];
+  dbg_t[0] = wall_clock64();
+#endif
   // n fastest inside an XCD's contiguous range: the 352-row query panel is shared by neighbouring tiles
   const int tile = has_tile ? p.tile0 + xcd_remap(blockIdx.x, p.tiles_here) : 0;
   const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;
@@ -165,6 +169,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     }
   }
 #endif
+#ifdef HVR_DBG_BT_CLK
+  dbg_t[1] = wall_clock64();
+#endif
   if (!has_tile) return;
 
   f32x4 acc[BT_FM][BT_FN];
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+#ifdef HVR_BT_LOCKSTEP
   for (int kt = 0; kt < nk; ++kt) {
     const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * BT_STAGE;
@@ -217,6 +225,85 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     __builtin_amdgcn_s_barrier();
   }
 
+#else
+  // ---- phase-staggered K loop ----
+  // The eight waves are two groups of four (wm = 0 / 1: waves w and w + 4 share SIMD w).  A K-step is four phases --
+  // (K half h, row fragments 0..5) and (h, 6..10) for h = 0, 1 -- and a phase is two sections with an s_barrier behind each:
+  //   L: request the phase's fragments from the LDS (the half's 4 key fragments + 6 / 5 query fragments) and this wave's
+  //      share of the next K-step's DMA;            C: lgkmcnt(0), then nothing but the phase's 24 / 20 MFMAs.
+  // Group 1 runs ONE BARRIER behind group 0 (it takes one extra s_barrier before the loop, group 0 one after it), so on
+  // every SIMD one wave is in a C section while its partner is in an L section: the matrix pipe always has a pure MFMA
+  // stream to run and the LDS / DMA issue of the partner goes down the other ports beside it, instead of both waves of a
+  // SIMD asking for the LDS together and for the matrix pipe together (the lock-step loop, HVR_BT_LOCKSTEP, ran its
+  // MFMAs at ~0.6 of the pipe's rate).
+  // Sections of K-step kt, numbered by barrier: group 0 reads its stage in sections 0, 2, 4, 6, group 1 in 1, 3, 5, 7 and
+  // its last reads have returned at the top of section 8 (= section 0 of kt + 1).  The other stage -- read last during
+  // K-step kt - 1 -- is therefore free from section 1 on: group 1 issues its DMA pieces in its L sections of phases 0 and 1
+  // (sections 1, 3), group 0 in phases 1 and 2 (sections 2, 4); every wave waits for its own pieces (vmcnt(0)) in front of
+  // the barrier that ends section 7, behind which group 0's first read of K-step kt + 1 sits.
+  {
+    constexpr int G0 = 6;  // row fragments of the first phase of a half (the second takes FM - G0)
+    const int dma_ph = wm ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
+    constexpr int DMA_TOTAL = BT_A_SLOTS + BT_B_SLOTS, DMA_FIRST = DMA_TOTAL / 2;
+    if (wm) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
+      char* nxt = smem + ((kt + 1) & 1) * BT_STAGE;
+      const int kn = kt + 1 < nk ? kt + 1 : kt;  // (the last step re-fetches itself into the idle stage: one uniform stream)
+      const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
+      uint4 kb[BT_FN], qa[G0];
+      static_for<4>([&](auto PH) {
+        constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? BT_FM - G0 : G0;
+        // ---- L ----
+        if constexpr ((ph & 1) == 0)
+          static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+        static_for<nr>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          qa[r] = lds_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+        });
+        if constexpr (ph < 3) {
+          if (dma_ph == ph) {
+            static_for<DMA_FIRST>([&](auto D) {
+              constexpr int d = decltype(D)::value;
+              if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
+              else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
+            });
+          } else if (dma_ph + 1 == ph) {
+            static_for<DMA_TOTAL - DMA_FIRST>([&](auto D) {
+              constexpr int d = DMA_FIRST + decltype(D)::value;
+              if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
+              else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
+            });
+          }
+        }
+        if constexpr (ph == 3) {
+          if (wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C ----
+        wait_lgkm<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        static_for<nr>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          static_for<BT_FN>([&](auto J) { mma(kb[decltype(J)::value], qa[r], acc[r0 + r][decltype(J)::value]); });
+        });
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ph == 3) {
+          if (!wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      });
+    }
+    if (!wm) __builtin_amdgcn_s_barrier();
+  }
+#endif
+
+#ifdef HVR_DBG_BT_CLK
+  dbg_t[2] = wall_clock64();
+#endif
 #ifdef HVR_DBG_BT_NOEPI
   {
     float t = 0.f;
@@ -228,7 +315,13 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     return;
   }
 #endif
+  {
   // ---------------- epilogue: block max / exp2 / pack / sums ----------------
+  // (the lane-derived values are re-derived from a laundered copy of the thread index: nothing but the accumulators and the
+  // loop's own addresses stays live across the K loop, which runs at the 256-register limit)
+  int etid = threadIdx.x;
+  asm volatile("" : "+v"(etid));
+  const int lane = etid & 63, frag_row = lane & 15, frag_grp = lane >> 4;
   // LDS (the ring is idle): [8][176] maxima, [8][176] sums, then one 16-row x 64-key bf16 staging block per wave
   float* red_max = reinterpret_cast<float*>(smem);
   float* red_sum = red_max + 8 * BT_WROWS;
@@ -294,6 +387,12 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         p.lstat[(long)m * p.ntile + t] = sum;
       }
     }
+  }
+#ifdef HVR_DBG_BT_CLK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dbg_t[3] = wall_clock64();
+    if (threadIdx.x == 0) printf("BTCLK %d %d %lld %lld %lld %lld\n", (int)blockIdx.x, (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) , dbg_t[0], dbg_t[1] - dbg_t[0], dbg_t[2] - dbg_t[0], dbg_t[3] - dbg_t[0]);
+#endif
   }
 }
 

@@ -50,14 +50,22 @@ __device__ __forceinline__ uint32_t lds_off(const void* p) {
 }
 template <int OFF> __device__ __forceinline__ uint4 lds_read128(uint32_t addr) {
   uint4 v;
+#ifdef HVR_DBG_BT_NOREADS
+  asm volatile("" : "=v"(v) : "v"(addr));
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#endif
   return v;
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void mma(const uint4& keys, const uint4& queries, f32x4& acc) {
   // keys as the MFMA "A" operand: lane ends up with 4 consecutive keys of one query row (see gemm.hip)
+#ifdef HVR_DBG_BT_NOMMA
+  acc[0] += __uint_as_float(keys.x ^ queries.x);
+#else
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, keys), __builtin_bit_cast(bf16x8, queries), acc, 0, 0, 0);
+#endif
 }
 
 // LDS reads that may still be outstanding when item t's query fragment is needed: the fragments requested after it
@@ -101,6 +109,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     if (i < BT_A_SLOTS - 1 || wave < (BT_BM * 8 - (BT_A_SLOTS - 1) * BT_NT) / 64) {
       int m = m0 + i * 64 + l_row;
       m = m < p.Mq ? m : p.Mq - 1;
+#ifdef HVR_DBG_BT_SAMEROW
+      m &= 63;
+#endif
       const char* src = (const char*)p.Q + ((long)m * p.ldq * 2 + l_chunk + kt * 128);
 #ifdef HVR_DBG_BT_NODMA
       if (kt == 0)
@@ -113,6 +124,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     constexpr int i = decltype(I)::value;
     int n = n0 + i * 64 + l_row;
     n = n < p.Mk ? n : p.Mk - 1;
+#ifdef HVR_DBG_BT_SAMEROW
+    n &= 63;
+#endif
     const char* src = (const char*)p.K + ((long)n * p.ldk * 2 + l_chunk + kt * 128);
 #ifdef HVR_DBG_BT_NODMA
     if (kt == 0)
@@ -245,6 +259,10 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     constexpr int G0 = 6;  // row fragments of the first phase of a half (the second takes FM - G0)
     const int dma_ph = wm ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
     constexpr int DMA_TOTAL = BT_A_SLOTS + BT_B_SLOTS, DMA_FIRST = DMA_TOTAL / 2;
+#ifdef HVR_DBG_BT_SEC
+    long long sec_t[21];
+    for (int q = 0; q < 21; ++q) sec_t[q] = 0;
+#endif
     if (wm) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
@@ -254,13 +272,20 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       uint4 kb[BT_FN], qa[G0];
       static_for<4>([&](auto PH) {
         constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? BT_FM - G0 : G0;
+#ifdef HVR_DBG_BT_SEC
+        if (kt == 8) sec_t[5 * ph] = __builtin_readcyclecounter();
+#endif
         // ---- L ----
-        if constexpr ((ph & 1) == 0)
-          static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
-        static_for<nr>([&](auto R) {
-          constexpr int r = decltype(R)::value;
-          qa[r] = lds_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
-        });
+        auto frag_reads = [&]() {
+          if constexpr ((ph & 1) == 0)
+            static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+          static_for<nr>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            qa[r] = lds_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+          });
+        };
+        frag_reads();
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph < 3) {
           if (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
@@ -280,9 +305,18 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
           if (wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
         }
         __builtin_amdgcn_sched_barrier(0);
+#if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
+        if (kt == 8) sec_t[5 * ph + 1] = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef HVR_DBG_BT_SEC
+        if (kt == 8) sec_t[5 * ph + 2] = __builtin_readcyclecounter();
+#endif
         // ---- C ----
         wait_lgkm<0>();
+#if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
+        if (kt == 8) sec_t[5 * ph + 3] = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         static_for<nr>([&](auto R) {
@@ -291,11 +325,23 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+#if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
+        if (kt == 8) sec_t[5 * ph + 4] = __builtin_readcyclecounter();
+#endif
         if constexpr (ph == 3) {
           if (!wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
       });
+#ifdef HVR_DBG_BT_SEC
+      if (kt == 8 && blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 4))
+      {
+        sec_t[20] = __builtin_readcyclecounter();
+        printf("BTSEC wg %d wave %d |", (int)blockIdx.x, wave);
+        for (int q = 1; q < 21; ++q) if (sec_t[q]) printf(" %lld%s", sec_t[q] - sec_t[0], q % 5 == 0 ? " |" : "");
+        printf("\n");
+      }
+#endif
     }
     if (!wm) __builtin_amdgcn_s_barrier();
   }

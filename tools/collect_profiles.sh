@@ -13,6 +13,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/r_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/r_$c -o rel -- python tools/rel_bench.py --iters 5 > /dev/null 2>&1
   python tools/rocpd_pmc.py $(find /tmp/r_$c -name "*.db" | head -1) $c > $out/rel_pmc_$(echo $c | tr A-Z a-z).txt
 done
+python tools/make_traffic_json.py $(find /tmp/r_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/r_WRITE_SIZE -name "*.db" | head -1) $out/relation_traffic.json
+# SQ / TCC passes: the relation core alone, then every kernel of the headline window (the conv classes: MFMA-busy, LDS, waits)
+rm -f $out/relation_pmc_sq.txt; bash tools/rel_pmc.sh $out/relation_pmc_sq.txt
+rm -f $out/window_pmc_sq.txt; i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); rm -rf /tmp/w_$i
+  HVR_FRAME_GROUPS=1 rocprofv3 --kernel-trace --pmc $set -d /tmp/w_$i -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-side-loops --no-graphs --no-f32-leg > /dev/null 2>&1
+  echo "--- pass $i: $set" >> $out/window_pmc_sq.txt
+  python tools/pmc_dump.py $(find /tmp/w_$i -name "*.db" | head -1) _kernel >> $out/window_pmc_sq.txt 2>&1
+done
 rm -rf /tmp/r_ks; rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --iters 10 > $out/rel_bench.txt 2>/dev/null
 python tools/rocpd_stats.py $(find /tmp/r_ks -name "*.db" | head -1) >> $out/rel_bench.txt
 python tools/probe/blaslt_ref.py > $out/hipblaslt_calibration.txt 2>/dev/null

@@ -8,7 +8,7 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); } } while (0)
 
-template <int INFLIGHT, bool PLAIN>
+template <int INFLIGHT, bool PLAIN, int DRAIN = 0>
 __global__ __launch_bounds__(1024) void dma_stream(const char* src, long panel_bytes, int rows_ld, int iters, float* sink, int shared_panel) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -40,17 +40,19 @@ __global__ __launch_bounds__(1024) void dma_stream(const char* src, long panel_b
       }
       piece += nw;
     }
-    if constexpr (!PLAIN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");  // the previous batch has landed
+    if constexpr (DRAIN == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // 2-stage pipeline: batch landed before the next is issued
+    else if constexpr (DRAIN == 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory"); __builtin_amdgcn_s_barrier(); }  // one batch stays in flight across the barrier
+    else if constexpr (!PLAIN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");  // the previous batch has landed
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (acc == 12345.f) sink[0] = acc;
 }
 
-template <int INFLIGHT, bool PLAIN>
+template <int INFLIGHT, bool PLAIN, int DRAIN = 0>
 static void run(const char* name, int waves, long panel_bytes, int rows_ld, int shared_panel, const char* d, float* sink) {
   const int iters = 400;
   const size_t lds = (size_t)waves * INFLIGHT * 2 * 1024;
-  auto k = dma_stream<INFLIGHT, PLAIN>;
+  auto k = dma_stream<INFLIGHT, PLAIN, DRAIN>;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k, dim3(256), dim3(waves * 64), lds, 0, d, panel_bytes, rows_ld, iters, sink, shared_panel);
@@ -77,6 +79,12 @@ int main() {
     run<8, false>("LDS-DMA", 16, 64 * 1024, 2048, shared, d, sink);
     run<8, true>("global_load_dwordx4 -> VGPR", 8, 64 * 1024, 2048, shared, d, sink);
   }
+  run<10, false, 1>("LDS-DMA drain/barrier per 10", 8, 64 * 1024, 2048, 0, d, sink);
+  run<10, false, 2>("LDS-DMA 1 batch across barrier", 8, 64 * 1024, 2048, 0, d, sink);
+  run<5, false, 1>("LDS-DMA drain/barrier per 5", 8, 64 * 1024, 2048, 0, d, sink);
+  run<5, false, 2>("LDS-DMA 1 batch(5) across barrier", 8, 64 * 1024, 2048, 0, d, sink);
+  run<10, false, 1>("LDS-DMA drain/barrier per 10", 8, 512 * 1024, 2048, 0, d, sink);
+  run<10, false, 2>("LDS-DMA 1 batch across barrier", 8, 512 * 1024, 2048, 0, d, sink);
   run<8, false>("LDS-DMA", 8, 512 * 1024, 2048, 0, d, sink);
   run<8, false>("LDS-DMA", 16, 512 * 1024, 2048, 0, d, sink);
   run<8, true>("global_load_dwordx4 -> VGPR", 8, 512 * 1024, 2048, 0, d, sink);

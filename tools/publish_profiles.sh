@@ -1,0 +1,18 @@
+#!/bin/bash
+# Copies the summaries tools/collect_profiles.sh left under gpurun_out/profiles/ (scratch) into profiles/ (tracked) under this
+# round's prefix:  tools/publish_profiles.sh r02
+set -euo pipefail
+cd "$(dirname "$0")/.."
+r=${1:?round prefix, e.g. r02}
+src=gpurun_out/profiles
+declare -A map=( [bench.json]=bench.json [bench_prof.json]=bench_profiled_run.json [bench_kernel_stats.txt]=bench_kernel_stats.txt
+  [bench_window_phases.txt]=bench_window_phases.txt [pmc_fetch_size.txt]=pmc_fetch_size.txt [pmc_write_size.txt]=pmc_write_size.txt
+  [rel_pmc_fetch_size.txt]=relation_pmc_fetch_size.txt [rel_pmc_write_size.txt]=relation_pmc_write_size.txt
+  [relation_pmc_sq.txt]=relation_pmc_sq.txt [relation_traffic.json]=relation_traffic.json [rel_bench.txt]=relation_kernel_stats.txt
+  [window_pmc_sq.txt]=window_pmc_sq.txt [hipblaslt_calibration.txt]=hipblaslt_calibration.txt [train_bench.json]=train_bench.json
+  [train_bench_f32.json]=train_bench_f32.json [train_bench_hvr.json]=train_bench_hvr.json [train_kernel_stats.txt]=train_kernel_stats.txt
+  [ingest_bench.json]=ingest_bench.json [bench_selsa.json]=bench_selsa.json )
+for f in "${!map[@]}"; do
+  if [ -s $src/$f ]; then cp $src/$f profiles/${r}_${map[$f]}; fi
+done
+ls profiles | grep "^${r}_"

@@ -895,7 +895,7 @@ static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
 //  11: 144x128 NS=4, 8 waves as 1 x 8
 const TileShape kTileShapes[kNumTileShapes] = {
     {128, 128, 2, 1.25f}, {128, 64, 3, 0.80f}, {144, 256, 1, 0.90f}, {144, 128, 2, 1.00f}, {256, 128, 1, 0.80f},
-    {144, 256, 1, 1.00f}, {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}, {144, 128, 1, 1.00f}, {128, 64, 2, 1.00f},
+    {256, 128, 1, 1.00f}, {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}, {128, 128, 1, 1.00f}, {128, 64, 2, 1.00f},
     {144, 256, 1, 1.00f}, {144, 128, 1, 1.00f}};
 
 int choose_tile(const GemmParams& p, int epi) {
@@ -954,10 +954,10 @@ static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t strea
       case 2: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS>(p, stream); break;
       case 3: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS>(p, stream);
       case 4: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS>(p, stream);
-      case 5: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 4, 3, 4, EPI, GLDS, 3>(p, stream); break;
+      case 5: if constexpr (EPI != EPI_APPLY) return launch_tile<T, 4, 2, 4, 4, EPI, GLDS, 3>(p, stream); break;
       case 6: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
       case 7: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream);
-      case 8: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 4, 3, 2, EPI, GLDS, 4>(p, stream); break;
+      case 8: return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream);
       case 9: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS, 3>(p, stream); break;
       case 10: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 1, 8, 9, 2, EPI, GLDS, 3>(p, stream); break;
       case 11: return launch_tile<T, 1, 8, 9, 1, EPI, GLDS, 4>(p, stream);

@@ -371,8 +371,13 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   // LDS (the ring is idle): [8][176] maxima, [8][176] sums, then one 16-row x 64-key bf16 staging block per wave
   float* red_max = reinterpret_cast<float*>(smem);
   float* red_sum = red_max + 8 * BT_WROWS;
-  constexpr int SPITCH = BT_WCOLS * 2 + 16;  // bytes per staged row (144: 16-byte aligned, rows 4 banks apart)
+  // staged rows are 128 bytes with no padding; bank-conflict-free on both sides (SQ_LDS_BANK_CONFLICT was 491 k cycles per
+  // launch with 144-byte rows): the 16-byte piece index is XOR-ed with (row & 7) -- the 16 lanes of a ds_read_b128 group then
+  // cover all 64 banks -- and rows 8..15 swap the two 8-byte halves of a piece, so that the 16 rows of a ds_write_b64 lane
+  // group (same fragment column, rows r and r + 8 on the same piece) land on 32 distinct banks; the h = 1 read swaps them back
+  constexpr int SPITCH = BT_WCOLS * 2;
   char* stg = smem + 2 * 8 * BT_WROWS * 4 + wave * (16 * SPITCH);
+  const int wr_lane = frag_row * SPITCH + (((frag_grp & 1) ^ (frag_row >> 3)) << 3);  // + ((2 j + (g >> 1)) ^ (row & 7)) * 16
   const int blk = wn >> 1;                                          // 128-key block of this wave inside the tile
   const bool blk_live = n0 + blk * 128 < p.ldp;                     // an odd block count leaves the last tile half empty
   const int ncol0 = n0 + wn * BT_WCOLS + frag_grp * 4;              // first key of this lane's fragment-0 columns
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], p.sl2, -tmax[i]));
       sum += (e[0] + e[1]) + (e[2] + e[3]);
-      *reinterpret_cast<uint2*>(stg + frag_row * SPITCH + (j * 16 + frag_grp * 4) * 2) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+      *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (frag_grp >> 1)) ^ (frag_row & 7)) << 4)) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
     }
     sum = quad_group_sum(sum);
     if (frag_grp == 0) red_sum[wave * BT_WROWS + i * 16 + frag_row] = sum;
@@ -416,7 +421,8 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = h * 8 + st_row, m = m0 + wm * BT_WROWS + i * 16 + row;
-      const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + st_chunk * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
+      if (h) v = make_uint4(v.z, v.w, v.x, v.y);
       if (m < p.Mq && blk_live)
         *reinterpret_cast<uint4*>(p.P + (long)m * p.ldp + n0 + wn * BT_WCOLS + st_chunk * 8) = v;
     }

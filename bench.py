@@ -12,6 +12,14 @@ steps, and one key-frame detection comes out (per-class arrays on the host, as t
 bbox2result returns them).  Frames are already resident in HBM when timing starts.  Ranks run
 independent clips (no data-path collective): weak scaling, value = N * steps / max-over-ranks time.
 
+Two timed regions of the same K steps, each bracketed by barrier + synchronize: (1) the eager single-lane loop -- the
+region the `roofline` HIP events are taken in (a kernel's own duration: one window on the chip) and reported as
+`single_lane`; (2) the HEADLINE region: the same windows replayed from hipGraphs on `--lanes` (2) HIP streams in turn, so
+that two independent clips are in flight -- one window's latency-bound phases (proposals, read-out, the relation stages'
+one-round kernels' prologues and epilogues) run beside the other's dense phases, one host call per window.  Every window of
+both regions is computed in full and its results are read on the host inside the region; the replayed windows' detections
+are identical to the eager ones (tests/test_graphs_gpu.py).  `--lanes 1 --no-graphs` makes region (1) the headline.
+
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (one process per
 GPU under torch.distributed.run, 127.0.0.1 rendezvous -- what tools/dist_test.sh:9-10 does for the reference) and refuses
 loudly when fewer than N devices are visible.
@@ -63,6 +71,9 @@ def parse(argv=None):
     ap.add_argument('--no-graphs', action='store_true', help='skip the hipGraph legs (graphed_clip / graphed_stream)')
     ap.add_argument('--inflight', type=int, default=int(os.environ.get('HVR_INFLIGHT', '1')),
                     help='independent windows enqueued on that many HIP streams in turn (throughput mode)')
+    ap.add_argument('--lanes', type=int, default=int(os.environ.get('HVR_LANES', '2')),
+                    help='headline region: windows replayed from hipGraphs on that many HIP streams in turn (1 with --no-graphs: the '
+                         'eager single-lane loop is the headline, as in round 1)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
     ap.add_argument('--stub', action='store_true',
                     help='host-logic self-test of the launcher / barrier / max-over-ranks / JSON contract without a GPU: the window '
@@ -397,6 +408,49 @@ def main(argv=None):
         return el, res, spans
 
     mine, res, rel = timed(args.steps, args.warmup, tags=('relation_full', 'relation_key'))
+    single_lane = dict(frames_per_s_per_gpu=round(args.steps / mine, 3), ms_per_step=round(mine / args.steps * 1e3, 3), steps=args.steps,
+                       what='eager launches, one window in flight per GPU (the round-1 headline loop): the region the roofline '
+                            'HIP events are taken in')
+    headline_mode = 'eager launches, %d window(s) in flight' % max(1, args.inflight)
+    n_lanes = max(1, args.inflight)
+    if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
+        # ---- headline region: K windows replayed from hipGraphs on `lanes` HIP streams in turn ----
+        from hvrnet_amd.graphs import GraphedClip
+        n_lanes = args.lanes
+        lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+        gcs = []
+        for st in lane_streams:
+            with torch.cuda.stream(st):
+                gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1))
+        pend_l = [None] * n_lanes
+
+        def replay(i):
+            k = i % n_lanes
+            out = pend_l[k].result() if pend_l[k] is not None else None   # a lane's previous window is read before its buffers are reused
+            with torch.cuda.stream(lane_streams[k]):
+                pend_l[k] = gcs[k].run()
+            return out
+
+        def drain():
+            last = None
+            for k in range(n_lanes):
+                if pend_l[k] is not None:
+                    last = pend_l[k].result()
+                    pend_l[k] = None
+            return last
+
+        for i in range(max(args.warmup, n_lanes)):
+            replay(i)
+        drain()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            replay(i)
+        res = drain()
+        sync()
+        mine = time.perf_counter() - t0
+        headline_mode = 'hipGraph replay (one graph per window), %d windows in flight on %d HIP streams' % (n_lanes, n_lanes)
+        del gcs
     elapsed, per_rank = mine, [mine]
     if world > 1:
         t = torch.tensor([mine], dtype=torch.float64, device=dev)
@@ -577,7 +631,10 @@ def main(argv=None):
             roofline = dict(kernel='relation core (the launches of hvr_relation_fwd: scores + apply), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
                             traffic_source=traffic_src, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
-                            flops_per_launch=full['work'] / full['calls'])
+                            flops_per_launch=full['work'] / full['calls'],
+                            measured_over='the eager single-lane region (`single_lane`, the same K windows): HIP events on the launch '
+                                          'stream around every hvr_relation_fwd call; a graph replay has no place for them, and with two '
+                                          'windows sharing the chip an interval is not the kernel\'s own duration')
         kc = {}
         for tag, d in classes.items():
             e = dict(calls=d['calls'], ms=round(d['ms'], 4))
@@ -596,11 +653,12 @@ def main(argv=None):
                                else 'configs[1]: faster_rcnn_r101_selsa_c5 inference, clip mode',
                                frames_per_window=T, proposals_per_frame=n_prop, input='3x600x1000 padded to 608x1008',
                                mode='clip (all T frames through backbone+res5+RPN+RoIAlign+head every step)',
-                               parallelism='dp%d independent clips, no collectives' % world, windows_in_flight=args.inflight,
+                               parallelism='dp%d independent clips, no collectives' % world, windows_in_flight=n_lanes, launch=headline_mode,
                                key_frame_detections=n_det),
                    roofline=roofline, kernel_classes=kc, gpus_requested=args.gpus,
                    per_rank=[dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)],
                    rccl_world_size=(dist.get_world_size() if world > 1 else 1))
+        out['single_lane'] = single_lane
         if f32_leg is not None:
             out['f32_parity_mode'] = f32_leg
         if ref_loop_fps is not None:

@@ -50,6 +50,41 @@ def test_graphed_clip_equals_the_eager_window(kind):
     assert n_det > 0
 
 
+@pytest.mark.parametrize('kind', ['hvr', 'selsa'])
+def test_two_graphed_clips_in_flight_on_two_streams_equal_the_eager_windows(kind):
+    """bench.py's headline region: windows replayed from hipGraphs on two HIP streams in turn, two DIFFERENT clips in flight at a
+    time.  Each lane has its own graph, output buffers and per-stream scratch, so every window must equal the eager result of
+    its own clip whatever the other lane is running."""
+    T, n_prop = 5, 24
+    make = hvr_config if kind == 'hvr' else selsa_config
+    model = hvrnet_amd.build_model(make(frame_interval=T // 2, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    metas = [S.synth_meta(HW, PAD) for _ in range(T)]
+    clips = [torch.cat([S.synth_frame(10 * c + i, img_hw=HW, pad_hw=PAD) for i in range(T)], 0).to(DEV) for c in range(4)]
+    want = []
+    with torch.no_grad():
+        for clip in clips:
+            c4 = model(img=clip, img_meta=metas, backbone_feat=True)[0]
+            want.append(model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True))
+    lanes = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    gcs = []
+    for st in lanes:
+        with torch.cuda.stream(st):
+            gcs.append(GraphedClip(model, clips[0], metas, rescale=True, n_out=1))
+    torch.cuda.synchronize()
+    pend = [None, None]
+    order = [0, 1, 2, 3, 3, 2, 1, 0, 1, 3]
+    for i, c in enumerate(order):
+        k = i % 2
+        if pend[k] is not None:
+            _check(kind, pend[k][0].result(), want[pend[k][1]])
+        with torch.cuda.stream(lanes[k]):
+            lanes[k].wait_stream(torch.cuda.current_stream())
+            pend[k] = (gcs[k].run(clips[c]), c)
+    for k in range(2):
+        assert not pend[k][0].respeculated
+        _check(kind, pend[k][0].result(), want[pend[k][1]])
+
+
 def test_graphed_clip_with_a_short_frame_takes_the_exact_path():
     """A harsh RPN NMS leaves some frame with fewer than nms_post proposals: the replay's speculative result is discarded and
     the window is re-run through the exact (ragged) eager path -- same answer as eager forward_feat(speculate=False)."""

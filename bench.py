@@ -574,6 +574,32 @@ def main(argv=None):
                               tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
                               what='tools/test.py steady state with the per-frame cache as two hipGraphs: one new frame through backbone / '
                                    'res5 / RPN / RoIAlign / fc_new_1 per output frame + relation stages and read-out on the T cached entries')
+        # the same loop pipelined: frame i + 1's per-frame part (graph FC on a second stream) runs beside window i's relation
+        # stages and read-out; one frame arrives per output frame, nothing is batched
+        gs.push_async(frames[0:1])
+        for i in range(T):
+            gs.commit()
+            gs.push_async(frames[(i + 1) % T:(i + 1) % T + 1])
+            gs.emit().result()
+        sync()
+        tg = time.perf_counter()
+        pend = None
+        for i in range(nsg):
+            gs.commit()
+            gs.push_async(frames[(i + 2) % T:(i + 2) % T + 1])
+            nxt = gs.emit()
+            if pend is not None:
+                pend.result()
+            pend = nxt
+        pend.result()
+        gs.commit()
+        sync()
+        el = time.perf_counter() - tg
+        graphed_stream['pipelined'] = dict(frames_per_s_per_gpu=round(nsg / el, 2), ms_per_frame=round(el / nsg * 1e3, 3), steps=nsg,
+                                           tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
+                                           what='the same loop with frame i + 1 going through backbone / res5 / RPN / RoIAlign / fc_new_1 on a '
+                                                'second HIP stream while window i runs its relation stages and read-out (push_async / commit; '
+                                                'identical detections, tests/test_graphs_gpu.py); still one new frame per output frame')
         del gs
         # the same loop with look-ahead batches (offline video: T frames through the per-frame part at once, then one output frame
         # at a time): what a single 600x1000 frame cannot give the chip -- 2 394 stride-16 rows are 17-19 row tiles for 256 CUs

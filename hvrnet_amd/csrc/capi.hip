@@ -17,6 +17,7 @@ namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
+hipError_t run_splitk_reduce_epi_bf16(const float*, void*, int, int, long, int, const float*, const void*, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
 hipError_t run_im2col_nhwc(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -111,9 +112,41 @@ static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int
   return HVR_OK;
 }
 
-int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
+// K slices for a tile-engine product (linear layer or conv) whose 128 x 64 tile grid leaves most of the chip idle (0 / 1 = not split): the slices bring
+// the launch to ~1.5 workgroups per CU, at least 4 K-steps each
+static int fewrow_slices(const GemmParams& p) {
+  static const int on = std::getenv("HVR_CONV_SPLITK") ? std::atoi(std::getenv("HVR_CONV_SPLITK")) : 1;
+  static const int target = std::getenv("HVR_CONV_SPLITK_WGS") ? std::atoi(std::getenv("HVR_CONV_SPLITK_WGS")) : 512;
+  static const int mink = std::getenv("HVR_CONV_SPLITK_MINK") ? std::atoi(std::getenv("HVR_CONV_SPLITK_MINK")) : 8;
+  static const int minper = std::getenv("HVR_CONV_SPLITK_PER") ? std::atoi(std::getenv("HVR_CONV_SPLITK_PER")) : 4;
+  if (!on || p.dtype != DT_BF16 || !p.staging || p.out_f32 || p.tile_hint != 0) return 1;
+  if (p.N % 8 || p.ldc % 8 || (p.resid && p.ldr % 8) || !aligned16(p.C) || (p.resid && !aligned16(p.resid)) || (p.bias && !aligned16(p.bias))) return 1;
+  const long tiles = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+  const int ksteps = p.K / 64;
+  if (tiles > 160 || ksteps < mink) return 1;
+  long s = (target + tiles / 2) / tiles;
+  if (s > ksteps / minper) s = ksteps / minper;
+  return s < 2 ? 1 : (int)s;
+}
+
+// split-K form of a tile-engine product: f32 partial tiles [slice][M][N] from the 128 x 64 shape (three workgroups per CU),
+// then one reduce + epilogue pass
+static hipError_t run_fewrow_split(const GemmParams& p, int slices, void* ws, hipStream_t stream) {
+  GemmParams q = p;
+  const int ksteps = p.K / 64;
+  q.ksplit_steps = (ksteps + slices - 1) / slices;
+  q.ksplit_count = (ksteps + q.ksplit_steps - 1) / q.ksplit_steps;
+  q.csplit_bytes = (long)p.M * p.N * 4;
+  q.C = ws; q.ldc = p.N; q.out_f32 = 1;
+  q.bias = nullptr; q.resid = nullptr; q.relu = 0;
+  q.tile_hint = 2;
+  hipError_t e = run_tile_op(q, EPI_LINEAR, stream);
+  if (e == hipSuccess) e = run_splitk_reduce_epi_bf16((const float*)ws, p.C, p.M, p.N, p.ldc, q.ksplit_count, p.bias, p.resid, p.ldr, p.relu, stream);
+  return e;
+}
+
+static int gemm_params(const hvr_gemm_desc* d, GemmParams& p) {
   if (!d) return fail(HVR_EINVAL, "null descriptor");
-  GemmParams p;
   int rc = fill_linear(p, d->A, d->B, d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->dtype, d->staging);
   if (rc) return rc;
   const int es = elem_size(d->dtype);
@@ -121,6 +154,20 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   if ((d->ldc * (d->out_f32 ? 4 : es)) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
+  return 0;
+}
+
+size_t hvr_gemm_fewrow_workspace_bytes(const hvr_gemm_desc* d) {
+  GemmParams p;
+  if (gemm_params(d, p)) return 0;
+  const int s = fewrow_slices(p);
+  return s > 1 ? (size_t)s * p.M * p.N * 4 : 0;
+}
+
+int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
+  GemmParams p;
+  const int rc = gemm_params(d, p);
+  if (rc) return rc;
   if (d->tile_hint == kPcHint128 || d->tile_hint == kPcHint256) {
     if (!pc_supported(p, EPI_LINEAR)) return fail(HVR_EUNSUPPORTED, "the producer / consumer tile kernel takes aligned bf16 operands with N %% 8 == 0");
     return check_launch(run_pc(p, EPI_LINEAR, d->tile_hint == kPcHint256 ? 256 : 128, (hipStream_t)stream), "hvr_gemm (pc)");
@@ -132,6 +179,9 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
     const long tiles = (long)((d->M + 143) / 144) * ((d->N + 127) / 128);
     if (tiles > 192 && tiles <= 256) return check_launch(run_pc(p, EPI_LINEAR, 128, (hipStream_t)stream), "hvr_gemm (pc)");
   }
+  const int slices = fewrow_slices(p);
+  if (slices > 1 && d->ws && aligned16(d->ws) && d->ws_bytes >= (size_t)slices * p.M * p.N * 4)
+    return check_launch(run_fewrow_split(p, slices, d->ws, (hipStream_t)stream), "hvr_gemm(split-K)");
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm");
 }
 
@@ -214,6 +264,14 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   return 0;
 }
 
+size_t hvr_conv2d_splitk_workspace_bytes(const hvr_conv_desc* d) {
+  GemmParams p;
+  int path = 0;
+  if (conv_params(d, p, path)) return 0;
+  const int s = (path == 0 ? fewrow_slices(p) : 1);
+  return s > 1 ? (size_t)s * p.M * p.N * 4 : 0;
+}
+
 int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   GemmParams p;
   int path = 0;
@@ -221,6 +279,11 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   if (rc) return rc;
   if (path == 1) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
   if (path == 2) return check_launch(run_conv3x3_c64(p, (hipStream_t)stream), "hvr_conv2d_nhwc(conv3x3_c64)");
+  const int slices = (path == 0 ? fewrow_slices(p) : 1);
+  if (slices > 1 && d->ws && aligned16(d->ws) && d->ws_bytes >= (size_t)slices * p.M * p.N * 4) {
+    const hipError_t e = run_fewrow_split(p, slices, d->ws, (hipStream_t)stream);
+    return check_launch(e, "hvr_conv2d_nhwc(split-K)");
+  }
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_conv2d_nhwc");
 }
 

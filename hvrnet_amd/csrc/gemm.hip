@@ -138,10 +138,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   char* Cb = (char*)p.C;
   int nk_slice = p.K / BKE;
   int blk0 = 0;  // EPI_APPLY: first 128-key block of this workgroup's K slice (slices are whole blocks)
+  int kt_base = 0;  // conv + split-K: first K-step of this workgroup's slice (the tap / channel offset is derived from it)
   if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
     if (p.ksplit_steps > 0) {
       const int kt0 = blockIdx.y * p.ksplit_steps;
-      Ab += (long)kt0 * 128;
+      if (kConvOk && p.conv) kt_base = kt0;  // an implicit-GEMM slice starts at filter tap (kt0 * BKE) / Cin: the gather takes the offset
+      else Ab += (long)kt0 * 128;
       Bb += (long)kt0 * 128;
       Cb += (long)blockIdx.y * p.csplit_bytes;
       nk_slice = nk_slice - kt0 < p.ksplit_steps ? nk_slice - kt0 : p.ksplit_steps;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     long a_koff;
     int dy = 0, dx = 0;
     if (kConvOk && p.conv) {
-      const int k = kt * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+      const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       dy = ky * p.dil;
       dx = kx * p.dil;
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 
     auto tap_of = [&](int kt) {
       if (kConvOk && p.conv) {
-        const int k = kt * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+        const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
         dy = ky * p.dil;
         dx = kx * p.dil;

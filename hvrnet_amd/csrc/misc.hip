@@ -600,6 +600,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
   *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
 }
 
+// the sum with a conv / linear epilogue: C = act(sum_s ws[s] + bias + resid), rounded once to bf16 (split-K convs of few-row
+// problems: one frame through the stride-16 stages); N % 8 == 0, 16-byte aligned rows of C and resid
+__global__ __launch_bounds__(256) void splitk_reduce_epi_bf16_kernel(const float* __restrict__ ws, bf16_t* __restrict__ C, int M, int N, long ldc,
+                                                                     int S, const float* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                                     long ldr, int relu) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x, per_row = N / 8, total = (long)M * per_row;
+  if (q >= total) return;
+  const long m = q / per_row, n = (q - m * per_row) * 8, stride = (long)M * N;
+  const float* src = ws + m * N + n;
+  float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  for (int s = 1; s < S; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(src + s * stride), v = *reinterpret_cast<const float4*>(src + s * stride + 4);
+    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+  }
+  if (bias) {
+    const float4 u = *reinterpret_cast<const float4*>(bias + n), v = *reinterpret_cast<const float4*>(bias + n + 4);
+    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+  }
+  if (resid) {
+    const uint4 t = *reinterpret_cast<const uint4*>(resid + m * ldr + n);
+    a.x += __uint_as_float(t.x << 16); a.y += __uint_as_float(t.x & 0xffff0000u);
+    a.z += __uint_as_float(t.y << 16); a.w += __uint_as_float(t.y & 0xffff0000u);
+    b.x += __uint_as_float(t.z << 16); b.y += __uint_as_float(t.z & 0xffff0000u);
+    b.z += __uint_as_float(t.w << 16); b.w += __uint_as_float(t.w & 0xffff0000u);
+  }
+  if (relu) {
+    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+    b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+  }
+  *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+}
+
+hipError_t run_splitk_reduce_epi_bf16(const float* ws, void* C, int M, int N, long ldc, int S, const float* bias, const void* resid, long ldr,
+                                      int relu, hipStream_t s) {
+  const long total = (long)M * (N / 8);
+  hipLaunchKernelGGL(splitk_reduce_epi_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S, bias,
+                     (const bf16_t*)resid, ldr, relu);
+  return hipGetLastError();
+}
+
 hipError_t run_splitk_reduce_bf16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
   const long total = (long)M * (N / 8);
   hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S);

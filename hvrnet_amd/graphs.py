@@ -138,15 +138,21 @@ class GraphedStream(object):
       push(frame)   graph F: backbone -> res5 / RPN / proposals / RoIAlign / fc_new_1 of ONE frame; its rows are appended to
                     the window buffers (the oldest frame's rows drop out: a device-side shift, part of the graph)
       emit()        graph W: the relation stages and the read-out on the T frames in the window buffers -> PendingGraphWindow
+      push_async(frame) / commit()   the same as push(), split in two: graph FC (the frame's per-frame part, on a second
+                    stream) runs beside the previous window's graph W; commit() appends its rows (graph C)
 
     Window buffers hold T entries in arrival order: fc_new_1 rows [T * n, 1024], proposals [T, n, 5], counts [T]; n = nms_post.
     A frame may be pushed several times without recomputing it (`repeat_last()`): the reference pads the first and last
     windows of a video with copies of a frame (test.py:201-212, 257-300)."""
 
-    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1):
+    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1, fewrow_split=True):
         assert frame.is_cuda and frame.dim() == 4 and frame.shape[0] == 1
         self.model, self.meta, self.rescale = model, meta, rescale
         self.lookahead = int(lookahead)
+        # one frame gives the stride-16 stages 2 394 rows: its convs / fc_new_1 run split over K (native.fewrow_split) --
+        # same products, f32 sums in slice order, so a frame's rows equal the batched computation to an output ulp, not bit
+        # for bit; fewrow_split=False keeps the unsplit kernels (the bit-identity tests)
+        self.fewrow_split = bool(fewrow_split)
         dev = frame.device
         self.T = int(model.bbox_head.t_dim)
         self.key = int(model.key_dim)
@@ -221,14 +227,44 @@ class GraphedStream(object):
                     out.enqueue_copies()
                 self._graphs_w.append(graph)
                 self._outs.append(out)
+        # Pipelined form (push_async / commit): the NEXT frame's per-frame part runs on its own stream beside the current
+        # window's relation stages and read-out -- the two are independent until the frame's rows enter the window buffers.
+        # Graph FC (frame -> staging rows `nxt`) is captured on that stream, with its own memory pool and its own per-stream
+        # scratch and side streams (it runs concurrently with the window graphs); graph C (staging rows -> window buffers)
+        # belongs to the main stream's family.
+        self._fstream = torch.cuda.Stream(device=dev)
+        self._fstream.wait_stream(self._stream)
+        self.frame_nxt = self.frame.clone()
+        self.nxt = dict(f1=torch.zeros_like(self.last['f1']), props=torch.zeros_like(self.last['props']), count=torch.zeros_like(self.last['count']))
+        with torch.no_grad(), torch.cuda.stream(self._fstream):
+            for _ in range(max(1, warmup)):
+                self._frame_entry(self.frame_nxt)
+            self._fstream.synchronize()
+            self.graph_fc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fc, stream=self._fstream):
+                e = self._frame_entry(self.frame_nxt)
+                self.nxt['f1'].copy_(e['f1'])
+                self.nxt['props'].copy_(e['props'])
+                self.nxt['count'].copy_(e['count'])
+        self._stream.wait_stream(self._fstream)
+        with torch.no_grad(), torch.cuda.stream(self._stream):
+            self.graph_c = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_c, stream=self._stream, pool=self.graph_f.pool()):
+                self.last['f1'].copy_(self.nxt['f1'])
+                self.last['props'].copy_(self.nxt['props'])
+                self.last['count'].copy_(self.nxt['count'])
+                self._push_from(self.last)
+        self._ev_fc, self._ev_commit, self._pending_frame = torch.cuda.Event(), None, None
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._hist = []  # the window's input frames (copies), for the exact re-run of a window that holds a short frame
 
     # ---- pieces (each runs eagerly during warm-up and inside a capture afterwards) ----
-    def _frame_entry(self):
+    def _frame_entry(self, frame=None):
+        from . import native
         m = self.model
-        c4 = m(img=self.frame, img_meta=[self.meta], backbone_feat=True)[0]
-        return m.frame_tensors(c4, self.meta)
+        with native.fewrow_split(self.fewrow_split):
+            c4 = m(img=self.frame if frame is None else frame, img_meta=[self.meta], backbone_feat=True)[0]
+            return m.frame_tensors(c4, self.meta)
 
     def _push_from(self, e):
         n, T = self.n, self.T
@@ -263,6 +299,31 @@ class GraphedStream(object):
             self.frame.copy_(frame, non_blocking=True)
         self.graph_f.replay()
         self._hist = (self._hist + [self.frame.clone()])[-self.T:]
+
+    def push_async(self, frame):
+        """A new frame arrives: its per-frame part (graph FC) starts on the frame stream and runs beside whatever the caller's
+        stream does next (normally `emit()` of the current window).  `commit()` moves its rows into the window buffers."""
+        assert self._pending_frame is None, 'commit() the frame in flight first'
+        cur = torch.cuda.current_stream(self.frame.device)
+        self._fstream.wait_stream(cur)                 # `frame` is produced on the caller's stream
+        if self._ev_commit is not None:
+            self._fstream.wait_event(self._ev_commit)  # the staging rows of the previous frame have been taken
+        with torch.cuda.stream(self._fstream):
+            self.frame_nxt.copy_(frame, non_blocking=True)
+            self.graph_fc.replay()
+            self._ev_fc.record(self._fstream)
+        self._pending_frame = frame.clone()
+
+    def commit(self):
+        """The frame started by push_async() enters the window buffers (graph C on the caller's stream, behind graph FC)."""
+        assert self._pending_frame is not None, 'push_async() first'
+        cur = torch.cuda.current_stream(self.frame.device)
+        cur.wait_event(self._ev_fc)
+        self.graph_c.replay()
+        self._ev_commit = torch.cuda.Event()
+        self._ev_commit.record(cur)
+        self._hist = (self._hist + [self._pending_frame])[-self.T:]
+        self._pending_frame = None
 
     def push_batch(self, frames):
         """`lookahead` frames arrive together: their per-frame rows are computed in one batch (graph FB) and staged; call

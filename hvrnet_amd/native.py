@@ -6,6 +6,7 @@ tensors it allocated with the torch allocator.  There is NO CPU fallback: a miss
 library or a CPU tensor raises (the reference's RoIAlign raises ``NotImplementedError`` on
 CPU input the same way, ``mmdet/ops/roi_align/roi_align.py:27-28``).
 """
+import contextlib
 import ctypes
 import math
 import os
@@ -36,7 +37,8 @@ class GemmDesc(ctypes.Structure):
                 ('lda', ctypes.c_int64), ('ldb', ctypes.c_int64), ('ldc', ctypes.c_int64),
                 ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p), ('ldr', ctypes.c_int64),
                 ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
-                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32)]
+                ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32),
+                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -48,7 +50,7 @@ class ConvDesc(ctypes.Structure):
                 ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p),
                 ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
                 ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32),
-                ('zero', ctypes.c_void_p)]
+                ('zero', ctypes.c_void_p), ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
 
 
 class TailDesc(ctypes.Structure):
@@ -81,10 +83,12 @@ SYMBOLS = {
     'hvr_abi_version': (_i, []),
     'hvr_last_error': (ctypes.c_char_p, []),
     'hvr_gemm': (_i, [ctypes.POINTER(GemmDesc), _vp]),
+    'hvr_gemm_fewrow_workspace_bytes': (_sz, [ctypes.POINTER(GemmDesc)]),
     'hvr_gemm_splitk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_gemm_splitk': (_i, [ctypes.POINTER(GemmDesc), _vp, _sz, _vp]),
     'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'hvr_conv2d_path': (_i, [ctypes.POINTER(ConvDesc)]),
+    'hvr_conv2d_splitk_workspace_bytes': (_sz, [ctypes.POINTER(ConvDesc)]),
     'hvr_bottleneck_tail': (_i, [ctypes.POINTER(TailDesc), _vp]),
     'hvr_bottleneck_tail_supported': (_i, [ctypes.POINTER(TailDesc)]),
     'hvr_bottleneck_tail_next': (_i, [ctypes.POINTER(TailNextDesc), _vp]),
@@ -287,6 +291,10 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
                  relu=int(relu), out_f32=int(out.dtype == torch.float32 and a.dtype != torch.float32),
                  dtype=_dt(a), staging=STAGING if staging is None else staging,
                  tile_hint=TILE_HINT if tile is None else tile)
+    nbytes = lib().hvr_gemm_fewrow_workspace_bytes(ctypes.byref(d)) if _fewrow[0] else 0   # few rows, long K: K slices + one reduce launch
+    if nbytes:
+        ws = _workspace(nbytes, a.device, 'gemm_fewrow')
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     with _span('gemm' if not (_prof and _prof['detail']) else 'gemm M%d N%d K%d' % (M, N, K), 2.0 * M * N * K):
         _check(lib().hvr_gemm(ctypes.byref(d), _stream()), 'hvr_gemm')
     return out
@@ -332,6 +340,12 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
                  staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile,
                  zero=zero_page(x.device).data_ptr())
+    # few-row problems (one frame through the stride-16 stages): the library cuts the K loop into slices when it is handed
+    # scratch for the f32 partial tiles (per stream, like every other workspace here)
+    nbytes = lib().hvr_conv2d_splitk_workspace_bytes(ctypes.byref(d)) if _fewrow[0] else 0
+    if nbytes:
+        ws = _workspace(nbytes, x.device, 'conv_splitk')
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     tag, work = 'conv', 2.0 * B * OH * OW * Cout * KH * KW * Cin
     if _prof is not None and ('*' in _prof['tags'] or 'conv' in _prof['tags'] or 'conv_expand' in _prof['tags']):
         if lib().hvr_conv2d_path(ctypes.byref(d)) == 1:
@@ -467,6 +481,23 @@ def maxpool3x3s2_nhwc(x):
 
 
 _ws_cache = {}
+
+
+# Few-row split-K (hvr_gemm_fewrow_workspace_bytes / hvr_conv2d_splitk_workspace_bytes): opt-in, because it changes the f32
+# summation order with the batch size -- a frame's rows computed alone would no longer equal the same rows computed in a
+# batch bit for bit, a property the cached / look-ahead loops are tested for.  graphs.GraphedStream turns it on for its
+# one-frame graphs (the stream loop's latency case); everything else runs the unsplit kernels.
+_fewrow = [False]
+
+
+@contextlib.contextmanager
+def fewrow_split(on=True):
+    prev = _fewrow[0]
+    _fewrow[0] = bool(on)
+    try:
+        yield
+    finally:
+        _fewrow[0] = prev
 
 
 def _workspace(nbytes, device, tag):

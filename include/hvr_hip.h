@@ -59,7 +59,13 @@ typedef struct hvr_gemm_desc {
   int32_t dtype;
   int32_t staging;
   int32_t tile_hint;       /* 0 = library picks the tile shape; k > 0 forces shape k-1 (tuning) */
+  void* ws; size_t ws_bytes;   /* hvr_gemm: few-row split-K scratch (hvr_gemm_fewrow_workspace_bytes) or NULL / 0 */
 } hvr_gemm_desc;
+/* Few-row products with an epilogue (one frame's 300 proposals through fc_new_1: 300 x 1024 x 12544 is 48 tiles of 128 x 64
+ * walking 196 K-steps each): bytes of caller-owned scratch with which hvr_gemm cuts K into grid.y slices of f32 partial tiles
+ * and applies bias / residual / ReLU in one reduce launch (bf16 operands and output).  0 = not split.  Without the scratch the
+ * product runs unsplit (same result up to the f32 summation order).  The same rule as hvr_conv2d_splitk_workspace_bytes. */
+size_t hvr_gemm_fewrow_workspace_bytes(const hvr_gemm_desc* d);
 int hvr_gemm(const hvr_gemm_desc* d, void* stream);
 /* The same product for outputs with few tiles and a long K (weight gradients: dW = dZ^T X has K = pixels): the K loop is cut
  * into slices that run as one launch, each writing an f32 partial into `ws`, and a second kernel sums them in a fixed order.
@@ -83,8 +89,17 @@ typedef struct hvr_conv_desc {
   const void* resid;       /* [B][OH][OW][Cout] or NULL */
   int32_t relu, out_f32, dtype, staging, tile_hint;
   const void* zero;
+  void* ws; size_t ws_bytes;   /* split-K workspace (see hvr_conv2d_splitk_workspace_bytes) or NULL / 0 */
 } hvr_conv_desc;
 int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
+/* Few-row convolutions (one 600x1000 frame gives the stride-16 stages 2 394 output pixels: 76 tiles of 128 x 64 for 256 CUs,
+ * each walking the whole K = 9 Cin loop alone -- the reference's steady-state loop, tools/test.py:214-250, runs the backbone
+ * on ONE new frame per output frame): bytes of caller-owned scratch with which hvr_conv2d_nhwc cuts the K loop into slices
+ * (grid.y), each slice writing an f32 partial tile, followed by one reduce launch that adds bias / residual, applies the
+ * ReLU and rounds once to bf16.  0 = this descriptor is not split (enough tiles, short K, f32, or a dedicated kernel takes it);
+ * the call then ignores ws.  With ws == NULL or ws_bytes smaller than this the conv runs unsplit (same result up to the f32
+ * summation order of the K slices).  HVR_CONV_SPLITK=0 in the environment turns the split off. */
+size_t hvr_conv2d_splitk_workspace_bytes(const hvr_conv_desc* d);
 /* Which kernel hvr_conv2d_nhwc would run for this descriptor, without launching anything (pointers are only inspected
  * for alignment): 0 = MFMA tile engine (gemm.hip), 1 = row-panel kernel for the Bottleneck's channel-expanding 1x1 conv
  * + residual (expand.hip: bf16, 1x1 stride 1, Cin = 64 / 128 / 256, a residual, Cout >= 2 Cin in whole 64-channel chunks,

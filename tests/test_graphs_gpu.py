@@ -118,7 +118,7 @@ def test_graphed_stream_equals_the_cached_frame_loop(kind):
     meta = S.synth_meta(HW, PAD)
     with torch.no_grad():
         want = VideoWindowRunner(model, T, cache_frames=True).run_video(frames, [meta] * len(frames))
-    gs = GraphedStream(model, frames[0], meta, rescale=True)
+    gs = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False)
     got = {}
     # first frame: the deque is padded with copies until it holds (T + 1) / 2 entries
     gs.push(frames[0])
@@ -150,6 +150,41 @@ def test_graphed_stream_equals_the_cached_frame_loop(kind):
 
 
 @pytest.mark.parametrize('kind', ['hvr', 'selsa'])
+def test_pipelined_stream_equals_the_sequential_stream(kind):
+    """push_async / commit: frame i + 1's per-frame part (graph FC, own stream / pool / scratch) runs beside window i's
+    relation stages and read-out (graph W).  Same kernels on the same rows: every emitted window equals the one the
+    sequential push() / emit() stream gives, bit for bit, over two passes of the video."""
+    fi, n_prop = 2, 24
+    T = 2 * fi + 1
+    make = hvr_config if kind == 'hvr' else selsa_config
+    model = hvrnet_amd.build_model(make(frame_interval=fi, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
+    frames = [S.synth_frame(i, img_hw=HW, pad_hw=PAD).to(DEV) for i in range(7)]
+    meta = S.synth_meta(HW, PAD)
+    seq = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False)
+    want = []
+    for rep in range(2):
+        for f in frames:
+            seq.push(f)
+            want.append(seq.emit().result())
+    gs = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False)
+    order = frames + frames
+    got, pend = [], None
+    gs.push_async(order[0])
+    for i in range(len(order)):
+        gs.commit()                       # frame i's rows enter the window
+        if i + 1 < len(order):
+            gs.push_async(order[i + 1])   # frame i + 1 computes beside window i
+        nxt = gs.emit()
+        if pend is not None:
+            got.append(pend.result())
+        pend = nxt
+    got.append(pend.result())
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        _check(kind, g, w)
+
+
+@pytest.mark.parametrize('kind', ['hvr', 'selsa'])
 def test_graphed_stream_with_look_ahead_batches_gives_the_same_frames(kind):
     """`lookahead` frames through the per-frame part in one batch (graph FB), then one `advance(i)` + `emit()` per output
     frame: the rows of a frame do not depend on what else is in its batch, so every emitted window equals the
@@ -160,13 +195,13 @@ def test_graphed_stream_with_look_ahead_batches_gives_the_same_frames(kind):
     model = hvrnet_amd.build_model(make(frame_interval=fi, nms_post=n_prop), S.synth_state_dict(kind), torch.bfloat16, DEV)
     frames = torch.cat([S.synth_frame(i, img_hw=HW, pad_hw=PAD) for i in range(2 * B)], 0).to(DEV)
     meta = S.synth_meta(HW, PAD)
-    one = GraphedStream(model, frames[0:1], meta, rescale=True)
+    one = GraphedStream(model, frames[0:1], meta, rescale=True, fewrow_split=False)
     want = []
     for i in range(frames.shape[0]):
         one.push(frames[i:i + 1])
         if i >= T - 1:
             want.append(one.emit().result())
-    look = GraphedStream(model, frames[0:1], meta, rescale=True, lookahead=B)
+    look = GraphedStream(model, frames[0:1], meta, rescale=True, lookahead=B, fewrow_split=False)
     got, seen = [], 0
     for b0 in range(0, frames.shape[0], B):
         look.push_batch(frames[b0:b0 + B])
@@ -178,3 +213,42 @@ def test_graphed_stream_with_look_ahead_batches_gives_the_same_frames(kind):
     assert len(got) == len(want) == frames.shape[0] - T + 1
     for g, w in zip(got, want):
         _check(kind, g, w)
+
+
+def test_one_frame_split_k_path_tracks_the_unsplit_kernels():
+    """GraphedStream's default one-frame graphs run the few-row split-K kernels (native.fewrow_split): one 600x1000 frame through
+    backbone / res5 / RPN / proposals / RoIAlign / fc_new_1 with the split on and off.  Same products, f32 sums in slice order:
+    the C4 map agrees to bf16 rounding noise (not bit for bit -- that is why the switch is opt-in), the proposal sets overlap,
+    and a replayed stream with the split on returns detections for every window."""
+    from hvrnet_amd import native
+    T, n_prop = 3, 64
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=T // 2, nms_post=n_prop), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    meta = S.synth_meta()
+    frames = [S.synth_frame(i).to(DEV) for i in range(4)]
+    with torch.no_grad():
+        c4_ref = model(img=frames[0], img_meta=[meta], backbone_feat=True)[0]
+        e_ref = model.frame_tensors(c4_ref, meta)
+        with native.fewrow_split(True):
+            c4 = model(img=frames[0], img_meta=[meta], backbone_feat=True)[0]
+            e = model.frame_tensors(c4, meta)
+    assert not torch.equal(c4, c4_ref), 'the split-K route was not taken'
+    scale = float(c4_ref.float().abs().max())
+    assert float((c4.float() - c4_ref.float()).abs().max()) < 0.03 * scale
+    assert float((c4.float() - c4_ref.float()).abs().mean()) < 0.002 * scale
+    # proposals: the boxes reappear (mean best IoU > 0.9) -- with random weights the RPN's scores are near-ties and its top-k / NMS
+    # order flips for a few of them
+    a, b = e['props'][:, :4].float(), e_ref['props'][:, :4].float()
+    lt, rb = torch.max(a[:, None, :2], b[None, :, :2]), torch.min(a[:, None, 2:], b[None, :, 2:])
+    inter = (rb - lt + 1).clamp(min=0).prod(-1)
+    area = lambda x: (x[:, 2] - x[:, 0] + 1) * (x[:, 3] - x[:, 1] + 1)
+    iou = inter / (area(a)[:, None] + area(b)[None] - inter)
+    best = iou.max(1).values
+    assert float(best.mean()) > 0.9 and float((best > 0.6).float().mean()) > 0.9, best
+    gs = GraphedStream(model, frames[0], meta, rescale=True)
+    assert gs.fewrow_split
+    for i in range(T):
+        gs.push(frames[i])
+    for f in frames:
+        gs.push(f)
+        res = gs.emit().result()
+        assert len(res) == 2 and all(len(r) == model.bbox_head.num_classes - 1 for r in res)

@@ -105,6 +105,68 @@ def test_expand_conv_panel_kernel(Cin, Cout, H, W, B, relu, with_res):
     assert torch.equal(got, w.view(Cout, Cin).t()[torch.arange(128) % Cin])
 
 
+@pytest.mark.parametrize('Cin,Cout,k,stride,pad,dil,with_res', [(256, 256, 3, 1, 1, 1, False), (1024, 256, 1, 1, 0, 1, False),
+                                                                (512, 512, 3, 1, 2, 2, False), (512, 256, 1, 2, 0, 1, False),
+                                                                (1024, 512, 3, 1, 1, 1, False), (2048, 512, 1, 1, 0, 1, True),
+                                                                (128, 128, 3, 2, 1, 1, False)])
+def test_split_k_conv_for_one_frame(Cin, Cout, k, stride, pad, dil, with_res):
+    """hvr_conv2d_nhwc with a split-K workspace (one 600x1000 frame's stride-16 maps: 38x63 = 2 394 output pixels, 76 tiles of
+    128 x 64): the K loop -- filter taps included, a slice starts inside the tap sequence -- is cut into grid.y slices of f32
+    partial tiles and one reduce launch applies bias / residual / ReLU.  Against the f32 statement of the op and against the
+    unsplit tile engine on the same operands (a tile hint keeps the split off): same products, f32 sums in a different order,
+    one bf16 rounding."""
+    B, H, W = 1, (38 if stride == 1 else 76), (63 if stride == 1 else 126)
+    x = _rand((B, Cin, H, W), torch.bfloat16, 91)
+    w = _rand((Cout, Cin, k, k), torch.bfloat16, 92, 0.03)
+    bias = _rand((Cout,), torch.float32, 93)
+    ref = F.conv2d(x.float(), w.float(), bias, stride=stride, padding=pad, dilation=dil)
+    resid = _rand(ref.shape, torch.bfloat16, 94) if with_res else None
+    if with_res:
+        ref = ref + resid.float()
+    ref = torch.relu(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wn = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV) if with_res else None
+    d = native.ConvDesc(x=xn.data_ptr(), w=wn.data_ptr(), y=xn.data_ptr(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=stride,
+                        pad=pad, dil=dil, bias=None, resid=None, relu=1, out_f32=0, dtype=native.HVR_BF16, staging=1, tile_hint=0,
+                        zero=native.zero_page(xn.device).data_ptr())
+    assert native.lib().hvr_conv2d_splitk_workspace_bytes(d) > 0, 'this shape is meant to take the split-K route'
+    with native.fewrow_split(True):
+        split = native.conv2d_nhwc(xn, wn, bias.to(DEV), rn, relu=True, stride=stride, pad=pad, dil=dil)
+    whole = native.conv2d_nhwc(xn, wn, bias.to(DEV), rn, relu=True, stride=stride, pad=pad, dil=dil)
+    assert not torch.equal(split, whole) or Cin * k * k < 1024, 'the split route was not taken'
+    torch.testing.assert_close(split.float().cpu().permute(0, 3, 1, 2), ref, **_tol(torch.bfloat16))
+    torch.testing.assert_close(split.float(), whole.float(), rtol=2 ** -7, atol=2 ** -6)
+    # a 15-frame batch of the same layer has tiles enough: not split
+    d.B = 15
+    assert native.lib().hvr_conv2d_splitk_workspace_bytes(d) == 0
+
+
+@pytest.mark.parametrize('M,N,K,with_res', [(300, 1024, 12544, False), (300, 1024, 1024, True), (37, 256, 4096, False)])
+def test_few_row_gemm_split_over_k(M, N, K, with_res):
+    """hvr_gemm with the few-row scratch (one frame's 300 proposals through fc_new_1: 48 tiles walking 196 K-steps): K slices +
+    one reduce launch with the epilogue; against the f32 statement and the unsplit engine."""
+    a = _rand((M, K), torch.bfloat16, 95)
+    w = _rand((N, K), torch.bfloat16, 96, 0.02)
+    bias = _rand((N,), torch.float32, 97)
+    resid = _rand((M, N), torch.bfloat16, 98) if with_res else None
+    ref = a.float() @ w.float().t() + bias
+    if with_res:
+        ref = ref + resid.float()
+    ref = torch.relu(ref)
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV) if with_res else None
+    d = native.GemmDesc(A=ad.data_ptr(), B=wd.data_ptr(), C=ad.data_ptr(), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=None, resid=None, ldr=0,
+                        relu=1, out_f32=0, dtype=native.HVR_BF16, staging=1, tile_hint=0)
+    assert native.lib().hvr_gemm_fewrow_workspace_bytes(d) > 0
+    with native.fewrow_split(True):
+        split = native.gemm(ad, wd, bd, rd, relu=True)
+    whole = native.gemm(ad, wd, bd, rd, relu=True)
+    torch.testing.assert_close(split.float().cpu(), ref, **_tol(torch.bfloat16))
+    torch.testing.assert_close(split.float(), whole.float(), rtol=2 ** -7, atol=2 ** -6)
+    d.M, d.N = 4500, 1024   # the head's full-window products: tiles enough
+    assert native.lib().hvr_gemm_fewrow_workspace_bytes(d) == 0
+
+
 @pytest.mark.parametrize('relu,with_bias', [(True, True), (False, False)])
 @pytest.mark.parametrize('B,H,W', [(2, 37, 53), (1, 32, 32), (3, 16, 80), (1, 152, 252)])
 def test_conv3x3_c64_persistent_kernel(B, H, W, relu, with_bias):

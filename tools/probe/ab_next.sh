@@ -1,5 +1,3 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2b
-rm -rf /tmp/gs; rocprofv3 --kernel-trace --stats -d /tmp/gs -o gs -- python tools/probe/graph_stream.py 8 > /dev/null 2>&1
-python tools/rocpd_stats.py $(find /tmp/gs -name "*.db" | head -1) > gpurun_out/r2b/stream_stats.txt
-python tools/rocpd_phases.py $(find /tmp/gs -name "*.db" | head -1) 4 > gpurun_out/r2b/stream_phases.txt 2>&1
+for w in 256 384 512 768; do for k in 8 16 30; do for per in 2 4 6; do
+echo -n "wgs $w mink $k per $per: "; HVR_CONV_SPLITK_WGS=$w HVR_CONV_SPLITK_MINK=$k HVR_CONV_SPLITK_PER=$per python tools/probe/stream_pipe.py 2>&1 | grep -v amdgpu | sed -n 5,8p | awk '{printf "%s ", $(NF-3)}'; echo
+done; done; done

@@ -52,6 +52,17 @@ __device__ __forceinline__ u32x4 load_u128_untracked(const void* p) {
   return v;
 }
 __device__ __forceinline__ void landed(u32x4& v) { asm volatile("" : "+v"(v)); }
+// 16 bytes per lane, global -> LDS, through buffer addressing: base (uniform) + voff (per lane) + soff (uniform); offsets from
+// 2^31 up are outside the resource and come back as zeros.  (The resource type exists in the device pass only: the host
+// pass, which just needs the kernel's stub, sees an empty body.)
+__device__ __forceinline__ void buffer_load_lds16(const void* base, char* lds, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+#else
+  (void)base; (void)lds; (void)voff; (void)soff;
+#endif
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // loads one K-step costs the wave that issues the fewest (the last one: slots are dealt to waves in order)
@@ -156,13 +167,30 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // row packed as (iy << 16) | (ix & 0xffff): half the registers of pointers + two ints, which the pipelined
   // shapes need for their fragments
   int a_off[A_SLOTS], a_yx[A_SLOTS];
-  // (B rows are weights / keys: their offsets are recomputed at issue time, two VALU ops per 1 KiB piece)
+  // (B rows are weights / keys: register-staged loads recompute their offsets at issue time, two VALU ops per piece)
   auto b_off = [&](int i) {
     const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
     int n = n0 + row;
     n = n < p.N ? n : p.N - 1;
     return (int)(((long)n * p.ldb + c * EPC) * (long)sizeof(T));
   };
+  // Direct-to-LDS loads go through BUFFER addressing (`buffer_load_dwordx4 ... offen lds`): address = resource base (SGPRs) +
+  // the slot's byte offset (one VGPR, fixed for the whole kernel) + the K-step's offset (one SGPR: K-step x 128 bytes, or the
+  // filter tap's pixel offset for a conv -- it is the same for every row).  A piece then costs no vector address arithmetic at
+  // all (a flat `global_load_lds` needs the 64-bit sum per lane per piece: 2.4 VALU + 2 SALU per MFMA in the round-2 counters,
+  // r02_window_pmc_sq.txt), and a conv's out-of-image tap is one select -- offset 2^31, past the resource's range, which the
+  // hardware answers with zeros -- instead of a compare pair, a 64-bit select and a load from a zero page.  The conv origin can
+  // lie `pad` rows / pixels in front of the tensor: the resource base is moved back by that much and every offset forward.
+  constexpr unsigned kOob = 0x80000000u;
+  int a_bias = 0;
+  if (kConvOk && p.conv) a_bias = (int)(((long)p.pad * p.W + p.pad) * p.Cin * (long)sizeof(T));
+  const char* const rs_a = Ab - a_bias;
+  const char* const rs_b = Bb;
+  int b_offr[GLDS ? B_SLOTS : 1];
+  if constexpr (GLDS) {
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) b_offr[i] = b_off(i);
+  }
 #pragma unroll
   for (int i = 0; i < A_SLOTS; ++i) {
     const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
@@ -172,7 +200,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
       const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
       a_yx[i] = (iy << 16) | (ix & 0xffff);
-      a_off[i] = (int)(((((long)b * p.H + iy) * p.W + ix) * (long)p.Cin + c * EPC) * (long)sizeof(T));
+      a_off[i] = (int)(((((long)b * p.H + iy) * p.W + ix) * (long)p.Cin + c * EPC) * (long)sizeof(T)) + (GLDS ? a_bias : 0);
     } else {
       a_yx[i] = 0;
       a_off[i] = (int)(((long)m * p.lda + c * EPC) * (long)sizeof(T));
@@ -195,16 +223,19 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        const char* src = Ab + ((long)a_off[i] + a_koff);
-        if (kConvOk && p.conv) {
-          const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
-          src = ok ? src : (const char*)p.zero;
-        }
         if constexpr (GLDS) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(stage + (i * NT + wave * 64) * 16),
-                                           16, 0, 0);
+          unsigned voff = (unsigned)a_off[i];
+          if (kConvOk && p.conv) {
+            const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
+            voff = ok ? voff : kOob;
+          }
+          buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
         } else {
+          const char* src = Ab + ((long)a_off[i] + a_koff);
+          if (kConvOk && p.conv) {
+            const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
+            src = ok ? src : (const char*)p.zero;
+          }
           a_reg[i] = *reinterpret_cast<const uint4*>(src);
         }
       }
@@ -212,12 +243,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = Bb + ((long)b_off(i) + (long)kt * 128);
         if constexpr (GLDS) {
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)src,
-              (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0, 0);
+          buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(kt * 128));
         } else {
+          const char* src = Bb + ((long)b_off(i) + (long)kt * 128);
           b_reg[i] = *reinterpret_cast<const uint4*>(src);
         }
       }
@@ -468,29 +497,25 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_a = [&](auto I, char* stage) {
       constexpr int i = decltype(I)::value;
       if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        const char* src = Ab + ((long)a_off[i] + a_koff);
+        unsigned voff = (unsigned)a_off[i];
         if (kConvOk && p.conv) {
           const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
-          src = ok ? src : (const char*)p.zero;
+          voff = ok ? voff : kOob;
         }
 #ifndef HVR_DBG_NODMA
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + (i * NT + wave * 64) * 16), 16, 0, 0);
+        buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
 #else
-        asm volatile("" ::"v"(src), "v"(stage));
+        asm volatile("" ::"v"(voff), "v"(stage));
 #endif
       }
     };
     auto dma_b = [&](auto I, int kt, char* stage) {
       constexpr int i = decltype(I)::value;
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
-        const char* src = Bb + ((long)b_off(i) + (long)kt * 128);
 #ifndef HVR_DBG_NODMA
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + BM * 128 + (i * NT + wave * 64) * 16), 16, 0,
-                                         0);
+        buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(kt * 128));
 #else
-        asm volatile("" ::"v"(src), "v"(stage));
+        asm volatile("" ::"v"(b_offr[i]), "v"(stage));
 #endif
       }
     };

@@ -1,3 +1,9 @@
-for w in 256 384 512 768; do for k in 8 16 30; do for per in 2 4 6; do
-echo -n "wgs $w mink $k per $per: "; HVR_CONV_SPLITK_WGS=$w HVR_CONV_SPLITK_MINK=$k HVR_CONV_SPLITK_PER=$per python tools/probe/stream_pipe.py 2>&1 | grep -v amdgpu | sed -n 5,8p | awk '{printf "%s ", $(NF-3)}'; echo
-done; done; done
+A="--no-cpu-baseline --no-train-step --no-f32-leg --no-side-loops --steps 30 --warmup 5"
+pick='import sys,json
+for l in sys.stdin:
+    if l.startswith("{"):
+        d=json.loads(l); print(d["value"], d["single_lane"]["frames_per_s_per_gpu"], d["graphed_stream"]["frames_per_s_per_gpu"])'
+for i in 1 2; do
+echo -n "base: "; python tools/probe/bench_lib.py $A 2>/dev/null | python -c "$pick"
+echo -n "nt:   "; HVR_BENCH_LIB=dbg/libhvr_nt.so python tools/probe/bench_lib.py $A 2>/dev/null | python -c "$pick"
+done

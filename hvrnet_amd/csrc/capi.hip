@@ -87,7 +87,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" {
 
-int hvr_abi_version(void) { return 1; }
+int hvr_abi_version(void) { return 2; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes)
 const char* hvr_last_error(void) { return g_err.c_str(); }
 
 static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,

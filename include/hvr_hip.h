@@ -37,7 +37,7 @@ extern "C" {
 #define HVR_LAYOUT_NCHW 0 /* reference layout */
 #define HVR_LAYOUT_NHWC 1 /* native layout of this library */
 
-int hvr_abi_version(void);
+int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields */
 const char* hvr_last_error(void);
 
 /* ------------------------------------------------------------------------------------

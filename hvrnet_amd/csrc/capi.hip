@@ -304,18 +304,27 @@ static int tail_params(const hvr_tail_desc* d, GemmParams& p) {
   return 0;
 }
 
+// the tile engine's form of the fused tail (K too long for the row-panel kernel: stage 3's 256 + 512 and res5's 512 + 1024):
+// one GEMM over K = C1 + C2 whose A operand switches from h to the sampled block input at K-step C1 / 64
+static bool tail_on_tile_engine(const GemmParams& p) {
+  static const int on = std::getenv("HVR_TAIL_TILE") ? std::atoi(std::getenv("HVR_TAIL_TILE")) : 1;
+  return on && p.dtype == DT_BF16 && p.K1 % 64 == 0 && (p.K - p.K1) % 64 == 0 && p.K1 >= 64 && p.K - p.K1 >= 64 && p.N % 8 == 0 && p.ldc % 8 == 0 &&
+         (long)p.M * (p.K - p.K1) * 2 < (1L << 31);
+}
+
 int hvr_bottleneck_tail_supported(const hvr_tail_desc* d) {
   GemmParams p;
   if (tail_params(d, p)) return 0;
-  return expand_supported(p) ? 1 : 0;
+  return (expand_supported(p) || tail_on_tile_engine(p)) ? 1 : 0;
 }
 
 int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream) {
   GemmParams p;
   const int rc = tail_params(d, p);
   if (rc) return rc;
-  if (!expand_supported(p)) return fail(HVR_EUNSUPPORTED, "no fused tail kernel for C1=%d C2=%d Cout=%d", d->C1, d->C2, d->Cout);
-  return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail");
+  if (expand_supported(p)) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail");
+  if (tail_on_tile_engine(p)) return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_bottleneck_tail(tile engine)");
+  return fail(HVR_EUNSUPPORTED, "no fused tail kernel for C1=%d C2=%d Cout=%d", d->C1, d->C2, d->Cout);
 }
 
 // closing 1x1 (+ projection shortcut or identity residual) + the next block's reducing 1x1 (expand.hip, NX > 0)

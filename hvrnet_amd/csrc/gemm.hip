@@ -206,6 +206,22 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       a_off[i] = (int)(((long)m * p.lda + c * EPC) * (long)sizeof(T));
     }
   }
+  // Second K segment (p.s2 > 0, plain products only: a Bottleneck's projection shortcut folded into its closing 1x1 --
+  // K-steps from K1 on read the block INPUT, an NHWC map [.][H2][W2][K - K1] sampled at stride s2, instead of A).
+  const bool seg2 = kConvOk && GLDS && p.s2 > 0;
+  const int k1_steps = seg2 ? p.K1 / BKE : 0x7fffffff;
+  int a_off2[GLDS ? A_SLOTS : 1];
+  if (seg2) {
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+      const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+      a_off2[i] = (int)(((((long)b * p.H2 + oy * p.s2) * p.W2 + ox * p.s2) * (long)(p.K - p.K1) + c * EPC) * (long)sizeof(T));
+    }
+  }
+  const char* const rs_a2 = (const char*)p.A2;
   uint4 a_reg[A_SLOTS], b_reg[B_SLOTS];  // register staging (unused when GLDS)
 
   auto issue_loads = [&](int kt, char* stage) {
@@ -229,7 +245,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
             const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
             voff = ok ? voff : kOob;
           }
-          buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
+          if (kt >= k1_steps) buffer_load_lds16(rs_a2, stage + (i * NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt - k1_steps) * 128));
+          else buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
         } else {
           const char* src = Ab + ((long)a_off[i] + a_koff);
           if (kConvOk && p.conv) {
@@ -482,8 +499,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     uint4 fa[2][FM], fb[2][FN];  // fragment sets: [0] = kk 0, [1] = kk 1
     long a_koff = 0;
     int dy = 0, dx = 0;  // conv: filter tap of the K-step being loaded
+    int kt_load = 0;     // the K-step being loaded (second-segment products switch operand at k1_steps)
 
     auto tap_of = [&](int kt) {
+      kt_load = kt;
       if (kConvOk && p.conv) {
         const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -503,7 +522,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           voff = ok ? voff : kOob;
         }
 #ifndef HVR_DBG_NODMA
-        buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
+        if (kt_load >= k1_steps) buffer_load_lds16(rs_a2, stage + (i * NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt_load - k1_steps) * 128));
+        else buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
 #else
         asm volatile("" ::"v"(voff), "v"(stage));
 #endif

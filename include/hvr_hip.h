@@ -115,7 +115,8 @@ int hvr_conv2d_path(const hvr_conv_desc* d);
  * in ONE pass: the downsample conv (1x1, stride s) becomes a second K segment of the expand product, so its [B][OH][OW][Cout]
  * output is neither written nor re-read as a residual.  h [B][OH][OW][C1] = conv2's output, x [B][H2][W2][C2] = the block
  * input, x_s its pixels (oy * s, ox * s); w [Cout][C1 + C2] = [W3 | Wd] rows with both BatchNorm scales folded in;
- * bias [Cout] = shift3 + shiftd (f32).  bf16, C1 + C2 in {128, 384} (stages 1 and 2 of the R-101: 64 + 64, 128 + 256),
+ * bias [Cout] = shift3 + shiftd (f32).  bf16; C1 + C2 in {128, 384} (stages 1 and 2 of the R-101: 64 + 64, 128 + 256) on the
+ * row-panel kernel, any other C1, C2 in whole 64-channel K-steps (stage 3: 256 + 512 at stride 2, res5: 512 + 1024) on the tile engine,
  * Cout a multiple of 128.  hvr_bottleneck_tail_supported: 1 when this descriptor runs, 0 otherwise (the caller then issues the
  * two convs separately through hvr_conv2d_nhwc). */
 typedef struct hvr_tail_desc {

@@ -564,11 +564,14 @@ print('ok', err)
 
 
 # ------------------------------------------------------------------------------- Bottleneck tail (projection shortcut as a second K segment)
-@pytest.mark.parametrize('C1,C2,Cout,stride,B,OH,OW', [(64, 64, 256, 1, 2, 38, 63), (128, 256, 512, 2, 3, 19, 32), (64, 64, 256, 1, 1, 152, 252)])
+@pytest.mark.parametrize('C1,C2,Cout,stride,B,OH,OW', [(64, 64, 256, 1, 2, 38, 63), (128, 256, 512, 2, 3, 19, 32), (64, 64, 256, 1, 1, 152, 252),
+                                                        (256, 512, 1024, 2, 2, 19, 32), (512, 1024, 2048, 1, 1, 38, 63)])
 def test_bottleneck_tail_fuses_the_projection_shortcut(C1, C2, Cout, stride, B, OH, OW):
     """hvr_bottleneck_tail: relu(h W3^T + x_s Wd^T + bias) with x_s = the block input sampled at the downsample conv's stride
     (resnet.py:248-264, first block of a stage) against the same expression in f32 -- and against the two-conv path it
-    replaces (downsample conv -> bf16 identity -> expand conv + residual), which differs only by the identity's rounding."""
+    replaces (downsample conv -> bf16 identity -> expand conv + residual), which differs only by the identity's rounding.
+    Stages 1-2 run on the row-panel kernel (expand.hip), stage 3 (256 + 512, stride 2) and res5 (512 + 1024) on the tile engine,
+    whose A operand switches from h to the sampled block input at K-step C1 / 64."""
     g = torch.Generator().manual_seed(C1 + Cout)
     H2, W2 = (OH - 1) * stride + 1 + (stride - 1), (OW - 1) * stride + 1   # a row / column beyond the last sampled pixel too
     h = (torch.randn((B, OH, OW, C1), generator=g)).to(torch.bfloat16)
@@ -650,5 +653,5 @@ def test_bottleneck_tail_says_when_it_does_not_apply():
     x = torch.zeros((1, 8, 16, 64), device=DEV)
     w, b = torch.zeros((256, 128), device=DEV), torch.zeros(256, device=DEV)
     assert not native.bottleneck_tail_supported(h, x, w, b, 1)
-    hb, xb = h.bfloat16(), torch.zeros((1, 8, 16, 512), device=DEV, dtype=torch.bfloat16)
-    assert not native.bottleneck_tail_supported(hb, xb, torch.zeros((256, 576), device=DEV, dtype=torch.bfloat16), b, 1)  # 64 + 512: no kernel
+    hb, xb = h.bfloat16(), torch.zeros((1, 8, 16, 96), device=DEV, dtype=torch.bfloat16)
+    assert not native.bottleneck_tail_supported(hb, xb, torch.zeros((256, 160), device=DEV, dtype=torch.bfloat16), b, 1)  # 64 + 96: no whole K-step

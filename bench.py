@@ -421,7 +421,7 @@ def main(argv=None):
         gcs = []
         for st in lane_streams:
             with torch.cuda.stream(st):
-                gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1))
+                gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1, throughput=True))
         pend_l = [None] * n_lanes
 
         def replay(i):

@@ -1,0 +1,286 @@
+// Big-tile MFMA kernel for the dense convolutions / linear layers of the stride-16 stages (bf16, gfx950):
+//     C[M][N] = act(A[M][K] . B[N][K]^T + bias),   A a plain matrix or an NHWC map gathered per filter tap (implicit GEMM)
+// Replaces conv + frozen BN + ReLU of mmdet/models/backbones/resnet.py:224-246 (conv1 / conv2 of the layer-3 and res5
+// Bottlenecks), shared_heads/res_layer.py:67-74 and the RPN's 3x3 (anchor_heads/rpn_head.py:30-33) when the caller asks for
+// THROUGHPUT rather than latency (tile_hint kBigHint: bench.py's headline region keeps two windows in flight).
+//
+// Why a second shape next to gemm.hip's 144 x 256 tiles: with N = 256 .. 512 output channels every tile streams the whole
+// weight matrix, and a 144-row tile -- all that one round of 256 CUs leaves a 35 910-pixel batch -- pays 51 KB of L2 -> LDS
+// delivery per K-step of 1 152 MFMA cycles plus 0.61 LDS fragment reads per MFMA: 34 % MFMA-busy (the
+// K-loop ablations).  Here ONE workgroup per CU owns 288 x 256: 70 KB per K-step of 2 304 MFMA cycles (30 B/clk instead of
+// 44), 8 waves as 2 x 4 with 144 x 64 wave tiles (0.36 fragment reads per MFMA), and the loop is relation_bt.hip's
+// phase-staggered one (two wave groups one barrier apart: on every SIMD one wave runs a pure MFMA section while its partner
+// issues LDS reads and DMA).  The grid is HALF as large (125 workgroups for layer 3): alone on the chip the launch is slower
+// than the 144-row shape, but it holds half the CUs for ~1.3x the time -- the other window's launches run on the other half.
+//
+// Loader: buffer-addressed LDS-DMA (resource base + one fixed VGPR offset per slot + one SGPR offset per K-step or filter
+// tap; an out-of-image tap is offset 2^31 = hardware zero fill), the XOR-swizzled LDS image of gemm.hip.  The MFMA sequence per
+// output element is the tile engine's (K ascending, two 32-wide halves per 128-byte K-step), so the outputs are BIT-identical
+// to it (tests/test_kernels_gpu.py).
+#include <cstdlib>
+#include "common.h"
+#include "gemm_params.h"
+
+namespace hvr {
+
+namespace {
+
+constexpr int BG_BN = 256, BG_NT = 512, BG_WN = 4, BG_FN = 4, BG_WCOLS = BG_FN * 16;
+constexpr int BG_B_SLOTS = BG_BN * 8 / BG_NT;  // 4
+
+__device__ __forceinline__ uint32_t bg_lds_off(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF> __device__ __forceinline__ uint4 bg_read128(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void bg_mma(const uint4& w, const uint4& x, f32x4& acc) {
+  // weights as the MFMA "A" operand: a lane ends up with 4 consecutive output channels of one pixel (see gemm.hip)
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+// 16 bytes per lane, global -> LDS, buffer addressing (see gemm.hip): offsets from 2^31 up read as zeros
+__device__ __forceinline__ void bg_load_lds16(const void* base, char* lds, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+#else
+  (void)base; (void)lds; (void)voff; (void)soff;
+#endif
+}
+
+}  // namespace
+
+// FM: 16-row fragments per wave along M (the tile is 2 FM x 16 rows: 9 -> 288)
+template <int FM>
+__global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
+  constexpr int BM = 2 * FM * 16, WROWS = FM * 16;
+  constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BG_BN * 128;
+  constexpr int A_SLOTS = (BM * 8 + BG_NT - 1) / BG_NT;
+  constexpr int LAST_WAVES = (BM * 8 - (A_SLOTS - 1) * BG_NT) / 64;  // waves that carry a piece of the last A slot
+  constexpr unsigned kOob = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / BG_WN, wn = wave % BG_WN;
+  const int tiles_n = p.N / BG_BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;  // n fastest: the tiles of a row panel share its A rows
+  const int m0 = pid_m * BM, n0 = pid_n * BG_BN;
+
+  // ---- loader: a thread's pieces sit 64 rows apart (slot i -> row i * 64 + tid / 8), all in the same swizzled 16-byte chunk ----
+  const int l_row = tid >> 3, l_chunk = ((tid & 7) ^ (l_row & 7)) * 16;
+  int a_bias = 0;
+  if (p.conv) a_bias = (int)(((long)p.pad * p.W + p.pad) * p.Cin * 2);
+  const char* const rs_a = (const char*)p.A - a_bias;
+  const char* const rs_b = (const char*)p.B;
+  int a_off[A_SLOTS], a_yx[A_SLOTS], b_off[BG_B_SLOTS];
+#pragma unroll
+  for (int i = 0; i < A_SLOTS; ++i) {
+    int m = m0 + i * 64 + l_row;
+    m = m < p.M ? m : p.M - 1;
+    if (p.conv) {
+      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+      const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
+      a_yx[i] = (iy << 16) | (ix & 0xffff);
+      a_off[i] = (int)((((long)b * p.H + iy) * p.W + ix) * (long)p.Cin * 2) + l_chunk + a_bias;
+    } else {
+      a_yx[i] = 0;
+      a_off[i] = (int)((long)m * p.lda * 2) + l_chunk;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BG_B_SLOTS; ++i) b_off[i] = (int)((long)(n0 + i * 64 + l_row) * p.ldb * 2) + l_chunk;
+
+  int a_koff = 0, dy = 0, dx = 0;  // of the K-step being loaded
+  auto tap_of = [&](int kt) {
+    if (p.conv) {
+      const int k = kt * 64, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      dy = ky * p.dil;
+      dx = kx * p.dil;
+      a_koff = ((dy * p.W + dx) * p.Cin + cin0) * 2;
+    } else {
+      a_koff = kt * 128;
+    }
+  };
+  auto dma_a = [&](auto I, char* stage) {
+    constexpr int i = decltype(I)::value;
+    if (i < A_SLOTS - 1 || wave < LAST_WAVES) {
+      unsigned voff = (unsigned)a_off[i];
+      if (p.conv) {
+        const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
+        voff = ok ? voff : kOob;
+      }
+      bg_load_lds16(rs_a, stage + (i * BG_NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane(a_koff));
+    }
+  };
+  auto dma_b = [&](auto I, int kt, char* stage) {
+    constexpr int i = decltype(I)::value;
+    bg_load_lds16(rs_b, stage + A_BYTES + (i * BG_NT + wave * 64) * 16, (unsigned)b_off[i], __builtin_amdgcn_readfirstlane(kt * 128));
+  };
+
+  // first K-step into stage 0
+  tap_of(0);
+  static_for<A_SLOTS>([&](auto I) { dma_a(I, smem); });
+  static_for<BG_B_SLOTS>([&](auto I) { dma_b(I, 0, smem); });
+
+  f32x4 acc[FM][BG_FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < BG_FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
+  const uint32_t a_lane = bg_lds_off(smem) + (wm * WROWS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+  const uint32_t b_lane = bg_lds_off(smem) + A_BYTES + (wn * BG_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+
+  const int nk = p.K / 64;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- phase-staggered K loop (relation_bt.hip): a K-step is four phases -- (K half h, row fragments 0..G0-1) and (h, G0..FM-1)
+  // for h = 0, 1 -- each an L section (fragment reads + this wave's share of the next K-step's DMA) and a C section (nothing but
+  // MFMAs) with an s_barrier behind each; wave group 1 (waves 4..7, the SIMD partners of 0..3) runs one barrier behind group 0 ----
+  {
+    constexpr int G0 = (FM + 1) / 2;
+    const int dma_ph = wm ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
+    constexpr int DMA_TOTAL = A_SLOTS + BG_B_SLOTS, DMA_FIRST = DMA_TOTAL / 2;
+    if (wm) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint32_t soff = (uint32_t)(kt & 1) * STAGE;
+      char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      const int kn = kt + 1 < nk ? kt + 1 : kt;  // (the last step re-fetches itself into the idle stage: one uniform stream)
+      const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
+      uint4 kb[BG_FN], qa[G0];
+      tap_of(kn);
+      static_for<4>([&](auto PH) {
+        constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? FM - G0 : G0;
+        // ---- L ----
+        if constexpr ((ph & 1) == 0)
+          static_for<BG_FN>([&](auto J) { kb[decltype(J)::value] = bg_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+        static_for<nr>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          qa[r] = bg_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ph < 3) {
+          if (dma_ph == ph) {
+            static_for<DMA_FIRST>([&](auto D) {
+              constexpr int d = decltype(D)::value;
+              if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt);
+              else dma_b(std::integral_constant<int, d - A_SLOTS>{}, kn, nxt);
+            });
+          } else if (dma_ph + 1 == ph) {
+            static_for<DMA_TOTAL - DMA_FIRST>([&](auto D) {
+              constexpr int d = DMA_FIRST + decltype(D)::value;
+              if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt);
+              else dma_b(std::integral_constant<int, d - A_SLOTS>{}, kn, nxt);
+            });
+          }
+        }
+        if constexpr (ph == 3) {
+          if (wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        static_for<nr>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          static_for<BG_FN>([&](auto J) { bg_mma(kb[decltype(J)::value], qa[r], acc[r0 + r][decltype(J)::value]); });
+        });
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ph == 3) {
+          if (!wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      });
+    }
+    if (!wm) __builtin_amdgcn_s_barrier();
+  }
+
+  // ---------------- epilogue: bias + ReLU, bf16, whole 128-byte row segments out through per-wave LDS staging ----------------
+  // lane holds out[m0 + wm WROWS + 16 i + frag_row][n0 + wn 64 + 16 j + 4 frag_grp + r] = acc[i][j][r]
+  {
+    int etid = threadIdx.x;
+    asm volatile("" : "+v"(etid));  // lane-derived values re-derived here: nothing but the accumulators lives across the loop
+    const int el = etid & 63, erow = el & 15, egrp = el >> 4;
+    constexpr int SPITCH = BG_WCOLS * 2;  // 128-byte staged rows, bank-conflict-free by the piece swizzle of relation_bt.hip
+    char* stg = smem + wave * (16 * SPITCH);
+    const int wr_lane = erow * SPITCH + (((egrp & 1) ^ (erow >> 3)) << 3);
+    float bias[BG_FN][4];
+#pragma unroll
+    for (int j = 0; j < BG_FN; ++j) {
+      const int n = n0 + wn * BG_WCOLS + j * 16 + egrp * 4;
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        bias[j][0] = b.x; bias[j][1] = b.y; bias[j][2] = b.z; bias[j][3] = b.w;
+      } else {
+        bias[j][0] = bias[j][1] = bias[j][2] = bias[j][3] = 0.f;
+      }
+    }
+    const int st_row = el >> 3, st_chunk = el & 7;
+    __syncthreads();  // every wave is done reading the ring (group 0 leaves the loop a barrier ahead of group 1's last reads)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < BG_FN; ++j) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[r] = acc[i][j][r] + bias[j][r];
+          if (p.relu) e[r] = fmaxf(e[r], 0.f);
+        }
+        *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (egrp >> 1)) ^ (erow & 7)) << 4)) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 8 + st_row, m = m0 + wm * WROWS + i * 16 + row;
+        uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
+        if (h) v = make_uint4(v.z, v.w, v.x, v.y);
+        if (m < p.M) *reinterpret_cast<uint4*>((bf16_t*)p.C + (long)m * p.ldc + n0 + wn * BG_WCOLS + st_chunk * 8) = v;
+      }
+    }
+  }
+}
+
+// The 288 x 256 shape applies to bf16 products with a bias / ReLU epilogue only (no residual, no f32 output, no split-K), whole
+// 256-channel column tiles and whole 128-byte K-steps inside one filter tap.  `throughput`: the caller keeps the rest of the chip
+// busy with other launches (tile_hint kBigHint).
+bool bigtile_supported(const GemmParams& p, bool throughput) {
+  if (p.dtype != DT_BF16 || !p.staging || p.resid || p.out_f32 || p.ksplit_steps > 0 || p.s2 > 0) return false;
+  if (p.N % BG_BN || p.K % 64 || p.K < 512 || p.ldc % 8 || p.lda % 8 || p.ldb % 8) return false;
+  if (p.conv && p.Cin % 64) return false;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
+                       reinterpret_cast<uintptr_t>(p.bias);
+  if (al & 15) return false;
+  if ((long)p.N * p.ldb * 2 >= (1L << 31)) return false;
+  // A grid that fills most of the chip by itself (N = 512: 250 tiles for a 15-frame batch) is faster than the 144-row shapes
+  // outright (res5's 3x3 165 -> 136 us, the RPN's 312 -> 260); half a chip's worth (N = 256: 125 tiles, layer 3's 3x3 65 us
+  // against 47 on twice the CUs) only pays in CU-time, i.e. for a caller that has other launches for the free half.
+  const long tiles = (long)((p.M + 287) / 288) * (p.N / BG_BN);
+  static const int on = std::getenv("HVR_BIGTILE") ? std::atoi(std::getenv("HVR_BIGTILE")) : 1;
+  static const int min_alone = std::getenv("HVR_BIGTILE_MIN") ? std::atoi(std::getenv("HVR_BIGTILE_MIN")) : 192;
+  static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 96;
+  return on && tiles >= (throughput ? min_shared : min_alone) && tiles <= 4096;
+}
+
+hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) {
+  constexpr int FM = 9, BM = 2 * FM * 16, lds = 2 * (BM + BG_BN) * 128;
+  static bool attr_set = false;
+  auto kern = big_tile_kernel<FM>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BG_BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(BG_NT), lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace hvr

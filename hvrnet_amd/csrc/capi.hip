@@ -168,6 +168,12 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   GemmParams p;
   const int rc = gemm_params(d, p);
   if (rc) return rc;
+  int hint = d->tile_hint;
+  if (hint == kBigHint || hint == 0) {  // the 288 x 256 shape where it applies (kBigHint: a throughput caller), else as with hint 0
+    const bool thr = hint == kBigHint;
+    p.tile_hint = hint = 0;
+    if (bigtile_supported(p, thr)) return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_gemm(big tile)");
+  }
   if (d->tile_hint == kPcHint128 || d->tile_hint == kPcHint256) {
     if (!pc_supported(p, EPI_LINEAR)) return fail(HVR_EUNSUPPORTED, "the producer / consumer tile kernel takes aligned bf16 operands with N %% 8 == 0");
     return check_launch(run_pc(p, EPI_LINEAR, d->tile_hint == kPcHint256 ? 256 : 128, (hipStream_t)stream), "hvr_gemm (pc)");
@@ -175,7 +181,7 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   // Long-K products whose 144 x 128 tile grid is one round of the chip (fc_new_1: 4500 x 1024 x 12544 -> 256 tiles of 196
   // K-steps): the producer / consumer kernel, 1.00-1.03 PF/s against the tile engine's 0.90 (tools/pc_bench.py).  Shorter K
   // loops do not amortise its one-wave-per-SIMD compute stream's prologue; there the tile engine stays ahead.
-  if (d->tile_hint == 0 && d->K >= 8192 && pc_supported(p, EPI_LINEAR)) {
+  if (hint == 0 && d->K >= 8192 && pc_supported(p, EPI_LINEAR)) {
     const long tiles = (long)((d->M + 143) / 144) * ((d->N + 127) / 128);
     if (tiles > 192 && tiles <= 256) return check_launch(run_pc(p, EPI_LINEAR, 128, (hipStream_t)stream), "hvr_gemm (pc)");
   }
@@ -255,12 +261,14 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   if (pointwise) p.zero = d->zero;  // (expand.hip reads it in place of a missing shift)
   // the expand convs of a Bottleneck (1x1, K <= 256, + residual) are HBM-bound: row-panel kernel (expand.hip)
   static const int use_expand = std::getenv("HVR_EXPAND") ? std::atoi(std::getenv("HVR_EXPAND")) : 1;
+  const bool hint0 = p.tile_hint == 0 || p.tile_hint == kBigHint;  // (the big-tile hint leaves the dedicated kernels their shapes)
   path = (pointwise && expand_supported(p) &&
-          (p.tile_hint == kExpandHint || (p.tile_hint == 0 && use_expand && p.resid && p.N >= 2 * p.K))) ? 1 : 0;
+          (p.tile_hint == kExpandHint || (hint0 && use_expand && p.resid && p.N >= 2 * p.K))) ? 1 : 0;
   if (p.tile_hint == kExpandHint) p.tile_hint = 0;
   // layer 1's 3x3 (64 -> 64): persistent kernel with the weights resident in the LDS (conv3x3.hip)
   static const int use_c3 = std::getenv("HVR_CONV3") ? std::atoi(std::getenv("HVR_CONV3")) : 1;
-  if (path == 0 && p.tile_hint == 0 && use_c3 && conv3x3_c64_supported(p)) path = 2;
+  if (path == 0 && hint0 && use_c3 && conv3x3_c64_supported(p)) path = 2;
+  if (path != 0 && p.tile_hint == kBigHint) p.tile_hint = 0;
   return 0;
 }
 
@@ -279,6 +287,10 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   if (rc) return rc;
   if (path == 1) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
   if (path == 2) return check_launch(run_conv3x3_c64(p, (hipStream_t)stream), "hvr_conv2d_nhwc(conv3x3_c64)");
+  if (path == 0 && (d->tile_hint == kBigHint || d->tile_hint == 0)) {
+    p.tile_hint = 0;
+    if (bigtile_supported(p, d->tile_hint == kBigHint)) return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_conv2d_nhwc(big tile)");
+  }
   const int slices = (path == 0 ? fewrow_slices(p) : 1);
   if (slices > 1 && d->ws && aligned16(d->ws) && d->ws_bytes >= (size_t)slices * p.M * p.N * 4) {
     const hipError_t e = run_fewrow_split(p, slices, d->ws, (hipStream_t)stream);
@@ -368,7 +380,12 @@ int hvr_conv2d_path(const hvr_conv_desc* d) {
   GemmParams p;
   int path = 0;
   const int rc = conv_params(d, p, path);
-  return rc ? rc : path;
+  if (rc) return rc;
+  if (path == 0 && (d->tile_hint == 0 || d->tile_hint == kBigHint)) {
+    p.tile_hint = 0;
+    if (bigtile_supported(p, d->tile_hint == kBigHint)) return 3;
+  }
+  return path;
 }
 
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream) {

@@ -72,9 +72,12 @@ class GraphedClip(object):
     (or pass them to `run`) before replaying.  A replay must have been read (`result()`) before the next one is launched:
     the outputs are static buffers."""
 
-    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2):
+    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2, throughput=False):
         assert frames.is_cuda and frames.dim() == 4 and frames.shape[0] == len(metas)
         self.model, self.metas, self.rescale = model, list(metas), rescale
+        # throughput: the graph is one of several replayed side by side (bench.py's lanes) -- its launches prefer CU-time to
+        # latency (native.throughput_mode: the 288 x 256 tiles on half the grid for layer 3's convs); same detections
+        self.throughput = bool(throughput)
         self.frames = frames.clone()
         self._num_classes = model.bbox_head.num_classes
         self._single = type(model).__name__ == 'SelsaRCNN'
@@ -101,9 +104,11 @@ class GraphedClip(object):
         torch.cuda.current_stream(dev).wait_stream(self._stream)
 
     def _enqueue(self):
+        from . import native
         m = self.model
-        c4 = m(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
-        return m.window_device_outputs(c4, self.metas, rescale=self.rescale)
+        with native.throughput_mode(self.throughput):
+            c4 = m(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
+            return m.window_device_outputs(c4, self.metas, rescale=self.rescale)
 
     def _exact(self):
         with torch.no_grad():

@@ -500,6 +500,24 @@ def fewrow_split(on=True):
         _fewrow[0] = prev
 
 
+BIG_TILE_HINT = 16   # gemm_params.h: kBigHint
+
+
+@contextlib.contextmanager
+def throughput_mode(on=True):
+    """Launches issued inside prefer CU-time over latency: convs / linear layers whose 288 x 256 tile grid covers only half the
+    chip (layer 3: 125 workgroups) still take the big-tile kernel (bigtile.hip) -- for callers that keep several windows in
+    flight (bench.py's headline region captures its window graphs inside this).  Same results bit for bit."""
+    global TILE_HINT
+    prev = TILE_HINT
+    if on and TILE_HINT == 0:
+        TILE_HINT = BIG_TILE_HINT
+    try:
+        yield
+    finally:
+        TILE_HINT = prev
+
+
 def _workspace(nbytes, device, tag):
     # one buffer per (use, stream): windows enqueued on different HIP streams run concurrently and must not share scratch
     key = (tag, device.index if isinstance(device, torch.device) else str(device), _raw_stream(device if isinstance(device, torch.device) else None))

@@ -105,7 +105,11 @@ size_t hvr_conv2d_splitk_workspace_bytes(const hvr_conv_desc* d);
  * + residual (expand.hip: bf16, 1x1 stride 1, Cin = 64 / 128 / 256, a residual, Cout >= 2 Cin in whole 64-channel chunks,
  * >= 128 output pixels; tile_hint 13 forces it where it applies, HVR_EXPAND=0 in the environment turns the automatic
  * choice off), 2 = persistent 3x3 kernel with LDS-resident weights for bf16 64 -> 64 channels, stride 1, pad 1, no
- * residual (conv3x3.hip: layer 1's conv2; HVR_CONV3=0 turns it off; any tile_hint keeps the tile engine);
+ * residual (conv3x3.hip: layer 1's conv2; HVR_CONV3=0 turns it off; any tile_hint keeps the tile engine),
+ * 3 = big-tile kernel (bigtile.hip: 288 x 256 output tiles, one workgroup per CU; bf16, bias / ReLU epilogue, Cout a multiple
+ * of 256, K >= 512 -- taken by default when its grid covers most of the chip (>= 192 tiles: res5's and the RPN's convs on a
+ * 15-frame batch), and from 96 tiles on with tile_hint 16, the hint of a caller that keeps several windows in flight and wants
+ * CU-time rather than latency; bit-identical to the tile engine; HVR_BIGTILE=0 turns it off);
  * negative = the descriptor would be rejected. */
 int hvr_conv2d_path(const hvr_conv_desc* d);
 

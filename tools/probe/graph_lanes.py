@@ -16,7 +16,7 @@ for L in (1, 2, 3, 4):
     gcs = []
     for s in lanes:
         with torch.cuda.stream(s):
-            gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1))
+            gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1, throughput=os.environ.get("HVR_THR", "1") == "1"))
     torch.cuda.synchronize()
     pend = [None] * L
     def go(i):

@@ -225,18 +225,47 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       }
     }
     const int st_row = el >> 3, st_chunk = el & 7;
+    // Residual (the Bottleneck's identity): fragment i's 16 x 64 block arrives in the store-phase mapping (whole 128-byte row
+    // segments, one block ahead), goes through the SAME swizzled staging image the outputs leave through, and every lane picks its
+    // four channels from where it is about to write them: (acc + bias) + resid in f32, ReLU, one rounding -- the tile engine's order.
+    const bool has_res = p.resid != nullptr;
+    auto load_res = [&](int i, uint4 (&rv)[2]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int m = m0 + wm * WROWS + i * 16 + h * 8 + st_row;
+        m = m < p.M ? m : p.M - 1;
+        rv[h] = *reinterpret_cast<const uint4*>((const bf16_t*)p.resid + (long)m * p.ldr + n0 + wn * BG_WCOLS + st_chunk * 8);
+      }
+    };
+    uint4 rnext[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    if (has_res) load_res(0, rnext);
     __syncthreads();  // every wave is done reading the ring (group 0 leaves the loop a barrier ahead of group 1's last reads)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+      if (has_res) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint4 v = h ? make_uint4(rnext[h].z, rnext[h].w, rnext[h].x, rnext[h].y) : rnext[h];
+          *reinterpret_cast<uint4*>(stg + (h * 8 + st_row) * SPITCH + ((st_chunk ^ st_row) << 4)) = v;
+        }
+        if (i + 1 < FM) load_res(i + 1, rnext);
+      }
 #pragma unroll
       for (int j = 0; j < BG_FN; ++j) {
+        char* slot = stg + wr_lane + (((2 * j + (egrp >> 1)) ^ (erow & 7)) << 4);
         float e[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          e[r] = acc[i][j][r] + bias[j][r];
-          if (p.relu) e[r] = fmaxf(e[r], 0.f);
+        for (int r = 0; r < 4; ++r) e[r] = acc[i][j][r] + bias[j][r];
+        if (has_res) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(slot);
+          e[0] += __uint_as_float(rr.x << 16); e[1] += __uint_as_float(rr.x & 0xffff0000u);
+          e[2] += __uint_as_float(rr.y << 16); e[3] += __uint_as_float(rr.y & 0xffff0000u);
         }
-        *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (egrp >> 1)) ^ (erow & 7)) << 4)) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = fmaxf(e[r], 0.f);
+        }
+        *reinterpret_cast<uint2*>(slot) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -249,12 +278,19 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   }
 }
 
-// The 288 x 256 shape applies to bf16 products with a bias / ReLU epilogue only (no residual, no f32 output, no split-K), whole
+// The 288 x 256 shape applies to bf16 products with a bias / residual / ReLU epilogue (no f32 output, no split-K), whole
 // 256-channel column tiles and whole 128-byte K-steps inside one filter tap.  `throughput`: the caller keeps the rest of the chip
 // busy with other launches (tile_hint kBigHint).
 bool bigtile_supported(const GemmParams& p, bool throughput) {
-  if (p.dtype != DT_BF16 || !p.staging || p.resid || p.out_f32 || p.ksplit_steps > 0 || p.s2 > 0) return false;
-  if (p.N % BG_BN || p.K % 64 || p.K < 512 || p.ldc % 8 || p.lda % 8 || p.ldb % 8) return false;
+  if (p.dtype != DT_BF16 || !p.staging || p.out_f32 || p.ksplit_steps > 0 || p.s2 > 0) return false;
+  if (p.N % BG_BN || p.K % 64 || p.ldc % 8 || p.lda % 8 || p.ldb % 8) return false;
+  if (p.resid && (p.ldr % 8 || (reinterpret_cast<uintptr_t>(p.resid) & 15))) return false;
+  // K >= 256: below that a tile is all prologue and epilogue and the row-panel kernel (expand.hip) is ahead -- layer 2's expand
+  // 77 vs 76 us, layer 1's 139 vs 126; layer 3's (K = 256) 40 vs 43 and res5's (K = 512) 117 vs 138 go the other way
+  static const int with_res = std::getenv("HVR_BIGTILE_RES") ? std::atoi(std::getenv("HVR_BIGTILE_RES")) : 1;
+  // (with two windows in flight the panel kernel's expand convs, two small workgroups per CU, pack better beside the other
+  // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint)
+  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || throughput)))) return false;
   if (p.conv && p.Cin % 64) return false;
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                        reinterpret_cast<uintptr_t>(p.bias);
@@ -267,6 +303,7 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   static const int on = std::getenv("HVR_BIGTILE") ? std::atoi(std::getenv("HVR_BIGTILE")) : 1;
   static const int min_alone = std::getenv("HVR_BIGTILE_MIN") ? std::atoi(std::getenv("HVR_BIGTILE_MIN")) : 192;
   static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 96;
+  if (p.tile_hint == kBigForce) return true;
   return on && tiles >= (throughput ? min_shared : min_alone) && tiles <= 4096;
 }
 

@@ -169,6 +169,10 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
   const int rc = gemm_params(d, p);
   if (rc) return rc;
   int hint = d->tile_hint;
+  if (hint == kBigForce) {
+    if (!bigtile_supported(p, true)) return fail(HVR_EUNSUPPORTED, "the big-tile kernel takes bf16 products with N %% 256 == 0 and K %% 64 == 0");
+    return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_gemm(big tile)");
+  }
   if (hint == kBigHint || hint == 0) {  // the 288 x 256 shape where it applies (kBigHint: a throughput caller), else as with hint 0
     const bool thr = hint == kBigHint;
     p.tile_hint = hint = 0;
@@ -261,9 +265,19 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   if (pointwise) p.zero = d->zero;  // (expand.hip reads it in place of a missing shift)
   // the expand convs of a Bottleneck (1x1, K <= 256, + residual) are HBM-bound: row-panel kernel (expand.hip)
   static const int use_expand = std::getenv("HVR_EXPAND") ? std::atoi(std::getenv("HVR_EXPAND")) : 1;
+  if (p.tile_hint == kBigForce) {
+    path = 0;
+    return 0;
+  }
   const bool hint0 = p.tile_hint == 0 || p.tile_hint == kBigHint;  // (the big-tile hint leaves the dedicated kernels their shapes)
+  bool big_first = false;  // the 288 x 256 tiles are ahead of the row-panel kernel from K = 256 on (layer 3's and res5's expand convs)
+  if (hint0 && pointwise) {
+    GemmParams q = p;
+    q.tile_hint = 0;
+    big_first = bigtile_supported(q, p.tile_hint == kBigHint);
+  }
   path = (pointwise && expand_supported(p) &&
-          (p.tile_hint == kExpandHint || (hint0 && use_expand && p.resid && p.N >= 2 * p.K))) ? 1 : 0;
+          (p.tile_hint == kExpandHint || (hint0 && use_expand && p.resid && p.N >= 2 * p.K && !big_first))) ? 1 : 0;
   if (p.tile_hint == kExpandHint) p.tile_hint = 0;
   // layer 1's 3x3 (64 -> 64): persistent kernel with the weights resident in the LDS (conv3x3.hip)
   static const int use_c3 = std::getenv("HVR_CONV3") ? std::atoi(std::getenv("HVR_CONV3")) : 1;
@@ -287,6 +301,10 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   if (rc) return rc;
   if (path == 1) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
   if (path == 2) return check_launch(run_conv3x3_c64(p, (hipStream_t)stream), "hvr_conv2d_nhwc(conv3x3_c64)");
+  if (path == 0 && d->tile_hint == kBigForce) {
+    if (!bigtile_supported(p, true)) return fail(HVR_EUNSUPPORTED, "the big-tile kernel takes bf16 convs with Cout %% 256 == 0 and Cin %% 64 == 0");
+    return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_conv2d_nhwc(big tile)");
+  }
   if (path == 0 && (d->tile_hint == kBigHint || d->tile_hint == 0)) {
     p.tile_hint = 0;
     if (bigtile_supported(p, d->tile_hint == kBigHint)) return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_conv2d_nhwc(big tile)");

@@ -78,7 +78,7 @@ bool pc_supported(const GemmParams& p, int epi);
 // Big-tile kernel (bigtile.hip): 288 x 256 tiles, one workgroup per CU on HALF the grid of the 144-row shapes -- for callers that
 // keep several windows in flight (throughput, not latency: tile_hint kBigHint), and by default where its grid fills the chip by
 // itself (N = 512); the tile engine runs everything else as with tile_hint 0
-constexpr int kBigHint = kNumTileShapes + 4;
+constexpr int kBigHint = kNumTileShapes + 4, kBigForce = kNumTileShapes + 5;  // (kBigForce: whatever the grid / epilogue -- tuning, tests)
 bool bigtile_supported(const GemmParams& p, bool throughput);
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream);
 hipError_t run_pc(const GemmParams& p, int epi, int bn, hipStream_t stream);

@@ -175,13 +175,19 @@ def test_bottleneck_expand_convs_take_the_panel_kernel():
     layers = [(152, 252, 64), (76, 126, 128), (38, 63, 256)]
     for frames in (15, 8, 7, 1):
         for H, W, c in layers:
-            assert native.conv2d_path(frames, H, W, c, 4 * c) == 1, (frames, c)
-    assert native.conv2d_path(15, 38, 63, 512, 2048) == 1                       # res5's expand convs too (8 waves x 16 rows)
-    assert native.conv2d_path(15, 38, 63, 256, 1024, resid=False) == 0          # automatic choice wants the residual
+            # from K = 256 on, a batch whose 288 x 256 tile grid covers the chip takes the big-tile kernel (bigtile.hip, path 3)
+            want = 3 if (c == 256 and frames > 1) else 1
+            assert native.conv2d_path(frames, H, W, c, 4 * c) == want, (frames, c)
+    assert native.conv2d_path(15, 38, 63, 512, 2048) == 3                       # res5's expand convs: big tiles (117 vs 138 us)
+    assert native.conv2d_path(1, 38, 63, 512, 2048) == 1                        # one frame: the panel kernel (8 waves x 16 rows)
+    assert native.conv2d_path(15, 38, 63, 512, 2048, tile=16) == 1              # a throughput caller keeps the panel kernel here
+    assert native.conv2d_path(15, 76, 126, 128, 512, resid=False) == 0          # the panel kernel's automatic choice wants the residual
     assert native.conv2d_path(15, 38, 63, 256, 1024, resid=False, tile=13) == 1
     assert native.conv2d_path(15, 38, 63, 1024, 4096, tile=13) == 0             # K = 1024: not a shape the kernel has
-    assert native.conv2d_path(15, 38, 63, 1024, 256) == 0                       # the reducing 1x1
-    assert native.conv2d_path(15, 38, 63, 256, 256, k=3, pad=1) == 0
+    assert native.conv2d_path(15, 38, 63, 1024, 256, resid=False) == 0          # the reducing 1x1: 125 big tiles are half a chip ...
+    assert native.conv2d_path(15, 38, 63, 1024, 256, resid=False, tile=16) == 3 # ... which a throughput caller (tile hint 16) takes
+    assert native.conv2d_path(15, 38, 63, 256, 256, k=3, pad=1, resid=False) == 0
+    assert native.conv2d_path(15, 38, 63, 512, 512, k=3, pad=2, dil=2, resid=False) == 3   # res5's 3x3: 250 big tiles
     # layer 1's conv2 (3x3, 64 -> 64, no residual) has its own persistent kernel (conv3x3.hip); nothing else does
     for frames in (15, 8, 7, 1):
         assert native.conv2d_path(frames, 152, 252, 64, 64, k=3, pad=1, resid=False) == 2

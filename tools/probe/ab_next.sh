@@ -1,9 +1,10 @@
-A="--no-cpu-baseline --no-train-step --no-f32-leg --no-side-loops --no-graphs --lanes 1 --steps 30 --warmup 5"
+A="--no-cpu-baseline --no-train-step --no-f32-leg --no-side-loops --steps 40 --warmup 5"
 pick='import sys,json
 for l in sys.stdin:
     if l.startswith("{"):
-        d=json.loads(l); k=d["kernel_classes"]; print(d["value"], round(k["conv"]["ms"]+k["conv_expand"]["ms"],3))'
+        d=json.loads(l); print(d["value"], d["single_lane"]["frames_per_s_per_gpu"])'
 for i in 1 2 3; do
-echo -n "fused: "; python bench.py $A 2>/dev/null | python -c "$pick"
-echo -n "split: "; HVR_TAIL_TILE=0 python bench.py $A 2>/dev/null | python -c "$pick"
+echo -n "big expand: "; python bench.py $A 2>/dev/null | python -c "$pick"
+echo -n "panel expand: "; HVR_BIGTILE_RES=0 python bench.py $A 2>/dev/null | python -c "$pick"
 done
+echo -n "no big tiles at all: "; HVR_BIGTILE=0 python bench.py $A 2>/dev/null | python -c "$pick"

@@ -93,8 +93,26 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < BG_B_SLOTS; ++i) b_off[i] = (int)((long)(n0 + i * 64 + l_row) * p.ldb * 2) + l_chunk;
 
-  int a_koff = 0, dy = 0, dx = 0;  // of the K-step being loaded
+  // second K segment (p.s2 > 0, plain products: a Bottleneck's projection shortcut folded into its closing 1x1, see gemm.hip):
+  // K-steps from K1 / 64 on read the block input, an NHWC map [.][H2][W2][K - K1] sampled at stride s2, through a second resource
+  const bool seg2 = p.s2 > 0;
+  const int k1_steps = seg2 ? p.K1 / 64 : 0x7fffffff;
+  const char* const rs_a2 = (const char*)p.A2;
+  int a_off2[A_SLOTS];
+#pragma unroll
+  for (int i = 0; i < A_SLOTS; ++i) {
+    a_off2[i] = 0;
+    if (seg2) {
+      int m = m0 + i * 64 + l_row;
+      m = m < p.M ? m : p.M - 1;
+      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+      a_off2[i] = (int)((((long)b * p.H2 + oy * p.s2) * p.W2 + ox * p.s2) * (long)(p.K - p.K1) * 2) + l_chunk;
+    }
+  }
+
+  int a_koff = 0, dy = 0, dx = 0, kt_load = 0;  // of the K-step being loaded
   auto tap_of = [&](int kt) {
+    kt_load = kt;
     if (p.conv) {
       const int k = kt * 64, tap = k / p.Cin, cin0 = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -113,7 +131,8 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
         voff = ok ? voff : kOob;
       }
-      bg_load_lds16(rs_a, stage + (i * BG_NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane(a_koff));
+      if (kt_load >= k1_steps) bg_load_lds16(rs_a2, stage + (i * BG_NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt_load - k1_steps) * 128));
+      else bg_load_lds16(rs_a, stage + (i * BG_NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane(a_koff));
     }
   };
   auto dma_b = [&](auto I, int kt, char* stage) {
@@ -282,7 +301,9 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 // 256-channel column tiles and whole 128-byte K-steps inside one filter tap.  `throughput`: the caller keeps the rest of the chip
 // busy with other launches (tile_hint kBigHint).
 bool bigtile_supported(const GemmParams& p, bool throughput) {
-  if (p.dtype != DT_BF16 || !p.staging || p.out_f32 || p.ksplit_steps > 0 || p.s2 > 0) return false;
+  if (p.dtype != DT_BF16 || !p.staging || p.out_f32 || p.ksplit_steps > 0) return false;
+  if (p.s2 > 0 && (p.conv || p.K1 % 64 || (p.K - p.K1) % 64 || p.K1 < 64 || (reinterpret_cast<uintptr_t>(p.A2) & 15) ||
+                   (long)p.M * (p.K - p.K1) * 2 >= (1L << 31))) return false;
   if (p.N % BG_BN || p.K % 64 || p.ldc % 8 || p.lda % 8 || p.ldb % 8) return false;
   if (p.resid && (p.ldr % 8 || (reinterpret_cast<uintptr_t>(p.resid) & 15))) return false;
   // K >= 256: below that a tile is all prologue and epilogue and the row-panel kernel (expand.hip) is ahead -- layer 2's expand

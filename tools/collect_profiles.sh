@@ -4,6 +4,8 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; mkdir -p $out
 python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
+python bench.py --head selsa --steps 20 --warmup 3 --no-train-step > $out/bench_selsa.json 2>/dev/null
+python bench.py --frames 21 --steps 10 --warmup 2 --no-train-step --no-f32-leg --no-side-loops --quick > $out/bench_T21.json 2>/dev/null   # the shipped window length (frame_interval = 10)
 rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-step > $out/bench_prof.json 2>/dev/null
 python tools/rocpd_stats.py $(find /tmp/p_ks -name "*.db" | head -1) > $out/bench_kernel_stats.txt
 python tools/rocpd_phases.py $(find /tmp/p_ks -name "*.db" | head -1) 4 > $out/bench_window_phases.txt 2>&1

@@ -142,30 +142,35 @@ def test_split_k_conv_for_one_frame(Cin, Cout, k, stride, pad, dil, with_res):
     assert native.lib().hvr_conv2d_splitk_workspace_bytes(d) == 0
 
 
+def big_rows(B, H, W, k, stride, pad, dil):
+    return B * ((H + 2 * pad - dil * (k - 1) - 1) // stride + 1) * ((W + 2 * pad - dil * (k - 1) - 1) // stride + 1)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad,dil', [(15, 38, 63, 256, 256, 3, 1, 1, 1), (15, 38, 63, 1024, 256, 1, 1, 0, 1),
                                                               (15, 38, 63, 512, 512, 3, 1, 2, 2), (8, 38, 63, 1024, 512, 3, 1, 1, 1),
                                                               (13, 37, 61, 256, 256, 3, 1, 1, 1), (15, 76, 126, 512, 256, 1, 2, 0, 1),
                                                               (21, 38, 63, 2048, 512, 1, 1, 0, 1)])
 def test_big_tile_kernel_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, pad, dil):
     """bigtile.hip (288 x 256 tiles, phase-staggered loop, buffer-addressed gather with hardware zero fill for out-of-image
-    taps) against F.conv2d and, BIT for bit, against the tile engine: same MFMA sequence per output element.  tile=16 is the
-    throughput caller's hint (half-chip grids allowed); hvr_conv2d_path reports 3 for it; the default (latency) choice takes the
-    kernel only when its grid covers most of the chip."""
+    taps) against F.conv2d and, BIT for bit, against the tile engine: same MFMA sequence per output element.  tile=17 forces the
+    kernel whatever its grid (the library's own choice takes it when the 288 x 256 grid covers most of the chip: hvr_conv2d_path
+    reports 3 then)."""
     x = _rand((B, H, W, Cin), torch.bfloat16, 71).to(DEV)
     w = _rand((Cout, k, k, Cin), torch.bfloat16, 72, 0.03).to(DEV)
     bias = _rand((Cout,), torch.float32, 73).to(DEV)
-    assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, tile=16, k=k, stride=stride, pad=pad, dil=dil) == 3
-    big = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=16)
+    tiles = ((big_rows(B, H, W, k, stride, pad, dil) + 287) // 288) * (Cout // 256)
+    assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, k=k, stride=stride, pad=pad, dil=dil) == (3 if tiles >= 192 else 0)
+    big = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=17)
     eng = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=11)   # 144 x 256, 8 waves
     assert torch.equal(big, eng)
     ref = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=stride, padding=pad, dilation=dil))
     torch.testing.assert_close(big.float().permute(0, 3, 1, 2), ref, **_tol(torch.bfloat16))
-    with native.throughput_mode(True):
+    with native.throughput_mode(True):   # (the hint changes which kernels run, never the result)
         assert torch.equal(native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil), big)
     # no ReLU / no bias, and the plain-GEMM entry point
     if k == 1 and stride == 1:
         a = x.view(-1, Cin)
-        g1 = native.gemm(a, w.view(Cout, Cin), None, relu=False, tile=16)
+        g1 = native.gemm(a, w.view(Cout, Cin), None, relu=False, tile=17)
         g0 = native.gemm(a, w.view(Cout, Cin), None, relu=False, tile=11)
         assert torch.equal(g1, g0)
 

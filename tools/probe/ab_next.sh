@@ -1,10 +1,6 @@
-A="--no-cpu-baseline --no-train-step --no-f32-leg --no-side-loops --steps 40 --warmup 5"
-pick='import sys,json
-for l in sys.stdin:
-    if l.startswith("{"):
-        d=json.loads(l); print(d["value"], d["single_lane"]["frames_per_s_per_gpu"])'
+export HVR_LANES_LIST=2
 for i in 1 2 3; do
-echo -n "big expand: "; python bench.py $A 2>/dev/null | python -c "$pick"
-echo -n "panel expand: "; HVR_BIGTILE_RES=0 python bench.py $A 2>/dev/null | python -c "$pick"
+echo -n "thr hint, min 96:  "; HVR_THR=1 python tools/probe/graph_lanes.py 60 2>&1 | grep lanes
+echo -n "thr hint, min 128: "; HVR_THR=1 HVR_BIGTILE_MIN_SHARED=128 python tools/probe/graph_lanes.py 60 2>&1 | grep lanes
+echo -n "no hint:           "; HVR_THR=0 python tools/probe/graph_lanes.py 60 2>&1 | grep lanes
 done
-echo -n "no big tiles at all: "; HVR_BIGTILE=0 python bench.py $A 2>/dev/null | python -c "$pick"

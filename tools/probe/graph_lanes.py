@@ -11,7 +11,7 @@ model = hvrnet_amd.build_model(hvr_config(frame_interval=T // 2, nms_post=n), S.
 frames = torch.cat([S.synth_frame(i) for i in range(T)], 0).to(dev)
 metas = [S.synth_meta() for _ in range(T)]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-for L in (1, 2, 3, 4):
+for L in [int(x) for x in os.environ.get("HVR_LANES_LIST", "1,2,3,4").split(",")]:
     lanes = [torch.cuda.Stream(device=dev) for _ in range(L)]
     gcs = []
     for s in lanes:

@@ -1,8 +1,8 @@
 // Big-tile MFMA kernel for the dense convolutions / linear layers of the stride-16 stages (bf16, gfx950):
 //     C[M][N] = act(A[M][K] . B[N][K]^T + bias),   A a plain matrix or an NHWC map gathered per filter tap (implicit GEMM)
 // Replaces conv + frozen BN + ReLU of mmdet/models/backbones/resnet.py:224-246 (conv1 / conv2 of the layer-3 and res5
-// Bottlenecks), shared_heads/res_layer.py:67-74 and the RPN's 3x3 (anchor_heads/rpn_head.py:30-33) when the caller asks for
-// THROUGHPUT rather than latency (tile_hint kBigHint: bench.py's headline region keeps two windows in flight).
+// Bottlenecks, their expand convs from K = 256 on), shared_heads/res_layer.py:67-74 and the RPN's 3x3
+// (anchor_heads/rpn_head.py:30-33) wherever a 288 x 256 tile grid still covers the chip.
 //
 // Why a second shape next to gemm.hip's 144 x 256 tiles: with N = 256 .. 512 output channels every tile streams the whole
 // weight matrix, and a 144-row tile -- all that one round of 256 CUs leaves a 35 910-pixel batch -- pays 51 KB of L2 -> LDS
@@ -10,8 +10,9 @@
 // K-loop ablations).  Here ONE workgroup per CU owns 288 x 256: 70 KB per K-step of 2 304 MFMA cycles (30 B/clk instead of
 // 44), 8 waves as 2 x 4 with 144 x 64 wave tiles (0.36 fragment reads per MFMA), and the loop is relation_bt.hip's
 // phase-staggered one (two wave groups one barrier apart: on every SIMD one wave runs a pure MFMA section while its partner
-// issues LDS reads and DMA).  The grid is HALF as large (125 workgroups for layer 3): alone on the chip the launch is slower
-// than the 144-row shape, but it holds half the CUs for ~1.3x the time -- the other window's launches run on the other half.
+// issues LDS reads and DMA).  The grid is HALF as large as the 144-row shapes': with N = 512 (res5, the RPN) it still covers the
+// chip and the launch is simply faster (165 -> 136 us); with N = 256 (layer 3: 125 workgroups) it is slower alone and measured
+// neutral beside a second window's launches, so the library does not take it there (bigtile_supported).
 //
 // Loader: buffer-addressed LDS-DMA (resource base + one fixed VGPR offset per slot + one SGPR offset per K-step or filter
 // tap; an out-of-image tap is offset 2^31 = hardware zero fill), the XOR-swizzled LDS image of gemm.hip.  The MFMA sequence per

@@ -53,10 +53,13 @@ __device__ __forceinline__ void bg_load_lds16(const void* base, char* lds, unsig
 
 }  // namespace
 
-// FM: 16-row fragments per wave along M (the tile is 2 FM x 16 rows: 9 -> 288)
-template <int FM>
+// FM0 / FM1: 16-row fragments per wave along M of wave group 0 (waves 0..3) / group 1 (waves 4..7): the tile is (FM0 + FM1) x 16
+// rows -- 9 + 9 = 288, or 5 + 4 = 144 (the one-round shape of a 35 910-pixel batch with N = 256: every SIMD carries one 5-fragment and
+// one 4-fragment wave, so the matrix work per SIMD is balanced; 0.45 / 0.5 LDS fragment reads per MFMA against the tile engine's 0.61
+// for the same 144 x 256 tile)
+template <int FM0, int FM1>
 __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
-  constexpr int BM = 2 * FM * 16, WROWS = FM * 16;
+  constexpr int BM = (FM0 + FM1) * 16;
   constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BG_BN * 128;
   constexpr int A_SLOTS = (BM * 8 + BG_NT - 1) / BG_NT;
   constexpr int LAST_WAVES = (BM * 8 - (A_SLOTS - 1) * BG_NT) / 64;  // waves that carry a piece of the last A slot
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / BG_WN, wn = wave % BG_WN;
+  const int wrow0 = wm ? FM0 * 16 : 0;  // first tile row of this wave
   const int tiles_n = p.N / BG_BN, tiles_m = (p.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;  // n fastest: the tiles of a row panel share its A rows
@@ -146,6 +150,8 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   static_for<A_SLOTS>([&](auto I) { dma_a(I, smem); });
   static_for<BG_B_SLOTS>([&](auto I) { dma_b(I, 0, smem); });
 
+  auto body = [&](auto FMC) {
+  constexpr int FM = decltype(FMC)::value;
   f32x4 acc[FM][BG_FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     for (int j = 0; j < BG_FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
-  const uint32_t a_lane = bg_lds_off(smem) + (wm * WROWS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+  const uint32_t a_lane = bg_lds_off(smem) + (wrow0 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
   const uint32_t b_lane = bg_lds_off(smem) + A_BYTES + (wn * BG_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
 
   const int nk = p.K / 64;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   }
 
   // ---------------- epilogue: bias + ReLU, bf16, whole 128-byte row segments out through per-wave LDS staging ----------------
-  // lane holds out[m0 + wm WROWS + 16 i + frag_row][n0 + wn 64 + 16 j + 4 frag_grp + r] = acc[i][j][r]
+  // lane holds out[m0 + wrow0 + 16 i + frag_row][n0 + wn 64 + 16 j + 4 frag_grp + r] = acc[i][j][r]
   {
     int etid = threadIdx.x;
     asm volatile("" : "+v"(etid));  // lane-derived values re-derived here: nothing but the accumulators lives across the loop
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     auto load_res = [&](int i, uint4 (&rv)[2]) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        int m = m0 + wm * WROWS + i * 16 + h * 8 + st_row;
+        int m = m0 + wrow0 + i * 16 + h * 8 + st_row;
         m = m < p.M ? m : p.M - 1;
         rv[h] = *reinterpret_cast<const uint4*>((const bf16_t*)p.resid + (long)m * p.ldr + n0 + wn * BG_WCOLS + st_chunk * 8);
       }
@@ -289,12 +295,19 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int row = h * 8 + st_row, m = m0 + wm * WROWS + i * 16 + row;
+        const int row = h * 8 + st_row, m = m0 + wrow0 + i * 16 + row;
         uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
         if (h) v = make_uint4(v.z, v.w, v.x, v.y);
         if (m < p.M) *reinterpret_cast<uint4*>((bf16_t*)p.C + (long)m * p.ldc + n0 + wn * BG_WCOLS + st_chunk * 8) = v;
       }
     }
+  }
+  };  // body
+  if constexpr (FM0 == FM1) {
+    body(std::integral_constant<int, FM0>{});
+  } else {
+    if (wm == 0) body(std::integral_constant<int, FM0>{});
+    else body(std::integral_constant<int, FM1>{});
   }
 }
 
@@ -323,20 +336,21 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   // against 47 on twice the CUs) only pays in CU-time, i.e. for a caller that has other launches for the free half.
   const long tiles = (long)((p.M + 287) / 288) * (p.N / BG_BN);
   static const int on = std::getenv("HVR_BIGTILE") ? std::atoi(std::getenv("HVR_BIGTILE")) : 1;
-  static const int min_alone = std::getenv("HVR_BIGTILE_MIN") ? std::atoi(std::getenv("HVR_BIGTILE_MIN")) : 192;
+  static const int min_alone = std::getenv("HVR_BIGTILE_MIN") ? std::atoi(std::getenv("HVR_BIGTILE_MIN")) : 170;
   // (half-chip grids under the throughput hint -- layer 3's 125 tiles -- were the idea behind the hint: 65 us on 125 CUs against 47
   // on 250 is -31 % CU-time.  With two windows in flight it measures neutral (graph replay alone: 158.3 vs 158.1 frames/s) to
   // -1.7 % (bench.py: 158.6 vs 161.4): the other window's launch is as often a full-chip grid that cannot use half a chip as a
   // half-chip one that can.  The threshold is therefore the same; HVR_BIGTILE_MIN_SHARED=96 brings the half-chip launches back.)
-  static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 192;
+  static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 170;
   if (p.tile_hint == kBigForce) return true;
   return on && tiles >= (throughput ? min_shared : min_alone) && tiles <= 4096;
 }
 
-hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) {
-  constexpr int FM = 9, BM = 2 * FM * 16, lds = 2 * (BM + BG_BN) * 128;
+template <int FM0, int FM1>
+static hipError_t launch_bigtile(const GemmParams& p, hipStream_t stream) {
+  constexpr int BM = (FM0 + FM1) * 16, lds = 2 * (BM + BG_BN) * 128;
   static bool attr_set = false;
-  auto kern = big_tile_kernel<FM>;
+  auto kern = big_tile_kernel<FM0, FM1>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
@@ -345,5 +359,9 @@ hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(BG_NT), lds, stream, p);
   return hipGetLastError();
 }
+
+hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) { return launch_bigtile<9, 9>(p, stream); }
+// (the same kernel on 144 x 256 tiles, <5, 4>: bit-identical too, but 61 us against the tile engine's 50 on layer 3's 3x3 -- a
+// two-stage ring with 16-20 MFMAs per section does not cover the DMA the way the engine's three-stage ring does; not instantiated)
 
 }  // namespace hvr

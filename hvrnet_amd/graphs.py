@@ -72,9 +72,15 @@ class GraphedClip(object):
     (or pass them to `run`) before replaying.  A replay must have been read (`result()`) before the next one is launched:
     the outputs are static buffers."""
 
-    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2, throughput=False):
-        assert frames.is_cuda and frames.dim() == 4 and frames.shape[0] == len(metas)
+    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2, throughput=False, windows=1):
+        assert frames.is_cuda and frames.dim() == 4 and frames.shape[0] == len(metas) and len(metas) % windows == 0
         self.model, self.metas, self.rescale = model, list(metas), rescale
+        # windows = W > 1: `frames` holds W independent clips back to back; ONE graph takes all W * T frames through the backbone
+        # in one batch -- 30 frames give layer 3's convs 250 of the 288 x 256 tiles (bigtile.hip) where 15 give 125 -- and then
+        # runs res5 / RPN / RoIAlign / head / read-out per clip.  run() returns W pending windows.  Frames are independent through
+        # the backbone, so every clip's detections are the single-clip graph's
+        self.windows = int(windows)
+        self.T = len(metas) // self.windows
         # throughput: the graph is one of several replayed side by side (bench.py's lanes) -- its launches prefer CU-time to
         # latency (native.throughput_mode: the 288 x 256 tiles on half the grid for layer 3's convs); same detections
         self.throughput = bool(throughput)
@@ -87,37 +93,40 @@ class GraphedClip(object):
         self._graphs, self._outs, self._turn, self._generation = [], [], 0, 0
         with torch.no_grad(), torch.cuda.stream(self._stream):
             for _ in range(max(1, warmup)):   # builds every lazily created object: packed weights, workspaces, side streams
-                branches, counts, full = self._enqueue()
+                per_window = self._enqueue()
             self._stream.synchronize()
-            self._full = full
-            # n_out graphs of the same window, each with its own output buffers (replayed in turn: window i + 1 can be
+            self._full = per_window[0][2]
+            # n_out graphs of the same window(s), each with its own output buffers (replayed in turn: window i + 1 can be
             # enqueued before window i's results are read); they share one memory pool -- same stream, never concurrent
             for k in range(max(1, n_out)):
-                out = _HostOut(branches, counts)   # pinned buffers exist before the capture (no host allocation inside it)
+                outs = [_HostOut(b, c) for b, c, _ in per_window]   # pinned buffers exist before the capture (no host allocation inside it)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self._stream, **(dict(pool=self._graphs[0].pool()) if self._graphs else {})):
-                    b2, c2, _ = self._enqueue()
-                    out.dev, out.counts_dev = [tuple(b) for b in b2], c2
-                    out.enqueue_copies()
+                    for out, (b2, c2, _) in zip(outs, self._enqueue()):
+                        out.dev, out.counts_dev = [tuple(b) for b in b2], c2
+                        out.enqueue_copies()
                 self._graphs.append(graph)
-                self._outs.append(out)
+                self._outs.append(outs)
         torch.cuda.current_stream(dev).wait_stream(self._stream)
 
     def _enqueue(self):
         from . import native
         m = self.model
+        T = self.T
         with native.throughput_mode(self.throughput):
             c4 = m(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
-            return m.window_device_outputs(c4, self.metas, rescale=self.rescale)
+            return [m.window_device_outputs(c4[w * T:(w + 1) * T], self.metas[w * T:(w + 1) * T], rescale=self.rescale)
+                    for w in range(self.windows)]
 
-    def _exact(self):
+    def _exact(self, w=0):
+        T = self.T
         with torch.no_grad():
-            c4 = self.model(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
-            return self.model.forward_feat(x=c4, img_meta=self.metas, rescale=self.rescale, speculate=False)
+            c4 = self.model(img=self.frames[w * T:(w + 1) * T], img_meta=self.metas[w * T:(w + 1) * T], backbone_feat=True)[0]
+            return self.model.forward_feat(x=c4, img_meta=self.metas[w * T:(w + 1) * T], rescale=self.rescale, speculate=False)
 
     def run(self, frames=None):
-        """Replays the window on the current stream; -> PendingGraphWindow.  With n_out graphs at most n_out - 1 earlier
-        windows may still be unread."""
+        """Replays the window on the current stream; -> PendingGraphWindow (a list of them, one per clip, when windows > 1).  With
+        n_out graphs at most n_out - 1 earlier replays may still be unread."""
         if frames is not None:
             self.frames.copy_(frames, non_blocking=True)
         if frames is not None:
@@ -129,12 +138,15 @@ class GraphedClip(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.frames.device))
 
-        def exact():
-            if gen != self._generation:
-                raise RuntimeError('a frame of this window kept fewer than nms_post proposals, but its input buffer has been overwritten by a '
-                                   'later run(frames=...): read result() before handing over the next clip')
-            return self._exact()
-        return PendingGraphWindow(self, self._outs[k], ev, exact)
+        def exact(w):
+            def go():
+                if gen != self._generation:
+                    raise RuntimeError('a frame of this window kept fewer than nms_post proposals, but its input buffer has been overwritten by a '
+                                       'later run(frames=...): read result() before handing over the next clip')
+                return self._exact(w)
+            return go
+        pend = [PendingGraphWindow(self, self._outs[k][w], ev, exact(w)) for w in range(self.windows)]
+        return pend[0] if self.windows == 1 else pend
 
 
 class GraphedStream(object):

@@ -85,6 +85,27 @@ def test_two_graphed_clips_in_flight_on_two_streams_equal_the_eager_windows(kind
         _check(kind, pend[k][0].result(), want[pend[k][1]])
 
 
+def test_graphed_clip_with_two_clips_per_graph_equals_the_eager_windows():
+    """GraphedClip(windows=2): the frames of two independent clips go through the backbone as ONE batch (30 frames give layer 3's
+    convs a chip-covering grid of 288 x 256 tiles), res5 / RPN / RoIAlign / head / read-out run per clip; each clip's detections
+    equal its own eager window."""
+    T, n_prop = 5, 24
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=T // 2, nms_post=n_prop), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    metas = [S.synth_meta(HW, PAD) for _ in range(T)]
+    clips = [torch.cat([S.synth_frame(10 * c + i, img_hw=HW, pad_hw=PAD) for i in range(T)], 0).to(DEV) for c in range(4)]
+    want = []
+    with torch.no_grad():
+        for clip in clips:
+            c4 = model(img=clip, img_meta=metas, backbone_feat=True)[0]
+            want.append(model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True))
+    g = GraphedClip(model, torch.cat(clips[:2], 0), metas + metas, rescale=True, windows=2)
+    for a, b in ((0, 1), (2, 3), (3, 0)):
+        pend = g.run(torch.cat([clips[a], clips[b]], 0))
+        assert len(pend) == 2
+        _check('hvr', pend[0].result(), want[a])
+        _check('hvr', pend[1].result(), want[b])
+
+
 def test_graphed_clip_with_a_short_frame_takes_the_exact_path():
     """A harsh RPN NMS leaves some frame with fewer than nms_post proposals: the replay's speculative result is discarded and
     the window is re-run through the exact (ragged) eager path -- same answer as eager forward_feat(speculate=False)."""

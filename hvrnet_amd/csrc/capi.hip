@@ -506,7 +506,9 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     if (rc) return rc;
     p.N = Mk;  // keys beyond Mk are masked inside the score epilogue
     p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
-    p.tile_hint = tile_scores;
+    // (few query rows -- the key stage, 300 x 4 500: 108 tiles walking 16 K-steps each -- are a latency chain: the 4-stage ring
+    // of the 128 x 128 shape keeps three K-steps of DMA in flight, 54.3 -> 50.8 us for the stage)
+    p.tile_hint = tile_scores ? tile_scores : ((dtype == HVR_BF16 && staging && Mq <= 1024) ? 9 : 0);
     p.group_m = gm_scores;
 #ifdef HVR_DEBUG_KNOBS
     if (dbg_ld0 & 1) { p.lda = 0; p.ldb = 0; }

@@ -1,6 +1,1 @@
-export HVR_LANES_LIST=2
-for i in 1 2 3; do
-echo -n "thr hint, min 96:  "; HVR_THR=1 python tools/probe/graph_lanes.py 60 2>&1 | grep lanes
-echo -n "thr hint, min 128: "; HVR_THR=1 HVR_BIGTILE_MIN_SHARED=128 python tools/probe/graph_lanes.py 60 2>&1 | grep lanes
-echo -n "no hint:           "; HVR_THR=0 python tools/probe/graph_lanes.py 60 2>&1 | grep lanes
-done
+for v in 0 9 8 4; do echo -n "HVR_TILE_SCORES=$v: "; HVR_TILE_SCORES=$v python tools/rel_bench.py --mq 300 --iters 50 2>&1 | grep relation; done

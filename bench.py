@@ -685,6 +685,9 @@ def main(argv=None):
                    per_rank=[dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)],
                    rccl_world_size=(dist.get_world_size() if world > 1 else 1))
         out['single_lane'] = single_lane
+        prop = torch.cuda.get_device_properties(dev)
+        out['device'] = dict(name=prop.name, cus=prop.multi_processor_count, hbm_gb=round(prop.total_memory / 2 ** 30, 1),
+                             note='boxes of this pool differ by up to 7 % on the same build (single_lane 137-149 frames/s)')
         if f32_leg is not None:
             out['f32_parity_mode'] = f32_leg
         if ref_loop_fps is not None:

@@ -49,7 +49,7 @@ def fold_conv_bn(conv, bn, dtype):
         bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
     if bn is not None and conv.bias is not None:
         bias = bias + conv.bias.detach().float() * scale
-    return w.permute(0, 2, 3, 1).contiguous().to(dtype), bias.contiguous()
+    return native.as_operand(w.permute(0, 2, 3, 1), dtype), bias.contiguous()
 
 
 class PackedMixin(object):
@@ -92,8 +92,12 @@ class PackedMixin(object):
 
 
 def set_compute_dtype(module, dtype):
-    """bf16 (fast path) or f32 (exact-f32 MFMA path) for every packed module below `module`."""
-    assert dtype in (torch.bfloat16, torch.float32)
+    """The operand format of every packed module below `module` -- the precision ladder of include/hvr_hip.h:
+    torch.bfloat16 (benchmark dtype, every dedicated kernel), torch.float16 (half operands on the tile engine),
+    native.SPLIT (split half: three half MFMAs per product, f32-grade results) or torch.float32 (exact-f32 MFMA).
+    Modules convert their inputs on entry, so sub-trees may differ: e.g. set_compute_dtype(model.backbone, native.SPLIT)
+    after set_compute_dtype(model, torch.float16)."""
+    assert dtype in native.COMPUTE_DTYPES, dtype
     for m in module.modules():
         if isinstance(m, PackedMixin):
             m.compute_dtype = dtype
@@ -288,7 +292,7 @@ class ResNet(nn.Module, PackedMixin):
         # fused bf16 stem: [n][ky][kx*4 + c], zero weight for the pad channel (c = 3) and the pad tap (kx = 7)
         wf = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w.device)
         wf[:, :, :7, :3] = w
-        return dict(stem=(wp.to(dtype), b), fused=wf.view(64, 7, 32).to(torch.bfloat16).contiguous())
+        return dict(stem=(native.as_operand(wp, dtype), b), fused=wf.view(64, 7, 32).to(torch.bfloat16).contiguous())
 
     def out_shape_nhwc(self, B, H, W):
         """Physical [B,h,w,C] shape of the LAST returned map for a [B,3,H,W] input (stem 7x7/2 + pool 3x3/2, then one

@@ -156,7 +156,7 @@ class _RelationHead(BBoxHead):
         w = torch.cat([cls.weight.detach().float(), reg.weight.detach().float()], 0)
         b = torch.cat([cls.bias.detach().float(), reg.bias.detach().float()], 0)
         w, b = _pad_rows(w, b)
-        return w.to(dtype), b
+        return native.as_operand(w, dtype), b
 
     def _pack(self, dtype):
         p = {}
@@ -167,14 +167,14 @@ class _RelationHead(BBoxHead):
             w = fc.weight.detach().float()
             if k == 1:
                 C, (ph, pw) = self.in_channels, self.roi_feat_size
-                p['fc1_chw'] = w.to(dtype).contiguous()  # RoI features flattened (c, ph, pw): the reference order
-                p['fc1_hwc'] = w.view(-1, C, ph, pw).permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dtype).contiguous()
+                p['fc1_chw'] = native.as_operand(w, dtype)  # RoI features flattened (c, ph, pw): the reference order
+                p['fc1_hwc'] = native.as_operand(w.view(-1, C, ph, pw).permute(0, 2, 3, 1).reshape(w.shape[0], -1), dtype)
             else:
-                p['fc%d' % k] = w.to(dtype).contiguous()
+                p['fc%d' % k] = native.as_operand(w, dtype)
             p['fcb%d' % k] = fc.bias.detach().float().contiguous()
-            p['wqk%d' % k] = torch.cat([q.weight.detach().float(), kk.weight.detach().float()], 0).to(dtype).contiguous()
+            p['wqk%d' % k] = native.as_operand(torch.cat([q.weight.detach().float(), kk.weight.detach().float()], 0), dtype)
             p['bqk%d' % k] = torch.cat([q.bias.detach().float(), kk.bias.detach().float()], 0).contiguous()
-            p['wz%d' % k] = z.weight.detach().float().view(z.weight.shape[0], -1).to(dtype).contiguous()
+            p['wz%d' % k] = native.as_operand(z.weight.detach().float().view(z.weight.shape[0], -1), dtype)
             p['bz%d' % k] = z.bias.detach().float().contiguous()
         p['out1'] = self._readout_pack(self.fc_cls, self.fc_reg, dtype)
         if hasattr(self, 'fc_cls_2'):

@@ -349,7 +349,8 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
 template <int FM0, int FM1>
 static hipError_t launch_bigtile(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = (FM0 + FM1) * 16, lds = 2 * (BM + BG_BN) * 128;
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr_set = attr_set_dev[current_device()];
   auto kern = big_tile_kernel<FM0, FM1>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -17,6 +17,7 @@ namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
+hipError_t run_splitk_reduce_f16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_epi_bf16(const float*, void*, int, int, long, int, const float*, const void*, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
@@ -82,24 +83,30 @@ static int check_launch(hipError_t e, const char* what) {
   return fail(HVR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
 }
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-static inline int elem_size(int dtype) { return dtype == HVR_BF16 ? 2 : 4; }
+static inline int elem_size(int dtype) { return (dtype == HVR_BF16 || dtype == HVR_F16) ? 2 : 4; }   // (split half: 4 bytes per logical element)
+static inline int kstep_elems(int dtype) { return dtype == HVR_F32 ? 32 : 64; }
+static inline bool valid_dtype(int dtype) { return dtype >= HVR_F32 && dtype <= HVR_F16S; }
+static inline bool aligned256(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 255) == 0; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
 
-int hvr_abi_version(void) { return 2; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes)
+int hvr_abi_version(void) { return 3; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S
 const char* hvr_last_error(void) { return g_err.c_str(); }
 
 static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
                        long ldc, int dtype, int staging) {
   std::memset(&p, 0, sizeof p);
-  if (dtype != HVR_F32 && dtype != HVR_BF16) return fail(HVR_EINVAL, "dtype %d is neither HVR_F32 nor HVR_BF16", dtype);
-  const int bke = 128 / elem_size(dtype);
+  if (!valid_dtype(dtype)) return fail(HVR_EINVAL, "dtype %d is none of HVR_F32 / HVR_BF16 / HVR_F16 / HVR_F16S", dtype);
+  const int bke = kstep_elems(dtype);
   if (!A || !B || !C) return fail(HVR_EINVAL, "null operand pointer");
   if (M <= 0 || N <= 0 || K <= 0) return fail(HVR_EINVAL, "empty problem M=%d N=%d K=%d", M, N, K);
   if (K % bke) return fail(HVR_EINVAL, "K=%d is not a multiple of the %d-element K-step", K, bke);
   if (N % 4) return fail(HVR_EINVAL, "N=%d is not a multiple of 4", N);
   if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return fail(HVR_EINVAL, "operands must be 16-byte aligned");
+  // split half: rows are whole [64 hi | 64 lo] groups and a matrix starts on a group boundary
+  if (dtype == HVR_F16S && (lda % 64 || ldb % 64 || !aligned256(A) || !aligned256(B)))
+    return fail(HVR_EINVAL, "split-half operands need 256-byte aligned bases and row pitches that are multiples of 64 elements");
   // the tile loaders keep 32-bit byte offsets into A and B
   const long es = elem_size(dtype);
   if ((long)M * lda * es >= (1L << 31) || (long)N * ldb * es >= (1L << 31))
@@ -152,6 +159,10 @@ static int gemm_params(const hvr_gemm_desc* d, GemmParams& p) {
   const int es = elem_size(d->dtype);
   if ((d->lda * es) % 16 || (d->ldb * es) % 16) return fail(HVR_EINVAL, "lda/ldb rows must be 16-byte multiples");
   if ((d->ldc * (d->out_f32 ? 4 : es)) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
+  if (d->dtype == HVR_F16S) {
+    if (!d->out_f32 && (d->N % 8 || d->ldc % 64 || !aligned256(d->C))) return fail(HVR_EINVAL, "split-half output: N %% 8 == 0, ldc %% 64 == 0, 256-byte aligned C");
+    if (d->resid && (d->N % 8 || d->ldr % 64 || !aligned256(d->resid))) return fail(HVR_EINVAL, "split-half residual: N %% 8 == 0, ldr %% 64 == 0, 256-byte aligned");
+  }
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
   return 0;
@@ -198,7 +209,8 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
 // slices for a GEMM whose output has too few tiles to fill the chip and whose K loop is long (weight gradients)
 static int splitk_slices(int M, int N, int K, int dtype) {
   const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const int ksteps = K / (128 / elem_size(dtype));
+  if (dtype == HVR_F16S) return 1;   // (the three-pass K loop is not sliced)
+  const int ksteps = K / kstep_elems(dtype);
   if (tiles >= 192 || ksteps < 32) return 1;
   long s = (512 + tiles - 1) / tiles;
   if (s > ksteps / 8) s = ksteps / 8;
@@ -207,7 +219,7 @@ static int splitk_slices(int M, int N, int K, int dtype) {
 }
 
 size_t hvr_gemm_splitk_workspace_bytes(int M, int N, int K, int dtype) {
-  if (M <= 0 || N <= 0 || K <= 0 || (dtype != HVR_F32 && dtype != HVR_BF16)) return 0;
+  if (M <= 0 || N <= 0 || K <= 0 || !valid_dtype(dtype)) return 0;
   const int s = splitk_slices(M, N, K, dtype);
   return s > 1 ? (size_t)s * M * N * 4 : 0;
 }
@@ -228,7 +240,7 @@ int hvr_gemm_splitk(const hvr_gemm_desc* d, void* ws, size_t ws_bytes, void* str
   if (slices <= 1) return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm_splitk");
   const size_t need = (size_t)slices * d->M * d->N * 4;
   if (!ws || ws_bytes < need || !aligned16(ws)) return fail(HVR_EINVAL, "split-K workspace too small (%zu < %zu) or unaligned", ws_bytes, need);
-  const int ksteps = d->K / (128 / es);
+  const int ksteps = d->K / kstep_elems(d->dtype);
   p.ksplit_steps = (ksteps + slices - 1) / slices;
   p.ksplit_count = (ksteps + p.ksplit_steps - 1) / p.ksplit_steps;
   p.csplit_bytes = (long)d->M * d->N * 4;
@@ -245,8 +257,11 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   const int OH = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
   const int OW = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
   if (OH <= 0 || OW <= 0) return fail(HVR_EINVAL, "empty conv output %dx%d", OH, OW);
-  const int bke = 128 / elem_size(d->dtype);
+  if (!valid_dtype(d->dtype)) return fail(HVR_EINVAL, "bad dtype %d", d->dtype);
+  const int bke = kstep_elems(d->dtype);
   if (d->Cin % bke) return fail(HVR_EINVAL, "Cin=%d is not a multiple of %d", d->Cin, bke);
+  if (d->dtype == HVR_F16S && !d->out_f32 && (d->Cout % 64 || !aligned256(d->y))) return fail(HVR_EINVAL, "split-half conv output: Cout %% 64 == 0, 256-byte aligned y");
+  if (d->dtype == HVR_F16S && d->resid && (d->Cout % 64 || !aligned256(d->resid))) return fail(HVR_EINVAL, "split-half conv residual: Cout %% 64 == 0, 256-byte aligned");
   const long M = (long)d->B * OH * OW;
   if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
   if ((long)d->B * d->H * d->W * d->Cin * (long)elem_size(d->dtype) >= (1L << 31))
@@ -414,7 +429,8 @@ int hvr_conv2d_path(const hvr_conv_desc* d) {
 
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream) {
   if (!img || !cols || B <= 0) return fail(HVR_EINVAL, "bad stem arguments");
-  if (KP < 147 || KP % (128 / elem_size(dtype))) return fail(HVR_EINVAL, "KP=%d must be >= 147 and a K-step multiple", KP);
+  if (dtype == HVR_F16S) return fail(HVR_EUNSUPPORTED, "the stem's patch matrix is gathered in f32 / bf16 / half (hvr_cast makes the split-half form)");
+  if (KP < 147 || KP % kstep_elems(dtype)) return fail(HVR_EINVAL, "KP=%d must be >= 147 and a K-step multiple", KP);
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
   return check_launch(run_im2col_stem(img, cols, B, H, W, OH, OW, KP, dtype, (hipStream_t)stream), "hvr_im2col_stem");
 }
@@ -427,6 +443,7 @@ int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* o
 
 int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
   if (!x || !y || C % 4) return fail(HVR_EINVAL, "bad maxpool arguments (C %% 4 == 0 required)");
+  if (dtype == HVR_F16S) return fail(HVR_EUNSUPPORTED, "max pooling runs on f32 / bf16 / half maps");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   return check_launch(run_maxpool3x3s2(x, y, B, H, W, C, OH, OW, dtype, (hipStream_t)stream), "hvr_maxpool3x3s2_nhwc");
 }
@@ -480,6 +497,24 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 
   GemmParams p;
   int rc;
+  if (dtype == HVR_F16S) {
+    // split half: probabilities (scores pass + one normalising sweep, both in the split format), V^T, then O = P V as a plain
+    // three-pass product -- no block weights inside a K loop whose accumulators change scale between passes
+    rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
+    if (rc) return rc;
+    if (ldv % 64 || !aligned256(V) || ldo % 64 || !aligned256(O) || D % 64) return fail(HVR_EINVAL, "split-half relation: D, ldv, ldo multiples of 64, 256-byte aligned V / O");
+    p.N = Mk; p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
+    rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores (split half)");
+    if (rc) return rc;
+    rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, s), "relation: normalise (split half)");
+    if (rc) return rc;
+    rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose (split half)");
+    if (rc) return rc;
+    rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
+    if (rc) return rc;
+    return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half)");
+  }
+  const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
   // tuning overrides, read once
   static const int tile_scores = env_tile("HVR_TILE_SCORES"), tile_apply = env_tile("HVR_TILE_APPLY");
   static const int gm_scores = std::getenv("HVR_GM_SCORES") ? std::atoi(std::getenv("HVR_GM_SCORES")) : 8;
@@ -508,7 +543,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
     // (few query rows -- the key stage, 300 x 4 500: 108 tiles walking 16 K-steps each -- are a latency chain: the 4-stage ring
     // of the 128 x 128 shape keeps three K-steps of DMA in flight, 54.3 -> 50.8 us for the stage)
-    p.tile_hint = tile_scores ? tile_scores : ((dtype == HVR_BF16 && staging && Mq <= 1024) ? 9 : 0);
+    p.tile_hint = tile_scores ? tile_scores : ((two_byte && staging && Mq <= 1024) ? 9 : 0);
     p.group_m = gm_scores;
 #ifdef HVR_DEBUG_KNOBS
     if (dbg_ld0 & 1) { p.lda = 0; p.ldb = 0; }
@@ -526,17 +561,18 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 #endif
   static const int no_split = env_tile("HVR_NO_APPLY_SPLIT");
   const int slices = no_split ? 1 : apply_slices(Mq, Mk, D);
-  if (slices > 1 && tile_apply == 0 && (dtype != HVR_BF16 || (ldo % 8 == 0 && aligned16(O)))) {
-    const int steps_per_blk = dtype == HVR_BF16 ? 2 : 4;
+  if (slices > 1 && tile_apply == 0 && (!two_byte || (ldo % 8 == 0 && aligned16(O)))) {
+    const int steps_per_blk = two_byte ? 2 : 4;
     const int per = 4;  // apply_slices: four 128-key blocks per slice
     p.ksplit_steps = per * steps_per_blk;
     p.ksplit_count = slices;
     p.csplit_bytes = (long)Mq * D * 4;
-    p.C = partial; p.ldc = D; p.out_f32 = dtype == HVR_BF16 ? 1 : 0;
+    p.C = partial; p.ldc = D; p.out_f32 = two_byte ? 1 : 0;
     p.tile_hint = 1;  // 128 x 128 tiles; the slices are latency chains of 8 K-steps (the pipelined shapes measure the same)
     hipError_t e = run_tile_op(p, EPI_APPLY, s);
     if (e == hipSuccess)
-      e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
+      e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s)
+          : dtype == HVR_F16 ? run_splitk_reduce_f16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
     return check_launch(e, "relation: apply (key slices)");
   }
   // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table): correct
@@ -619,7 +655,7 @@ int hvr_colsum(const void* dY, float* db, int M, int N, int64_t ld, int dtype, v
 
 int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout, int Cin, int KH, int KW, int out_dtype, void* stream) {
   if (!w || !scale || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return fail(HVR_EINVAL, "bad pack_conv_weight arguments");
-  if (out_dtype != HVR_F32 && out_dtype != HVR_BF16) return fail(HVR_EINVAL, "bad dtype");
+  if (out_dtype != HVR_F32 && out_dtype != HVR_BF16 && out_dtype != HVR_F16) return fail(HVR_EINVAL, "bad dtype");
   return check_launch(run_pack_conv_weight(w, scale, out, Cout, Cin, KH * KW, out_dtype, (hipStream_t)stream), "hvr_pack_conv_weight");
 }
 
@@ -879,6 +915,13 @@ int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls,
 int hvr_cast(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, void* stream) {
   if (n == 0) return HVR_OK;
   if (!in || !out) return fail(HVR_EINVAL, "null pointer");
+  if (!valid_dtype(from_dtype) || !valid_dtype(to_dtype) || from_dtype == to_dtype) return fail(HVR_EINVAL, "bad cast %d -> %d", from_dtype, to_dtype);
+  const bool classic = (from_dtype == HVR_F32 && to_dtype == HVR_BF16) || (from_dtype == HVR_BF16 && to_dtype == HVR_F32);
+  if (!classic) {   // 8 elements per thread; split half moves whole 64-element groups
+    const bool split = from_dtype == HVR_F16S || to_dtype == HVR_F16S;
+    if (n % (split ? 64 : 8) || !aligned16(in) || !aligned16(out) || (from_dtype == HVR_F16S && !aligned256(in)) || (to_dtype == HVR_F16S && !aligned256(out)))
+      return fail(HVR_EINVAL, "hvr_cast to / from half formats: n %% 8 == 0 (split half: n %% 64 == 0, 256-byte aligned), 16-byte aligned buffers");
+  }
   return check_launch(run_cast(in, out, n, from_dtype, to_dtype, (hipStream_t)stream), "hvr_cast");
 }
 

@@ -37,7 +37,7 @@ def main(*paths):
             if scratch > allow or (spill and not allow):
                 bad.append('%s: %d VGPRs spilled, %d bytes of scratch' % (name, spill, scratch))
             continue
-        m = re.match(r'_ZN3hvr11tile_kernelI[tf]Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)E', name)
+        m = re.match(r'_ZN3hvr11tile_kernelI(?:t|f|NS_5f16_tE|NS_6f16s_tE)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)E', name)
         if not m:
             continue
         wm, wn, fm, fn, epi, glds, respre, ns = [int(x) for x in m.groups()]

@@ -11,7 +11,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bf16_t;  // raw bf16 bits in memory
 
 // dtype codes of the C ABI (include/hvr_hip.h)
-enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2, DT_F16S = 3 };
+
+// IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 rate with a 10-bit mantissa): raw bits, a type of its own so that the
+// kernels can be instantiated on it next to bf16_t
+enum class f16_t : unsigned short {};
+// "Split half" operands (DT_F16S): a logical element x is the pair  hi = half(x),  lo = half((x - hi) * 2^11)  -- 22 significant
+// bits, x ~ hi + lo * 2^-11 -- and a product is three half MFMAs, hi*lo + lo*hi (scaled by 2^-11) + hi*hi, accumulated in f32:
+// f32-grade results at a third of the half rate instead of the exact-f32 MFMA's sixteenth.  Memory layout of a row of C elements
+// (C a multiple of 64): C / 64 groups of [64 hi halves (128 bytes)][64 lo halves (128 bytes)], i.e. 4 bytes per logical element
+// and every 64-element K-step of a plane one contiguous 128-byte line.  f16s_t is the 4-byte container element.
+struct f16s_t { uint32_t v; };
+constexpr float kSplitScale = 2048.f, kSplitInv = 1.f / 2048.f;
+constexpr float kHalfMax = 65504.f;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
@@ -24,7 +36,60 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
+typedef _Float16 hw_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {  // round-to-nearest-even, as torch's float->half cast
+  const hw_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_f16x2));
+}
+__device__ __forceinline__ void unpack2h(uint32_t u, float& lo, float& hi) {
+  const hw_f16x2 h = __builtin_bit_cast(hw_f16x2, u);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+__device__ __forceinline__ f16_t f2h(float f) { return (f16_t)(pack2h(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float h2f(f16_t v) {
+  float lo, hi;
+  unpack2h((uint32_t)(unsigned short)v, lo, hi);
+  return lo;
+}
+// two f32 values -> their split-half pair words (values beyond the half range saturate instead of turning into inf - inf)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  a = fminf(fmaxf(a, -kHalfMax), kHalfMax);
+  b = fminf(fmaxf(b, -kHalfMax), kHalfMax);
+  hi = pack2h(a, b);
+  float ha, hb;
+  unpack2h(hi, ha, hb);
+  lo = pack2h((a - ha) * kSplitScale, (b - hb) * kSplitScale);
+}
+__device__ __forceinline__ void merge2(uint32_t hi, uint32_t lo, float& a, float& b) {
+  float ha, hb, la, lb;
+  unpack2h(hi, ha, hb);
+  unpack2h(lo, la, lb);
+  a = fmaf(la, kSplitInv, ha);
+  b = fmaf(lb, kSplitInv, hb);
+}
+// byte offset of logical column n inside a split-half row (hi plane; the lo plane is 128 bytes further)
+__device__ __host__ __forceinline__ long split_col_bytes(long n) { return (n >> 6) * 256 + (n & 63) * 2; }
+
+// 2-byte operand types: pack / unpack of a pair
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack2bf(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack2h(lo, hi); }
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t u, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t u, float& lo, float& hi) {
+  lo = __uint_as_float(u << 16);
+  hi = __uint_as_float(u & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t u, float& lo, float& hi) { unpack2h(u, lo, hi); }
+
 template <typename T> struct ElemTraits;
+template <> struct ElemTraits<f16_t> {
+  static constexpr int kCode = DT_F16;
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float load(const f16_t* p) { return h2f(*p); }
+  __device__ static __forceinline__ void store(f16_t* p, float v) { *p = f2h(v); }
+};
 template <> struct ElemTraits<float> {
   static constexpr int kCode = DT_F32;
   static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
@@ -44,6 +109,14 @@ __device__ __forceinline__ void store4(float* p, const float v[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+__device__ __forceinline__ void store4(f16_t* p, const float v[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+}
+__device__ __forceinline__ void load4(const f16_t* p, float v[4]) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  unpack2h(t.x, v[0], v[1]);
+  unpack2h(t.y, v[2], v[3]);
 }
 __device__ __forceinline__ void load4(const float* p, float v[4]) {
   float4 t = *reinterpret_cast<const float4*>(p);
@@ -83,6 +156,14 @@ __device__ __forceinline__ float quad_group_sum(float x) {
   const unsigned v = __float_as_uint(m);
   const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// one-time per-device kernel attribute setup (hipFuncSetAttribute is per device: a process driving several GPUs needs it on each)
+constexpr int kMaxDevices = 16;
+inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d >= 0 && d < kMaxDevices ? d : 0;
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})

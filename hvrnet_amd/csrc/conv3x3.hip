@@ -202,7 +202,8 @@ hipError_t run_conv3x3_c64(const GemmParams& g, hipStream_t stream) {
   p.H = g.H; p.W = g.W; p.B = g.M / (g.H * g.W); p.relu = g.relu;
   p.tiles_x = (g.W + C3_T - 1) / C3_T; p.tiles_y = (g.H + C3_T - 1) / C3_T;
   p.ntiles = p.B * p.tiles_x * p.tiles_y;
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
     attr_set = true;

@@ -366,7 +366,8 @@ static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
   constexpr int RF = KF > 8 ? 1 : 2;
   constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4 + 2 * NX * 16 * 128;  // two W chunks + shifts (+ two Wn chunks)
   static_assert(lds <= (RF == 2 ? 80 : 160) * 1024, "two workgroups per CU (one with 8 waves at K = 512)");
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr_set = attr_set_dev[current_device()];
   auto kern = expand_res_kernel<KF, RES, NC, RF, NX>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -1,0 +1,1028 @@
+// The MFMA tile engine's kernel template and its dispatch (see gemm.hip for the overview).  Included by the translation units
+// that instantiate it: gemm.hip (bf16, f32) and gemm_f16.hip (half, split half) -- two files so that they compile side by side.
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "gemm_params.h"
+
+namespace hvr {
+
+constexpr bool kAsmLdsReads = true;  // see tile_kernel::do_step
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ uint4 lds_read128(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ uint4 lds_read128_off(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// A global load the compiler does not track: the caller guarantees (by counting vmcnt) that it has landed before the
+// value is consumed, and marks that point with `landed()`.
+__device__ __forceinline__ float load_f32_untracked(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void landed(float& v) { asm volatile("" : "+v"(v)); }
+// 16-byte flavour.  The destination must stay where it is until `landed()`: a kernel that uses untracked loads must
+// not spill (a spill would store the register before the load has written it) -- hvrnet_amd/csrc/check_regs.py
+// verifies that on every build from the compiler's resource remarks.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 load_u128_untracked(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void landed(u32x4& v) { asm volatile("" : "+v"(v)); }
+// 16 bytes per lane, global -> LDS, through buffer addressing: base (uniform) + voff (per lane) + soff (uniform); offsets from
+// 2^31 up are outside the resource and come back as zeros.  (The resource type exists in the device pass only: the host
+// pass, which just needs the kernel's stub, sees an empty body.)
+__device__ __forceinline__ void buffer_load_lds16(const void* base, char* lds, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, soff, 0, 0);
+#else
+  (void)base; (void)lds; (void)voff; (void)soff;
+#endif
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// loads one K-step costs the wave that issues the fewest (the last one: slots are dealt to waves in order)
+constexpr int min_wave_loads(int rows, int nt) {
+  int n = 0;
+  for (int i = 0; i * nt < rows * 8; ++i) n += (i * nt + (nt - 64) < rows * 8) ? 1 : 0;
+  return n;
+}
+
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16_t> {
+  // one 16-byte chunk per lane = 8 consecutive k
+  template <bool ZERO>
+  static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
+    // ZERO: start a fresh accumulation (C operand is the inline constant 0, no register clear)
+    const f32x4 c = ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+  }
+  static constexpr int kChunkSteps = 2;  // chunk reads per 128-byte K-step (2 x 4 lane groups)
+};
+
+template <> struct Mma<f16_t> {
+  template <bool ZERO>
+  static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
+    const f32x4 c = ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  }
+  static constexpr int kChunkSteps = 2;
+};
+// split-half operands: every LDS image holds ONE plane of each operand (which one is the loader's business), so a K-step is a
+// plain half K-step
+template <> struct Mma<f16s_t> : Mma<f16_t> {};
+
+template <> struct Mma<float> {
+  // one 16-byte chunk per lane = 4 consecutive k; the 4 lane groups cover 16 k per
+  // read, element i of every lane forms MFMA i (any k permutation is fine as long as
+  // both operands use the same one).
+  template <bool ZERO>
+  static __device__ __forceinline__ void run(const uint4& w, const uint4& x, f32x4& acc) {
+    const f32x4 c = ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), c, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+  }
+  static constexpr int kChunkSteps = 2;
+};
+
+// RESPRE: the residual tile is fetched into registers in one burst at the top of the epilogue (in the store-phase
+// mapping) instead of one dependent load per store-phase iteration.
+//
+// NS: LDS stages.  NS = 2 is the classic double buffer (the next K-step's loads are issued at the top of a step and
+// drained at its bottom).  NS = 3 / 4 keep NS - 1 K-steps of LDS-DMA in flight: the waits are counted by hand
+// (`s_waitcnt vmcnt(n)` with n = the loads of the steps that may stay outstanding), which needs the inline-asm
+// fragment reads -- the compiler would otherwise drain every DMA in front of the first LDS read it can see.
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false, int NS = 2>
+__global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
+  constexpr int BM = WM * FM * 16, BN = WN * FN * 16, NT = WM * WN * 64;
+  // SPLIT (f16s_t, common.h): 4 bytes per logical element in memory, [64 hi | 64 lo] half groups; the K loop walks the
+  // operands three times -- A_hi x B_lo, A_lo x B_hi, then (accumulators scaled by 2^-11) A_hi x B_hi -- each pass a plain
+  // half K loop whose loader picks the plane: LDS image, fragment reads and MFMAs are those of the f16 kernel.
+  constexpr bool SPLIT = std::is_same<T, f16s_t>::value;
+  constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr int EB = (int)sizeof(T);             // bytes per logical element in global memory
+  constexpr int BKE = F32 ? 32 : 64;             // elements per K-step (128 bytes of one plane)
+  constexpr int KSG = SPLIT ? 256 : 128;         // global bytes per K-step of a row
+  constexpr int A_SLOTS = (BM * 8 + NT - 1) / NT, B_SLOTS = (BN * 8 + NT - 1) / NT;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr bool ASM_READS = GLDS && kAsmLdsReads && (NS > 2 || !(WM == 3 && FN == 4) || EPI == EPI_APPLY);
+  static_assert(NS == 2 || (ASM_READS && NS <= 4), "deep pipelines need the hand-counted waits");
+  constexpr int MINL = min_wave_loads(BM, NT) + min_wave_loads(BN, NT);
+  constexpr bool kConvOk = EPI == EPI_LINEAR;  // the relation passes never gather: drop the conv state there
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int pid_m = tile / tiles_n, pid_n = tile % tiles_n;  // n fastest: the A panel is reused across the N tiles
+  if (p.group_m > 1) {
+    // grouped order for problems whose B operand is as large as A (relation scores / apply): `group_m` row tiles
+    // share each B panel while their A panels stay L2-resident, instead of streaming all of B once per row tile
+    const int per_group = p.group_m * tiles_n, gid = tile / per_group, first = gid * p.group_m;
+    const int gsz = tiles_m - first < p.group_m ? tiles_m - first : p.group_m;
+    const int in_group = tile - gid * per_group;
+    pid_m = first + in_group % gsz;
+    pid_n = in_group / gsz;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+  // split-K (EPI_LINEAR plain GEMMs; EPI_APPLY with few query rows, whose block weights g are global per row so that the
+  // slices' partials simply add): gridDim.y slices of `ksplit_steps` K-steps each write their own f32 partial
+  // [M][N] at C + blockIdx.y * csplit_bytes; a weight-gradient GEMM has a few output tiles and a K of 10^4..10^5, which
+  // one workgroup per tile would walk alone while most of the chip idles.  The slice is folded into the base pointers.
+  const char* Ab = (const char*)p.A;
+  const char* Bb = (const char*)p.B;
+  char* Cb = (char*)p.C;
+  int nk_slice = p.K / BKE;
+  int blk0 = 0;  // EPI_APPLY: first 128-key block of this workgroup's K slice (slices are whole blocks)
+  int kt_base = 0;  // conv + split-K: first K-step of this workgroup's slice (the tap / channel offset is derived from it)
+  if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
+    if (p.ksplit_steps > 0) {
+      const int kt0 = blockIdx.y * p.ksplit_steps;
+      if (kConvOk && p.conv) kt_base = kt0;  // an implicit-GEMM slice starts at filter tap (kt0 * BKE) / Cin: the gather takes the offset
+      else Ab += (long)kt0 * KSG;
+      Bb += (long)kt0 * KSG;
+      Cb += (long)blockIdx.y * p.csplit_bytes;
+      nk_slice = nk_slice - kt0 < p.ksplit_steps ? nk_slice - kt0 : p.ksplit_steps;
+      blk0 = kt0 / (128 / BKE);
+    }
+  }
+
+  // ---------------- loader setup: one 16-byte chunk per (thread, slot) ----------------
+  // 32-bit byte offsets from p.A / p.B (the C ABI rejects operands of 2 GiB and more) and the conv origin of the
+  // row packed as (iy << 16) | (ix & 0xffff): half the registers of pointers + two ints, which the pipelined
+  // shapes need for their fragments
+  int a_off[A_SLOTS], a_yx[A_SLOTS];
+  // (B rows are weights / keys: register-staged loads recompute their offsets at issue time, two VALU ops per piece)
+  auto b_off = [&](int i) {
+    const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
+    return (int)((long)n * p.ldb * EB + c * 16);
+  };
+  // Direct-to-LDS loads go through BUFFER addressing (`buffer_load_dwordx4 ... offen lds`): address = resource base (SGPRs) +
+  // the slot's byte offset (one VGPR, fixed for the whole kernel) + the K-step's offset (one SGPR: K-step x 128 bytes, or the
+  // filter tap's pixel offset for a conv -- it is the same for every row).  A piece then costs no vector address arithmetic at
+  // all (a flat `global_load_lds` needs the 64-bit sum per lane per piece: 2.4 VALU + 2 SALU per MFMA in the round-2 counters,
+  // r02_window_pmc_sq.txt), and a conv's out-of-image tap is one select -- offset 2^31, past the resource's range, which the
+  // hardware answers with zeros -- instead of a compare pair, a 64-bit select and a load from a zero page.  The conv origin can
+  // lie `pad` rows / pixels in front of the tensor: the resource base is moved back by that much and every offset forward.
+  constexpr unsigned kOob = 0x80000000u;
+  int a_bias = 0;
+  if (kConvOk && p.conv) a_bias = (int)(((long)p.pad * p.W + p.pad) * p.Cin * (long)EB);
+  const char* const rs_a = Ab - a_bias;
+  const char* const rs_b = Bb;
+  int b_offr[GLDS ? B_SLOTS : 1];
+  if constexpr (GLDS) {
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) b_offr[i] = b_off(i);
+  }
+#pragma unroll
+  for (int i = 0; i < A_SLOTS; ++i) {
+    const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    if (kConvOk && p.conv) {
+      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+      const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
+      a_yx[i] = (iy << 16) | (ix & 0xffff);
+      a_off[i] = (int)((((long)b * p.H + iy) * p.W + ix) * (long)p.Cin * EB + c * 16) + (GLDS ? a_bias : 0);
+    } else {
+      a_yx[i] = 0;
+      a_off[i] = (int)((long)m * p.lda * EB + c * 16);
+    }
+  }
+  // Second K segment (p.s2 > 0, plain products only: a Bottleneck's projection shortcut folded into its closing 1x1 --
+  // K-steps from K1 on read the block INPUT, an NHWC map [.][H2][W2][K - K1] sampled at stride s2, instead of A).
+  const bool seg2 = kConvOk && GLDS && p.s2 > 0;
+  const int k1_steps = seg2 ? p.K1 / BKE : 0x7fffffff;
+  int a_off2[GLDS ? A_SLOTS : 1];
+  if (seg2) {
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+      const int s = i * NT + tid, row = s >> 3, c = (s & 7) ^ (row & 7);
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
+      a_off2[i] = (int)((((long)b * p.H2 + oy * p.s2) * p.W2 + ox * p.s2) * (long)(p.K - p.K1) * EB + c * 16);
+    }
+  }
+  const char* const rs_a2 = (const char*)p.A2;
+  uint4 a_reg[A_SLOTS], b_reg[B_SLOTS];  // register staging (unused when GLDS)
+
+  // SPLIT: K-step kv of the 3 * nk_slice-step loop -> the operand K-step it reads and the plane offsets of A and B
+  // (pass 0: A_hi x B_lo, pass 1: A_lo x B_hi, pass 2: A_hi x B_hi); everything else: the identity
+  const int nk_real = nk_slice;
+  auto kmap = [&](int kv, int& a_plane, int& b_plane) {
+    a_plane = 0;
+    b_plane = 0;
+    if constexpr (SPLIT) {
+      const int pass = kv >= 2 * nk_real ? 2 : (kv >= nk_real ? 1 : 0);
+      a_plane = pass == 1 ? 128 : 0;
+      b_plane = pass == 0 ? 128 : 0;
+      return kv - pass * nk_real;
+    }
+    return kv;
+  };
+
+  auto issue_loads = [&](int kv, char* stage) {
+    long a_koff;
+    int dy = 0, dx = 0, a_plane, b_plane;
+    const int kt = kmap(kv, a_plane, b_plane);
+    if (kConvOk && p.conv) {
+      const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      dy = ky * p.dil;
+      dx = kx * p.dil;
+      a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB + a_plane;
+    } else {
+      a_koff = (long)kt * KSG + a_plane;
+    }
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+      if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
+        if constexpr (GLDS) {
+          unsigned voff = (unsigned)a_off[i];
+          if (kConvOk && p.conv) {
+            const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
+            voff = ok ? voff : kOob;
+          }
+          if (kt >= k1_steps) buffer_load_lds16(rs_a2, stage + (i * NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt - k1_steps) * KSG));
+          else buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
+        } else {
+          const char* src = Ab + ((long)a_off[i] + a_koff);
+          if (kConvOk && p.conv) {
+            const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
+            src = ok ? src : (const char*)p.zero;
+          }
+          a_reg[i] = *reinterpret_cast<const uint4*>(src);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) {
+      if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
+        if constexpr (GLDS) {
+          buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(kt * KSG + b_plane));
+        } else {
+          const char* src = Bb + ((long)b_off(i) + (long)kt * KSG + b_plane);
+          b_reg[i] = *reinterpret_cast<const uint4*>(src);
+        }
+      }
+    }
+  };
+
+  auto commit_stage = [&](char* stage) {
+    if constexpr (!GLDS) {
+#pragma unroll
+      for (int i = 0; i < A_SLOTS; ++i)
+        if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8)
+          *reinterpret_cast<uint4*>(stage + (i * NT + tid) * 16) = a_reg[i];
+#pragma unroll
+      for (int i = 0; i < B_SLOTS; ++i)
+        if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8)
+          *reinterpret_cast<uint4*>(stage + BM * 128 + (i * NT + tid) * 16) = b_reg[i];
+    }
+  };
+
+  // ---------------- accumulators ----------------
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // EPI_APPLY keeps a second accumulator set: `acc` is the running total, `pacc` the
+  // current 128-key block's un-scaled partial product.  The next block's weights g are fetched at the very top of
+  // a block, ahead of that block's LDS-DMA, by loads the compiler does not track (a tracked load makes it drain the
+  // whole DMA queue in front of the first use): the hand-counted vmcnt wait of the block's last K-step covers them.
+  constexpr int GN = EPI == EPI_APPLY ? FM : 1;
+  f32x4 pacc[GN][EPI == EPI_APPLY ? FN : 1];
+  float gcur[GN], gnext[GN];
+  float gref[GN];  // per row: m* + log2(L), so that the block weight is g = 2^(m_t - gref)
+  constexpr int STEPS_PER_BLOCK = 128 / BKE;  // K-steps per 128-key statistics block
+  const int nk = SPLIT ? 3 * nk_slice : nk_slice;
+  // SPLIT: the cross terms (passes 0 and 1) carry the lo planes' 2^11: one multiply per accumulator in front of the hi x hi pass
+  auto split_rescale = [&](int kv) {
+    if constexpr (SPLIT) {
+      if (kv == 2 * nk_real) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] *= kSplitInv;
+      }
+    }
+  };
+  const int nblk = nk / STEPS_PER_BLOCK;
+  // statistics row of fragment row i of this lane (rows past M read row M - 1: their outputs are never stored)
+  auto stat_row = [&](int i) {
+    const int m = m0 + (wm * FM + i) * 16 + (lane & 15);
+    return (m < p.M ? m : p.M - 1) * p.ntile;
+  };
+  // Per-row combine of the score pass's tile statistics, g[m][t] = 2^(m_t - m*) / L with L = sum_t l_t 2^(m_t - m*)
+  // (v_exp_f32 / v_log_f32 directly: one instruction each, 1 ulp; exp2f / log2f wrap them in denormal handling these
+  // weights never need): the four lanes that share a row split the key tiles, then merge their (max, sum) pairs.  It is
+  // serial work in front of the tile's first MFMA, so (a) it runs AFTER the pipeline's first K-steps have been requested
+  // and (b) its loads go out in batches of 8 tiles x FM rows -- one memory round trip per batch instead of one per tile.
+  auto apply_prologue = [&]() {
+    if constexpr (EPI == EPI_APPLY) {
+      constexpr int TB = 8;
+      float mx[FM], l[FM];
+      int rowo[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) { mx[i] = -INFINITY; l[i] = 0.f; rowo[i] = stat_row(i); }
+      for (int t0 = lane >> 4; t0 < p.ntile; t0 += 4 * TB) {
+        float mt[FM][TB], lt[FM][TB];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const int t = t0 + 4 * u;
+            const bool ok = t < p.ntile;
+            const int tt = ok ? t : p.ntile - 1;
+            const float a = p.mstat[rowo[i] + tt], b = p.lstat[rowo[i] + tt];
+            mt[i][u] = ok ? a : -INFINITY;   // a tile past the end: weight 0 (mx stays finite: t0 itself is a real tile)
+            lt[i][u] = ok ? b : 0.f;
+          }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const float mn = fmaxf(mx[i], mt[i][u]);
+            l[i] = l[i] * __builtin_amdgcn_exp2f(mx[i] - mn) + lt[i][u] * __builtin_amdgcn_exp2f(mt[i][u] - mn);  // 0 * exp2(-inf) = 0
+            mx[i] = mn;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        float m_ = mx[i], l_ = l[i];
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float mo = __shfl_xor(m_, o), lo = __shfl_xor(l_, o);
+          const float mn = fmaxf(m_, mo);  // a lane without tiles carries (-inf, 0); some lane has a finite max
+          l_ = (m_ == mn ? l_ : l_ * __builtin_amdgcn_exp2f(m_ - mn)) + (mo == mn ? lo : lo * __builtin_amdgcn_exp2f(mo - mn));
+          m_ = mn;
+        }
+        gref[i] = m_ + __builtin_amdgcn_logf(l_);
+        gcur[i] = __builtin_amdgcn_exp2f(p.mstat[rowo[i] + blk0] - gref[i]);
+        landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
+        gnext[i] = 0.f;
+      }
+    }
+  };
+
+  const int frag_row = lane & 15, frag_grp = lane >> 4, swz = lane & 7;
+  // per-lane part of the fragment read addresses (kk = 1 is the same address with bit 6 flipped)
+  const uint32_t a_lane = lds_addr(smem) + (wm * FM * 16 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+  const uint32_t b_lane = lds_addr(smem) + BM * 128 + (wn * FN * 16 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
+
+  // Residual tile (RESPRE): one 16-byte piece per (thread, store-phase slot).  The pipelined loop fetches it right
+  // after its prologue DMA with loads the compiler does not track, so that it travels under the whole K loop; the
+  // hand-counted waits of the first NS - 2 K-steps let those loads stay in flight (they are younger than the prologue's
+  // DMA groups), every later wait covers them.  Addresses are clamped, not predicated: every wave must issue the
+  // same number of loads for the counts to hold.
+  constexpr int E_ROWS = FM * 16, E_CH = BN / 8, E_ITERS = (E_ROWS * E_CH + NT - 1) / NT;
+  static_assert(!RESPRE || sizeof(T) == 2, "RESPRE is the bf16 residual path");
+  constexpr bool RES_EARLY = RESPRE && NS > 2 && BN != 256;  // (the 144x256 shapes have no registers left)
+  constexpr int RES_LOADS = RES_EARLY ? WM * E_ITERS : 0;
+  u32x4 rres[RESPRE ? WM : 1][RESPRE ? E_ITERS : 1];
+
+  // ---------------- main loop ----------------
+  if constexpr (NS == 2) {
+    // Double buffer, one barrier per K-step: the next step's loads are issued at the top of a step and drained at
+    // its bottom (the compiler waits for them in front of the barrier).
+    issue_loads(0, smem);
+    apply_prologue();
+    commit_stage(smem);
+    __syncthreads();
+
+    // `first` / `last`: position of this K-step inside a 128-key statistics block (EPI_APPLY only;
+    // compile-time constants after unrolling, so the zero-C MFMA and the block combine fold away elsewhere)
+    auto do_step = [&](int kt, bool first, bool last) {
+      char* cur = smem + (kt & 1) * STAGE_BYTES;
+      char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      const bool more = kt + 1 < nk;
+      split_rescale(kt);
+      if constexpr (EPI == EPI_APPLY) {
+        if (first) {
+          if (kt + STEPS_PER_BLOCK < nk) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + kt / STEPS_PER_BLOCK + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // the g loads stay ahead of this step's DMA in the vmcnt queue
+        }
+      }
+      if (more) issue_loads(kt + 1, nxt);
+      if constexpr (ASM_READS) {
+        // Fragment reads through inline asm: the compiler does not see them as LDS accesses, so it does not park an
+        // s_waitcnt vmcnt(0) in front of them for the LDS-DMA just issued into the OTHER stage -- the next K-step's
+        // loads stay in flight under this step's MFMAs (it tracks pending LDS-DMA per LDS object and there is one).
+        // LDS returns data in order, so `lgkmcnt(FM + FN)` after all 2 x (FM + FN) reads means "kk = 0 has landed".
+        // (The 6-wave 144x128 shape is register-bound and has only 24 MFMAs per wave-step to cover the rigid
+        // read / wait structure: measured slower on the short-K convs, so it keeps compiler-scheduled reads there --
+        // except in the relation apply pass.)
+        const uint32_t soff = (uint32_t)(cur - smem);
+        const uint32_t a0 = a_lane + soff, b0 = b_lane + soff, a1 = a0 ^ 64u, b1 = b0 ^ 64u;
+        uint4 xa[2][FM], wb[2][FN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint32_t ab = kk ? a1 : a0, bb = kk ? b1 : b0;
+          static_for<FM>([&](auto I) { xa[kk][decltype(I)::value] = lds_read128_off<decltype(I)::value * 2048>(ab); });
+          static_for<FN>([&](auto J) { wb[kk][decltype(J)::value] = lds_read128_off<decltype(J)::value * 2048>(bb); });
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          __builtin_amdgcn_sched_barrier(0);  // pin: MFMAs of kk = 0 stay above the second wait
+          if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);  // and no MFMA is hoisted above the wait it depends on
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              if constexpr (EPI == EPI_APPLY) {
+                if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
+                else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
+              } else {
+                Mma<T>::template run<false>(wb[kk][j], xa[kk][i], acc[i][j]);
+              }
+            }
+        }
+      } else {
+        const char* a_base = cur + (wm * FM * 16 + frag_row) * 128;
+        const char* b_base = cur + BM * 128 + (wn * FN * 16 + frag_row) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
+          uint4 xa[FM], wb[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) xa[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * 128 + chunk);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wb[j] = *reinterpret_cast<const uint4*>(b_base + j * 16 * 128 + chunk);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              if constexpr (EPI == EPI_APPLY) {
+                if (first && kk == 0) Mma<T>::template run<true>(wb[j], xa[i], pacc[i][j]);
+                else Mma<T>::template run<false>(wb[j], xa[i], pacc[i][j]);
+              } else {
+                Mma<T>::template run<false>(wb[j], xa[i], acc[i][j]);
+              }
+            }
+        }
+      }
+      if constexpr (EPI == EPI_APPLY) {
+        if (last) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
+            landed(gnext[i]);
+            gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - gref[i]);
+          }
+        }
+      }
+      if (more) commit_stage(nxt);
+      __syncthreads();
+    };
+    if constexpr (EPI == EPI_APPLY) {
+      for (int kb = 0; kb < nk; kb += STEPS_PER_BLOCK) {
+#pragma unroll
+        for (int st = 0; st < STEPS_PER_BLOCK; ++st) do_step(kb + st, st == 0, st == STEPS_PER_BLOCK - 1);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) do_step(kt, false, false);
+    }
+  } else {
+    // NS-slot LDS ring with a hand-placed instruction stream.  A K-step is two halves (kk = 0 / 1, 32 bf16 of K each);
+    // each half issues its FM x FN MFMAs with one "filler" after every MFMA: first the fragment reads of the NEXT
+    // half (into the other fragment register set), then this step's share of the LDS-DMA for K-step kt + NS - 1
+    // (A slots in half 0, B slots in half 1).  The per-CU load path (64 B/clk) and the LDS therefore run UNDER the
+    // MFMAs instead of in a burst in front of them, and a half never waits for data requested less than a half ago.
+    //   half 0:  lgkmcnt(0)                      -> frags(kt, 0) landed
+    //   half 1:  lgkmcnt(0)                      -> frags(kt, 1) landed: this wave is done reading slot kt % NS
+    //            vmcnt(n), s_barrier             -> K-step kt + 1 is in LDS for everyone; slot kt % NS is free
+    // The waits are counted by hand (vmcnt counts this wave's loads in issue order; n = the loads that may stay in
+    // flight, i.e. those of the K-steps after kt + 1, taken for the wave that issues the fewest).
+    static_assert(EPI != EPI_APPLY || STEPS_PER_BLOCK == 2, "the pipelined apply loop assumes 2 K-steps per block");
+    constexpr int MIN_A = min_wave_loads(BM, NT);
+    constexpr int NR = FM + FN, NM = FM * FN;
+    uint4 fa[2][FM], fb[2][FN];  // fragment sets: [0] = kk 0, [1] = kk 1
+    long a_koff = 0;
+    int dy = 0, dx = 0;  // conv: filter tap of the K-step being loaded
+    int kt_load = 0;     // the K-step being loaded (second-segment products switch operand at k1_steps)
+    int b_koff = 0;      // its byte offset in a B row
+
+    auto tap_of = [&](int kv) {
+      int a_plane, b_plane;
+      const int kt = kmap(kv, a_plane, b_plane);
+      kt_load = kt;
+      b_koff = kt * KSG + b_plane;
+      if (kConvOk && p.conv) {
+        const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        dy = ky * p.dil;
+        dx = kx * p.dil;
+        a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB + a_plane;
+      } else {
+        a_koff = (long)kt * KSG + a_plane;
+      }
+    };
+    auto dma_a = [&](auto I, char* stage) {
+      constexpr int i = decltype(I)::value;
+      if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
+        unsigned voff = (unsigned)a_off[i];
+        if (kConvOk && p.conv) {
+          const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
+          voff = ok ? voff : kOob;
+        }
+#ifndef HVR_DBG_NODMA
+        if (kt_load >= k1_steps) buffer_load_lds16(rs_a2, stage + (i * NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt_load - k1_steps) * KSG));
+        else buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
+#else
+        asm volatile("" ::"v"(voff), "v"(stage));
+#endif
+      }
+    };
+    auto dma_b = [&](auto I, char* stage) {   // (of the K-step tap_of() was last called for)
+      constexpr int i = decltype(I)::value;
+      if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
+#ifndef HVR_DBG_NODMA
+        buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(b_koff));
+#else
+        asm volatile("" ::"v"(b_offr[i]), "v"(stage));
+#endif
+      }
+    };
+    // fragment read r of half kk from the slot at byte offset soff
+    auto read_frag = [&](auto R, auto KK, uint32_t soff) {
+      constexpr int r = decltype(R)::value, kk = decltype(KK)::value;
+#ifdef HVR_DBG_NOLDSREAD
+      (void)soff;
+#else
+      if constexpr (r < FM) fa[kk][r] = lds_read128_off<r * 2048>((a_lane + soff) ^ (kk ? 64u : 0u));
+      else fb[kk][r - FM] = lds_read128_off<(r - FM) * 2048>((b_lane + soff) ^ (kk ? 64u : 0u));
+#endif
+    };
+
+    // prologue: NS - 1 K-steps in flight, K-step 0 landed, its first half's fragments requested
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) issue_loads(s, smem + s * STAGE_BYTES);
+    apply_prologue();
+    if constexpr (RES_EARLY) {
+#pragma unroll
+      for (int pass = 0; pass < WM; ++pass)
+#pragma unroll
+        for (int it = 0; it < E_ITERS; ++it) {
+          int c = it * NT + tid;
+          c = c < E_ROWS * E_CH ? c : E_ROWS * E_CH - 1;
+          const int r = c / E_CH, cc = c - r * E_CH;
+          int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
+          m = m < p.M ? m : p.M - 1;
+          n = n < p.N ? n : p.N - 8;
+          rres[pass][it] = load_u128_untracked(reinterpret_cast<const T*>(p.resid) + (long)m * p.ldr + n);
+        }
+    }
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * MINL + RES_LOADS>();
+    else wait_vmcnt<RES_LOADS>();
+    __builtin_amdgcn_s_barrier();
+    static_for<NR>([&](auto R) { read_frag(R, std::integral_constant<int, 0>{}, 0u); });
+
+    int cs = 0;  // ring slot of the K-step being computed
+    // LOAD: this step issues the DMA of K-step kt + NS - 1: 1 / 0 at compile time (the steady-state loop must not
+    // branch between its MFMAs), 2 = decided at run time from kt (loop tails).  NEXT: a K-step kt + 1 exists (its
+    // first fragments are requested in half 1).  FIRST / LAST: position inside a 128-key block (EPI_APPLY).
+    auto pipe_step = [&](int kt, auto LOAD, auto NEXT, auto FIRST, auto LAST) {
+      constexpr int lmode = decltype(LOAD)::value;
+      constexpr bool next = decltype(NEXT)::value, first = decltype(FIRST)::value, last = decltype(LAST)::value;
+      const bool load = lmode == 2 ? kt + NS - 1 < nk : lmode == 1;
+      const uint32_t soff = (uint32_t)cs * STAGE_BYTES;
+      const int ns = cs + 1 == NS ? 0 : cs + 1;
+      char* lstage = smem + (cs == 0 ? NS - 1 : cs - 1) * STAGE_BYTES;  // freed by the previous step's barrier
+      if constexpr (EPI == EPI_APPLY && first) {
+        if (kt + STEPS_PER_BLOCK < nk) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + kt / STEPS_PER_BLOCK + 1);
+        }
+      }
+      if (load) tap_of(kt + NS - 1);
+      split_rescale(kt);
+      static_for<2>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        constexpr int ND = kk == 0 ? A_SLOTS : B_SLOTS;
+        constexpr bool reads = kk == 0 || next;  // half 1 requests the next step's first fragments
+        constexpr int NF = (reads ? NR : 0) + ND;
+        constexpr int PER = (NF + NM - 1) / NM;  // fillers after each MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (kk == 1) {
+          // loads that may stay in flight: the K-steps after kt + 1 (full groups), plus the A half of the group
+          // this step is issuing; an apply block's g loads sit exactly that far back, hence one fewer there
+          constexpr int G = (EPI == EPI_APPLY && NS == 4) ? 1 : 0;
+          // (the residual prefetch is younger than the DMA groups of K-steps 1 .. NS - 2: it may stay in flight
+          // while those are awaited)
+          if (RES_EARLY && kt <= NS - 3) {
+            if (load) wait_vmcnt<(NS - 3) * MINL + MIN_A - G + RES_LOADS>();
+            else if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G + RES_LOADS>();
+            else wait_vmcnt<RES_LOADS>();
+          } else {
+            if (load) wait_vmcnt<(NS - 3) * MINL + MIN_A - G>();
+            else if (NS == 4 && kt + 2 < nk) wait_vmcnt<MINL - G>();
+            else wait_vmcnt<0>();
+          }
+          __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NM>([&](auto Q) {
+          constexpr int q = decltype(Q)::value, i = q / FN, j = q % FN;
+          if constexpr (EPI == EPI_APPLY) {
+            if constexpr (first && kk == 0) Mma<T>::template run<true>(fb[kk][j], fa[kk][i], pacc[i][j]);
+            else Mma<T>::template run<false>(fb[kk][j], fa[kk][i], pacc[i][j]);
+          } else {
+            Mma<T>::template run<false>(fb[kk][j], fa[kk][i], acc[i][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<PER>([&](auto U) {
+            constexpr int f = q * PER + decltype(U)::value;
+            constexpr int fr = reads ? f : f + NR;  // filler index in the (reads, DMA) order
+            if constexpr (f < NF) {
+              if constexpr (fr < NR) {
+                if constexpr (kk == 0) read_frag(std::integral_constant<int, fr>{}, std::integral_constant<int, 1>{}, soff);
+                else read_frag(std::integral_constant<int, fr>{}, std::integral_constant<int, 0>{}, (uint32_t)ns * STAGE_BYTES);
+              } else if (load) {
+                if constexpr (kk == 0) dma_a(std::integral_constant<int, fr - NR>{}, lstage);
+                else dma_b(std::integral_constant<int, fr - NR>{}, lstage);
+              }
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      if constexpr (EPI == EPI_APPLY && last) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(gcur[i], pacc[i][j][r], acc[i][j][r]);
+          landed(gnext[i]);
+          gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - gref[i]);
+        }
+      }
+      cs = ns;
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    constexpr std::integral_constant<int, 1> L1{};
+    constexpr std::integral_constant<int, 0> L0{};
+    constexpr std::integral_constant<int, 2> LR{};
+    if constexpr (EPI == EPI_APPLY) {  // nk is even: 128-key blocks of two K-steps
+      int kt = 0;
+      for (; kt + NS < nk; kt += 2) {  // both steps of the block load
+        pipe_step(kt, L1, Y, Y, N);
+        pipe_step(kt + 1, L1, Y, N, Y);
+      }
+      for (; kt < nk; kt += 2) {  // the last NS / 2 blocks: the second step never loads
+        pipe_step(kt, LR, Y, Y, N);
+        if (kt + 2 < nk) pipe_step(kt + 1, L0, Y, N, Y);
+        else pipe_step(kt + 1, L0, N, N, Y);
+      }
+    } else {
+      int kt = 0;
+      for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, L1, Y, N, N);
+      for (; kt + 1 < nk; ++kt) pipe_step(kt, L0, Y, N, N);
+      if (kt < nk) pipe_step(kt, L0, N, N, N);
+    }
+  }
+
+  // ---------------- residual fetch (RESPRE): all of the tile's residual loads are issued here, at the top of the
+  // epilogue (no LDS DMA is in flight any more, so the barriers below do not drain them): one overlapped round
+  // trip instead of one per store-phase iteration ----------------
+  if constexpr (RES_EARLY) {
+    wait_vmcnt<0>();  // K loops shorter than the ring never reach a wait that covers the residual prefetch
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass)
+#pragma unroll
+      for (int it = 0; it < E_ITERS; ++it) landed(rres[pass][it]);
+  }
+  if constexpr (RESPRE && !RES_EARLY) {
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass)
+#pragma unroll
+      for (int it = 0; it < E_ITERS; ++it) {
+        const int c = it * NT + tid, r = c / E_CH, cc = c - r * E_CH;
+        const int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
+        rres[pass][it] = u32x4{0u, 0u, 0u, 0u};
+        if (c < E_ROWS * E_CH && m < p.M && n < p.N) rres[pass][it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.resid) + (long)m * p.ldr + n);
+      }
+  }
+
+  // ---------------- epilogues ----------------
+  // lane holds, for fragment (i, j): m = .. + (lane & 15), n = .. + (lane >> 4) * 4 + r
+  if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
+    // Stage the f32 tile through LDS (one wave-row block of FM*16 rows per pass) so that every global
+    // access of the epilogue is a full 16-byte-per-lane row segment: residual loads and output stores
+    // are whole lines instead of the 8-byte pieces of the MFMA fragment layout.
+    constexpr int ROWS = FM * 16, LDW = BN + 4, CH = BN / 8;
+    float* ebuf = reinterpret_cast<float*>(smem);
+    const int out_es = p.out_f32 ? 4 : EB;
+    const bool wide_c = ((p.ldc * out_es) & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && (p.N & 7) == 0;
+    const bool wide_r = p.resid && ((p.ldr * (long)EB) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass) {
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int col = (wn * FN + j) * 16 + frag_grp * 4;
+            f32x4 v = acc[i][j];
+            if (p.bias && n0 + col < p.N) {
+              const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
+              v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            *reinterpret_cast<f32x4*>(ebuf + (i * 16 + frag_row) * LDW + col) = v;
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < (ROWS * CH + NT - 1) / NT; ++it) {
+        const int c = it * NT + tid;
+        if (c >= ROWS * CH) continue;
+        const int r = c / CH, cc = c - r * CH;
+        const int m = m0 + pass * ROWS + r, n = n0 + cc * 8;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        const float4 lo = *reinterpret_cast<const float4*>(ebuf + r * LDW + cc * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ebuf + r * LDW + cc * 8 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        const bool full = n + 8 <= p.N;  // N % 4 == 0: a chunk is either 8 or 4 valid columns
+        if constexpr (RESPRE) {
+          float rv[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) unpack2<T>(rres[pass][it][e], rv[2 * e], rv[2 * e + 1]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        } else if constexpr (SPLIT) {
+          if (p.resid) {  // (the C ABI admits split operands in whole 8-column chunks only: `full` holds)
+            const char* rp = reinterpret_cast<const char*>(p.resid) + (long)m * p.ldr * 4 + split_col_bytes(n);
+            const uint4 th = *reinterpret_cast<const uint4*>(rp), tl = *reinterpret_cast<const uint4*>(rp + 128);
+            float rv[8];
+            merge2(th.x, tl.x, rv[0], rv[1]); merge2(th.y, tl.y, rv[2], rv[3]);
+            merge2(th.z, tl.z, rv[4], rv[5]); merge2(th.w, tl.w, rv[6], rv[7]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+        } else if (p.resid) {
+          const T* rp = reinterpret_cast<const T*>(p.resid) + (long)m * p.ldr + n;
+          float rv[8];
+          if (full && wide_r) {
+            if constexpr (sizeof(T) == 2) {
+              const uint4 t = *reinterpret_cast<const uint4*>(rp);
+              unpack2<T>(t.x, rv[0], rv[1]); unpack2<T>(t.y, rv[2], rv[3]);
+              unpack2<T>(t.z, rv[4], rv[5]); unpack2<T>(t.w, rv[6], rv[7]);
+            } else {
+              load4(rp, rv);
+              load4(rp + 4, rv + 4);
+            }
+          } else {
+            load4(rp, rv);
+            if (full) load4(rp + 4, rv + 4);
+            else rv[4] = rv[5] = rv[6] = rv[7] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.out_f32 || F32) {
+          float* cp = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n;
+          store4(cp, v);
+          if (full) store4(cp + 4, v + 4);
+        } else if constexpr (SPLIT) {
+          char* cp = Cb + (long)m * p.ldc * 4 + split_col_bytes(n);
+          uint4 h, l;
+          split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y);
+          split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
+          *reinterpret_cast<uint4*>(cp) = h;
+          *reinterpret_cast<uint4*>(cp + 128) = l;
+        } else if constexpr (sizeof(T) == 2) {
+          T* cp = reinterpret_cast<T*>(Cb) + (long)m * p.ldc + n;
+          if (full && wide_c) {
+            *reinterpret_cast<uint4*>(cp) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+          } else {
+            store4(cp, v);
+            if (full) store4(cp + 4, v + 4);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {  // EPI_SCORES: per (row, 128-key tile) max / sum and P~ = exp(s - tilemax)
+    static_assert(EPI != EPI_SCORES || BN == 128, "score tiles are 128 keys wide");
+#ifdef HVR_DBG_NOSCORE_EPI
+    if (p.scale != 12345.f) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 12345.f) p.mstat[0] = t;
+      return;
+    }
+#endif
+    // LDS scratch (the main loop is done): the P~ tile, staged so that it leaves in whole 16-byte row segments,
+    // and [WN][BM] floats for the max / sum exchange between the column waves
+    constexpr int PITCH = BN * (int)sizeof(T) + 8;  // bytes per staged row; 66 dwords: the 8-byte writes of a lane
+                                                    // group (16 rows) land on 32 distinct banks
+    char* pbuf = smem;
+    float* red = reinterpret_cast<float*>(smem + BM * PITCH);
+    const float sl2 = p.scale * 1.4426950408889634f;  // logits in log2 units
+    const bool ragged = n0 + BN > p.N;                // only the last key tile masks columns
+    float tmax[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + (wn * FN + j) * 16 + frag_grp * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = acc[i][j][r];  // raw dot products: the (positive) scale is folded into the exponent's FMA below
+          if (ragged) s = (n + r < p.N) ? s : -INFINITY;
+          acc[i][j][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      tmax[i] = mx;
+      if (frag_grp == 0) red[wn * BM + (wm * FM + i) * 16 + frag_row] = mx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int w = 0; w < WN; ++w) tmax[i] = fmaxf(tmax[i], red[w * BM + (wm * FM + i) * 16 + frag_row]);
+      tmax[i] *= sl2;  // log2 units from here on
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = (wm * FM + i) * 16 + frag_row;
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = (wn * FN + j) * 16 + frag_grp * 4;
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], sl2, -tmax[i]));  // masked keys: exp2(-inf) = 0
+        if constexpr (sizeof(T) == 2) {
+          // (the row sum is taken before rounding: the rounding errors of a tile's 128 values average out far below
+          // the bf16 resolution of the output, and re-expanding the packed values costs as much VALU as the exponentials)
+          const uint32_t lo = pack2<T>(e[0], e[1]), hi = pack2<T>(e[2], e[3]);
+          sum += (e[0] + e[1]) + (e[2] + e[3]);
+          *reinterpret_cast<uint2*>(pbuf + row * PITCH + col * 2) = make_uint2(lo, hi);
+        } else if constexpr (SPLIT) {
+          uint32_t h0, l0, h1, l1;
+          split2(e[0], e[1], h0, l0);
+          split2(e[2], e[3], h1, l1);
+          sum += (e[0] + e[1]) + (e[2] + e[3]);
+          char* dst = pbuf + row * PITCH + split_col_bytes(col);   // the staged row has the memory layout of the 128-key tile
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + 128) = make_uint2(l0, l1);
+        } else {
+          sum += (e[0] + e[1]) + (e[2] + e[3]);
+          *reinterpret_cast<float2*>(pbuf + row * PITCH + col * 4) = make_float2(e[0], e[1]);
+          *reinterpret_cast<float2*>(pbuf + row * PITCH + col * 4 + 8) = make_float2(e[2], e[3]);
+        }
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      if (frag_grp == 0) red[wn * BM + row] = sum;
+    }
+    __syncthreads();
+    {  // P~ leaves in 16-byte row segments (ldc is a multiple of 128 keys: every column of the tile exists)
+      constexpr int CH = BN * (int)sizeof(T) / 16;  // chunks per row
+#pragma unroll
+      for (int it = 0; it < (BM * CH + NT - 1) / NT; ++it) {
+        const int c = it * NT + tid;
+        if ((BM * CH) % NT != 0 && c >= BM * CH) continue;
+        const int r = c / CH, cc = c - r * CH, m = m0 + r;
+        const uint2 lo = *reinterpret_cast<const uint2*>(pbuf + r * PITCH + cc * 16);
+        const uint2 hi = *reinterpret_cast<const uint2*>(pbuf + r * PITCH + cc * 16 + 8);
+#ifdef HVR_DBG_NOPSTORE
+        if (m < p.M && p.scale == 12345.f)
+#else
+        if (m < p.M)
+#endif
+          *reinterpret_cast<uint4*>(Cb + ((long)m * p.ldc + n0) * (long)sizeof(T) + cc * 16) =
+              make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+    if (wn == 0 && frag_grp == 0) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = (wm * FM + i) * 16 + frag_row, m = m0 + row;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) sum += red[w * BM + row];
+        if (m < p.M) {
+          const int t = n0 / 128;
+          p.mstat[(long)m * p.ntile + t] = tmax[i];  // log2 units
+          p.lstat[(long)m * p.ntile + t] = sum;
+        }
+      }
+    }
+  }
+}
+
+// ---------------- host-side dispatch ----------------
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false, int NS = 2>
+static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
+  constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
+  constexpr size_t stage = NS * (size_t)(BM + BN) * 128;
+  constexpr size_t epi = EPI == EPI_SCORES ? (size_t)BM * (BN * sizeof(T) + 8) + (size_t)WN * BM * 4  // P~ tile + exchange
+                                           : (size_t)FM * 16 * (BN + 4) * 4;                      // one wave-row block, f32
+  constexpr size_t lds = stage > epi ? stage : epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS, RESPRE, NS>;
+  static bool attr_set[kMaxDevices] = {};   // the attribute is per device
+  const int dev = current_device();
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
+  return hipGetLastError();
+}
+
+template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, int NS = 2>
+static hipError_t launch_tile(const GemmParams& p, hipStream_t stream) {
+  if constexpr (EPI == EPI_LINEAR && GLDS && sizeof(T) == 2) {
+    const bool pre = p.resid && (p.N & 7) == 0 && ((p.ldr * 2) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
+    if (pre) return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, true, NS>(p, stream);
+  }
+  return launch_tile_impl<T, WM, WN, FM, FN, EPI, GLDS, false, NS>(p, stream);
+}
+
+template <typename T, int EPI, bool GLDS>
+static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t stream) {
+  if constexpr (GLDS && !std::is_same<T, float>::value) {
+    switch (tile) {
+      case 1: if constexpr (EPI != EPI_SCORES) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS>(p, stream); break;
+      case 2: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS>(p, stream); break;
+      case 3: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS>(p, stream);
+      case 4: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS>(p, stream);
+      case 5: if constexpr (EPI != EPI_APPLY) return launch_tile<T, 4, 2, 4, 4, EPI, GLDS, 3>(p, stream); break;
+      case 6: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
+      case 7: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream);
+      case 8: return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream);
+      case 9: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS, 3>(p, stream); break;
+      case 10: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 1, 8, 9, 2, EPI, GLDS, 3>(p, stream); break;
+      case 11: return launch_tile<T, 1, 8, 9, 1, EPI, GLDS, 4>(p, stream);
+      default: break;
+    }
+    return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);
+  } else {
+    if (tile == 1) {
+      if constexpr (EPI != EPI_SCORES) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS>(p, stream);
+    }
+    return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);
+  }
+}
+
+template <typename T, int EPI>
+static hipError_t dispatch_shape(const GemmParams& p, hipStream_t stream) {
+  const int tile = choose_tile(p, EPI);
+  return p.staging == 1 ? dispatch_tile<T, EPI, true>(p, tile, stream) : dispatch_tile<T, EPI, false>(p, tile, stream);
+}
+
+}  // namespace hvr

@@ -2,6 +2,7 @@
 // 7x7 stem's patch gather, 3x3/2 max pooling, the class softmax and box decode.
 // All are coalesced 16-byte-per-lane streaming kernels (no LDS reuse to exploit), except
 // the transpose which stages a 64x64 tile through LDS.
+#include <type_traits>
 #include "common.h"
 
 namespace hvr {
@@ -108,6 +109,44 @@ __global__ void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __
   }
 }
 
+// ---- casts between any two operand formats, 8 logical elements per thread (n % 8 == 0; split half: n % 64 == 0) ----
+template <typename T> __device__ __forceinline__ void load8(const char* base, long i, float v[8]) {
+  if constexpr (std::is_same<T, float>::value) {
+    load4(reinterpret_cast<const float*>(base) + i, v);
+    load4(reinterpret_cast<const float*>(base) + i + 4, v + 4);
+  } else if constexpr (std::is_same<T, f16s_t>::value) {
+    const char* q = base + split_col_bytes(i);
+    const uint4 h = *reinterpret_cast<const uint4*>(q), l = *reinterpret_cast<const uint4*>(q + 128);
+    merge2(h.x, l.x, v[0], v[1]); merge2(h.y, l.y, v[2], v[3]); merge2(h.z, l.z, v[4], v[5]); merge2(h.w, l.w, v[6], v[7]);
+  } else {
+    const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(base) + i);
+    unpack2<T>(t.x, v[0], v[1]); unpack2<T>(t.y, v[2], v[3]); unpack2<T>(t.z, v[4], v[5]); unpack2<T>(t.w, v[6], v[7]);
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(char* base, long i, const float v[8]) {
+  if constexpr (std::is_same<T, float>::value) {
+    store4(reinterpret_cast<float*>(base) + i, v);
+    store4(reinterpret_cast<float*>(base) + i + 4, v + 4);
+  } else if constexpr (std::is_same<T, f16s_t>::value) {
+    char* q = base + split_col_bytes(i);
+    uint4 h, l;
+    split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
+    *reinterpret_cast<uint4*>(q) = h;
+    *reinterpret_cast<uint4*>(q + 128) = l;
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(base) + i) =
+        make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+  }
+}
+template <typename TI, typename TO>
+__global__ void cast8_kernel(const char* __restrict__ in, char* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+    float v[8];
+    load8<TI>(in, i, v);
+    store8<TO>(out, i, v);
+  }
+}
+
 // ---- [B][C][HW] <-> [B][HW][C] (API-boundary layout changes only) ----
 template <typename TI, typename TO>
 __global__ void permute_bchw_kernel(const TI* __restrict__ in, TO* __restrict__ out, int C, int HW, int to_nhwc) {
@@ -207,6 +246,38 @@ __global__ __launch_bounds__(256) void transpose_pad_bf16x8_kernel(const bf16_t*
   }
 }
 
+// split half: a 64 x 64 logical tile is one [hi | lo] group per input row and one per output row -- two independent 64 x 64
+// transposes of 16-bit words (blockIdx.z = plane).  R, C, ldx, ldt in logical elements; C, ldx, ldt multiples of 64.
+__global__ __launch_bounds__(256) void transpose_pad_split_kernel(const char* __restrict__ in, char* __restrict__ out, int R, int C,
+                                                                  long ldx, long ldt) {
+  constexpr int PITCH = 64 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char tile[64 * PITCH];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x, plane = blockIdx.z * 128;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, i = s >> 3, q = s & 7;
+    const int r = r0 + i;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R) v = *reinterpret_cast<const uint4*>(in + (long)r * ldx * 4 + (long)(c0 >> 6) * 256 + plane + q * 16);
+    *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, q = s >> 6, i = s & 63;
+    const int c = c0 + i;
+    if (c >= C) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = *reinterpret_cast<const unsigned short*>(tile + (q * 8 + 2 * e) * PITCH + i * 2);
+      const uint32_t hi = *reinterpret_cast<const unsigned short*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+      w[e] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(out + (long)c * ldt * 4 + (long)(r0 >> 6) * 256 + plane + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // ---- relation backward helpers (attention backward of one relation stage; the products are tile-engine GEMMs) ----
 // P[m][:] *= 2^(m_t - m*) / L per 128-key block t: turns the score pass's block-relative exponentials into the softmax
 // probabilities (selsa_bbox_head.py:172, nn.Softmax(dim=2)); padding columns of P are zero and stay zero.
@@ -233,6 +304,32 @@ __global__ __launch_bounds__(256) void relation_normalize_kernel(T* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= w;
     store4(row + j, v);
+  }
+}
+
+// the same on a split-half P (rows of ldp / 64 [hi | lo] groups): 8 logical columns per thread step
+__global__ __launch_bounds__(256) void relation_normalize_split_kernel(char* __restrict__ P, const float* __restrict__ mstat,
+                                                                       const float* __restrict__ lstat, int ntile, long ldp) {
+  __shared__ float g[128];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    float mx = -INFINITY;
+    for (int t = tid; t < ntile; t += 64) mx = fmaxf(mx, mstat[(long)m * ntile + t]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float l = 0.f;
+    for (int t = tid; t < ntile; t += 64) l += lstat[(long)m * ntile + t] * exp2f(mstat[(long)m * ntile + t] - mx);
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    for (int t = tid; t < ntile; t += 64) g[t] = exp2f(mstat[(long)m * ntile + t] - mx) / l;
+  }
+  __syncthreads();
+  char* row = P + (long)m * ldp * 4;
+  for (long j = (long)tid * 8; j < ldp; j += 256 * 8) {
+    float v[8];
+    load8<f16s_t>(row, j, v);
+    const float w = g[j >> 7];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= w;
+    store8<f16s_t>(row, j, v);
   }
 }
 
@@ -438,6 +535,10 @@ hipError_t run_pack_conv_weight(const float* w, const float* sc, void* out, int 
   const long total = (long)Cout * Cin * KK;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, w, sc, (bf16_t*)out, Cout, Cin, KK);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<f16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, w, sc, (f16_t*)out, Cout, Cin, KK);
+  else if (dtype != DT_F32)
+    return hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, w, sc, (float*)out, Cout, Cin, KK);
   return hipGetLastError();
@@ -454,6 +555,10 @@ hipError_t run_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int C
   const long work = (long)B * OH * OW * KH * KW * (Cin / 4);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(im2col_nhwc_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(im2col_nhwc_kernel<f16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const f16_t*)x, (f16_t*)cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW);
+  else if (dtype != DT_F32)
+    return hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(im2col_nhwc_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const float*)x, (float*)cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW);
   return hipGetLastError();
@@ -463,6 +568,10 @@ hipError_t run_scale_rows(const void* w, const float* sc, void* out, int R, long
   const long work = (long)R * (C / 4);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const bf16_t*)w, sc, (bf16_t*)out, R, C);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(scale_rows_kernel<f16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const f16_t*)w, sc, (f16_t*)out, R, C);
+  else if (dtype != DT_F32)
+    return hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const float*)w, sc, (float*)out, R, C);
   return hipGetLastError();
@@ -548,6 +657,8 @@ hipError_t run_sgd_step(float* p, const float* g, float* buf, long n, float lr, 
 hipError_t run_relu_bwd(const void* dY, const void* Y, void* dZ, long n, int dtype, hipStream_t s) {
   const int g = grid_for((n + 3) / 4, 256);
   if (dtype == DT_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dY, (const bf16_t*)Y, (bf16_t*)dZ, n);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(relu_bwd_kernel<f16_t>, dim3(g), dim3(256), 0, s, (const f16_t*)dY, (const f16_t*)Y, (f16_t*)dZ, n);
+  else if (dtype != DT_F32) return hipErrorInvalidValue;
   else hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dY, (const float*)Y, (float*)dZ, n);
   return hipGetLastError();
 }
@@ -563,6 +674,8 @@ hipError_t run_colsum(const void* dY, float* db, int M, int N, long ld, int dtyp
   float* part = S == 1 ? db : ws;
   const dim3 grid((N + 63) / 64, S);
   if (dtype == DT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dY, part, M, N, ld);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)dY, part, M, N, ld);
+  else if (dtype != DT_F32) return hipErrorInvalidValue;
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dY, part, M, N, ld);
   if (S > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, db, N, S);
   return hipGetLastError();
@@ -585,7 +698,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // the same sum rounded once to bf16 (the relation apply pass's split-K form); N % 8 == 0, 16-byte aligned rows
-__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, bf16_t* __restrict__ C, int M, int N, long ldc,
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, T* __restrict__ C, int M, int N, long ldc,
                                                                  int S) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x, per_row = N / 8, total = (long)M * per_row;
   if (q >= total) return;
@@ -597,7 +711,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
     a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
   }
-  *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+  *reinterpret_cast<uint4*>(C + m * ldc + n) = make_uint4(pack2<T>(a.x, a.y), pack2<T>(a.z, a.w), pack2<T>(b.x, b.y), pack2<T>(b.z, b.w));
 }
 
 // the sum with a conv / linear epilogue: C = act(sum_s ws[s] + bias + resid), rounded once to bf16 (split-K convs of few-row
@@ -644,7 +758,12 @@ hipError_t run_splitk_reduce_epi_bf16(const float* ws, void* C, int M, int N, lo
 
 hipError_t run_splitk_reduce_bf16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
   const long total = (long)M * (N / 8);
-  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S);
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S);
+  return hipGetLastError();
+}
+hipError_t run_splitk_reduce_f16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
+  const long total = (long)M * (N / 8);
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel<f16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (f16_t*)C, M, N, ldc, S);
   return hipGetLastError();
 }
 
@@ -665,6 +784,10 @@ hipError_t run_det_loss(const float* logits, int ldl, int cls_off, int reg_off, 
 hipError_t run_relation_normalize(void* P, const float* mstat, const float* lstat, int Mq, int ntile, long ldp, int dtype, hipStream_t s) {
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(relation_normalize_kernel<bf16_t>, dim3(Mq), dim3(256), 0, s, (bf16_t*)P, mstat, lstat, ntile, ldp);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(relation_normalize_kernel<f16_t>, dim3(Mq), dim3(256), 0, s, (f16_t*)P, mstat, lstat, ntile, ldp);
+  else if (dtype == DT_F16S)
+    hipLaunchKernelGGL(relation_normalize_split_kernel, dim3(Mq), dim3(256), 0, s, (char*)P, mstat, lstat, ntile, ldp);
   else
     hipLaunchKernelGGL(relation_normalize_kernel<float>, dim3(Mq), dim3(256), 0, s, (float*)P, mstat, lstat, ntile, ldp);
   return hipGetLastError();
@@ -675,6 +798,11 @@ hipError_t run_relation_dscore(const void* P, const void* dP, const void* dO, co
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(relation_dscore_kernel<bf16_t>, dim3(Mq), dim3(256), 0, s, (const bf16_t*)P, (const bf16_t*)dP,
                        (const bf16_t*)dO, (const bf16_t*)O, (bf16_t*)dS, ldp, D, ldgo, ldo, scale);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(relation_dscore_kernel<f16_t>, dim3(Mq), dim3(256), 0, s, (const f16_t*)P, (const f16_t*)dP,
+                       (const f16_t*)dO, (const f16_t*)O, (f16_t*)dS, ldp, D, ldgo, ldo, scale);
+  else if (dtype != DT_F32)
+    return hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(relation_dscore_kernel<float>, dim3(Mq), dim3(256), 0, s, (const float*)P, (const float*)dP, (const float*)dO,
                        (const float*)O, (float*)dS, ldp, D, ldgo, ldo, scale);
@@ -683,11 +811,17 @@ hipError_t run_relation_dscore(const void* P, const void* dP, const void* dO, co
 
 hipError_t run_transpose_pad(const void* in, void* out, int R, int C, long ldx, long ldt, int dtype, hipStream_t s) {
   dim3 grid((C + 63) / 64, (int)((ldt + 63) / 64));
-  const bool wide = dtype == DT_BF16 && C % 8 == 0 && ldx % 8 == 0 && ldt % 8 == 0 &&
+  // (the 2-byte kernels move raw 16-bit words: bf16 and half alike)
+  const bool two = dtype == DT_BF16 || dtype == DT_F16;
+  const bool wide = two && C % 8 == 0 && ldx % 8 == 0 && ldt % 8 == 0 &&
                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  if (wide)
+  if (dtype == DT_F16S) {
+    if (C % 64 || ldx % 64 || ldt % 64 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)) return hipErrorInvalidValue;
+    grid.z = 2;
+    hipLaunchKernelGGL(transpose_pad_split_kernel, grid, dim3(256), 0, s, (const char*)in, (char*)out, R, C, ldx, ldt);
+  } else if (wide)
     hipLaunchKernelGGL(transpose_pad_bf16x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, R, C, ldx, ldt);
-  else if (dtype == DT_BF16)
+  else if (two)
     hipLaunchKernelGGL(transpose_pad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, R, C, ldx, ldt);
   else
     hipLaunchKernelGGL(transpose_pad_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, R, C, ldx, ldt);
@@ -698,6 +832,11 @@ hipError_t run_im2col_stem(const float* img, void* cols, int B, int H, int W, in
   if (dtype == DT_BF16) {
     const long work = (long)B * OH * OW * (KP / 8);
     hipLaunchKernelGGL(im2col_stem_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (bf16_t*)cols, B, H, W, OH, OW, KP);
+  } else if (dtype == DT_F16) {
+    const long work = (long)B * OH * OW * (KP / 8);
+    hipLaunchKernelGGL(im2col_stem_kernel<f16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (f16_t*)cols, B, H, W, OH, OW, KP);
+  } else if (dtype != DT_F32) {
+    return hipErrorInvalidValue;
   } else {
     const long work = (long)B * OH * OW * (KP / 4);
     hipLaunchKernelGGL(im2col_stem_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (float*)cols, B, H, W, OH, OW, KP);
@@ -709,6 +848,10 @@ hipError_t run_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int 
   const long work = (long)B * OH * OW * (C / 4);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C, OH, OW);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<f16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const f16_t*)in, (f16_t*)out, B, H, W, C, OH, OW);
+  else if (dtype != DT_F32)
+    return hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(work, 256)), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C, OH, OW);
   return hipGetLastError();
@@ -720,14 +863,33 @@ hipError_t run_cast(const void* in, void* out, long n, int from, int to, hipStre
     hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(g), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
   else if (from == DT_BF16 && to == DT_F32)
     hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(g), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
-  else
+  else {
+    // every other pair, 8 elements per thread (capi.hip checks n % 8 / n % 64 and the alignment)
+    const int g8 = grid_for((n + 7) / 8, 256);
+    const char* ip = (const char*)in;
+    char* op = (char*)out;
+#define HVR_CAST8(FI, TI, FO, TO) \
+    if (from == FI && to == FO) { hipLaunchKernelGGL((cast8_kernel<TI, TO>), dim3(g8), dim3(256), 0, s, ip, op, n); return hipGetLastError(); }
+    HVR_CAST8(DT_F32, float, DT_F16, f16_t) HVR_CAST8(DT_F16, f16_t, DT_F32, float)
+    HVR_CAST8(DT_F32, float, DT_F16S, f16s_t) HVR_CAST8(DT_F16S, f16s_t, DT_F32, float)
+    HVR_CAST8(DT_BF16, bf16_t, DT_F16, f16_t) HVR_CAST8(DT_F16, f16_t, DT_BF16, bf16_t)
+    HVR_CAST8(DT_BF16, bf16_t, DT_F16S, f16s_t) HVR_CAST8(DT_F16S, f16s_t, DT_BF16, bf16_t)
+    HVR_CAST8(DT_F16, f16_t, DT_F16S, f16s_t) HVR_CAST8(DT_F16S, f16s_t, DT_F16, f16_t)
+#undef HVR_CAST8
     return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
 hipError_t run_permute(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from, int to, hipStream_t s) {
   const int R = to_nhwc ? C : HW, Cn = to_nhwc ? HW : C;
   dim3 grid((Cn + 63) / 64, (R + 63) / 64, B);
+  if (from == DT_F16S || to == DT_F16S) return hipErrorInvalidValue;
+#define HVR_PERM(FI, TI, FO, TO) \
+  if (from == FI && to == FO) { hipLaunchKernelGGL((permute_bchw_kernel<TI, TO>), grid, dim3(256), 0, s, (const TI*)in, (TO*)out, C, HW, to_nhwc); return hipGetLastError(); }
+  HVR_PERM(DT_F32, float, DT_F16, f16_t) HVR_PERM(DT_F16, f16_t, DT_F32, float) HVR_PERM(DT_F16, f16_t, DT_F16, f16_t)
+  HVR_PERM(DT_BF16, bf16_t, DT_F16, f16_t) HVR_PERM(DT_F16, f16_t, DT_BF16, bf16_t)
+#undef HVR_PERM
   if (from == DT_F32 && to == DT_F32)
     hipLaunchKernelGGL((permute_bchw_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, C, HW, to_nhwc);
   else if (from == DT_F32 && to == DT_BF16)

@@ -982,7 +982,8 @@ hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, i
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
   const int nb = (n + 63) / 64;
-  static bool attr = false;
+  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr = attr_dev[current_device()];
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
     attr = true;
@@ -990,7 +991,8 @@ hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, i
   // a small survivor cap (the RPN's nms_post): the greedy kernel prices max_keep x n IoUs instead of n^2 / 2
   static const bool no_greedy = std::getenv("HVR_NMS_MASK") != nullptr;
   if (max_keep > 0 && max_keep <= 1024 && !no_greedy) {
-    static bool gattr = false;
+    static bool gattr_dev[kMaxDevices] = {};
+    bool& gattr = gattr_dev[current_device()];
     if (!gattr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       gattr = true;
@@ -1014,7 +1016,8 @@ hipError_t run_rpn_select(const void* cls, const void* reg, long cls_stride, lon
   while (kp2 < rp.npre) kp2 <<= 1;
   if (kp2 > 8192) return hipErrorInvalidValue;
   const size_t lds = (size_t)kp2 * 8;
-  static bool attr = false;
+  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr = attr_dev[current_device()];
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_select_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_select_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
@@ -1052,7 +1055,8 @@ hipError_t run_multiclass_nms(const float* boxes, const float* scores, int R, in
   if (max_num >= (ncls - 1) * R || (size_t)np2 * 8 + (size_t)sp2 * 8 > 160 * 1024 - 3072) sp2 = 0;
   const size_t lds = (size_t)np2 * 8 + (size_t)sp2 * 8;
   if (lds > 160 * 1024 - 3072) return hipErrorInvalidValue;
-  static bool attr = false;
+  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr = attr_dev[current_device()];
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mc_nms_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 3072);
     attr = true;

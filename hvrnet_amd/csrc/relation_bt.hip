@@ -462,7 +462,8 @@ bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, lo
 }
 
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
     attr_set = true;

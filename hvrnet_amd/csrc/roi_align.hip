@@ -107,15 +107,13 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ 
 // kernel's data-dependent `continue` keeps the compiler from overlapping one sample's loads with the next sample's
 // (the kernel is latency-bound: 4 500 workgroups of short dependent gather chains).  A sample outside the map keeps
 // the reference's "skip" (roi_align_kernel.cu:29-35): its taps read pixel (0, 0) and are not accumulated.
-__device__ __forceinline__ void unpack8(const uint4& v, float f[8]) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+template <typename T> __device__ __forceinline__ void unpack8(const uint4& v, float f[8]) {
+  unpack2<T>(v.x, f[0], f[1]); unpack2<T>(v.y, f[2], f[3]); unpack2<T>(v.z, f[4], f[5]); unpack2<T>(v.w, f[6], f[7]);
 }
 
-__global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_s2(const bf16_t* __restrict__ feat, const float* __restrict__ rois,
-                                                                  bf16_t* __restrict__ out, int C, int H, int W, int PH, int PW,
+template <typename T>   // bf16_t / f16_t
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_s2(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                                  T* __restrict__ out, int C, int H, int W, int PH, int PW,
                                                                   float spatial_scale) {
   const int k = blockIdx.x;
   const int lanes_c = C / 8;
@@ -123,7 +121,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_s2(const bf16_t* 
   const int cl = threadIdx.x % lanes_c, grp = threadIdx.x / lanes_c;
   if (grp >= groups) return;
   const RoiGeom g = roi_geom(rois + (long)k * 5, spatial_scale, 2, PH, PW);
-  const bf16_t* fb = feat + (long)g.batch * H * W * C + cl * 8;
+  const T* fb = feat + (long)g.batch * H * W * C + cl * 8;
   for (int bin = grp; bin < PH * PW; bin += groups) {
     const int ph = bin / PW, pw = bin - ph * PW;
     BilinearTap t[4];
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_s2(const bf16_t* 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float lt[8], rt[8], lb[8], rb[8];
-      unpack8(v[s][0], lt); unpack8(v[s][1], rt); unpack8(v[s][2], lb); unpack8(v[s][3], rb);
+      unpack8<T>(v[s][0], lt); unpack8<T>(v[s][1], rt); unpack8<T>(v[s][2], lb); unpack8<T>(v[s][3], rb);
       if (t[s].inside) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += (t[s].w1 * lt[e] + t[s].w2 * rt[e] + t[s].w3 * lb[e] + t[s].w4 * rb[e]);
@@ -156,8 +154,8 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_s2(const bf16_t* 
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] /= 4.f;
-    bf16_t* dst = out + ((long)k * PH * PW + bin) * C + cl * 8;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+    T* dst = out + ((long)k * PH * PW + bin) * C + cl * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2<T>(acc[0], acc[1]), pack2<T>(acc[2], acc[3]), pack2<T>(acc[4], acc[5]), pack2<T>(acc[6], acc[7]));
   }
 }
 
@@ -229,31 +227,39 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const float
   }
 }
 
+template <typename T>
+static hipError_t launch_roi_align_nhwc_h16(const void* feat, const float* rois, void* out, int C, int H, int W, int K, int PH, int PW, float scale,
+                                            int sample_num, hipStream_t s) {
+  const bool al16 = ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && sample_num == 2 && al16) {
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_bf16_s2<T>, dim3(K), dim3(256), 0, s, (const T*)feat, rois, (T*)out, C, H, W, PH, PW, scale);
+  } else if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
+    hipLaunchKernelGGL((roi_align_fwd_nhwc<T, 8>), dim3(K), dim3(256), 0, s, (const T*)feat, rois, (T*)out, C, H, W, PH, PW, scale, sample_num);
+  } else if (C % 4 == 0 && C / 4 <= 256) {
+    hipLaunchKernelGGL((roi_align_fwd_nhwc<T, 4>), dim3(K), dim3(256), 0, s, (const T*)feat, rois, (T*)out, C, H, W, PH, PW, scale, sample_num);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t run_roi_align_fwd(const void* feat, const float* rois, void* out, int B, int C, int H, int W, int K, int PH,
                              int PW, float scale, int sample_num, int dtype, int layout, hipStream_t s) {
   (void)B;
   if (K == 0) return hipSuccess;
+  if (dtype == DT_F16S) return hipErrorInvalidValue;   // (split-half callers interpolate in f32 and cast)
   if (layout == 1) {
-    if (dtype == DT_BF16) {
-      const bool al16 = ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-      if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && sample_num == 2 && al16) {
-        hipLaunchKernelGGL(roi_align_fwd_nhwc_bf16_s2, dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale);
-      } else if (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) {
-        hipLaunchKernelGGL((roi_align_fwd_nhwc<bf16_t, 8>), dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale, sample_num);
-      } else if (C % 4 == 0 && C / 4 <= 256) {
-        hipLaunchKernelGGL((roi_align_fwd_nhwc<bf16_t, 4>), dim3(K), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, PH, PW, scale, sample_num);
-      } else {
-        return hipErrorInvalidValue;
-      }
-    } else {
-      if (C % 4 != 0 || C / 4 > 256) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((roi_align_fwd_nhwc<float, 4>), dim3(K), dim3(256), 0, s, (const float*)feat, rois, (float*)out, C, H, W, PH, PW, scale, sample_num);
-    }
+    if (dtype == DT_BF16) return launch_roi_align_nhwc_h16<bf16_t>(feat, rois, out, C, H, W, K, PH, PW, scale, sample_num, s);
+    if (dtype == DT_F16) return launch_roi_align_nhwc_h16<f16_t>(feat, rois, out, C, H, W, K, PH, PW, scale, sample_num, s);
+    if (C % 4 != 0 || C / 4 > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((roi_align_fwd_nhwc<float, 4>), dim3(K), dim3(256), 0, s, (const float*)feat, rois, (float*)out, C, H, W, PH, PW, scale, sample_num);
   } else {
     const long total = (long)K * C * PH * PW;
     const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     if (dtype == DT_BF16)
       hipLaunchKernelGGL(roi_align_fwd_nchw<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois, (bf16_t*)out, total, C, H, W, PH, PW, scale, sample_num);
+    else if (dtype == DT_F16)
+      hipLaunchKernelGGL(roi_align_fwd_nchw<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)feat, rois, (f16_t*)out, total, C, H, W, PH, PW, scale, sample_num);
     else
       hipLaunchKernelGGL(roi_align_fwd_nchw<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, (float*)out, total, C, H, W, PH, PW, scale, sample_num);
   }

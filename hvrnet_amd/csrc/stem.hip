@@ -140,7 +140,8 @@ hipError_t run_stem_fused(const float* img, const void* wpk, const float* bias, 
   const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
   const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
   constexpr int lds = ST_PATCH_BYTES + ST_CONV_BYTES;
-  static bool attr = false;
+  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
+  bool& attr = attr_dev[current_device()];
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;

@@ -18,7 +18,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhvr_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hvr_hip.h')
 
-HVR_F32, HVR_BF16 = 0, 1
+HVR_F32, HVR_BF16, HVR_F16, HVR_F16S = 0, 1, 2, 3
+ABI_VERSION = 3
+# Split-half tensors (HVR_F16S, include/hvr_hip.h: [64 hi | 64 lo] half groups, 4 bytes per logical element) travel through
+# torch as int32 tensors of the LOGICAL shape: element size, strides, row / 64-column slicing, cat, clone and zeros all mean
+# the right thing on the container, and nothing but this library ever interprets the bytes.  `SPLIT` is the dtype sentinel
+# (`set_compute_dtype(model, native.SPLIT)`).
+SPLIT = torch.int32
+COMPUTE_DTYPES = (torch.bfloat16, torch.float16, SPLIT, torch.float32)
+DTYPE_NAMES = {torch.bfloat16: 'bf16', torch.float16: 'f16', SPLIT: 'f16x2', torch.float32: 'f32'}
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
 # default operand staging of the MFMA tile engine (0 register-staged, 1 global->LDS DMA)
@@ -162,6 +170,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if handle.hvr_abi_version() != ABI_VERSION:
+            raise HvrError('libhvr_hip.so has ABI version %d, this binding needs %d: rebuild it (hvrnet_amd/csrc/build.sh)'
+                           % (handle.hvr_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
@@ -187,7 +198,11 @@ def _dt(t):
         return HVR_F32
     if t.dtype == torch.bfloat16:
         return HVR_BF16
-    raise HvrError('unsupported tensor dtype %s (float32 / bfloat16 only)' % t.dtype)
+    if t.dtype == torch.float16:
+        return HVR_F16
+    if t.dtype == SPLIT:
+        return HVR_F16S
+    raise HvrError('unsupported tensor dtype %s (float32 / bfloat16 / float16 / the split-half container int32)' % t.dtype)
 
 
 def _need_cuda(*ts):
@@ -270,7 +285,15 @@ def zero_page(device):
 
 
 def kstep(dtype):
-    return 64 if dtype == torch.bfloat16 else 32
+    return 32 if dtype == torch.float32 else 64
+
+
+def as_operand(t, dtype):
+    """An f32 tensor (weights at pack time) in the operand format `dtype`, contiguous."""
+    t = t.contiguous()
+    if dtype == SPLIT:
+        return cast(t.float(), SPLIT)
+    return t.to(dtype)
 
 
 # ----------------------------------------------------------------------------------------
@@ -443,7 +466,8 @@ def conv2d_path(B, H, W, Cin, Cout, k=1, stride=1, pad=0, dil=1, dtype=torch.bfl
     fake = 1 << 20
     d = ConvDesc(x=fake, w=fake, y=fake, B=B, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=stride, pad=pad, dil=dil,
                  bias=fake if bias else None, resid=fake if resid else None, relu=1, out_f32=int(out_f32),
-                 dtype=HVR_BF16 if dtype == torch.bfloat16 else HVR_F32, staging=STAGING, tile_hint=tile, zero=fake)
+                 dtype={torch.bfloat16: HVR_BF16, torch.float16: HVR_F16, SPLIT: HVR_F16S}.get(dtype, HVR_F32), staging=STAGING,
+                 tile_hint=tile, zero=fake)
     return int(lib().hvr_conv2d_path(ctypes.byref(d)))
 
 
@@ -453,9 +477,9 @@ def im2col_stem(img, dtype, kp=192):
     assert img.dtype == torch.float32 and img.is_contiguous()
     B, _, H, W = img.shape
     OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    cols = torch.empty((B * OH * OW, kp), dtype=dtype, device=img.device)
+    cols = torch.empty((B * OH * OW, kp), dtype=torch.float32 if dtype == SPLIT else dtype, device=img.device)
     _check(lib().hvr_im2col_stem(_ptr(img), _ptr(cols), B, H, W, kp, _dt(cols), _stream()), 'hvr_im2col_stem')
-    return cols, OH, OW
+    return (cast(cols, SPLIT) if dtype == SPLIT else cols), OH, OW
 
 
 def stem_fused(img, wpk, bias):
@@ -473,6 +497,8 @@ def stem_fused(img, wpk, bias):
 
 def maxpool3x3s2_nhwc(x):
     _need_cuda(x)
+    if x.dtype == SPLIT:   # pooled in f32 (max does not act per half plane)
+        return cast(maxpool3x3s2_nhwc(cast(x, torch.float32)), SPLIT)
     B, H, W, C = x.shape
     OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
@@ -805,6 +831,8 @@ def det_loss_sampled(logits, cls_off, reg_off, ncls, labels, label_weights, bbox
 def roi_align_fwd(feat, rois, out_h, out_w, spatial_scale, sample_num, layout):
     """layout NCHW: feat [B,C,H,W] -> [K,C,oh,ow]; NHWC: feat [B,H,W,C] -> [K,oh,ow,C] (physical shapes)."""
     _need_cuda(feat, rois)
+    if feat.dtype == SPLIT:   # interpolated in f32, handed back in the split format
+        return cast(roi_align_fwd(cast(feat, torch.float32), rois, out_h, out_w, spatial_scale, sample_num, layout), SPLIT)
     rois = rois.contiguous().float()
     K = rois.shape[0]
     if layout == LAYOUT_NCHW:
@@ -950,6 +978,9 @@ def nchw_to_nhwc(x, dtype=None):
     """[B,C,H,W] contiguous -> physical [B,H,W,C] (optionally casting)."""
     _need_cuda(x)
     x = x.contiguous()
+    if dtype == SPLIT or x.dtype == SPLIT:
+        assert x.dtype != SPLIT, 'split-half tensors are NHWC only'
+        return cast(nchw_to_nhwc(x, torch.float32), SPLIT)
     B, C, H, W = x.shape
     out = torch.empty((B, H, W, C), dtype=dtype or x.dtype, device=x.device)
     _check(lib().hvr_permute_nchw_nhwc(_ptr(x), _ptr(out), B, C, H * W, 1, _dt(x), _dt(out), _stream()), 'hvr_permute')
@@ -960,6 +991,9 @@ def nhwc_to_nchw(x, dtype=None):
     """physical [B,H,W,C] contiguous -> [B,C,H,W] contiguous."""
     _need_cuda(x)
     x = x.contiguous()
+    if x.dtype == SPLIT:
+        x = cast(x, torch.float32)
+    assert dtype != SPLIT, 'split-half tensors are NHWC only'
     B, H, W, C = x.shape
     out = torch.empty((B, C, H, W), dtype=dtype or x.dtype, device=x.device)
     _check(lib().hvr_permute_nchw_nhwc(_ptr(x), _ptr(out), B, C, H * W, 0, _dt(x), _dt(out), _stream()), 'hvr_permute')

@@ -11,8 +11,20 @@
  *   - return 0 on success, a negative HVR_E* code otherwise; hvr_last_error() gives the
  *     message of the calling thread's last failure (the reference printf()s "wrong roi
  *     size" and carries on, roi_align_cuda.cpp:39-42 -- this library never does that);
- *   - dtype: HVR_F32 = 0, HVR_BF16 = 1 (element type of activations / weights; all
- *     accumulation, softmax, box and score arithmetic is f32);
+ *   - dtype: HVR_F32 = 0, HVR_BF16 = 1, HVR_F16 = 2, HVR_F16S = 3 (element type of activations /
+ *     weights; all accumulation, softmax, box and score arithmetic is f32) -- the precision ladder:
+ *       HVR_BF16  bf16 operands, the benchmark dtype BASELINE.json names (v_mfma_f32_16x16x32_bf16);
+ *       HVR_F16   IEEE half operands: the same rate and bytes, 8 x finer mantissa, range 65504;
+ *       HVR_F16S  "split half": a logical element x is stored as hi = half(x), lo = half((x - hi) * 2^11)
+ *                 (22 significant bits) and a product is three half MFMAs -- hi*lo + lo*hi, scaled by 2^-11, + hi*hi --
+ *                 accumulated in f32: f32-grade results at 1/3 of the half MFMA rate.  Memory layout of a row of C
+ *                 elements (C % 64 == 0): C / 64 groups of [64 hi halves][64 lo halves] = 4 bytes per logical element;
+ *                 leading dimensions stay in logical elements, bases are 256-byte aligned, column offsets multiples
+ *                 of 64.  hvr_cast converts to and from it.  Taken by hvr_gemm, hvr_conv2d_nhwc, hvr_relation_fwd,
+ *                 hvr_relation_probs, hvr_transpose_pad and hvr_cast; the other entry points return HVR_EUNSUPPORTED;
+ *       HVR_F32   exact f32 (v_mfma_f32_16x16x4_f32, 1/16 of the half rate): the parity mode.
+ *     The reference computes in f32 (no fp16 key in configs/faster_rcnn_r101_{selsa,hrnmp}_c5.py); its optional
+ *     mixed-precision islands are mmdet/core/fp16/decorators.py:9-160.
  *   - re-entrant, no global mutable state besides one-time kernel attribute setup.
  */
 #ifndef HVR_HIP_H_
@@ -33,11 +45,13 @@ extern "C" {
 
 #define HVR_F32 0
 #define HVR_BF16 1
+#define HVR_F16 2
+#define HVR_F16S 3
 
 #define HVR_LAYOUT_NCHW 0 /* reference layout */
 #define HVR_LAYOUT_NHWC 1 /* native layout of this library */
 
-int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields */
+int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S */
 const char* hvr_last_error(void);
 
 /* ------------------------------------------------------------------------------------
@@ -293,6 +307,8 @@ int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls,
                        void* stream);
 
 /* ---- layout / dtype plumbing at the API boundary ---- */
+/* any pair of the four dtypes; pairs other than f32 <-> bf16 move 8 elements per thread: n % 8 == 0 and 16-byte aligned buffers
+ * (split half: n % 64 == 0 -- a contiguous tensor whose last dimension is a multiple of 64 -- and 256-byte alignment) */
 int hvr_cast(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, void* stream);
 /* to_nhwc != 0: [B][C][HW] -> [B][HW][C]; else the inverse */
 int hvr_permute_nchw_nhwc(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from_dtype,

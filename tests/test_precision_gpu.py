@@ -1,0 +1,209 @@
+"""Kernel-level numerics of the precision ladder between the bf16 benchmark mode and the exact-f32 parity mode
+(include/hvr_hip.h: HVR_F16 = IEEE half operands, HVR_F16S = split half -- three half MFMAs per product), on the GPU,
+against a float64 statement of the same op on the same seeded inputs.  The reference computes in f32 throughout
+(configs/faster_rcnn_r101_hrnmp_c5.py has no fp16 key; mmdet/core/fp16/decorators.py:9-160 are its optional islands).
+
+Tolerances, each stated where it is used:
+  * half: operands are rounded to half before both sides see them, so what is left is the f32 accumulation order and the
+    half rounding of stored outputs (2^-11 relative);
+  * split half: operands carry 22 significant bits (hi + lo * 2^-11), products are exact in the MFMA, sums are f32 --
+    the result tracks the f64 product of the UN-rounded f32 inputs to ~1e-6 of the output scale.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hvrnet_amd import native  # noqa: E402
+
+DEV = 'cuda:0'
+SPLIT = native.SPLIT
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _to(x, dtype):
+    """f32 host tensor -> device operand in `dtype` (split half goes through hvr_cast)."""
+    return native.as_operand(x.to(DEV), dtype)
+
+
+def _back(y):
+    return native.cast(y, torch.float32).cpu() if y.dtype != torch.float32 else y.cpu()
+
+
+def test_split_half_cast_round_trip_keeps_22_bits():
+    """f32 -> split half -> f32: |error| <= 2^-21 |x| for values in the half range, exact zeros stay zero, values beyond
+    65504 saturate (no inf - inf), tiny values keep an absolute error below 2^-35."""
+    x = _rand((37, 192), 1, 3.0)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 1e5, -1e5, 1e-6])
+    x[1, :4] = torch.tensor([6e-5, 3e-8, 1e-9, 1234.5678])
+    s = native.cast(x.to(DEV), SPLIT)
+    assert s.dtype == SPLIT and s.shape == x.shape
+    y = native.cast(s, torch.float32).cpu()
+    ok = x.abs() <= 65504
+    err = (y - x).abs()
+    assert (err[ok] <= x.abs()[ok] * 2.0 ** -21 + 2.0 ** -35).all(), err[ok].max()
+    assert y[0, 0] == 0 and y[0, 1] == 0 and y[0, 2] == 1 and y[0, 3] == -1
+    assert y[0, 5] == 65504 and y[0, 6] == -65504 and torch.isfinite(y).all()
+    # the split form is what a half cast gives for values a half holds exactly
+    h = _rand((8, 64), 2).half().float()
+    assert torch.equal(native.cast(native.cast(h.to(DEV), SPLIT), torch.float32).cpu(), h)
+    # half <-> f32 agree with torch's casts; bf16 <-> half go through f32
+    z = _rand((5, 64), 3, 10.0)
+    assert torch.equal(native.cast(z.to(DEV), torch.float16).cpu(), z.half())
+    assert torch.equal(native.cast(z.half().to(DEV), torch.float32).cpu(), z.half().float())
+    assert torch.equal(native.cast(z.bfloat16().to(DEV), torch.float16).cpu(), z.bfloat16().float().half())
+    with pytest.raises(native.HvrError):
+        native.cast(torch.zeros((3, 40), device=DEV), SPLIT)   # rows must be whole 64-element groups
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize('dtype', [torch.float16, SPLIT])
+def test_every_tile_shape_on_half_and_split_operands(dtype, tile):
+    """hvr_gemm on half / split-half operands through every tile shape of the engine (hint 0 = the cost model's pick; the
+    pipelined 3 / 4-stage shapes walk the split K loop's three passes through the same LDS ring): bias + residual + ReLU,
+    against float64.  Ragged M and N."""
+    M, N, K = 300, 328, 1024
+    a, w, bias, resid = _rand((M, K), 11), _rand((N, K), 12, 0.05), _rand((N,), 13), _rand((M, 384), 14)
+    ad, wd, rd = _to(a, dtype), _to(w, dtype), _to(resid, dtype)
+    af, wf, rf = _back(ad).double(), _back(wd).double(), _back(rd).double()[:, :N]
+    ref = torch.relu(af @ wf.t() + bias.double() + rf)
+    out = torch.zeros((M, 384), dtype=dtype, device=DEV)
+    # N = 328 is not a whole number of 64-column groups: split half takes N % 8 == 0 outputs inside a wider (ldc % 64 == 0) matrix
+    y = native.gemm(ad, wd, bias.to(DEV), rd[:, :N], relu=True, tile=tile, out=out[:, :N])
+    scale = ref.abs().max().item()
+    err = (_back(out)[:, :N].double() - ref).abs().max().item()
+    if dtype == SPLIT:
+        # operands: 2^-21 relative each (already inside af / wf), accumulation in f32 over K = 1024, output split again
+        assert err < 3e-6 * scale, (err, scale)
+        # and against the UN-rounded f32 inputs: f32-grade
+        ref32 = torch.relu(a.double() @ w.double().t() + bias.double() + resid.double()[:, :N])
+        assert (_back(out)[:, :N].double() - ref32).abs().max().item() < 5e-6 * scale
+    else:
+        assert err < 2.0 ** -10 * scale, (err, scale)          # one half rounding of the output
+    assert y.data_ptr() == out.data_ptr()
+    assert (_back(out)[:, N:] == 0).all()                        # columns beyond N untouched
+    # f32 output of the same product: no output rounding at all
+    y32 = native.gemm(ad, wd, out_f32=True, tile=tile)
+    assert y32.dtype == torch.float32
+    e32 = (y32.cpu().double() - af @ wf.t()).abs().max().item()
+    assert e32 < 2e-6 * scale, (e32, scale)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, SPLIT])
+@pytest.mark.parametrize('cfg', [
+    dict(Cin=64, Cout=64, k=3, stride=1, pad=1, dil=1, H=19, W=23),
+    dict(Cin=128, Cout=128, k=3, stride=1, pad=2, dil=2, H=17, W=21),   # res5-style dilation
+    dict(Cin=256, Cout=128, k=1, stride=2, pad=0, dil=1, H=20, W=31),   # caffe-style strided 1x1
+    dict(Cin=64, Cout=256, k=1, stride=1, pad=0, dil=1, H=9, W=14),
+    dict(Cin=256, Cout=256, k=3, stride=1, pad=1, dil=1, H=38, W=63),   # layer 3's 3x3 at window size (pipelined shapes)
+])
+def test_conv_on_half_and_split_operands(cfg, dtype):
+    """hvr_conv2d_nhwc (implicit GEMM: the filter-tap gather, hardware zero fill of padding taps, strides, dilation) with
+    bias + residual + ReLU on half / split-half maps against float64 conv2d of the operands as the kernel sees them."""
+    B = 2
+    x = _rand((B, cfg['Cin'], cfg['H'], cfg['W']), 21)
+    w = _rand((cfg['Cout'], cfg['Cin'], cfg['k'], cfg['k']), 22, 0.05)
+    bias = _rand((cfg['Cout'],), 23)
+    xn, wn = _to(x.permute(0, 2, 3, 1), dtype), _to(w.permute(0, 2, 3, 1), dtype)
+    xf, wf = _back(xn).permute(0, 3, 1, 2).double(), _back(wn).permute(0, 3, 1, 2).double()
+    ref = F.conv2d(xf, wf, bias.double(), stride=cfg['stride'], padding=cfg['pad'], dilation=cfg['dil'])
+    resid = _rand(tuple(ref.shape), 24)
+    rn = _to(resid.permute(0, 2, 3, 1), dtype)
+    ref = torch.relu(ref + _back(rn).permute(0, 3, 1, 2).double())
+    y = native.conv2d_nhwc(xn, wn, bias.to(DEV), rn, relu=True, stride=cfg['stride'], pad=cfg['pad'], dil=cfg['dil'])
+    assert y.dtype == dtype and tuple(y.shape) == (B, ref.shape[2], ref.shape[3], cfg['Cout'])
+    scale = ref.abs().max().item()
+    err = (_back(y).permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err < (3e-6 if dtype == SPLIT else 2.0 ** -10) * scale, (err, scale)
+    y32 = native.conv2d_nhwc(xn, wn, bias.to(DEV), None, relu=False, stride=cfg['stride'], pad=cfg['pad'], dil=cfg['dil'], out_f32=True)
+    ref32 = F.conv2d(xf, wf, bias.double(), stride=cfg['stride'], padding=cfg['pad'], dilation=cfg['dil'])
+    assert (y32.cpu().permute(0, 3, 1, 2).double() - ref32).abs().max().item() < 2e-6 * scale
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, SPLIT])
+@pytest.mark.parametrize('Mq,Mk', [(300, 300), (96, 1500), (300, 4500), (1100, 1100)])
+def test_relation_on_half_and_split_operands(Mq, Mk, dtype):
+    """hvr_relation_fwd = softmax(q k^T / sqrt(D)) v (selsa_bbox_head.py:166-182) on half / split-half operands against
+    float64 attention over the operands as the kernel sees them.  Split half: the scores pass writes the block-relative
+    exponentials in the split format, one sweep normalises them, O = P V is a plain three-pass product."""
+    D = 1024
+    q, k, v = _rand((Mq, D), 31, 0.5), _rand((Mk, D), 32, 0.5), _rand((Mk, D), 33)
+    qd, kd, vd = _to(q, dtype), _to(k, dtype), _to(v, dtype)
+    qf, kf, vf = _back(qd).double(), _back(kd).double(), _back(vd).double()
+    ref = torch.softmax(qf @ kf.t() / math.sqrt(D), dim=1) @ vf
+    o = native.relation_fwd(qd, kd, vd, 1.0 / math.sqrt(D))
+    assert o.dtype == dtype
+    scale = ref.abs().max().item()
+    err = (_back(o).double() - ref).abs().max().item()
+    # half: P~ is rounded to half (2^-11 relative per probability, averaged over the keys) and so is the output
+    assert err < (1e-5 if dtype == SPLIT else 2e-3) * scale, (err, scale)
+
+
+def test_relation_split_half_peaky_rows():
+    """One key dominates a row by e^40 and sits in a different 128-key block than the runner-up (block maxima differ by far
+    more than the half range of exp2): the normalising sweep works from the f32 block statistics."""
+    D, Mq, Mk = 1024, 64, 700
+    q, k, v = _rand((Mq, D), 41, 0.2), _rand((Mk, D), 42, 0.2), _rand((Mk, D), 43)
+    k[5] = q[3] * 40.0
+    k[600] = q[3] * 39.0
+    qd, kd, vd = _to(q, SPLIT), _to(k, SPLIT), _to(v, SPLIT)
+    qf, kf, vf = _back(qd).double(), _back(kd).double(), _back(vd).double()
+    ref = torch.softmax(qf @ kf.t() / math.sqrt(D), dim=1) @ vf
+    o = _back(native.relation_fwd(qd, kd, vd, 1.0 / math.sqrt(D))).double()
+    assert torch.isfinite(o).all()
+    assert (o - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('R,C', [(300, 1024), (4500, 1024), (65, 64)])
+def test_transpose_pad_split_half_is_exact(R, C):
+    x = _rand((R, C), 51)
+    xs = native.cast(x.to(DEV), SPLIT)
+    ldt = (R + 127) // 128 * 128
+    t = native.transpose_pad(xs, ldt)
+    assert t.dtype == SPLIT and tuple(t.shape) == (C, ldt)
+    back = native.cast(t, torch.float32).cpu()
+    assert torch.equal(back[:, :R], native.cast(xs, torch.float32).cpu().t())
+    assert (back[:, R:] == 0).all()
+
+
+def test_roi_align_and_pooling_on_half_and_split_maps():
+    """RoIAlign (roi_align_kernel.cu:63-141) on half maps uses the bf16 kernels' gathers with half unpacking; split-half maps
+    are interpolated in f32 and handed back in the split format: both against the f32 kernel on the same (rounded) map."""
+    B, H, W, C = 3, 38, 63, 256
+    feat = _rand((B, H, W, C), 61)
+    g = torch.Generator().manual_seed(62)
+    K = 200
+    x1, y1 = torch.rand(K, generator=g) * 900, torch.rand(K, generator=g) * 500
+    rois = torch.stack([torch.randint(0, B, (K,), generator=g).float(), x1, y1, x1 + torch.rand(K, generator=g) * 300 + 4,
+                        y1 + torch.rand(K, generator=g) * 200 + 4], 1)
+    for dtype, tol in ((torch.float16, 2.0 ** -10), (SPLIT, 1e-6)):
+        fd = _to(feat, dtype)
+        want = native.roi_align_fwd(native.cast(fd, torch.float32), rois.to(DEV), 7, 7, 1 / 16.0, 2, native.LAYOUT_NHWC).cpu()
+        got = native.roi_align_fwd(fd, rois.to(DEV), 7, 7, 1 / 16.0, 2, native.LAYOUT_NHWC)
+        assert got.dtype == dtype and tuple(got.shape) == (K, 7, 7, C)
+        assert (_back(got) - want).abs().max().item() <= tol * want.abs().max().item()
+    x = _rand((2, 21, 33, 64), 63)
+    want = native.maxpool3x3s2_nhwc(x.to(DEV)).cpu()
+    for dtype in (torch.float16, SPLIT):
+        xd = _to(x, dtype)
+        got = native.maxpool3x3s2_nhwc(xd)
+        assert got.dtype == dtype
+        assert torch.equal(_back(got), native.maxpool3x3s2_nhwc(native.cast(xd, torch.float32)).cpu())
+        assert (_back(got) - want).abs().max().item() <= 2.0 ** -10 * want.abs().max().item()
+
+
+def test_split_half_rejects_what_it_cannot_address():
+    a = native.cast(torch.zeros((64, 128), device=DEV), SPLIT)
+    w = native.cast(torch.zeros((64, 128), device=DEV), SPLIT)
+    with pytest.raises(native.HvrError):     # a column slice that does not start on a 64-element group
+        native.gemm(a[:, 32:96], w[:, :64])
+    out = torch.zeros((64, 100), dtype=SPLIT, device=DEV)
+    with pytest.raises(native.HvrError):     # output rows must be whole groups
+        native.gemm(a, w, out=out[:, :64])

@@ -47,7 +47,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TF = {'bf16': 2500.0, 'f32': 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md; split half (f16x2) spends three half MFMAs per product, so the
+# algorithmic flops it can deliver peak at a third of the half rate
+MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f16x2': 2500.0 / 3.0, 'f32': 157.3}
+MODE_WHAT = {
+    'bf16': 'bf16 operands (v_mfma_f32_16x16x32_bf16), f32 accumulation / softmax / box arithmetic: the benchmark dtype BASELINE.json names',
+    'f16': 'IEEE half operands (v_mfma_f32_16x16x32_f16) on the tile engine: the bf16 rate, 8 x finer mantissa',
+    'f16x2': 'split half: every operand as hi + lo * 2^-11 halves (22 bits), three half MFMAs per product, f32 accumulation',
+    'f32': 'f32 operands on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the half rate)'}
 HBM_PEAK_GBS = 8000.0
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7           # per GPU, SURVEY.md section 5
 # trainable f32 parameters whose gradients one training step exchanges (176 MB HVR / 271 MB SELSA)
@@ -60,12 +67,17 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--head', default='hvr', choices=['hvr', 'selsa'])
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f16x2', 'f32'], help='compute mode of the headline region')
+    ap.add_argument('--ladder', default='f16,f16x2,f32',
+                    help='other compute modes timed after the headline (eager single lane with the relation launches tagged + the '
+                         'headline\'s graph replay), each with its detections compared with the CPU oracle: the `precision_ladder` table')
+    ap.add_argument('--repeats', type=int, default=5, help='the headline region (K steps) is timed this many times: value = the median, '
+                                                           '`value_spread` lists all of them')
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--proposals', type=int, default=300)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle leg (and with it the `parity` object)')
     ap.add_argument('--quick', action='store_true', help='cpu_baseline on a 3-frame sample (scaled) instead of whole windows')
-    ap.add_argument('--no-f32-leg', action='store_true', help='skip the f32 parity-mode timing')
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the precision ladder (the other compute modes\' timings)')
     ap.add_argument('--no-train-step', action='store_true', help='skip the training-step side measurement (tools/train_bench.py)')
     ap.add_argument('--no-side-loops', action='store_true', help='skip ref_loop / cached_loop / two_in_flight (profiling runs)')
     ap.add_argument('--no-graphs', action='store_true', help='skip the hipGraph legs (graphed_clip / graphed_stream)')
@@ -216,6 +228,16 @@ def parity_object(head, dtype_name, got, want):
                              max_box_err=round(tr['max_box_err'], 4)))
 
 
+def same_detections(a, b):
+    """Two results of the same window (per-class [k,5] arrays, one list per branch for the HVR head): every array equal bit for bit."""
+    import numpy as np
+
+    def flat(r):
+        return [np.asarray(x) for br in (r if isinstance(r[0], (list, tuple)) else [r]) for x in br]
+    fa, fb = flat(a), flat(b)
+    return bool(len(fa) == len(fb) and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(fa, fb)))
+
+
 def train_step_side_measurement(head):
     """configs[4] beside the headline, never as `value`: one training iteration of the same detector family (HNMBRCNN: 5 videos x 3
     frames in, 3 chosen; SelsaRCNN: 1 key + 2 reference frames) at 600x1000 / 300 proposals, bf16 operands with f32 master weights,
@@ -354,7 +376,8 @@ def main(argv=None):
 
     T, n_prop = args.frames, args.proposals
     assert T % 2 == 1
-    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    MODES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16x2': native.SPLIT, 'f32': torch.float32}
+    dt = MODES[args.dtype]
     cfg = (hvr_config if args.head == 'hvr' else selsa_config)(frame_interval=T // 2, nms_post=n_prop)
     sd = S.synth_state_dict(args.head)
     model = hvrnet_amd.build_model(cfg, sd, dt, dev)
@@ -388,6 +411,16 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def over_ranks(seconds):
+        """-> (max over ranks, every rank's own time)"""
+        if world == 1:
+            return seconds, [seconds]
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([seconds], dtype=torch.float64, device=dev))
+        return float(t.item()), [float(x.item()) for x in allt]
+
     def timed(steps, warmup, tags=None):
         pend = None
         for _ in range(warmup):
@@ -407,21 +440,15 @@ def main(argv=None):
         spans = native.profile_end() if tags else None
         return el, res, spans
 
-    mine, res, rel = timed(args.steps, args.warmup, tags=('relation_full', 'relation_key'))
-    single_lane = dict(frames_per_s_per_gpu=round(args.steps / mine, 3), ms_per_step=round(mine / args.steps * 1e3, 3), steps=args.steps,
-                       what='eager launches, one window in flight per GPU (the round-1 headline loop): the region the roofline '
-                            'HIP events are taken in')
-    headline_mode = 'eager launches, %d window(s) in flight' % max(1, args.inflight)
-    n_lanes = max(1, args.inflight)
-    if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
-        # ---- headline region: K windows replayed from hipGraphs on `lanes` HIP streams in turn ----
+    def graph_regions(n_lanes, steps, warmup, repeats):
+        """K windows replayed from hipGraphs (one graph per window, captured in the model's current compute mode) on n_lanes
+        HIP streams in turn, the region timed `repeats` times -> ([seconds per region], last result)."""
         from hvrnet_amd.graphs import GraphedClip
-        n_lanes = args.lanes
         lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
         gcs = []
         for st in lane_streams:
             with torch.cuda.stream(st):
-                gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1, throughput=True))
+                gcs.append(GraphedClip(model, frames, metas, rescale=True, n_out=1, throughput=n_lanes > 1))
         pend_l = [None] * n_lanes
 
         def replay(i):
@@ -439,37 +466,95 @@ def main(argv=None):
                     pend_l[k] = None
             return last
 
-        for i in range(max(args.warmup, n_lanes)):
+        for i in range(max(warmup, n_lanes)):
             replay(i)
         drain()
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            replay(i)
-        res = drain()
-        sync()
-        mine = time.perf_counter() - t0
-        headline_mode = 'hipGraph replay (one graph per window), %d windows in flight on %d HIP streams' % (n_lanes, n_lanes)
+        times, last = [], None
+        for _ in range(repeats):
+            sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                replay(i)
+            last = drain()
+            sync()
+            times.append(time.perf_counter() - t0)
         del gcs
-    elapsed, per_rank = mine, [mine]
-    if world > 1:
-        t = torch.tensor([mine], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(allt, torch.tensor([mine], dtype=torch.float64, device=dev))
-        per_rank = [float(x.item()) for x in allt]
+        return times, last
 
-    # ---- the same window in the f32 compute mode (exact-f32 MFMA): the mode whose outputs meet north_star's 1e-3 ----
-    f32_leg = res_f32 = None
-    if args.dtype == 'bf16' and not args.no_f32_leg and world == 1:
-        hvrnet_amd.set_compute_dtype(model, torch.float32)
-        n32 = max(2, min(args.steps, 5))
-        el32, res_f32, _ = timed(n32, 1)
-        f32_leg = dict(frames_per_s=round(n32 / el32, 3), ms_per_step=round(el32 / n32 * 1e3, 3), steps=n32, dtype='f32',
-                       what='the same clip-mode window with f32 operands on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 '
-                            'rate): the compute mode whose detections match the CPU reference path to 1e-3')
+    def roofline_of(mode, rel_spans, where):
+        full = (rel_spans or {}).get('relation_full', dict(calls=0, ms=0.0, work=0.0))
+        if not full['calls']:
+            return None
+        peak = MFMA_PEAK_TF[mode]
+        ach = full['work'] / (full['ms'] * 1e-3) / 1e12
+        traffic, traffic_src = (relation_traffic() if T * n_prop == 4500 and mode == 'bf16' else (None, 'collected for the 4500-row bf16 problem only'))
+        return dict(kernel='relation core (the launches of hvr_relation_fwd), Mq=Mk=%d D=1024, %s operands' % (T * n_prop, mode), bound='mfma',
+                    achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
+                    traffic_source=traffic_src, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
+                    flops_per_launch=full['work'] / full['calls'],
+                    peak_note=dict(bf16='dense bf16 MFMA', f16='dense half MFMA', f32='exact-f32 MFMA (16x16x4)',
+                                   f16x2='dense half MFMA / 3: three MFMAs (hi*lo, lo*hi, hi*hi) per algorithmic product')[mode],
+                    measured_over=where)
+
+    median = lambda xs: sorted(xs)[len(xs) // 2]   # noqa: E731
+    where_eager = ('the eager single-lane region (`single_lane`, the same K windows): HIP events on the launch stream around every '
+                   'hvr_relation_fwd call; a graph replay has no place for them, and with two windows sharing the chip an interval is '
+                   'not the kernel\'s own duration')
+    # ---- region (1): the eager single-lane loop, relation launches tagged; timed `repeats` times (at least 3) ----
+    sl_times, rel = [], {}
+    for r in range(max(1, min(args.repeats, 3))):
+        el, res, spans = timed(args.steps, args.warmup if r == 0 else 1, tags=('relation_full', 'relation_key'))
+        sl_times.append(el)
+        for tag, d in spans.items():
+            e = rel.setdefault(tag, dict(calls=0, ms=0.0, work=0.0))
+            e['calls'] += d['calls']; e['ms'] += d['ms']; e['work'] += d['work']
+    mine = median(sl_times)
+    single_lane = dict(frames_per_s_per_gpu=round(args.steps / mine, 3), ms_per_step=round(mine / args.steps * 1e3, 3), steps=args.steps,
+                       regions=[round(args.steps / t_, 2) for t_ in sl_times],
+                       what='eager launches, one window in flight per GPU (the round-1 headline loop), the region timed %d times (median '
+                            'reported): the region the roofline HIP events are taken in' % len(sl_times))
+    headline_mode = 'eager launches, %d window(s) in flight' % max(1, args.inflight)
+    n_lanes = max(1, args.inflight)
+    region_times = sl_times
+    if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
+        # ---- headline region: K windows replayed from hipGraphs on `lanes` HIP streams in turn, timed `repeats` times ----
+        n_lanes = args.lanes
+        region_times, res = graph_regions(n_lanes, args.steps, args.warmup, max(1, args.repeats))
+        headline_mode = 'hipGraph replay (one graph per window), %d windows in flight on %d HIP streams' % (n_lanes, n_lanes)
+    # per region the slowest rank counts; the reported region is the median one
+    per_region = [over_ranks(t_) for t_ in region_times]
+    order = sorted(range(len(per_region)), key=lambda i: per_region[i][0])
+    elapsed, per_rank = per_region[order[len(order) // 2]]
+    value_spread = dict(regions=len(per_region), frames_per_s=[round(world * args.steps / t_[0], 2) for t_ in per_region],
+                        min=round(world * args.steps / max(t_[0] for t_ in per_region), 2),
+                        max=round(world * args.steps / min(t_[0] for t_ in per_region), 2),
+                        rel_spread=round((max(t_[0] for t_ in per_region) - min(t_[0] for t_ in per_region)) / elapsed, 4),
+                        what='the headline region (K = %d steps, barrier + synchronize on both sides) timed %d times back to back; '
+                             '`value` / `ms_per_step` are the median region' % (args.steps, len(per_region)))
+
+    # ---- the precision ladder: the same window in the other compute modes (rank 0, N = 1) ----
+    ladder = {}
+    if not args.no_f32_leg and world == 1:
+        for mode in [m for m in args.ladder.split(',') if m and m != args.dtype]:
+            hvrnet_amd.set_compute_dtype(model, MODES[mode])
+            n_m = max(2, min(args.steps, 5 if mode == 'f32' else 10))
+            el_m, res_m, spans_m = timed(n_m, 1, tags=('relation_full', 'relation_key'))
+            row = dict(dtype=mode, what=MODE_WHAT[mode], single_lane=dict(frames_per_s=round(n_m / el_m, 3), ms_per_step=round(el_m / n_m * 1e3, 3), steps=n_m),
+                       roofline=roofline_of(mode, spans_m, 'the eager single-lane windows of this mode'))
+            if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
+                tg, res_g = graph_regions(args.lanes, n_m, 2, 1)
+                row['graph_replay'] = dict(frames_per_s=round(n_m / tg[0], 3), ms_per_step=round(tg[0] / n_m * 1e3, 3), steps=n_m, lanes=args.lanes,
+                                           what='the headline\'s launch mode: hipGraph replay, %d windows in flight' % args.lanes)
+                row['_res'] = res_g
+            else:
+                row['_res'] = res_m
+            ladder[mode] = row
         hvrnet_amd.set_compute_dtype(model, dt)
+    f32_leg = None
+    if 'f32' in ladder:
+        f32_leg = dict(frames_per_s=ladder['f32']['single_lane']['frames_per_s'], ms_per_step=ladder['f32']['single_lane']['ms_per_step'],
+                       steps=ladder['f32']['single_lane']['steps'], dtype='f32', roofline=ladder['f32']['roofline'],
+                       what='the same clip-mode window with f32 operands on the exact-f32 MFMA (eager, one lane): see precision_ladder')
 
     ref_loop_fps = cached_loop_fps = overlap2_fps = None
     n_loop = max(3, min(args.steps, 10))
@@ -546,8 +631,7 @@ def main(argv=None):
         sync()
         el = time.perf_counter() - tg
         graphed_clip = dict(frames_per_s_per_gpu=round(ng / el, 3), ms_per_step=round(el / ng * 1e3, 3), steps=ng,
-                            same_detections=bool(all(len(a) == len(b) for a, b in zip(res_graph[-1] if args.head == 'hvr' else res_graph,
-                                                                                      res[-1] if args.head == 'hvr' else res))),
+                            same_detections=same_detections(res_graph, res),
                             what='the headline window (clip mode, all T frames) replayed as ONE hipGraph per window, two graphs in turn '
                                  'so that window i + 1 is enqueued before window i is read')
         del gc
@@ -647,20 +731,8 @@ def main(argv=None):
     if rank == 0:
         branch = res[-1] if args.head == 'hvr' else res
         n_det = int(sum(len(r) for r in branch))
-        full = rel.get('relation_full', dict(calls=0, ms=0.0, work=0.0))
         peak = MFMA_PEAK_TF[args.dtype]
-        roofline = None
-        traffic, traffic_src = (relation_traffic() if T * n_prop == 4500 and args.dtype == 'bf16'
-                                else (None, 'collected for the 4500-row bf16 problem only'))
-        if full['calls']:
-            ach = full['work'] / (full['ms'] * 1e-3) / 1e12
-            roofline = dict(kernel='relation core (the launches of hvr_relation_fwd: scores + apply), Mq=Mk=%d D=1024' % (T * n_prop), bound='mfma',
-                            achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
-                            traffic_source=traffic_src, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
-                            flops_per_launch=full['work'] / full['calls'],
-                            measured_over='the eager single-lane region (`single_lane`, the same K windows): HIP events on the launch '
-                                          'stream around every hvr_relation_fwd call; a graph replay has no place for them, and with two '
-                                          'windows sharing the chip an interval is not the kernel\'s own duration')
+        roofline = roofline_of(args.dtype, rel, where_eager)
         kc = {}
         for tag, d in classes.items():
             e = dict(calls=d['calls'], ms=round(d['ms'], 4))
@@ -681,7 +753,7 @@ def main(argv=None):
                                mode='clip (all T frames through backbone+res5+RPN+RoIAlign+head every step)',
                                parallelism='dp%d independent clips, no collectives' % world, windows_in_flight=n_lanes, launch=headline_mode,
                                key_frame_detections=n_det),
-                   roofline=roofline, kernel_classes=kc, gpus_requested=args.gpus,
+                   value_spread=value_spread, roofline=roofline, kernel_classes=kc, gpus_requested=args.gpus,
                    per_rank=[dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)],
                    rccl_world_size=(dist.get_world_size() if world > 1 else 1))
         out['single_lane'] = single_lane
@@ -706,6 +778,11 @@ def main(argv=None):
             out['graphed_clip'] = graphed_clip
             out['graphed_stream'] = graphed_stream
         if ar is not None:
+            # what the first real multi-GPU training run should see: the HVR step is ~21.9 ms on one GPU (profiles/r02_train_bench_hvr.json)
+            step_ms = 21.9 if args.head == 'hvr' else 17.8
+            ar['expected_share_of_train_step'] = dict(step_ms_one_gpu=step_ms, measured_allreduce_ms=ar['ms'],
+                                                      share_if_not_overlapped=round(ar['ms'] / (step_ms + ar['ms']), 4),
+                                                      est_ring_share=round(ar['est_ring_one_link_ms'] / (step_ms + ar['est_ring_one_link_ms']), 4))
             out['train_allreduce'] = ar
         if world == 1 and not args.no_cpu_baseline:
             if args.quick:
@@ -714,8 +791,34 @@ def main(argv=None):
                 out['cpu_baseline'], want = cpu_baseline_full(args.head, T, n_prop, sd, frame_ids)
             if want is not None:
                 out['parity'] = parity_object(args.head, args.dtype, res, want)
-                if res_f32 is not None:
-                    out['f32_parity_mode']['parity'] = parity_object(args.head, 'f32', res_f32, want)
+                for row in ladder.values():
+                    row['parity'] = parity_object(args.head, row['dtype'], row['_res'], want)
+                if f32_leg is not None:
+                    out['f32_parity_mode']['parity'] = ladder['f32']['parity']
+        # the precision ladder: every compute mode's throughput next to how far its detections are from the CPU reference path
+        # (north_star: class indices exact, scores / boxes within 1e-3)
+        if ladder or 'parity' in out:
+            head_row = dict(dtype=args.dtype, what=MODE_WHAT[args.dtype], single_lane=dict(frames_per_s=single_lane['frames_per_s_per_gpu'],
+                                                                                          ms_per_step=single_lane['ms_per_step'], steps=args.steps),
+                            roofline=roofline, headline=True)
+            if headline_mode.startswith('hipGraph'):
+                head_row['graph_replay'] = dict(frames_per_s=out['value'], ms_per_step=out['ms_per_step'], steps=args.steps, lanes=n_lanes)
+            if 'parity' in out:
+                head_row['parity'] = out['parity']
+            rows = [head_row] + [{k: v for k, v in row.items() if k != '_res'} for row in ladder.values()]
+            for row in rows:
+                pr = row.get('parity')
+                if pr is not None:
+                    row['meets_north_star_tolerance'] = bool(pr['class_flips'] == 0 and pr['max_score_err'] < 1e-3 and pr['max_box_err'] < 1e-3 + 1e-5 * 1000.0)
+            out['precision_ladder'] = dict(
+                tolerance='north_star: class indices exact (class_flips = 0), scores within 1e-3, box coordinates within 1e-3 px (+ 1e-5 '
+                          'relative: the f32 ulp at 1000 px is 6e-5) of oracle.clip_forward on the same frames, final branch',
+                rows=rows)
+            ok = [r for r in rows if r.get('meets_north_star_tolerance')]
+            if ok:
+                best = max(ok, key=lambda r: (r.get('graph_replay') or r['single_lane'])['frames_per_s'])
+                out['precision_ladder']['fastest_mode_within_tolerance'] = dict(dtype=best['dtype'],
+                                                                                frames_per_s=(best.get('graph_replay') or best['single_lane'])['frames_per_s'])
         if world == 1 and not args.no_train_step:
             ts = train_step_side_measurement(args.head)
             if ts is not None:

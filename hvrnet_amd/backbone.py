@@ -62,6 +62,9 @@ class PackedMixin(object):
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_packed())
 
     def _drop_packed(self):
+        if self._packed is not None:
+            from . import graphs   # captured hipGraphs read the packed buffers by address: they must not replay after this
+            graphs.invalidate_all('packed weights of %s were rebuilt' % type(self).__name__)
         self._packed = None
         self._packed_ready = None
 

@@ -19,9 +19,28 @@ torch.cuda.CUDAGraph is the capture mechanism (hipStreamBeginCapture / hipGraphL
 build's own, launched through the C ABI on the capturing streams.  Results are identical to the eager path (same kernels,
 same order per stream): tests/test_graphs_gpu.py.
 """
+import weakref
+
 import torch
 
 from .box_ops import bbox2result
+
+# Captured graphs hold raw device pointers: of the packed weights (PackedMixin.packed) and of the per-stream scratch buffers
+# (native._workspace).  native._workspace keeps every buffer it handed out during a capture alive for the life of the process;
+# packed weights are rebuilt by load_state_dict / set_compute_dtype / an optimizer step -- when that happens while graphs are
+# alive, the graphs are marked stale here and refuse to replay (PackedMixin._drop_packed -> invalidate_all).
+_LIVE = weakref.WeakSet()
+
+
+def invalidate_all(reason):
+    for g in list(_LIVE):
+        g._stale = reason
+
+
+def _check_live(g):
+    if g._stale is not None:
+        raise RuntimeError('this captured graph reads buffers that were freed after its capture (%s): build a new %s'
+                           % (g._stale, type(g).__name__))
 
 
 class _HostOut(object):
@@ -47,6 +66,10 @@ class PendingGraphWindow(object):
     def __init__(self, owner, out, event, exact):
         self._owner, self._out, self._event, self._exact, self._result = owner, out, event, exact, None
         self.respeculated = False
+
+    @property
+    def read(self):
+        return self._result is not None
 
     def result(self):
         if self._result is None:
@@ -87,6 +110,7 @@ class GraphedClip(object):
         self.frames = frames.clone()
         self._num_classes = model.bbox_head.num_classes
         self._single = type(model).__name__ == 'SelsaRCNN'
+        self._stale, self._unread = None, {}
         dev = frames.device
         self._stream = torch.cuda.Stream(device=dev)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
@@ -108,6 +132,7 @@ class GraphedClip(object):
                 self._graphs.append(graph)
                 self._outs.append(outs)
         torch.cuda.current_stream(dev).wait_stream(self._stream)
+        _LIVE.add(self)
 
     def _enqueue(self):
         from . import native
@@ -133,6 +158,11 @@ class GraphedClip(object):
             self._generation += 1
         gen = self._generation
         k = self._turn % len(self._graphs)
+        _check_live(self)
+        # graph k's pinned output buffers are about to be overwritten: its previous replay must have been read
+        if any(not p_.read for p_ in self._unread.get(k, ())):
+            raise RuntimeError('replaying output slot %d of %d before result() of its previous window was called (n_out = %d graphs allow '
+                               '%d unread windows)' % (k, len(self._graphs), len(self._graphs), len(self._graphs) - 1))
         self._turn += 1
         self._graphs[k].replay()
         ev = torch.cuda.Event()
@@ -146,6 +176,7 @@ class GraphedClip(object):
                 return self._exact(w)
             return go
         pend = [PendingGraphWindow(self, self._outs[k][w], ev, exact(w)) for w in range(self.windows)]
+        self._unread[k] = pend
         return pend[0] if self.windows == 1 else pend
 
 
@@ -176,10 +207,18 @@ class GraphedStream(object):
         self.frame = frame.clone()
         self._num_classes = model.bbox_head.num_classes
         self._single = type(model).__name__ == 'SelsaRCNN'
+        self._stale, self._unread = None, {}
         self._stream = torch.cuda.Stream(device=dev)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         T = self.T
         with torch.no_grad(), torch.cuda.stream(self._stream):
+            if self.lookahead > 1:
+                # the LARGEST shapes first: the look-ahead batch sizes this stream's scratch buffers (native._workspace regrows a
+                # buffer by replacing it) before any graph captures their addresses
+                self.batch = self.frame.new_zeros((self.lookahead,) + tuple(self.frame.shape[1:]))
+                for _ in range(max(1, warmup)):
+                    c4 = self.model(img=self.batch, img_meta=[self.meta] * self.lookahead, backbone_feat=True)[0]
+                    self.model.frames_tensors(c4, [self.meta] * self.lookahead)
             e = None
             for _ in range(max(1, warmup)):
                 e = self._frame_entry()
@@ -214,7 +253,6 @@ class GraphedStream(object):
             self.graph_fb, self._stage_graphs = None, []
             if self.lookahead > 1:
                 B = self.lookahead
-                self.batch = self.frame.new_zeros((B,) + tuple(self.frame.shape[1:]))
                 metas = [self.meta] * B
                 for _ in range(max(1, warmup)):
                     c4 = self.model(img=self.batch, img_meta=metas, backbone_feat=True)[0]
@@ -274,6 +312,7 @@ class GraphedStream(object):
         self._ev_fc, self._ev_commit, self._pending_frame = torch.cuda.Event(), None, None
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._hist = []  # the window's input frames (copies), for the exact re-run of a window that holds a short frame
+        _LIVE.add(self)
 
     # ---- pieces (each runs eagerly during warm-up and inside a capture afterwards) ----
     def _frame_entry(self, frame=None):
@@ -303,6 +342,9 @@ class GraphedStream(object):
         return m.head_device_outputs(self.f1, cur_range, key_rois, self.counts, self.meta, rescale=self.rescale)
 
     def _exact(self, hist):
+        if len(hist) != self.T:
+            raise RuntimeError('a window that holds a short frame is re-run from its %d input frames, but only %d have been pushed since '
+                               'this object was built' % (self.T, len(hist)))
         with torch.no_grad():
             frames = torch.cat(hist, 0)
             metas = [self.meta] * frames.shape[0]
@@ -314,6 +356,7 @@ class GraphedStream(object):
         """A new frame arrives: graph F (its rows enter the window buffers)."""
         if frame is not None:
             self.frame.copy_(frame, non_blocking=True)
+        _check_live(self)
         self.graph_f.replay()
         self._hist = (self._hist + [self.frame.clone()])[-self.T:]
 
@@ -325,6 +368,7 @@ class GraphedStream(object):
         self._fstream.wait_stream(cur)                 # `frame` is produced on the caller's stream
         if self._ev_commit is not None:
             self._fstream.wait_event(self._ev_commit)  # the staging rows of the previous frame have been taken
+        _check_live(self)
         with torch.cuda.stream(self._fstream):
             self.frame_nxt.copy_(frame, non_blocking=True)
             self.graph_fc.replay()
@@ -346,9 +390,10 @@ class GraphedStream(object):
         """`lookahead` frames arrive together: their per-frame rows are computed in one batch (graph FB) and staged; call
         `advance(i)` to move frame i of the batch into the window buffers."""
         assert self.graph_fb is not None and frames.shape[0] == self.lookahead
+        _check_live(self)
         self.batch.copy_(frames, non_blocking=True)
         self.graph_fb.replay()
-        self._batch_frames = frames
+        self._batch_frames = frames.clone()   # (the caller may reuse its decode buffer: a re-run of a short-frame window reads these)
 
     def advance(self, i):
         self._stage_graphs[i].replay()
@@ -360,9 +405,15 @@ class GraphedStream(object):
 
     def emit(self):
         k = self._turn % len(self._graphs_w)
+        _check_live(self)
+        prev = self._unread.get(k)
+        if prev is not None and not prev.read:
+            raise RuntimeError('emitting into output slot %d of %d before result() of its previous window was called' % (k, len(self._graphs_w)))
         self._turn += 1
         self._graphs_w[k].replay()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.frame.device))
         hist = list(self._hist[-self.T:])   # this window's frames: later pushes must not change what a re-run sees
-        return PendingGraphWindow(self, self._outs[k], ev, lambda: self._exact(hist))
+        pend = PendingGraphWindow(self, self._outs[k], ev, lambda: self._exact(hist))
+        self._unread[k] = pend
+        return pend

@@ -544,13 +544,26 @@ def throughput_mode(on=True):
         TILE_HINT = prev
 
 
+_ws_captured = set()   # keys whose current buffer was handed out during a stream capture
+_ws_retired = []       # replaced buffers a captured graph may still address: never freed
+
+
 def _workspace(nbytes, device, tag):
     # one buffer per (use, stream): windows enqueued on different HIP streams run concurrently and must not share scratch
     key = (tag, device.index if isinstance(device, torch.device) else str(device), _raw_stream(device if isinstance(device, torch.device) else None))
     ws = _ws_cache.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None or ws.numel() < nbytes:
+        if capturing:
+            raise HvrError('scratch buffer %r must grow (%d -> %d bytes) inside a stream capture: warm the largest shapes up first'
+                           % (tag, 0 if ws is None else ws.numel(), nbytes))
+        if ws is not None and key in _ws_captured:
+            _ws_retired.append(ws)   # a captured graph holds this address (hvrnet_amd/graphs.py): keep it alive
+            _ws_captured.discard(key)
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
+    if capturing:
+        _ws_captured.add(key)
     return ws
 
 

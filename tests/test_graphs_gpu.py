@@ -273,3 +273,50 @@ def test_one_frame_split_k_path_tracks_the_unsplit_kernels():
         gs.push(f)
         res = gs.emit().result()
         assert len(res) == 2 and all(len(r) == model.bbox_head.num_classes - 1 for r in res)
+
+
+def test_look_ahead_stream_also_takes_single_frames_and_guards_its_buffers():
+    """A look-ahead object can still be fed one frame at a time (graph F was captured against scratch buffers sized by the
+    look-ahead batch, not by a one-frame run that a later batch would have outgrown); an output slot cannot be replayed before its
+    previous window was read; a graph whose packed weights were rebuilt refuses to replay."""
+    fi, n_prop, B = 1, 24, 4
+    T = 2 * fi + 1
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=fi, nms_post=n_prop), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    frames = torch.cat([S.synth_frame(i, img_hw=HW, pad_hw=PAD) for i in range(B)], 0).to(DEV)
+    meta = S.synth_meta(HW, PAD)
+    one = GraphedStream(model, frames[0:1], meta, rescale=True, fewrow_split=False)
+    look = GraphedStream(model, frames[0:1], meta, rescale=True, lookahead=B, fewrow_split=False)
+    look.push_batch(frames)
+    for i in range(B):
+        look.advance(i)
+    via_batch = look.emit().result()
+    for i in range(B):                       # the same frames again, one push() at a time, through graph F of the look-ahead object
+        look.push(frames[i:i + 1])
+        one.push(frames[i:i + 1])
+    _check('hvr', look.emit().result(), via_batch)
+    _check('hvr', one.emit().result(), via_batch)
+    # the caller's batch buffer may be reused after push_batch: the object keeps its own copy for re-runs
+    buf = frames.clone()
+    look.push_batch(buf)
+    buf.zero_()
+    look.advance(0)
+    assert torch.equal(look._hist[-1], frames[0:1])
+    # n_out = 2: a third emit() without reading the first raises instead of overwriting its pinned buffers
+    p1 = one.emit()
+    p2 = one.emit()
+    with pytest.raises(RuntimeError):
+        one.emit()
+    p1.result(); p2.result()
+    one.emit().result()
+    # stale graphs
+    g = GraphedClip(model, torch.cat([frames[:T]], 0), [meta] * T, rescale=True, n_out=1)
+    g.run().result()
+    pend = g.run()
+    with pytest.raises(RuntimeError):
+        g.run()                              # slot 0 unread
+    pend.result()
+    hvrnet_amd.set_compute_dtype(model, torch.bfloat16)     # drops (and later rebuilds) every packed weight buffer
+    with pytest.raises(RuntimeError):
+        g.run()
+    with pytest.raises(RuntimeError):
+        one.push(frames[0:1])

@@ -318,10 +318,14 @@ class ResNet(nn.Module, PackedMixin):
         dt = self.compute_dtype
         if dt == torch.bfloat16 and self.fused_stem:
             y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
-        else:  # generic route (f32 parity mode): patch matrix + GEMM + pooling
+        else:  # generic route (f32 / half / split-half modes): patch matrix + GEMM + pooling
             cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
-            y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
-            y = native.maxpool3x3s2_nhwc(y)
+            if dt == native.SPLIT:   # pooled in f32 (max does not act per half plane): the GEMM hands its f32 tile over directly
+                y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True, out_f32=True).view(x.shape[0], OH, OW, 64)
+                y = native.cast(native.maxpool3x3s2_nhwc(y), dt)
+            else:
+                y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)
+                y = native.maxpool3x3s2_nhwc(y)
         outs = []
         if out is not None:
             assert len(self.out_indices) == 1, 'out= needs a single returned map'

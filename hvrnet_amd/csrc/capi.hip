@@ -429,7 +429,7 @@ int hvr_conv2d_path(const hvr_conv_desc* d) {
 
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream) {
   if (!img || !cols || B <= 0) return fail(HVR_EINVAL, "bad stem arguments");
-  if (dtype == HVR_F16S) return fail(HVR_EUNSUPPORTED, "the stem's patch matrix is gathered in f32 / bf16 / half (hvr_cast makes the split-half form)");
+  if (dtype == HVR_F16S && (KP % 64 || !aligned256(cols))) return fail(HVR_EINVAL, "split-half patch rows: KP %% 64 == 0, 256-byte aligned");
   if (KP < 147 || KP % kstep_elems(dtype)) return fail(HVR_EINVAL, "KP=%d must be >= 147 and a K-step multiple", KP);
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
   return check_launch(run_im2col_stem(img, cols, B, H, W, OH, OW, KP, dtype, (hipStream_t)stream), "hvr_im2col_stem");

@@ -147,6 +147,30 @@ __global__ void cast8_kernel(const char* __restrict__ in, char* __restrict__ out
   }
 }
 
+// the stem's patch rows (im2col_stem_kernel) written straight in the split-half format: 8 elements of a row per thread
+__global__ void im2col_stem_split_kernel(const float* __restrict__ img, char* __restrict__ cols, int B, int H, int W, int OH, int OW, int KP) {
+  const int chunks = KP / 8;
+  const long total = (long)B * OH * OW * chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % chunks);
+    const long m = idx / chunks;
+    const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((long)OW * OH));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ch * 8 + e;
+      float x = 0.f;
+      if (k < 147) {
+        const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+        const int iy = oy * 2 - 3 + ky, ix = ox * 2 - 3 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) x = img[(((long)b * 3 + c) * H + iy) * W + ix];
+      }
+      v[e] = x;
+    }
+    store8<f16s_t>(cols + m * KP * 4, ch * 8, v);
+  }
+}
+
 // ---- [B][C][HW] <-> [B][HW][C] (API-boundary layout changes only) ----
 template <typename TI, typename TO>
 __global__ void permute_bchw_kernel(const TI* __restrict__ in, TO* __restrict__ out, int C, int HW, int to_nhwc) {
@@ -835,6 +859,9 @@ hipError_t run_im2col_stem(const float* img, void* cols, int B, int H, int W, in
   } else if (dtype == DT_F16) {
     const long work = (long)B * OH * OW * (KP / 8);
     hipLaunchKernelGGL(im2col_stem_kernel<f16_t>, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (f16_t*)cols, B, H, W, OH, OW, KP);
+  } else if (dtype == DT_F16S) {
+    const long work = (long)B * OH * OW * (KP / 8);
+    hipLaunchKernelGGL(im2col_stem_split_kernel, dim3(grid_for(work, 256)), dim3(256), 0, s, img, (char*)cols, B, H, W, OH, OW, KP);
   } else if (dtype != DT_F32) {
     return hipErrorInvalidValue;
   } else {

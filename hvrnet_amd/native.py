@@ -477,9 +477,9 @@ def im2col_stem(img, dtype, kp=192):
     assert img.dtype == torch.float32 and img.is_contiguous()
     B, _, H, W = img.shape
     OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    cols = torch.empty((B * OH * OW, kp), dtype=torch.float32 if dtype == SPLIT else dtype, device=img.device)
+    cols = torch.empty((B * OH * OW, kp), dtype=dtype, device=img.device)
     _check(lib().hvr_im2col_stem(_ptr(img), _ptr(cols), B, H, W, kp, _dt(cols), _stream()), 'hvr_im2col_stem')
-    return (cast(cols, SPLIT) if dtype == SPLIT else cols), OH, OW
+    return cols, OH, OW
 
 
 def stem_fused(img, wpk, bias):

@@ -207,3 +207,38 @@ def test_split_half_rejects_what_it_cannot_address():
     out = torch.zeros((64, 100), dtype=SPLIT, device=DEV)
     with pytest.raises(native.HvrError):     # output rows must be whole groups
         native.gemm(a, w, out=out[:, :64])
+
+
+def test_stem_patch_rows_in_half_and_split_formats():
+    """hvr_im2col_stem writes the 7x7/2 stem's patch matrix (resnet.py:456-466) directly in the operand format: the split-half
+    rows equal hvr_cast of the f32 rows bit for bit, the half rows equal torch's cast."""
+    img = _rand((2, 3, 61, 95), 71, 50.0).to(DEV)
+    cols32, OH, OW = native.im2col_stem(img, torch.float32)
+    cols_s, _, _ = native.im2col_stem(img, SPLIT)
+    assert cols_s.dtype == SPLIT and cols_s.shape == cols32.shape == (2 * OH * OW, 192)
+    assert torch.equal(cols_s, native.cast(cols32, SPLIT))
+    cols_h, _, _ = native.im2col_stem(img, torch.float16)
+    assert torch.equal(cols_h, cols32.half())
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, SPLIT])
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad,dil', [(15, 38, 63, 512, 512, 3, 1, 2, 2), (8, 38, 63, 1024, 512, 3, 1, 1, 1),
+                                                              (13, 37, 61, 256, 256, 3, 1, 1, 1), (15, 38, 63, 2048, 512, 1, 1, 0, 1)])
+def test_big_tile_kernel_on_half_and_split_operands_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, pad, dil, dtype):
+    """bigtile.hip (288 x 256 tiles) instantiated on half and split-half operands: the same MFMA sequence per output element as
+    the tile engine (split half: the same three passes and the same 2^-11 rescale point), so the outputs are bit-identical --
+    tile=17 forces the kernel, tile=11 the engine's 144 x 256 shape."""
+    x = _to(_rand((B, H, W, Cin), 81), dtype)
+    w = _to(_rand((Cout, k, k, Cin), 82, 0.03), dtype)
+    bias = _rand((Cout,), 83).to(DEV)
+    big = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=17)
+    eng = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=11)
+    assert big.dtype == dtype and torch.equal(big, eng)
+    tiles = ((B * H * W + 287) // 288) * (Cout // 256)     # (stride 1, same-size outputs)
+    assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, k=k, stride=stride, pad=pad, dil=dil, dtype=dtype) == (3 if tiles >= 170 else 0)
+    if dtype == torch.float16:   # residual epilogue (half only; split half keeps residual convs on the tile engine)
+        r = _to(_rand((B, H, W, Cout), 84), dtype)
+        assert torch.equal(native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=17),
+                           native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=11))
+    else:
+        assert native.conv2d_path(B, H, W, Cin, Cout, resid=True, k=k, stride=stride, pad=pad, dil=dil, dtype=dtype) == 0

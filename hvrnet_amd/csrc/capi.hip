@@ -61,7 +61,7 @@ hipError_t run_rpn_gather(const float*, const long long*, const int*, int, int, 
 hipError_t run_multiclass_nms(const float*, const float*, int, int, float, float, int, float*, long long*, int*, void*,
                               hipStream_t);
 size_t multiclass_nms_workspace_bytes(int R, int ncls);
-hipError_t run_stem_fused(const float*, const void*, const float*, void*, int, int, int, hipStream_t);
+hipError_t run_stem_fused(const float*, const void*, const float*, void*, int, int, int, int, hipStream_t);
 }  // namespace hvr
 
 using namespace hvr;
@@ -334,7 +334,7 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
 
 static int tail_params(const hvr_tail_desc* d, GemmParams& p) {
   if (!d) return fail(HVR_EINVAL, "null descriptor");
-  if (d->dtype != HVR_BF16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail is bf16 only");
+  if (d->dtype != HVR_BF16 && d->dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail takes bf16 or half operands");
   if (d->B <= 0 || d->OH <= 0 || d->OW <= 0 || d->stride2 <= 0) return fail(HVR_EINVAL, "empty tail problem");
   if ((d->OH - 1) * d->stride2 >= d->H2 || (d->OW - 1) * d->stride2 >= d->W2) return fail(HVR_EINVAL, "the sampled pixels fall outside x");
   const long M = (long)d->B * d->OH * d->OW;
@@ -353,7 +353,7 @@ static int tail_params(const hvr_tail_desc* d, GemmParams& p) {
 // one GEMM over K = C1 + C2 whose A operand switches from h to the sampled block input at K-step C1 / 64
 static bool tail_on_tile_engine(const GemmParams& p) {
   static const int on = std::getenv("HVR_TAIL_TILE") ? std::atoi(std::getenv("HVR_TAIL_TILE")) : 1;
-  return on && p.dtype == DT_BF16 && p.K1 % 64 == 0 && (p.K - p.K1) % 64 == 0 && p.K1 >= 64 && p.K - p.K1 >= 64 && p.N % 8 == 0 && p.ldc % 8 == 0 &&
+  return on && (p.dtype == DT_BF16 || p.dtype == DT_F16) && p.K1 % 64 == 0 && (p.K - p.K1) % 64 == 0 && p.K1 >= 64 && p.K - p.K1 >= 64 && p.N % 8 == 0 && p.ldc % 8 == 0 &&
          (long)p.M * (p.K - p.K1) * 2 < (1L << 31);
 }
 
@@ -386,7 +386,7 @@ static int tail_next_params(const hvr_tail_next_desc* d, GemmParams& p) {
     const int rc = tail_params(&t, p);
     if (rc) return rc;
   } else {
-    if (t.dtype != HVR_BF16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail_next is bf16 only");
+    if (t.dtype != HVR_BF16 && t.dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail_next takes bf16 or half operands");
     if (t.B <= 0 || t.OH <= 0 || t.OW <= 0) return fail(HVR_EINVAL, "empty tail problem");
     const long M = (long)t.B * t.OH * t.OW;
     if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
@@ -435,10 +435,14 @@ int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, i
   return check_launch(run_im2col_stem(img, cols, B, H, W, OH, OW, KP, dtype, (hipStream_t)stream), "hvr_im2col_stem");
 }
 
-int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream) {
+int hvr_stem_fused_dtype(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, int dtype, void* stream) {
   if (!img || !wpk || !bias || !out || B <= 0 || H < 7 || W < 7) return fail(HVR_EINVAL, "bad fused-stem arguments");
+  if (dtype != HVR_BF16 && dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "the fused stem computes on bf16 or half operands");
   if (!aligned16(wpk) || !aligned16(out) || !aligned16(bias)) return fail(HVR_EINVAL, "fused stem operands must be 16-byte aligned");
-  return check_launch(run_stem_fused(img, wpk, bias, out, B, H, W, (hipStream_t)stream), "hvr_stem_fused");
+  return check_launch(run_stem_fused(img, wpk, bias, out, B, H, W, dtype, (hipStream_t)stream), "hvr_stem_fused");
+}
+int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream) {
+  return hvr_stem_fused_dtype(img, wpk, bias, out, B, H, W, HVR_BF16, stream);
 }
 
 int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
@@ -525,13 +529,13 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 #ifdef HVR_DEBUG_KNOBS  // tuning builds only (tools/build_dbg.sh): alias every operand row to row 0 (no memory-system cost)
   static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
 #endif
-  const bool bt = dtype == HVR_BF16 && staging && !no_bt && scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt);
+  const bool bt = two_byte && staging && !no_bt && scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt);
   if (bt) {
     // window-sized problems: one 336 x 256 score tile per CU, V^T written by the same launch (relation_bt.hip)
     ScoresBTParams b;
     b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
     b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
-    b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f;
+    b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = dtype == HVR_F16;
     rc = check_launch(run_scores_bt(b, s), "relation: scores (big tile)");
     if (rc) return rc;
   } else {

@@ -33,7 +33,7 @@ def main(*paths):
             # (checked in the .s, `-save-temps`: no scratch access between the loop's barriers): pc_tile_kernel<4, LINEAR, 3>
             # a few epilogue addresses before the loop (<= 32 B), pc_tile_kernel<2, APPLY, 4> the folded accumulators between
             # the last block and the epilogue's LDS staging (<= 256 B).  Anything beyond that fails the build.
-            allow = 32 if name.startswith('_ZN3hvr14pc_tile_kernelILi4ELi0E') else (256 if name.startswith('_ZN3hvr14pc_tile_kernelILi2ELi2E') else 0)
+            allow = 32 if re.match(r'_ZN3hvr14pc_tile_kernelI(?:t|NS_5f16_tE)Li4ELi0E', name) else (256 if re.match(r'_ZN3hvr14pc_tile_kernelI(?:t|NS_5f16_tE)Li2ELi2E', name) else 0)
             if scratch > allow or (spill and not allow):
                 bad.append('%s: %d VGPRs spilled, %d bytes of scratch' % (name, spill, scratch))
             continue

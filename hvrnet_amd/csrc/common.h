@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
+#include <type_traits>
 #include <stdint.h>
 
 namespace hvr {
@@ -82,6 +83,14 @@ template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t u, float& l
   hi = __uint_as_float(u & 0xffff0000u);
 }
 template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t u, float& lo, float& hi) { unpack2h(u, lo, hi); }
+
+// one 16x16x32 MFMA on 2-byte operands: bf16_t -> v_mfma_f32_16x16x32_bf16, f16_t -> v_mfma_f32_16x16x32_f16
+template <typename T> __device__ __forceinline__ f32x4 mfma_half(const uint4& a, const uint4& b, const f32x4& c) {
+  if constexpr (std::is_same<T, bf16_t>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<f16_t> {

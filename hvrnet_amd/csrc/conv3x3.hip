@@ -56,6 +56,7 @@ struct Conv3x3Params {
   int tiles_x, tiles_y, ntiles;
 };
 
+template <typename T>   // bf16_t / f16_t (raw 16-bit words everywhere but the MFMA and the output pack)
 __global__ __launch_bounds__(C3_NT, 1) void conv3x3_c64_kernel(const Conv3x3Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wl = smem;
@@ -152,8 +153,7 @@ __global__ __launch_bounds__(C3_NT, 1) void conv3x3_c64_kernel(const Conv3x3Para
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const f32x4 cin = s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j];
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s & 1][j]),
-                                                              __builtin_bit_cast(bf16x8, xf[s & 1][i]), cin, 0, 0, 0);
+          acc[i][j] = mfma_half<T>(wf[s & 1][j], xf[s & 1][i], cin);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(C3_NT, 1) void conv3x3_c64_kernel(const Conv3x3Para
         const int j = e >> 1, r = 2 * (e & 1);
         float lo = acc[i][j][r] + sh[2 * e], hi = acc[i][j][r + 1] + sh[2 * e + 1];
         if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        o[e] = pack2bf(lo, hi);
+        o[e] = pack2<T>(lo, hi);
       }
       if (oy < p.H && ox < p.W) {
         char* dst = (char*)p.y + ((((long)b * p.H + oy) * p.W + ox) * 64 + g * 16) * 2;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(C3_NT, 1) void conv3x3_c64_kernel(const Conv3x3Para
 
 // bf16, 3x3, stride 1, pad 1, no dilation, 64 -> 64 channels, no residual, 16-byte aligned operands
 bool conv3x3_c64_supported(const GemmParams& p) {
-  if (p.dtype != DT_BF16 || !p.conv || p.out_f32 || p.resid) return false;
+  if ((p.dtype != DT_BF16 && p.dtype != DT_F16) || !p.conv || p.out_f32 || p.resid) return false;
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.dil != 1 || p.Cin != 64 || p.N != 64) return false;
   if (p.OH != p.H || p.OW != p.W || !p.zero) return false;
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C);
@@ -205,11 +205,13 @@ hipError_t run_conv3x3_c64(const GemmParams& g, hipStream_t stream) {
   static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
   bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
     attr_set = true;
   }
   const int grid = p.ntiles < 256 ? p.ntiles : 256;
-  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(C3_NT), C3_LDS, stream, p);
+  if (g.dtype == DT_F16) hipLaunchKernelGGL(conv3x3_c64_kernel<f16_t>, dim3(grid), dim3(C3_NT), C3_LDS, stream, p);
+  else hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, dim3(grid), dim3(C3_NT), C3_LDS, stream, p);
   return hipGetLastError();
 }
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ int swz_key(int row) { return (((row >> 4) & 3) << 1)
 // i + 1): after a chunk's epilogue the lane's packed bf16 outputs -- 16 consecutive channels of one pixel -- ARE the MFMA
 // B fragments of that product (k-slot e of lane group g <-> channel 16 g + e, + 8 for the second MFMA); Wn streams
 // through the LDS in 64-input-channel chunks beside W.  The next block then never reads this block's output for its conv1.
-template <int KF, bool RES, int NC, int RF, int NX>
+// HT: bf16_t or f16_t -- the operands move as raw 16-bit words; only the MFMA opcode and the pack / unpack of outputs and residual differ
+template <typename HT, int KF, bool RES, int NC, int RF, int NX>
 __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand_res_kernel(const GemmParams p) {
   constexpr int K = KF * 32, FJ = X_FJ, BN = X_BN, BM = X_BM, NT = 64 * (X_BM / 16 / RF);
   constexpr int CHUNK = BN * K * 2;               // bytes of one W chunk
@@ -239,8 +240,7 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
 #ifdef HVR_DBG_X_NOMMA
             if (t == 0) acc[i][hf * H + j] = __builtin_bit_cast(f32x4, wf[hf][j]); else acc[i][hf * H + j][0] += __uint_as_float(wf[hf][j].x ^ x[i][t][0]);
 #else
-            acc[i][hf * H + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[hf][j]),
-                                                                          __builtin_bit_cast(bf16x8, x[i][t]), cin, 0, 0, 0);
+            acc[i][hf * H + j] = mfma_half<HT>(wf[hf][j], __builtin_bit_cast(uint4, x[i][t]), cin);
 #endif
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -274,11 +274,13 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
           float lo = acc[i][j][r] + __uint_as_float(shw[r]);
           float hi = acc[i][j][r + 1] + __uint_as_float(shw[r + 1]);
           if constexpr (RES) {
-            lo += __uint_as_float(rcur[i][v][h] << 16);
-            hi += __uint_as_float(rcur[i][v][h] & 0xffff0000u);
+            float rl, rh;
+            unpack2<HT>(rcur[i][v][h], rl, rh);
+            lo += rl;
+            hi += rh;
           }
           if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-          o[h] = pack2bf(lo, hi);
+          o[h] = pack2<HT>(lo, hi);
         }
 #ifdef HVR_DBG_X_NOSTORE
         if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u)
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RF; ++i) {
-          hacc[i][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, yv[i][0]), hacc[i][jo], 0, 0, 0);
-          hacc[i][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, yv[i][1]), hacc[i][jo], 0, 0, 0);
+          hacc[i][jo] = mfma_half<HT>(w0, __builtin_bit_cast(uint4, yv[i][0]), hacc[i][jo]);
+          hacc[i][jo] = mfma_half<HT>(w1, __builtin_bit_cast(uint4, yv[i][1]), hacc[i][jo]);
         }
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
             const int j = 2 * v + (h >> 1), r = 2 * (h & 1);
             const float lo = fmaxf(hacc[i][4 * hg + j][r] + bn[4 * j + r], 0.f);
             const float hi = fmaxf(hacc[i][4 * hg + j][r + 1] + bn[4 * j + r + 1], 0.f);
-            o[h] = pack2bf(lo, hi);
+            o[h] = pack2<HT>(lo, hi);
           }
           *reinterpret_cast<uint4*>(dst + hg * 128 + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -349,7 +351,7 @@ static int expand_nc(int M, int N) {
 // an even number of 64-channel chunks (the expand convs of layers 1-3 and res5: K = 64 / 128 / 256 / 512, N = 4 K), or the
 // first block of a stage with its projection shortcut as a second K segment (K = 64 + 64, 128 + 256: hvr_bottleneck_tail).
 bool expand_supported(const GemmParams& p) {
-  if (p.dtype != DT_BF16 || p.conv || p.out_f32 || p.ksplit_steps > 0) return false;
+  if ((p.dtype != DT_BF16 && p.dtype != DT_F16) || p.conv || p.out_f32 || p.ksplit_steps > 0) return false;
   if (!(p.K == 64 || p.K == 128 || p.K == 256 || p.K == 512 || (p.K == 384 && p.s2 > 0))) return false;
   if (p.s2 > 0 && (p.K1 % 32 || p.K1 <= 0 || p.K1 >= p.K || (p.K - p.K1) % 8 || (reinterpret_cast<uintptr_t>(p.A2) & 15) || p.resid)) return false;
   if (p.N % X_BN || p.M < X_BM || expand_nc(p.M, p.N) == 0) return false;
@@ -361,14 +363,14 @@ bool expand_supported(const GemmParams& p) {
   return true;
 }
 
-template <int KF, bool RES, int NC, int NX = 0>
+template <typename T, int KF, bool RES, int NC, int NX = 0>
 static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
   constexpr int RF = KF > 8 ? 1 : 2;
   constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4 + 2 * NX * 16 * 128;  // two W chunks + shifts (+ two Wn chunks)
   static_assert(lds <= (RF == 2 ? 80 : 160) * 1024, "two workgroups per CU (one with 8 waves at K = 512)");
   static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
   bool& attr_set = attr_set_dev[current_device()];
-  auto kern = expand_res_kernel<KF, RES, NC, RF, NX>;
+  auto kern = expand_res_kernel<T, KF, RES, NC, RF, NX>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
@@ -377,34 +379,35 @@ static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int KF, bool RES>
+template <typename T, int KF, bool RES>
 static hipError_t launch_expand_res(const GemmParams& p, hipStream_t stream) {
   switch (expand_nc(p.M, p.N)) {
     case 16:
-      if constexpr (KF == 8) return launch_expand_nc<KF, RES, 16>(p, stream);
+      if constexpr (KF == 8) return launch_expand_nc<T, KF, RES, 16>(p, stream);
       else return hipErrorInvalidValue;
-    case 8: return launch_expand_nc<KF, RES, 8>(p, stream);
-    case 4: return launch_expand_nc<KF, RES, 4>(p, stream);
-    case 2: return launch_expand_nc<KF, RES, 2>(p, stream);
+    case 8: return launch_expand_nc<T, KF, RES, 8>(p, stream);
+    case 4: return launch_expand_nc<T, KF, RES, 4>(p, stream);
+    case 2: return launch_expand_nc<T, KF, RES, 2>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-template <int KF>
+template <typename T, int KF>
 static hipError_t launch_expand(const GemmParams& p, hipStream_t stream) {
-  return p.resid ? launch_expand_res<KF, true>(p, stream) : launch_expand_res<KF, false>(p, stream);
+  return p.resid ? launch_expand_res<T, KF, true>(p, stream) : launch_expand_res<T, KF, false>(p, stream);
 }
 
 // with the next block's conv1: the workgroup owns all N channels (NC = N / 64); stage 1 (N = 256, Cn = 64) and stage 2
 // (N = 512, Cn = 128) of the R-101, with or without the projection-shortcut segment
+template <typename T>
 static hipError_t run_expand_next(const GemmParams& p, hipStream_t stream) {
   if (p.N == 256 && p.Cn == 64) {
-    if (p.K == 64 && p.resid) return launch_expand_nc<2, true, 4, 4>(p, stream);
-    if (p.K == 128 && !p.resid) return launch_expand_nc<4, false, 4, 4>(p, stream);
+    if (p.K == 64 && p.resid) return launch_expand_nc<T, 2, true, 4, 4>(p, stream);
+    if (p.K == 128 && !p.resid) return launch_expand_nc<T, 4, false, 4, 4>(p, stream);
   }
   if (p.N == 512 && p.Cn == 128) {
-    if (p.K == 128 && p.resid) return launch_expand_nc<4, true, 8, 8>(p, stream);
-    if (p.K == 384 && !p.resid) return launch_expand_nc<12, false, 8, 8>(p, stream);
+    if (p.K == 128 && p.resid) return launch_expand_nc<T, 4, true, 8, 8>(p, stream);
+    if (p.K == 384 && !p.resid) return launch_expand_nc<T, 12, false, 8, 8>(p, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -417,16 +420,21 @@ bool expand_next_supported(const GemmParams& p) {
   return false;
 }
 
-hipError_t run_expand(const GemmParams& p, hipStream_t stream) {
-  if (p.Wn) return run_expand_next(p, stream);
+template <typename T>
+static hipError_t run_expand_t(const GemmParams& p, hipStream_t stream) {
+  if (p.Wn) return run_expand_next<T>(p, stream);
   switch (p.K) {
-    case 64: return launch_expand<2>(p, stream);
-    case 128: return launch_expand<4>(p, stream);
-    case 256: return launch_expand<8>(p, stream);
-    case 384: return launch_expand<12>(p, stream);
-    case 512: return launch_expand<16>(p, stream);
+    case 64: return launch_expand<T, 2>(p, stream);
+    case 128: return launch_expand<T, 4>(p, stream);
+    case 256: return launch_expand<T, 8>(p, stream);
+    case 384: return launch_expand<T, 12>(p, stream);
+    case 512: return launch_expand<T, 16>(p, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t run_expand(const GemmParams& p, hipStream_t stream) {
+  return p.dtype == DT_F16 ? run_expand_t<f16_t>(p, stream) : run_expand_t<bf16_t>(p, stream);
 }
 
 }  // namespace hvr

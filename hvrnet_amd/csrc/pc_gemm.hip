@@ -63,9 +63,9 @@ __device__ __forceinline__ float pc_load_untracked(const float* p) {
 }
 __device__ __forceinline__ void pc_landed(float& v) { asm volatile("" : "+v"(v)); }
 
-template <bool ZERO> __device__ __forceinline__ void pc_mma(const uint4& w, const uint4& x, f32x4& acc) {
+template <typename HT, bool ZERO> __device__ __forceinline__ void pc_mma(const uint4& w, const uint4& x, f32x4& acc) {
   const f32x4 c = ZERO ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+  acc = mfma_half<HT>(w, x, c);
 }
 
 // fragment reads that may still be outstanding when item t's x-fragment is needed (t = position inside a half of PC_FM
@@ -82,7 +82,7 @@ constexpr int pc_pending(int t, int ahead_left, int fn, bool kb_issued, bool g_i
 
 }  // namespace
 
-template <int FN, int EPI, int NS>
+template <typename HT, int FN, int EPI, int NS>   // HT: bf16_t / f16_t
 __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
   constexpr int BN = PC_CW * FN * 16;
   constexpr int ROWS = PC_BM + BN;                       // rows of one LDS stage image: x rows, then weight rows
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
 #ifndef HVR_DBG_PC_NOMMA
       static_for<FN>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        if constexpr (EPI == EPI_APPLY) pc_mma<zero_c>(fb[kk][j], fa[slot], pacc[i][j]);
-        else pc_mma<false>(fb[kk][j], fa[slot], acc[i][j]);
+        if constexpr (EPI == EPI_APPLY) pc_mma<HT, zero_c>(fb[kk][j], fa[slot], pacc[i][j]);
+        else pc_mma<HT, false>(fb[kk][j], fa[slot], acc[i][j]);
       });
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -370,11 +370,11 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
     const float4 hi = *reinterpret_cast<const float4*>(ebuf + r * LDW + cc * 8 + 4);
     v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     if (p.resid) {
-      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + (long)m * p.ldr + n);
-      v[0] += __uint_as_float(t.x << 16); v[1] += __uint_as_float(t.x & 0xffff0000u);
-      v[2] += __uint_as_float(t.y << 16); v[3] += __uint_as_float(t.y & 0xffff0000u);
-      v[4] += __uint_as_float(t.z << 16); v[5] += __uint_as_float(t.z & 0xffff0000u);
-      v[6] += __uint_as_float(t.w << 16); v[7] += __uint_as_float(t.w & 0xffff0000u);
+      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const HT*>(p.resid) + (long)m * p.ldr + n);
+      float rv[8];
+      unpack2<HT>(t.x, rv[0], rv[1]); unpack2<HT>(t.y, rv[2], rv[3]); unpack2<HT>(t.z, rv[4], rv[5]); unpack2<HT>(t.w, rv[6], rv[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
     }
     if (p.relu) {
 #pragma unroll
@@ -385,15 +385,15 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
       store4(cp, v);
       store4(cp + 4, v + 4);
     } else {
-      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
-      *reinterpret_cast<uint4*>(cp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+      HT* cp = reinterpret_cast<HT*>(p.C) + (long)m * p.ldc + n;
+      *reinterpret_cast<uint4*>(cp) = make_uint4(pack2<HT>(v[0], v[1]), pack2<HT>(v[2], v[3]), pack2<HT>(v[4], v[5]), pack2<HT>(v[6], v[7]));
     }
   }
 }
 
 // ---------------- host side ----------------
 bool pc_supported(const GemmParams& p, int epi) {
-  if (p.dtype != DT_BF16 || !p.staging || p.conv || p.ksplit_steps > 0) return false;
+  if ((p.dtype != DT_BF16 && p.dtype != DT_F16) || !p.staging || p.conv || p.ksplit_steps > 0) return false;
   if (epi != EPI_LINEAR && epi != EPI_APPLY) return false;
   if (p.K % 64 || p.K < 128 || p.N % 8 || p.M < 1) return false;
   if (epi == EPI_APPLY && (p.K % 128 || p.K / 128 != p.ntile)) return false;
@@ -407,7 +407,7 @@ bool pc_supported(const GemmParams& p, int epi) {
   return true;
 }
 
-template <int FN, int EPI, int NS>
+template <typename T, int FN, int EPI, int NS>
 static hipError_t launch_pc(const GemmParams& p, hipStream_t stream) {
   constexpr int BN = PC_CW * FN * 16;
   // the apply pass keeps its block-weight table [ntile][144] f32 behind the ring: everything the LDS has left
@@ -416,7 +416,7 @@ static hipError_t launch_pc(const GemmParams& p, hipStream_t stream) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
   bool& attr_set = attr_set_dev[current_device()];
-  auto kern = pc_tile_kernel<FN, EPI, NS>;
+  auto kern = pc_tile_kernel<T, FN, EPI, NS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -428,9 +428,14 @@ static hipError_t launch_pc(const GemmParams& p, hipStream_t stream) {
 
 // bn: 128 (FN = 2, 4-slot ring) or 256 (FN = 4, 3-slot ring)
 hipError_t run_pc(const GemmParams& p, int epi, int bn, hipStream_t stream) {
-  if (epi == EPI_APPLY) return launch_pc<2, EPI_APPLY, 4>(p, stream);
-  if (bn == 256) return launch_pc<4, EPI_LINEAR, 3>(p, stream);
-  return launch_pc<2, EPI_LINEAR, 4>(p, stream);
+  if (p.dtype == DT_F16) {
+    if (epi == EPI_APPLY) return launch_pc<f16_t, 2, EPI_APPLY, 4>(p, stream);
+    if (bn == 256) return launch_pc<f16_t, 4, EPI_LINEAR, 3>(p, stream);
+    return launch_pc<f16_t, 2, EPI_LINEAR, 4>(p, stream);
+  }
+  if (epi == EPI_APPLY) return launch_pc<bf16_t, 2, EPI_APPLY, 4>(p, stream);
+  if (bn == 256) return launch_pc<bf16_t, 4, EPI_LINEAR, 3>(p, stream);
+  return launch_pc<bf16_t, 2, EPI_LINEAR, 4>(p, stream);
 }
 
 }  // namespace hvr

@@ -17,6 +17,7 @@ struct ScoresBTParams {
   long ldq, ldk, ldv, ldp;
   float sl2;        // scale * log2(e)
   int tile0, tiles_here;  // set by run_scores_bt per launch: this launch's slice of the tile grid
+  int f16;                // operands are IEEE half (HVR_F16) instead of bf16
 };
 
 // true when the one-round 352 x 256 tiling applies (bf16, aligned operands, a tile grid that fills most of the chip)

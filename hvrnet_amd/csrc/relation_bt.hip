@@ -59,12 +59,12 @@ template <int OFF> __device__ __forceinline__ uint4 lds_read128(uint32_t addr) {
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ void mma(const uint4& keys, const uint4& queries, f32x4& acc) {
+template <typename T> __device__ __forceinline__ void mma(const uint4& keys, const uint4& queries, f32x4& acc) {
   // keys as the MFMA "A" operand: lane ends up with 4 consecutive keys of one query row (see gemm.hip)
 #ifdef HVR_DBG_BT_NOMMA
   acc[0] += __uint_as_float(keys.x ^ queries.x);
 #else
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, keys), __builtin_bit_cast(bf16x8, queries), acc, 0, 0, 0);
+  acc = mfma_half<T>(keys, queries, acc);
 #endif
 }
 
@@ -81,6 +81,7 @@ constexpr int pending_after(int t) {
 
 }  // namespace
 
+template <typename HT>   // bf16_t / f16_t: operands move as raw 16-bit words; the MFMA opcode and the P~ pack differ
 __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresBTParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       __builtin_amdgcn_sched_barrier(0);
       wait_lgkm<pending_after(t)>();
       __builtin_amdgcn_sched_barrier(0);
-      static_for<BT_FN>([&](auto J) { mma(kb[kk][decltype(J)::value], qa[t % BT_RING], acc[i][decltype(J)::value]); });
+      static_for<BT_FN>([&](auto J) { mma<HT>(kb[kk][decltype(J)::value], qa[t % BT_RING], acc[i][decltype(J)::value]); });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (t + BT_AHEAD < BT_ITEMS) read_q(std::integral_constant<int, t + BT_AHEAD>{});
       if constexpr (t == BT_KB_AT)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         __builtin_amdgcn_s_setprio(1);
         static_for<nr>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          static_for<BT_FN>([&](auto J) { mma(kb[decltype(J)::value], qa[r], acc[r0 + r][decltype(J)::value]); });
+          static_for<BT_FN>([&](auto J) { mma<HT>(kb[decltype(J)::value], qa[r], acc[r0 + r][decltype(J)::value]); });
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], p.sl2, -tmax[i]));
       sum += (e[0] + e[1]) + (e[2] + e[3]);
-      *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (frag_grp >> 1)) ^ (frag_row & 7)) << 4)) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+      *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (frag_grp >> 1)) ^ (frag_row & 7)) << 4)) = make_uint2(pack2<HT>(e[0], e[1]), pack2<HT>(e[2], e[3]));
     }
     sum = quad_group_sum(sum);
     if (frag_grp == 0) red_sum[wave * BT_WROWS + i * 16 + frag_row] = sum;
@@ -465,7 +466,8 @@ hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
   static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
   bool& attr_set = attr_set_dev[current_device()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
     attr_set = true;
   }
   const int ntiles = ((p.Mq + BT_BM - 1) / BT_BM) * (int)((p.ldp + BT_BN - 1) / BT_BN);
@@ -474,7 +476,8 @@ hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
     q.tile0 = t0;
     q.tiles_here = ntiles - t0 < 256 ? ntiles - t0 : 256;
     // the first launch is a full grid: the workgroups without a tile still carry their share of the V^T copy
-    hipLaunchKernelGGL(relation_scores_bt_kernel, dim3(t0 == 0 ? 256 : q.tiles_here), dim3(BT_NT), BT_LDS, stream, q);
+    if (p.f16) hipLaunchKernelGGL(relation_scores_bt_kernel<f16_t>, dim3(t0 == 0 ? 256 : q.tiles_here), dim3(BT_NT), BT_LDS, stream, q);
+    else hipLaunchKernelGGL(relation_scores_bt_kernel<bf16_t>, dim3(t0 == 0 ? 256 : q.tiles_here), dim3(BT_NT), BT_LDS, stream, q);
   }
   return hipGetLastError();
 }

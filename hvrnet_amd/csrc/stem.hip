@@ -32,12 +32,13 @@ constexpr int ST_CROW = 68;                                // conv-out row pitch
 constexpr int ST_PATCH_BYTES = (ST_IR + 3) * ST_PCOLS * 4 * 2;  // +3 rows: fragments past pixel 296 read (and discard) them
 constexpr int ST_CONV_BYTES = ST_FRAGS * 16 * ST_CROW * 2;
 
+template <typename T>   // bf16_t / f16_t
 __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict__ img, const uint4* __restrict__ wpk,
-                                                         const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
+                                                         const float* __restrict__ bias, T* __restrict__ out, int H,
                                                          int W, int CH, int CW, int PH, int PW) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* patch = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* cbuf = reinterpret_cast<bf16_t*>(smem + ST_PATCH_BYTES);
+  T* patch = reinterpret_cast<T*>(smem);
+  T* cbuf = reinterpret_cast<T*>(smem + ST_PATCH_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px0 = blockIdx.x * ST_PW, py0 = blockIdx.y * ST_PH, b = blockIdx.z;
   const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // first conv pixel of the region (may be -1)
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
     const int iy = iy0 + r, ix = ix0 + c;
     const bool ok = r < ST_IR && c < ST_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     const float v0 = ok ? pv[it][0] : 0.f, v1 = ok ? pv[it][1] : 0.f, v2 = ok ? pv[it][2] : 0.f;
-    if (i < ST_ITEMS) *reinterpret_cast<uint2*>(patch + (long)i * 4) = make_uint2(pack2bf(v0, v1), pack2bf(v2, 0.f));
+    if (i < ST_ITEMS) *reinterpret_cast<uint2*>(patch + (long)i * 4) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, 0.f));
   }
   __syncthreads();
 
@@ -91,8 +92,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
       const uint4 a = *reinterpret_cast<const uint4*>(abase + ky * ST_PCOLS * 8);
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
-        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf][ky]), __builtin_bit_cast(bf16x8, a),
-                                                          acc[nf], 0, 0, 0);
+        acc[nf] = mfma_half<T>(wf[nf][ky], a, acc[nf]);
     }
     // lane holds channels nf*16 + (lane>>4)*4 .. +3 of pixel p
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
       for (int dx = 0; dx < 3; ++dx) {
         const int gx = 2 * px - 1 + dx;
         if ((unsigned)gx >= (unsigned)CW) continue;
-        const bf16_t* src = cbuf + ((gy - cy0) * ST_CW + (gx - cx0)) * ST_CROW + ch * 8;
+        const T* src = cbuf + ((gy - cy0) * ST_CW + (gx - cx0)) * ST_CROW + ch * 8;
         float v[8];
         load4(src, v);
         load4(src + 4, v + 4);
@@ -130,24 +130,28 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
         for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
       }
     }
-    bf16_t* dst = out + (((long)b * PH + py) * PW + px) * 64 + ch * 8;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2bf(best[0], best[1]), pack2bf(best[2], best[3]), pack2bf(best[4], best[5]),
-                                                pack2bf(best[6], best[7]));
+    T* dst = out + (((long)b * PH + py) * PW + px) * 64 + ch * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(pack2<T>(best[0], best[1]), pack2<T>(best[2], best[3]), pack2<T>(best[4], best[5]),
+                                                pack2<T>(best[6], best[7]));
   }
 }
 
-hipError_t run_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, hipStream_t s) {
+hipError_t run_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, int dtype, hipStream_t s) {
   const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
   const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
   constexpr int lds = ST_PATCH_BYTES + ST_CONV_BYTES;
   static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
   bool& attr = attr_dev[current_device()];
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-  hipLaunchKernelGGL(stem_fused_kernel, grid, dim3(256), lds, s, img, (const uint4*)wpk, bias, (bf16_t*)out, H, W, CH, CW, PH, PW);
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(stem_fused_kernel<f16_t>, grid, dim3(256), lds, s, img, (const uint4*)wpk, bias, (f16_t*)out, H, W, CH, CW, PH, PW);
+  else
+    hipLaunchKernelGGL(stem_fused_kernel<bf16_t>, grid, dim3(256), lds, s, img, (const uint4*)wpk, bias, (bf16_t*)out, H, W, CH, CW, PH, PW);
   return hipGetLastError();
 }
 

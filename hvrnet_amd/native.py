@@ -104,6 +104,7 @@ SYMBOLS = {
     'hvr_im2col_stem': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_stem_fused': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'hvr_stem_fused_dtype': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'hvr_relation_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_relation_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     'hvr_relation_probs_workspace_bytes': (_sz, [_i, _i]),
@@ -390,7 +391,7 @@ def _tail_desc(h, x, w, bias, stride2, relu, y):
 
 def bottleneck_tail_supported(h, x, w, bias, stride2):
     """True when hvr_bottleneck_tail has a fused kernel for these shapes (bf16, C1 + C2 in {128, 384}, ...)."""
-    if not (h.is_cuda and h.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and h.is_contiguous() and x.is_contiguous()):
+    if not (h.is_cuda and h.dtype in (torch.bfloat16, torch.float16) and x.dtype == h.dtype and h.is_contiguous() and x.is_contiguous()):
         return False
     return bool(lib().hvr_bottleneck_tail_supported(ctypes.byref(_tail_desc(h, x, w, bias, stride2, True, None))))
 
@@ -430,7 +431,7 @@ def _tail_next_desc(h, x, resid, w, bias, stride2, wn, bias_n, y, hn):
 def bottleneck_tail_next_supported(h, x, resid, w, bias, stride2, wn, bias_n):
     """True when hvr_bottleneck_tail_next runs these shapes: (Cout, Cn) = (256, 64) / (512, 128), bf16, contiguous maps."""
     ts = [t for t in (h, x, resid) if t is not None]
-    if not all(t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() for t in ts):
+    if not all(t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.dtype == h.dtype and t.is_contiguous() for t in ts):
         return False
     if (x is None) == (resid is None) or wn.dim() != 2 or wn.shape[1] != w.shape[0] or not wn.is_contiguous():
         return False
@@ -485,13 +486,13 @@ def im2col_stem(img, dtype, kp=192):
 def stem_fused(img, wpk, bias):
     """img [B,3,H,W] f32 NCHW -> conv7x7/2 + bias + ReLU + maxpool3x3/2 as physical NHWC bf16 [B,PH,PW,64]."""
     _need_cuda(img, wpk, bias)
-    assert img.dtype == torch.float32 and img.is_contiguous() and wpk.dtype == torch.bfloat16 and wpk.shape == (64, 7, 32)
+    assert img.dtype == torch.float32 and img.is_contiguous() and wpk.dtype in (torch.bfloat16, torch.float16) and wpk.shape == (64, 7, 32)
     B, _, H, W = img.shape
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
-    out = torch.empty((B, PH, PW, 64), dtype=torch.bfloat16, device=img.device)
+    out = torch.empty((B, PH, PW, 64), dtype=wpk.dtype, device=img.device)
     with _span('stem', 2.0 * B * CH * CW * 64 * 147):
-        _check(lib().hvr_stem_fused(_ptr(img), _ptr(wpk), _ptr(bias), _ptr(out), B, H, W, _stream()), 'hvr_stem_fused')
+        _check(lib().hvr_stem_fused_dtype(_ptr(img), _ptr(wpk), _ptr(bias), _ptr(out), B, H, W, _dt(wpk), _stream()), 'hvr_stem_fused')
     return out
 
 

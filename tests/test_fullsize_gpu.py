@@ -125,8 +125,8 @@ def test_full_size_window_f32_matches_the_oracle(O, clip, head, dtype):
 LADDER_FLOOR = {
     ('bf16', 'hvr'): dict(prop_overlap_mean=0.84, same_class_frac=0.73, max_score_err=0.02, c4_rel=2.0e-2),
     ('bf16', 'selsa'): dict(prop_overlap_mean=0.84, same_class_frac=0.73, max_score_err=0.02, c4_rel=2.0e-2),
-    ('f16', 'hvr'): dict(prop_overlap_mean=0.95, same_class_frac=0.92, max_score_err=3e-3, c4_rel=2.5e-3),
-    ('f16', 'selsa'): dict(prop_overlap_mean=0.95, same_class_frac=0.92, max_score_err=3e-3, c4_rel=2.5e-3),
+    ('f16', 'hvr'): dict(prop_overlap_mean=0.95, same_class_frac=0.88, max_score_err=3e-3, c4_rel=2.5e-3),
+    ('f16', 'selsa'): dict(prop_overlap_mean=0.95, same_class_frac=0.88, max_score_err=3e-3, c4_rel=2.5e-3),
 }
 
 

@@ -242,3 +242,86 @@ def test_big_tile_kernel_on_half_and_split_operands_equals_the_tile_engine(B, H,
                            native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=11))
     else:
         assert native.conv2d_path(B, H, W, Cin, Cout, resid=True, k=k, stride=stride, pad=pad, dil=dil, dtype=dtype) == 0
+
+
+# ---- the dedicated bf16 kernels instantiated on half operands: each against the tile engine on the same operands ----
+H16 = torch.float16
+
+
+@pytest.mark.parametrize('Cin,Cout,H,W,B,with_res', [(64, 256, 19, 23, 2, True), (128, 512, 13, 31, 3, True), (256, 1024, 38, 63, 2, True),
+                                                     (512, 2048, 11, 13, 3, True), (64, 128, 12, 11, 1, False)])
+def test_expand_panel_kernel_on_half_operands(Cin, Cout, H, W, B, with_res):
+    """expand.hip on half operands (tile hint 13) against the tile engine (hint 1): same products, f32 sums in a different order,
+    one half rounding -- and bit-exact one-hot rows (transposition detector)."""
+    x, w = _to(_rand((B, H, W, Cin), 91), H16), _to(_rand((Cout, 1, 1, Cin), 92, 0.05), H16)
+    bias = _rand((Cout,), 93).to(DEV)
+    r = _to(_rand((B, H, W, Cout), 94), H16) if with_res else None
+    forced = native.conv2d_nhwc(x, w, bias, r, relu=True, tile=13)
+    engine = native.conv2d_nhwc(x, w, bias, r, relu=True, tile=1)
+    auto = native.conv2d_nhwc(x, w, bias, r, relu=True)
+    assert forced.dtype == H16
+    torch.testing.assert_close(forced.float(), engine.float(), rtol=2 ** -10, atol=2 ** -10)
+    torch.testing.assert_close(auto.float(), engine.float(), rtol=2 ** -10, atol=2 ** -10)
+    eye = torch.zeros((1, 1, 128, Cin), dtype=H16)
+    eye[0, 0, torch.arange(128), torch.arange(128) % Cin] = 1
+    got = native.conv2d_nhwc(eye.to(DEV), w, None, None, relu=False, tile=13).view(128, Cout)
+    assert torch.equal(got, w.view(Cout, Cin).t()[(torch.arange(128) % Cin).to(DEV)])
+
+
+def test_layer1_3x3_stem_and_tails_on_half_operands():
+    """conv3x3.hip (bit-identical to the tile engine), the fused stem (against the patch-matrix route in half), and the fused
+    Bottleneck tails (hvr_bottleneck_tail / _tail_next) against the separate convs, all on half operands."""
+    x, w = _to(_rand((2, 37, 53, 64), 101), H16), _to(_rand((64, 3, 3, 64), 102, 0.05), H16)
+    bias = _rand((64,), 103).to(DEV)
+    assert native.conv2d_path(2, 37, 53, 64, 64, k=3, pad=1, resid=False, dtype=H16) == 2
+    assert torch.equal(native.conv2d_nhwc(x, w, bias, None, relu=True, pad=1), native.conv2d_nhwc(x, w, bias, None, relu=True, pad=1, tile=1))
+    # stem
+    img = _rand((2, 3, 64, 96), 104, 50.0).to(DEV)
+    w7 = _rand((64, 3, 7, 7), 105, 0.05).half()
+    wf = torch.zeros((64, 7, 8, 4))
+    wf[:, :, :7, :3] = w7.float().permute(0, 2, 3, 1)
+    wp = torch.zeros((64, 192))
+    wp[:, :147] = w7.float().permute(0, 2, 3, 1).reshape(64, 147)
+    y = native.stem_fused(img, wf.view(64, 7, 32).half().to(DEV), bias)
+    cols, OH, OW = native.im2col_stem(img, H16)
+    ref = native.maxpool3x3s2_nhwc(native.gemm(cols, wp.half().to(DEV), bias, relu=True).view(2, OH, OW, 64))
+    assert y.dtype == H16 and y.shape == ref.shape
+    torch.testing.assert_close(y.float(), ref.float(), rtol=2 ** -9, atol=2 ** -9 * float(ref.float().abs().max()))
+    # tails: layer1.0 (projection block) with and without the next block's conv1
+    B, OH, OW, C1, C2, Cout, Cn = 2, 38, 63, 64, 64, 256, 64
+    h, xin = _to(_rand((B, OH, OW, C1), 106), H16), _to(_rand((B, OH, OW, C2), 107), H16)
+    w3, wd = _rand((Cout, C1), 108, 0.1), _rand((Cout, C2), 109, 0.1)
+    wt = _to(torch.cat([w3, wd], 1), H16)
+    bt = _rand((Cout,), 110, 0.1).to(DEV)
+    assert native.bottleneck_tail_supported(h, xin, wt, bt, 1)
+    out = native.bottleneck_tail(h, xin, wt, bt, stride2=1, relu=True)
+    ref = torch.relu(_back(h).view(-1, C1).double() @ _back(wt)[:, :C1].double().t() + _back(xin).view(-1, C2).double() @ _back(wt)[:, C1:].double().t()
+                     + bt.cpu().double())
+    assert (_back(out).view(-1, Cout).double() - ref).abs().max().item() < 2 ** -10 * ref.abs().max().item()
+    wn, bn = _to(_rand((Cn, Cout), 111, 0.05), H16), _rand((Cn,), 112, 0.1).to(DEV)
+    assert native.bottleneck_tail_next_supported(h, xin, None, wt, bt, 1, wn, bn)
+    y2, hn = native.bottleneck_tail_next(h, xin, None, wt, bt, wn, bn, stride2=1)
+    assert torch.equal(y2, out)
+    hn_ref = torch.relu(_back(out).view(-1, Cout).double() @ _back(wn).double().t() + bn.cpu().double())
+    assert (_back(hn).view(-1, Cn).double() - hn_ref).abs().max().item() < 2 ** -10 * hn_ref.abs().max().item()
+
+
+@pytest.mark.parametrize('M,N,K,tile', [(300, 256, 1280, 14), (4500, 1024, 1024, 15), (145, 136, 128, 14)])
+def test_producer_consumer_kernel_on_half_operands_equals_the_tile_engine(M, N, K, tile):
+    a, w = _to(_rand((M, K), 121), H16), _to(_rand((N, K), 122, 0.1), H16)
+    bias, r = _rand((N,), 123).to(DEV), _to(_rand((M, N), 124), H16)
+    assert torch.equal(native.gemm(a, w, bias, r, relu=True, tile=tile), native.gemm(a, w, bias, r, relu=True, tile=1))
+
+
+def test_relation_window_size_big_tile_path_on_half_operands():
+    """The one-round 352 x 256 scores kernel (relation_bt.hip) + the pipelined apply pass on half operands at window size."""
+    Mq = Mk = 4500
+    D = 1024
+    q, k, v = _rand((Mq, D), 131, 1.5).half(), _rand((Mk, D), 132, 1.5).half(), _rand((Mk, D), 133).half()
+    k[Mk - 2] = (q[7].float() * 3).half()
+    out = native.relation_fwd(q.to(DEV), k.to(DEV), v.to(DEV), 1.0 / 32)
+    rows = torch.cat([torch.arange(0, 16), torch.arange(340, 370), torch.arange(Mq - 40, Mq)])
+    ref = torch.softmax((q[rows].double() @ k.double().t()) / 32, dim=1) @ v.double()
+    assert (out[rows.to(DEV)].float().cpu().double() - ref).abs().max().item() < 2e-3 * float(v.float().abs().max())
+    ones = native.relation_fwd(q.to(DEV), k.to(DEV), torch.ones_like(v).to(DEV), 1.0 / 32)
+    torch.testing.assert_close(ones.float(), torch.ones_like(ones.float()), rtol=0, atol=2e-3)

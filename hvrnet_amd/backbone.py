@@ -295,8 +295,11 @@ class ResNet(nn.Module, PackedMixin):
         # fused bf16 stem: [n][ky][kx*4 + c], zero weight for the pad channel (c = 3) and the pad tap (kx = 7)
         wf = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w.device)
         wf[:, :, :7, :3] = w
-        half = dtype if dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
-        return dict(stem=(native.as_operand(wp, dtype), b), fused=wf.view(64, 7, 32).to(half).contiguous())
+        if dtype == native.SPLIT:
+            fused = native.stem_split_weights(wf.view(64, 7, 32))
+        else:
+            fused = wf.view(64, 7, 32).to(dtype if dtype in (torch.bfloat16, torch.float16) else torch.bfloat16).contiguous()
+        return dict(stem=(native.as_operand(wp, dtype), b), fused=fused)
 
     def out_shape_nhwc(self, B, H, W):
         """Physical [B,h,w,C] shape of the LAST returned map for a [B,3,H,W] input (stem 7x7/2 + pool 3x3/2, then one
@@ -317,7 +320,7 @@ class ResNet(nn.Module, PackedMixin):
             raise NotImplementedError('ResNet runs on the GPU only (no CPU fallback)')
         p = self.packed(x.device)
         dt = self.compute_dtype
-        if dt in (torch.bfloat16, torch.float16) and self.fused_stem:
+        if dt in (torch.bfloat16, torch.float16, native.SPLIT) and self.fused_stem:
             y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
         else:  # generic route (f32 / split-half modes): patch matrix + GEMM + pooling
             cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
@@ -352,7 +355,7 @@ class ResNet(nn.Module, PackedMixin):
         p = self.packed(x.device)
         dt = self.compute_dtype
         with torch.no_grad():
-            if dt in (torch.bfloat16, torch.float16) and self.fused_stem:
+            if dt in (torch.bfloat16, torch.float16, native.SPLIT) and self.fused_stem:
                 y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
             else:
                 cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)

@@ -437,8 +437,9 @@ int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, i
 
 int hvr_stem_fused_dtype(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, int dtype, void* stream) {
   if (!img || !wpk || !bias || !out || B <= 0 || H < 7 || W < 7) return fail(HVR_EINVAL, "bad fused-stem arguments");
-  if (dtype != HVR_BF16 && dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "the fused stem computes on bf16 or half operands");
+  if (dtype != HVR_BF16 && dtype != HVR_F16 && dtype != HVR_F16S) return fail(HVR_EUNSUPPORTED, "the fused stem computes on bf16, half or split-half operands");
   if (!aligned16(wpk) || !aligned16(out) || !aligned16(bias)) return fail(HVR_EINVAL, "fused stem operands must be 16-byte aligned");
+  if (dtype == HVR_F16S && !aligned256(out)) return fail(HVR_EINVAL, "split-half stem output must be 256-byte aligned");
   return check_launch(run_stem_fused(img, wpk, bias, out, B, H, W, dtype, (hipStream_t)stream), "hvr_stem_fused");
 }
 int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream) {

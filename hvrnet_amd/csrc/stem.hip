@@ -136,6 +136,128 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
   }
 }
 
+// The same stem on split-half operands (common.h: x ~ hi + lo * 2^-11): the input patch and the weights as two half planes each,
+// three MFMAs per product -- w_lo x a_hi and w_hi x a_lo into a cross accumulator (scaled 2^11), w_hi x a_hi into the main one --,
+// the conv pixels kept in f32 in the LDS (the pooling maximum does not act per plane), the pooled pixel written as one
+// [64 hi | 64 lo] group.  wpk: [2][64][7][32] half, plane 0 = hi(w), plane 1 = half((w - hi) * 2^11).  The weight fragments of
+// two 16-channel groups stay in registers at a time (both planes: 112 registers), the fragments are walked twice.
+constexpr int ST_CROWF = 68;                                // conv-out row pitch in f32
+constexpr int ST_PLANE_BYTES = (ST_IR + 3) * ST_PCOLS * 4 * 2;
+constexpr int ST_SPLIT_LDS = 2 * ST_PLANE_BYTES + ST_FRAGS * 16 * ST_CROWF * 4;
+
+__global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __restrict__ img, const uint4* __restrict__ wpk,
+                                                               const float* __restrict__ bias, char* __restrict__ out, int H, int W,
+                                                               int CH, int CW, int PH, int PW) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch_hi = smem;
+  char* patch_lo = smem + ST_PLANE_BYTES;
+  float* cbuf = reinterpret_cast<float*>(smem + 2 * ST_PLANE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px0 = blockIdx.x * ST_PW, py0 = blockIdx.y * ST_PH, b = blockIdx.z;
+  const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;
+  const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;
+  const float* ib = img + (long)b * 3 * H * W;
+  constexpr int ST_ITEMS = (ST_IR + 3) * ST_PCOLS, ST_ITERS = (ST_ITEMS + 255) / 256;
+  float pv[ST_ITERS][3];
+#pragma unroll
+  for (int it = 0; it < ST_ITERS; ++it) {
+    const int i = it * 256 + tid;
+    const int r = i / ST_PCOLS, c = i - r * ST_PCOLS;
+    const int iy = iy0 + r, ix = ix0 + c;
+    const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+    const long o = (long)cy * W + cx;
+    pv[it][0] = ib[o];
+    pv[it][1] = ib[o + (long)H * W];
+    pv[it][2] = ib[o + 2L * H * W];
+  }
+#pragma unroll
+  for (int it = 0; it < ST_ITERS; ++it) {
+    const int i = it * 256 + tid;
+    const int r = i / ST_PCOLS, c = i - r * ST_PCOLS;
+    const int iy = iy0 + r, ix = ix0 + c;
+    const bool ok = r < ST_IR && c < ST_IC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const float v0 = ok ? pv[it][0] : 0.f, v1 = ok ? pv[it][1] : 0.f, v2 = ok ? pv[it][2] : 0.f;
+    uint32_t h01, l01, h2, l2;
+    split2(v0, v1, h01, l01);
+    split2(v2, 0.f, h2, l2);
+    if (i < ST_ITEMS) {
+      *reinterpret_cast<uint2*>(patch_hi + (long)i * 8) = make_uint2(h01, h2);
+      *reinterpret_cast<uint2*>(patch_lo + (long)i * 8) = make_uint2(l01, l2);
+    }
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {   // output channels 32 half .. 32 half + 31
+    uint4 wh[2][7], wl[2][7];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int idx = (((half * 2 + nf) * 16 + (lane & 15)) * 7 + ky) * 4 + (lane >> 4);
+        wh[nf][ky] = wpk[idx];
+        wl[nf][ky] = wpk[64 * 7 * 4 + idx];
+      }
+    for (int f = wave; f < ST_FRAGS; f += 4) {
+      const int p = f * 16 + (lane & 15);
+      const int cy = p / ST_CW, cx = p - cy * ST_CW;
+      const int aoff = ((2 * cy) * ST_PCOLS + 2 * cx) * 8 + (lane >> 4) * 16;
+      f32x4 acc[2], accx[2];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) { acc[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(patch_hi + aoff + ky * ST_PCOLS * 8);
+        const uint4 al = *reinterpret_cast<const uint4*>(patch_lo + aoff + ky * ST_PCOLS * 8);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          accx[nf] = mfma_half<f16_t>(wl[nf][ky], ah, accx[nf]);
+          accx[nf] = mfma_half<f16_t>(wh[nf][ky], al, accx[nf]);
+          acc[nf] = mfma_half<f16_t>(wh[nf][ky], ah, acc[nf]);
+        }
+      }
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const int n = (half * 2 + nf) * 16 + (lane >> 4) * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        const float4 v = make_float4(fmaxf(fmaf(accx[nf][0], kSplitInv, acc[nf][0]) + bv.x, 0.f), fmaxf(fmaf(accx[nf][1], kSplitInv, acc[nf][1]) + bv.y, 0.f),
+                                     fmaxf(fmaf(accx[nf][2], kSplitInv, acc[nf][2]) + bv.z, 0.f), fmaxf(fmaf(accx[nf][3], kSplitInv, acc[nf][3]) + bv.w, 0.f));
+        *reinterpret_cast<float4*>(cbuf + p * ST_CROWF + n) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int i = tid; i < ST_PH * ST_PW * 8; i += 256) {
+    const int ch = i & 7, q = i >> 3, qy = q / ST_PW, qx = q - qy * ST_PW;
+    const int py = py0 + qy, px = px0 + qx;
+    if (py >= PH || px >= PW) continue;
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int gy = 2 * py - 1 + dy;
+      if ((unsigned)gy >= (unsigned)CH) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int gx = 2 * px - 1 + dx;
+        if ((unsigned)gx >= (unsigned)CW) continue;
+        const float* src = cbuf + ((gy - cy0) * ST_CW + (gx - cx0)) * ST_CROWF + ch * 8;
+        const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+        best[0] = fmaxf(best[0], a.x); best[1] = fmaxf(best[1], a.y); best[2] = fmaxf(best[2], a.z); best[3] = fmaxf(best[3], a.w);
+        best[4] = fmaxf(best[4], c.x); best[5] = fmaxf(best[5], c.y); best[6] = fmaxf(best[6], c.z); best[7] = fmaxf(best[7], c.w);
+      }
+    }
+    uint4 h, l;
+    split2(best[0], best[1], h.x, l.x); split2(best[2], best[3], h.y, l.y);
+    split2(best[4], best[5], h.z, l.z); split2(best[6], best[7], h.w, l.w);
+    char* dst = out + (((long)b * PH + py) * PW + px) * 256 + ch * 16;   // one [64 hi | 64 lo] group per pixel
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + 128) = l;
+  }
+}
+
 hipError_t run_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, int dtype, hipStream_t s) {
   const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
   const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
@@ -148,6 +270,16 @@ hipError_t run_stem_fused(const float* img, const void* wpk, const float* bias, 
     attr = true;
   }
   dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
+  if (dtype == DT_F16S) {
+    static bool sattr_dev[kMaxDevices] = {};
+    bool& sattr = sattr_dev[current_device()];
+    if (!sattr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_SPLIT_LDS);
+      sattr = true;
+    }
+    hipLaunchKernelGGL(stem_fused_split_kernel, grid, dim3(256), ST_SPLIT_LDS, s, img, (const uint4*)wpk, bias, (char*)out, H, W, CH, CW, PH, PW);
+    return hipGetLastError();
+  }
   if (dtype == DT_F16)
     hipLaunchKernelGGL(stem_fused_kernel<f16_t>, grid, dim3(256), lds, s, img, (const uint4*)wpk, bias, (f16_t*)out, H, W, CH, CW, PH, PW);
   else

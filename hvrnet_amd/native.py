@@ -486,14 +486,24 @@ def im2col_stem(img, dtype, kp=192):
 def stem_fused(img, wpk, bias):
     """img [B,3,H,W] f32 NCHW -> conv7x7/2 + bias + ReLU + maxpool3x3/2 as physical NHWC bf16 [B,PH,PW,64]."""
     _need_cuda(img, wpk, bias)
-    assert img.dtype == torch.float32 and img.is_contiguous() and wpk.dtype in (torch.bfloat16, torch.float16) and wpk.shape == (64, 7, 32)
+    assert img.dtype == torch.float32 and img.is_contiguous() and wpk.dtype in (torch.bfloat16, torch.float16)
+    split = wpk.dim() == 4   # [2, 64, 7, 32] half: the hi / lo planes of split-half weights (stem_split_weights)
+    assert tuple(wpk.shape) == ((2, 64, 7, 32) if split else (64, 7, 32)) and (not split or wpk.dtype == torch.float16) and wpk.is_contiguous()
     B, _, H, W = img.shape
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
-    out = torch.empty((B, PH, PW, 64), dtype=wpk.dtype, device=img.device)
+    out = torch.empty((B, PH, PW, 64), dtype=SPLIT if split else wpk.dtype, device=img.device)
     with _span('stem', 2.0 * B * CH * CW * 64 * 147):
-        _check(lib().hvr_stem_fused_dtype(_ptr(img), _ptr(wpk), _ptr(bias), _ptr(out), B, H, W, _dt(wpk), _stream()), 'hvr_stem_fused')
+        _check(lib().hvr_stem_fused_dtype(_ptr(img), _ptr(wpk), _ptr(bias), _ptr(out), B, H, W, HVR_F16S if split else _dt(wpk), _stream()),
+               'hvr_stem_fused')
     return out
+
+
+def stem_split_weights(wf):
+    """f32 fused-stem weights [64, 7, 32] -> [2, 64, 7, 32] half: plane 0 = half(w), plane 1 = half((w - plane 0) * 2^11)."""
+    hi = wf.half()
+    lo = ((wf - hi.float()) * 2048.0).half()
+    return torch.stack([hi, lo], 0).contiguous()
 
 
 def maxpool3x3s2_nhwc(x):

@@ -170,7 +170,8 @@ int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, i
  * img NCHW f32 [B][3][H][W]; wpk bf16 [64][7][32] with wpk[n][ky][kx*4+c] = w[n][c][ky][kx] (zeros for c = 3 or
  * kx = 7); bias f32 [64]; out bf16 NHWC [B][PH][PW][64], PH = ((H-1)/2+1 - 1)/2 + 1. */
 int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream);
-/* the same with half operands: dtype HVR_BF16 or HVR_F16 (wpk and out in that format) */
+/* the same in the other half formats: dtype HVR_BF16 / HVR_F16 (wpk and out in that format) or HVR_F16S -- split half: wpk is
+ * [2][64][7][32] half, plane 0 = half(w), plane 1 = half((w - plane 0) * 2^11); out [B][PH][PW][64] in the split-half layout */
 int hvr_stem_fused_dtype(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, int dtype, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on NHWC (resnet.py:466,526) */
 int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);

@@ -325,3 +325,24 @@ def test_relation_window_size_big_tile_path_on_half_operands():
     assert (out[rows.to(DEV)].float().cpu().double() - ref).abs().max().item() < 2e-3 * float(v.float().abs().max())
     ones = native.relation_fwd(q.to(DEV), k.to(DEV), torch.ones_like(v).to(DEV), 1.0 / 32)
     torch.testing.assert_close(ones.float(), torch.ones_like(ones.float()), rtol=0, atol=2e-3)
+
+
+def test_fused_stem_on_split_half_operands():
+    """The fused 7x7/2 conv + ReLU + 3x3/2 max-pool on split-half operands (three MFMAs per product, f32 pooling, the pooled
+    pixel written as one [64 hi | 64 lo] group) against float64 conv / pool of the f32 inputs: f32-grade; and against the
+    patch-matrix route in the same format."""
+    img = _rand((2, 3, 75, 101), 141, 50.0)
+    w7 = _rand((64, 3, 7, 7), 142, 0.05)
+    bias = _rand((64,), 143)
+    wf = torch.zeros((64, 7, 8, 4))
+    wf[:, :, :7, :3] = w7.permute(0, 2, 3, 1)
+    y = native.stem_fused(img.to(DEV), native.stem_split_weights(wf.view(64, 7, 32).to(DEV)), bias.to(DEV))
+    ref = F.max_pool2d(torch.relu(F.conv2d(img.double(), w7.double(), bias.double(), stride=2, padding=3)), 3, 2, 1)
+    assert y.dtype == SPLIT and tuple(y.shape) == (2, ref.shape[2], ref.shape[3], 64)
+    got = _back(y).permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+    wp = torch.zeros((64, 192))
+    wp[:, :147] = w7.permute(0, 2, 3, 1).reshape(64, 147)
+    cols, OH, OW = native.im2col_stem(img.to(DEV), SPLIT)
+    alt = native.maxpool3x3s2_nhwc(native.gemm(cols, _to(wp, SPLIT), bias.to(DEV), relu=True, out_f32=True).view(2, OH, OW, 64)).cpu()
+    assert (_back(y) - alt).abs().max().item() < 3e-6 * alt.abs().max().item()

@@ -19,11 +19,13 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--mq', type=int, default=4500)
 ap.add_argument('--mk', type=int, default=4500)
 ap.add_argument('--d', type=int, default=1024)
+ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f16x2', 'f32'])
 args = ap.parse_args()
 torch.manual_seed(0)
-q = torch.randn(args.mq, args.d, device='cuda').bfloat16()
-k = torch.randn(args.mk, args.d, device='cuda').bfloat16()
-v = torch.randn(args.mk, args.d, device='cuda').bfloat16()
+DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16x2': native.SPLIT, 'f32': torch.float32}[args.dtype]
+q = native.as_operand(torch.randn(args.mq, args.d, device='cuda'), DT)
+k = native.as_operand(torch.randn(args.mk, args.d, device='cuda'), DT)
+v = native.as_operand(torch.randn(args.mk, args.d, device='cuda'), DT)
 for _ in range(3):
     native.relation_fwd(q, k, v, 1 / 32, staging=1)
 torch.cuda.synchronize()
@@ -34,4 +36,4 @@ for _ in range(args.iters):
 e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / args.iters
-print('relation Mq=%d Mk=%d D=%d  %.4f ms  %.1f TF/s' % (args.mq, args.mk, args.d, ms, 4.0 * args.mq * args.mk * args.d / ms / 1e9))
+print('relation %s Mq=%d Mk=%d D=%d  %.4f ms  %.1f TF/s' % (args.dtype, args.mq, args.mk, args.d, ms, 4.0 * args.mq * args.mk * args.d / ms / 1e9))

@@ -296,10 +296,10 @@ class ResNet(nn.Module, PackedMixin):
         wf = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w.device)
         wf[:, :, :7, :3] = w
         if dtype == native.SPLIT:
-            fused = native.stem_split_weights(wf.view(64, 7, 32))
+            fused, fused_bias = native.stem_split_weights(wf.view(64, 7, 32)), native.stem_split_bias(b)
         else:
-            fused = wf.view(64, 7, 32).to(dtype if dtype in (torch.bfloat16, torch.float16) else torch.bfloat16).contiguous()
-        return dict(stem=(native.as_operand(wp, dtype), b), fused=fused)
+            fused, fused_bias = wf.view(64, 7, 32).to(dtype if dtype in (torch.bfloat16, torch.float16) else torch.bfloat16).contiguous(), b
+        return dict(stem=(native.as_operand(wp, dtype), b), fused=fused, fused_bias=fused_bias)
 
     def out_shape_nhwc(self, B, H, W):
         """Physical [B,h,w,C] shape of the LAST returned map for a [B,3,H,W] input (stem 7x7/2 + pool 3x3/2, then one
@@ -321,7 +321,7 @@ class ResNet(nn.Module, PackedMixin):
         p = self.packed(x.device)
         dt = self.compute_dtype
         if dt in (torch.bfloat16, torch.float16, native.SPLIT) and self.fused_stem:
-            y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
+            y = native.stem_fused(x.contiguous().float(), p['fused'], p['fused_bias'])
         else:  # generic route (f32 / split-half modes): patch matrix + GEMM + pooling
             cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
             if dt == native.SPLIT:   # pooled in f32 (max does not act per half plane): the GEMM hands its f32 tile over directly
@@ -356,7 +356,7 @@ class ResNet(nn.Module, PackedMixin):
         dt = self.compute_dtype
         with torch.no_grad():
             if dt in (torch.bfloat16, torch.float16, native.SPLIT) and self.fused_stem:
-                y = native.stem_fused(x.contiguous().float(), p['fused'], p['stem'][1])
+                y = native.stem_fused(x.contiguous().float(), p['fused'], p['fused_bias'])
             else:
                 cols, OH, OW = native.im2col_stem(x.contiguous().float(), dt, STEM_KP)
                 y = native.gemm(cols, p['stem'][0], p['stem'][1], relu=True).view(x.shape[0], OH, OW, 64)

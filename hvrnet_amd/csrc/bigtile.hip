@@ -42,7 +42,7 @@ template <typename T> __device__ __forceinline__ void bg_mma(const uint4& w, con
   // weights as the MFMA "A" operand: a lane ends up with 4 consecutive output channels of one pixel (see gemm.hip)
   if constexpr (std::is_same<T, bf16_t>::value)
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-  else   // half and split half (one plane of each operand per LDS image, see gemm_tile.h)
+  else
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
 }
 // 16 bytes per lane, global -> LDS, buffer addressing (see gemm.hip): offsets from 2^31 up read as zeros
@@ -61,13 +61,11 @@ __device__ __forceinline__ void bg_load_lds16(const void* base, char* lds, unsig
 // rows -- 9 + 9 = 288, or 5 + 4 = 144 (the one-round shape of a 35 910-pixel batch with N = 256: every SIMD carries one 5-fragment and
 // one 4-fragment wave, so the matrix work per SIMD is balanced; 0.45 / 0.5 LDS fragment reads per MFMA against the tile engine's 0.61
 // for the same 144 x 256 tile)
-// T: bf16_t, f16_t (the same kernel on the half MFMA) or f16s_t (split half, common.h: 4 bytes per logical element in [64 hi | 64 lo]
-// groups; the K loop walks the operands three times -- A_hi x B_lo, A_lo x B_hi, accumulators x 2^-11, A_hi x B_hi -- exactly as
-// gemm_tile.h's, so the outputs are bit-identical to the tile engine's in every format; bias + ReLU epilogue only).
+// T: bf16_t or f16_t (the same kernel on the half MFMA); split-half operands stay on the tile engine, whose fused three-MFMA K-step
+// (gemm_tile.h) already halves the LDS traffic per MFMA this kernel exists to reduce
 template <typename T, int FM0, int FM1>
 __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
-  constexpr bool SPLIT = std::is_same<T, f16s_t>::value;
-  constexpr int EB = (int)sizeof(T), KSG = SPLIT ? 256 : 128;
+  constexpr int EB = (int)sizeof(T), KSG = 128;
   constexpr int BM = (FM0 + FM1) * 16;
   constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BG_BN * 128;
   constexpr int A_SLOTS = (BM * 8 + BG_NT - 1) / BG_NT;
@@ -126,24 +124,17 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 
   int a_koff = 0, b_koff = 0, dy = 0, dx = 0, kt_load = 0;  // of the K-step being loaded
   const int nk_real = p.K / 64;
-  auto tap_of = [&](int kv) {
-    int kt = kv, a_plane = 0, b_plane = 0;
-    if constexpr (SPLIT) {   // pass 0: A_hi x B_lo, pass 1: A_lo x B_hi, pass 2: A_hi x B_hi
-      const int pass = kv >= 2 * nk_real ? 2 : (kv >= nk_real ? 1 : 0);
-      kt = kv - pass * nk_real;
-      a_plane = pass == 1 ? 128 : 0;
-      b_plane = pass == 0 ? 128 : 0;
-    }
+  auto tap_of = [&](int kt) {
     kt_load = kt;
-    b_koff = kt * KSG + b_plane;
+    b_koff = kt * KSG;
     if (p.conv) {
       const int k = kt * 64, tap = k / p.Cin, cin0 = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       dy = ky * p.dil;
       dx = kx * p.dil;
-      a_koff = ((dy * p.W + dx) * p.Cin + cin0) * EB + a_plane;
+      a_koff = ((dy * p.W + dx) * p.Cin + cin0) * EB;
     } else {
-      a_koff = kt * KSG + a_plane;
+      a_koff = kt * KSG;
     }
   };
   auto dma_a = [&](auto I, char* stage) {
@@ -180,7 +171,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const uint32_t a_lane = bg_lds_off(smem) + (wrow0 + frag_row) * 128 + ((frag_grp ^ swz) * 16);
   const uint32_t b_lane = bg_lds_off(smem) + A_BYTES + (wn * BG_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
 
-  const int nk = SPLIT ? 3 * nk_real : nk_real;
+  const int nk = nk_real;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -199,14 +190,6 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
       uint4 kb[BG_FN], qa[G0];
       tap_of(kn);
-      if constexpr (SPLIT) {   // the cross terms carry the lo planes' 2^11
-        if (kt == 2 * nk_real) {
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < BG_FN; ++j) acc[i][j] *= kSplitInv;
-        }
-      }
       static_for<4>([&](auto PH) {
         constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? FM - G0 : G0;
         // ---- L ----
@@ -263,7 +246,6 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     asm volatile("" : "+v"(etid));  // lane-derived values re-derived here: nothing but the accumulators lives across the loop
     const int el = etid & 63, erow = el & 15, egrp = el >> 4;
     constexpr int SPITCH = BG_WCOLS * 2;  // 128-byte staged rows, bank-conflict-free by the piece swizzle of relation_bt.hip
-    constexpr int LO_STG = SPLIT ? 8 * 16 * SPITCH : 0;   // split half: the lo planes' staging blocks sit behind the eight hi blocks
     char* stg = smem + wave * (16 * SPITCH);
     const int wr_lane = erow * SPITCH + (((egrp & 1) ^ (erow >> 3)) << 3);
     float bias[BG_FN][4];
@@ -291,11 +273,11 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       }
     };
     uint4 rnext[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
-    if (!SPLIT && has_res) load_res(0, rnext);
+    if (has_res) load_res(0, rnext);
     __syncthreads();  // every wave is done reading the ring (group 0 leaves the loop a barrier ahead of group 1's last reads)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      if (!SPLIT && has_res) {
+      if (has_res) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint4 v = h ? make_uint4(rnext[h].z, rnext[h].w, rnext[h].x, rnext[h].y) : rnext[h];
@@ -309,45 +291,25 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         float e[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = acc[i][j][r] + bias[j][r];
-        if constexpr (!SPLIT) {
-          if (has_res) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(slot);
-            float r0_, r1_, r2_, r3_;
-            unpack2<T>(rr.x, r0_, r1_);
-            unpack2<T>(rr.y, r2_, r3_);
-            e[0] += r0_; e[1] += r1_; e[2] += r2_; e[3] += r3_;
-          }
+        if (has_res) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(slot);
+          float r0_, r1_, r2_, r3_;
+          unpack2<T>(rr.x, r0_, r1_);
+          unpack2<T>(rr.y, r2_, r3_);
+          e[0] += r0_; e[1] += r1_; e[2] += r2_; e[3] += r3_;
         }
         if (p.relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = fmaxf(e[r], 0.f);
         }
-        if constexpr (SPLIT) {
-          uint32_t h0, l0, h1, l1;
-          split2(e[0], e[1], h0, l0);
-          split2(e[2], e[3], h1, l1);
-          *reinterpret_cast<uint2*>(slot) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(slot + LO_STG) = make_uint2(l0, l1);
-        } else {
-          *reinterpret_cast<uint2*>(slot) = make_uint2(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]));
-        }
+        *reinterpret_cast<uint2*>(slot) = make_uint2(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]));
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = h * 8 + st_row, m = m0 + wrow0 + i * 16 + row;
         uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
         if (h) v = make_uint4(v.z, v.w, v.x, v.y);
-        if constexpr (SPLIT) {   // the wave's 64 columns are one [hi | lo] group of the output row
-          uint4 vl = *reinterpret_cast<const uint4*>(stg + LO_STG + row * SPITCH + ((st_chunk ^ st_row) << 4));
-          if (h) vl = make_uint4(vl.z, vl.w, vl.x, vl.y);
-          char* dst = (char*)p.C + (long)m * p.ldc * 4 + (long)((n0 + wn * BG_WCOLS) >> 6) * 256 + st_chunk * 16;
-          if (m < p.M) {
-            *reinterpret_cast<uint4*>(dst) = v;
-            *reinterpret_cast<uint4*>(dst + 128) = vl;
-          }
-        } else {
-          if (m < p.M) *reinterpret_cast<uint4*>((unsigned short*)p.C + (long)m * p.ldc + n0 + wn * BG_WCOLS + st_chunk * 8) = v;
-        }
+        if (m < p.M) *reinterpret_cast<uint4*>((unsigned short*)p.C + (long)m * p.ldc + n0 + wn * BG_WCOLS + st_chunk * 8) = v;
       }
     }
   }
@@ -364,8 +326,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 // 256-channel column tiles and whole 128-byte K-steps inside one filter tap.  `throughput`: the caller keeps the rest of the chip
 // busy with other launches (tile_hint kBigHint).
 bool bigtile_supported(const GemmParams& p, bool throughput) {
-  if (p.dtype == DT_F32 || !p.staging || p.out_f32 || p.ksplit_steps > 0) return false;
-  if (p.dtype == DT_F16S && (p.resid || p.s2 > 0 || p.ldc % 64 || p.lda % 64 || p.ldb % 64)) return false;   // split half: bias + ReLU epilogue only
+  if ((p.dtype != DT_BF16 && p.dtype != DT_F16) || !p.staging || p.out_f32 || p.ksplit_steps > 0) return false;
   if (p.s2 > 0 && (p.conv || p.K1 % 64 || (p.K - p.K1) % 64 || p.K1 < 64 || (reinterpret_cast<uintptr_t>(p.A2) & 15) ||
                    (long)p.M * (p.K - p.K1) * 2 >= (1L << 31))) return false;
   if (p.N % BG_BN || p.K % 64 || p.ldc % 8 || p.lda % 8 || p.ldb % 8) return false;
@@ -380,7 +341,7 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                        reinterpret_cast<uintptr_t>(p.bias);
   if (al & 15) return false;
-  if ((long)p.N * p.ldb * (p.dtype == DT_F16S ? 4 : 2) >= (1L << 31)) return false;
+  if ((long)p.N * p.ldb * 2 >= (1L << 31)) return false;
   // A grid that fills most of the chip by itself (N = 512: 250 tiles for a 15-frame batch) is faster than the 144-row shapes
   // outright (res5's 3x3 165 -> 136 us, the RPN's 312 -> 260); half a chip's worth (N = 256: 125 tiles, layer 3's 3x3 65 us
   // against 47 on twice the CUs) only pays in CU-time, i.e. for a caller that has other launches for the free half.
@@ -413,7 +374,6 @@ static hipError_t launch_bigtile(const GemmParams& p, hipStream_t stream) {
 
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) {
   if (p.dtype == DT_F16) return launch_bigtile<f16_t, 9, 9>(p, stream);
-  if (p.dtype == DT_F16S) return launch_bigtile<f16s_t, 9, 9>(p, stream);
   return launch_bigtile<bf16_t, 9, 9>(p, stream);
 }
 // (the same kernel on 144 x 256 tiles, <5, 4>: bit-identical too, but 61 us against the tile engine's 50 on layer 3's 3x3 -- a

@@ -19,7 +19,7 @@ hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStrea
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_f16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_epi_bf16(const float*, void*, int, int, long, int, const float*, const void*, long, int, hipStream_t);
-hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, hipStream_t);
+hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, float, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
 hipError_t run_im2col_nhwc(const void*, void*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_scale_rows(const void*, const float*, void*, int, long, int, hipStream_t);
@@ -47,7 +47,7 @@ hipError_t run_mining_argreduce(const float*, int, int, long, const long long*, 
 hipError_t run_relation_dscore(const void*, const void*, const void*, const void*, void*, int, long, int, long, long, float, int, hipStream_t);
 hipError_t run_im2col_stem(const float*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t run_maxpool3x3s2(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
-hipError_t run_cast(const void*, void*, long, int, int, hipStream_t);
+hipError_t run_cast(const void*, void*, long, int, int, float, hipStream_t);
 hipError_t run_permute(const void*, void*, int, int, int, int, int, int, hipStream_t);
 hipError_t run_det_decode(const float*, int, int, int, int, const float*, int, const float*, const float*, float, float,
                           float, float, float*, float*, hipStream_t);
@@ -84,9 +84,9 @@ static int check_launch(hipError_t e, const char* what) {
 }
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 static inline int elem_size(int dtype) { return (dtype == HVR_BF16 || dtype == HVR_F16) ? 2 : 4; }   // (split half: 4 bytes per logical element)
-static inline int kstep_elems(int dtype) { return dtype == HVR_F32 ? 32 : 64; }
+static inline int kstep_elems(int dtype) { return (dtype == HVR_F32 || dtype == HVR_F16S) ? 32 : 64; }
 static inline bool valid_dtype(int dtype) { return dtype >= HVR_F32 && dtype <= HVR_F16S; }
-static inline bool aligned256(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 255) == 0; }
+static inline bool aligned128(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; }   // a split-half [32 hi | 32 lo] group
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
@@ -105,8 +105,8 @@ static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int
   if (N % 4) return fail(HVR_EINVAL, "N=%d is not a multiple of 4", N);
   if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return fail(HVR_EINVAL, "operands must be 16-byte aligned");
   // split half: rows are whole [64 hi | 64 lo] groups and a matrix starts on a group boundary
-  if (dtype == HVR_F16S && (lda % 64 || ldb % 64 || !aligned256(A) || !aligned256(B)))
-    return fail(HVR_EINVAL, "split-half operands need 256-byte aligned bases and row pitches that are multiples of 64 elements");
+  if (dtype == HVR_F16S && (lda % 32 || ldb % 32 || !aligned128(A) || !aligned128(B)))
+    return fail(HVR_EINVAL, "split-half operands need 128-byte aligned bases and row pitches that are multiples of 32 elements");
   // the tile loaders keep 32-bit byte offsets into A and B
   const long es = elem_size(dtype);
   if ((long)M * lda * es >= (1L << 31) || (long)N * ldb * es >= (1L << 31))
@@ -160,11 +160,12 @@ static int gemm_params(const hvr_gemm_desc* d, GemmParams& p) {
   if ((d->lda * es) % 16 || (d->ldb * es) % 16) return fail(HVR_EINVAL, "lda/ldb rows must be 16-byte multiples");
   if ((d->ldc * (d->out_f32 ? 4 : es)) % 8) return fail(HVR_EINVAL, "ldc rows must be 8-byte multiples");
   if (d->dtype == HVR_F16S) {
-    if (!d->out_f32 && (d->N % 8 || d->ldc % 64 || !aligned256(d->C))) return fail(HVR_EINVAL, "split-half output: N %% 8 == 0, ldc %% 64 == 0, 256-byte aligned C");
-    if (d->resid && (d->N % 8 || d->ldr % 64 || !aligned256(d->resid))) return fail(HVR_EINVAL, "split-half residual: N %% 8 == 0, ldr %% 64 == 0, 256-byte aligned");
+    if (!d->out_f32 && (d->N % 8 || d->ldc % 32 || !aligned128(d->C))) return fail(HVR_EINVAL, "split-half output: N %% 8 == 0, ldc %% 32 == 0, 128-byte aligned C");
+    if (d->resid && (d->N % 8 || d->ldr % 32 || !aligned128(d->resid))) return fail(HVR_EINVAL, "split-half residual: N %% 8 == 0, ldr %% 32 == 0, 128-byte aligned");
   }
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->ldr; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
+  p.alpha = d->alpha; p.beta = d->beta;
   return 0;
 }
 
@@ -260,8 +261,8 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   if (!valid_dtype(d->dtype)) return fail(HVR_EINVAL, "bad dtype %d", d->dtype);
   const int bke = kstep_elems(d->dtype);
   if (d->Cin % bke) return fail(HVR_EINVAL, "Cin=%d is not a multiple of %d", d->Cin, bke);
-  if (d->dtype == HVR_F16S && !d->out_f32 && (d->Cout % 64 || !aligned256(d->y))) return fail(HVR_EINVAL, "split-half conv output: Cout %% 64 == 0, 256-byte aligned y");
-  if (d->dtype == HVR_F16S && d->resid && (d->Cout % 64 || !aligned256(d->resid))) return fail(HVR_EINVAL, "split-half conv residual: Cout %% 64 == 0, 256-byte aligned");
+  if (d->dtype == HVR_F16S && !d->out_f32 && (d->Cout % 32 || !aligned128(d->y))) return fail(HVR_EINVAL, "split-half conv output: Cout %% 32 == 0, 128-byte aligned y");
+  if (d->dtype == HVR_F16S && d->resid && (d->Cout % 32 || !aligned128(d->resid))) return fail(HVR_EINVAL, "split-half conv residual: Cout %% 32 == 0, 128-byte aligned");
   const long M = (long)d->B * OH * OW;
   if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
   if ((long)d->B * d->H * d->W * d->Cin * (long)elem_size(d->dtype) >= (1L << 31))
@@ -277,6 +278,7 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
   }
   p.bias = d->bias; p.resid = d->resid; p.ldr = d->Cout; p.relu = d->relu; p.out_f32 = d->out_f32;
   p.tile_hint = d->tile_hint;
+  p.alpha = d->alpha; p.beta = d->beta;
   if (pointwise) p.zero = d->zero;  // (expand.hip reads it in place of a missing shift)
   // the expand convs of a Bottleneck (1x1, K <= 256, + residual) are HBM-bound: row-panel kernel (expand.hip)
   static const int use_expand = std::getenv("HVR_EXPAND") ? std::atoi(std::getenv("HVR_EXPAND")) : 1;
@@ -429,7 +431,7 @@ int hvr_conv2d_path(const hvr_conv_desc* d) {
 
 int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, int dtype, void* stream) {
   if (!img || !cols || B <= 0) return fail(HVR_EINVAL, "bad stem arguments");
-  if (dtype == HVR_F16S && (KP % 64 || !aligned256(cols))) return fail(HVR_EINVAL, "split-half patch rows: KP %% 64 == 0, 256-byte aligned");
+  if (dtype == HVR_F16S && (KP % 32 || !aligned128(cols))) return fail(HVR_EINVAL, "split-half patch rows: KP %% 32 == 0, 128-byte aligned");
   if (KP < 147 || KP % kstep_elems(dtype)) return fail(HVR_EINVAL, "KP=%d must be >= 147 and a K-step multiple", KP);
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
   return check_launch(run_im2col_stem(img, cols, B, H, W, OH, OW, KP, dtype, (hipStream_t)stream), "hvr_im2col_stem");
@@ -439,7 +441,7 @@ int hvr_stem_fused_dtype(const float* img, const void* wpk, const float* bias, v
   if (!img || !wpk || !bias || !out || B <= 0 || H < 7 || W < 7) return fail(HVR_EINVAL, "bad fused-stem arguments");
   if (dtype != HVR_BF16 && dtype != HVR_F16 && dtype != HVR_F16S) return fail(HVR_EUNSUPPORTED, "the fused stem computes on bf16, half or split-half operands");
   if (!aligned16(wpk) || !aligned16(out) || !aligned16(bias)) return fail(HVR_EINVAL, "fused stem operands must be 16-byte aligned");
-  if (dtype == HVR_F16S && !aligned256(out)) return fail(HVR_EINVAL, "split-half stem output must be 256-byte aligned");
+  if (dtype == HVR_F16S && !aligned128(out)) return fail(HVR_EINVAL, "split-half stem output must be 128-byte aligned");
   return check_launch(run_stem_fused(img, wpk, bias, out, B, H, W, dtype, (hipStream_t)stream), "hvr_stem_fused");
 }
 int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream) {
@@ -507,16 +509,17 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     // three-pass product -- no block weights inside a K loop whose accumulators change scale between passes
     rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
     if (rc) return rc;
-    if (ldv % 64 || !aligned256(V) || ldo % 64 || !aligned256(O) || D % 64) return fail(HVR_EINVAL, "split-half relation: D, ldv, ldo multiples of 64, 256-byte aligned V / O");
+    if (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
     p.N = Mk; p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
     rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores (split half)");
     if (rc) return rc;
-    rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, s), "relation: normalise (split half)");
+    rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, 1.f, s), "relation: normalise (split half)");
     if (rc) return rc;
     rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose (split half)");
     if (rc) return rc;
     rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
     if (rc) return rc;
+    p.alpha = 1.f / kSplitProbScale;   // the probabilities are stored x 2^12 (gemm_tile.h, EPI_SCORES)
     return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half)");
   }
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
@@ -612,7 +615,7 @@ int hvr_relation_probs(const void* Q, int64_t ldq, const void* K, int64_t ldk, v
   p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
   rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation probs: scores");
   if (rc) return rc;
-  return check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, s), "relation probs: normalise");
+  return check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, 1.f / kSplitProbScale, s), "relation probs: normalise");
 }
 
 int hvr_relation_dscore(const void* P, const void* dP, const void* dO, int64_t ldgo, const void* O, int64_t ldo, void* dS,
@@ -918,16 +921,22 @@ int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls,
 
 // ---- plumbing ----
 int hvr_cast(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, void* stream) {
+  return hvr_cast_scaled(in, out, n, from_dtype, to_dtype, 1.f, stream);
+}
+
+int hvr_cast_scaled(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, float scale, void* stream) {
   if (n == 0) return HVR_OK;
   if (!in || !out) return fail(HVR_EINVAL, "null pointer");
-  if (!valid_dtype(from_dtype) || !valid_dtype(to_dtype) || from_dtype == to_dtype) return fail(HVR_EINVAL, "bad cast %d -> %d", from_dtype, to_dtype);
-  const bool classic = (from_dtype == HVR_F32 && to_dtype == HVR_BF16) || (from_dtype == HVR_BF16 && to_dtype == HVR_F32);
+  if (!valid_dtype(from_dtype) || !valid_dtype(to_dtype) || (from_dtype == to_dtype && (scale == 1.f || from_dtype != HVR_F32)))
+    return fail(HVR_EINVAL, "bad cast %d -> %d", from_dtype, to_dtype);
+  if (!(scale > 0.f)) return fail(HVR_EINVAL, "cast scale must be positive");
+  const bool classic = scale == 1.f && ((from_dtype == HVR_F32 && to_dtype == HVR_BF16) || (from_dtype == HVR_BF16 && to_dtype == HVR_F32));
   if (!classic) {   // 8 elements per thread; split half moves whole 64-element groups
-    const bool split = from_dtype == HVR_F16S || to_dtype == HVR_F16S;
-    if (n % (split ? 64 : 8) || !aligned16(in) || !aligned16(out) || (from_dtype == HVR_F16S && !aligned256(in)) || (to_dtype == HVR_F16S && !aligned256(out)))
-      return fail(HVR_EINVAL, "hvr_cast to / from half formats: n %% 8 == 0 (split half: n %% 64 == 0, 256-byte aligned), 16-byte aligned buffers");
+    const bool split = from_dtype == HVR_F16S || to_dtype == HVR_F16S;   // split half moves whole 32-element groups
+    if (n % (split ? 32 : 8) || !aligned16(in) || !aligned16(out) || (from_dtype == HVR_F16S && !aligned128(in)) || (to_dtype == HVR_F16S && !aligned128(out)))
+      return fail(HVR_EINVAL, "hvr_cast to / from half formats: n %% 8 == 0 (split half: n %% 32 == 0, 128-byte aligned), 16-byte aligned buffers");
   }
-  return check_launch(run_cast(in, out, n, from_dtype, to_dtype, (hipStream_t)stream), "hvr_cast");
+  return check_launch(run_cast(in, out, n, from_dtype, to_dtype, scale, (hipStream_t)stream), "hvr_cast");
 }
 
 int hvr_permute_nchw_nhwc(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from_dtype, int to_dtype,

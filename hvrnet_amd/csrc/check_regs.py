@@ -43,7 +43,10 @@ def main(*paths):
         wm, wn, fm, fn, epi, glds, respre, ns = [int(x) for x in m.groups()]
         spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
         bn = wn * fn * 16
-        untracked = epi == 2 or (ns > 2 and respre == 1 and bn != 256)
+        # the split-half K-step keeps three fragment sets on the B side: its pipelined shapes are sized to fit without scratch traffic
+        # in the loop (the 6-wave 144 x 256 ring does not and is never chosen for split operands, gemm.hip: choose_tile)
+        split_pipe = 'f16s_t' in name and ns > 2 and not (wm == 3 and fn == 8)
+        untracked = epi == 2 or (ns > 2 and respre == 1 and bn != 256) or split_pipe
         if untracked:
             seen += 1
             if spill:

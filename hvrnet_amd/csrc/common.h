@@ -17,13 +17,17 @@ enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2, DT_F16S = 3 };
 // IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 rate with a 10-bit mantissa): raw bits, a type of its own so that the
 // kernels can be instantiated on it next to bf16_t
 enum class f16_t : unsigned short {};
-// "Split half" operands (DT_F16S): a logical element x is the pair  hi = half(x),  lo = half((x - hi) * 2^11)  -- 22 significant
-// bits, x ~ hi + lo * 2^-11 -- and a product is three half MFMAs, hi*lo + lo*hi (scaled by 2^-11) + hi*hi, accumulated in f32:
-// f32-grade results at a third of the half rate instead of the exact-f32 MFMA's sixteenth.  Memory layout of a row of C elements
-// (C a multiple of 64): C / 64 groups of [64 hi halves (128 bytes)][64 lo halves (128 bytes)], i.e. 4 bytes per logical element
-// and every 64-element K-step of a plane one contiguous 128-byte line.  f16s_t is the 4-byte container element.
+// "Split half" operands (DT_F16S): a logical element x is the pair  hi = half(x),  lo = half(x - hi)  -- 22 significant bits for
+// |x| >= 2^-3, an absolute error below 2^-24 beneath that (lo is then a half subnormal, which the MFMA honours) -- and a product
+// is three half MFMAs, hi*hi + hi*lo + lo*hi, accumulated in f32: f32-grade results at a third of the half rate instead of the
+// exact-f32 MFMA's sixteenth.  Memory layout of a row of C elements (C a multiple of 32): C / 32 groups of
+// [32 hi halves (64 bytes)][32 lo halves (64 bytes)], i.e. 4 bytes per logical element, and one 128-byte line holds BOTH planes
+// of a 32-element K-step: the tile engine stages it with the loader it uses for every other format and issues the three MFMAs
+// from one LDS image (gemm_tile.h).  f16s_t is the 4-byte container element.
 struct f16s_t { uint32_t v; };
-constexpr float kSplitScale = 2048.f, kSplitInv = 1.f / 2048.f;
+constexpr int kSplitGroup = 32;     // logical elements per [hi | lo] group
+constexpr int kSplitPlane = 64;     // byte distance from a hi chunk to its lo chunk
+constexpr float kSplitProbScale = 4096.f;   // the relation's probabilities are stored x 2^12 in the split format (gemm_tile.h, capi.hip)
 constexpr float kHalfMax = 65504.f;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -61,17 +65,17 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   hi = pack2h(a, b);
   float ha, hb;
   unpack2h(hi, ha, hb);
-  lo = pack2h((a - ha) * kSplitScale, (b - hb) * kSplitScale);
+  lo = pack2h(a - ha, b - hb);
 }
 __device__ __forceinline__ void merge2(uint32_t hi, uint32_t lo, float& a, float& b) {
   float ha, hb, la, lb;
   unpack2h(hi, ha, hb);
   unpack2h(lo, la, lb);
-  a = fmaf(la, kSplitInv, ha);
-  b = fmaf(lb, kSplitInv, hb);
+  a = ha + la;
+  b = hb + lb;
 }
-// byte offset of logical column n inside a split-half row (hi plane; the lo plane is 128 bytes further)
-__device__ __host__ __forceinline__ long split_col_bytes(long n) { return (n >> 6) * 256 + (n & 63) * 2; }
+// byte offset of logical column n inside a split-half row (hi plane; the lo plane is kSplitPlane bytes further)
+__device__ __host__ __forceinline__ long split_col_bytes(long n) { return (n >> 5) * 128 + (n & 31) * 2; }
 
 // 2-byte operand types: pack / unpack of a pair
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);

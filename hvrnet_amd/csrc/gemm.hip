@@ -49,7 +49,7 @@ int choose_tile(const GemmParams& p, int epi) {
   // area x wg_per_cu / eff; a trailing partial round that leaves CUs with fewer co-resident workgroups
   // is cheaper, but not proportionally (a lone workgroup cannot saturate a CU).
   static const double kPartial[4][4] = {{0, 0, 0, 0}, {0, 1.0, 0, 0}, {0, 0.8, 1.0, 0}, {0, 0.5, 0.8, 1.0}};
-  const int ksteps = p.dtype == DT_F32 ? p.K / 32 : (p.dtype == DT_F16S ? 3 * (p.K / 64) : p.K / 64);
+  const int ksteps = (p.dtype == DT_F32 || p.dtype == DT_F16S) ? p.K / 32 : p.K / 64;
   int best = 0;
   double best_cost = 1e300;
   // candidates: the base shapes plus the pipelined variants that win on this path's problems
@@ -61,6 +61,7 @@ int choose_tile(const GemmParams& p, int epi) {
     if (epi == EPI_APPLY && (t == 2 || t == 6 || t >= 10)) continue;  // two accumulator sets do not fit 144x256;
                                                                        // 1 x 8 waves re-read the whole P~ tile per wave
     if (p.N <= 64 && s.bn > 64 && t != 0) continue;
+    if (p.dtype == DT_F16S && t == 6) continue;   // (the 6-wave 144 x 256 ring has no registers for the split K-step's third B set)
     const long tiles = (long)((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
     const long slots = 256L * s.wg_per_cu;
     const long full = tiles / slots, rem = tiles % slots;

@@ -34,6 +34,9 @@ struct GemmParams {
   const void* resid;  // [M][ldr] (operand dtype) or null
   long ldr;
   int relu, out_f32;
+  float alpha;  // split-half products (EPI_LINEAR): the accumulators are multiplied by alpha (a power of two: the caller stores small-
+                // magnitude operands -- weights, probabilities -- scaled up so that their lo halves are normal numbers); 0 = 1
+  float beta;   // split-half products: factor on the bias (a caller that keeps its activations scaled hands the bias in true units); 0 = 1
   // EPI_SCORES / EPI_APPLY
   float scale;
   float* mstat;    // [M][ntile] tile max (log2 units)

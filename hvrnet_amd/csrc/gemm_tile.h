@@ -81,8 +81,7 @@ template <> struct Mma<f16_t> {
   }
   static constexpr int kChunkSteps = 2;
 };
-// split-half operands: every LDS image holds ONE plane of each operand (which one is the loader's business), so a K-step is a
-// plain half K-step
+// split-half operands: the fragments are half fragments of one plane; which planes meet in an MFMA is the K loop's business
 template <> struct Mma<f16s_t> : Mma<f16_t> {};
 
 template <> struct Mma<float> {
@@ -110,14 +109,16 @@ template <> struct Mma<float> {
 template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16, NT = WM * WN * 64;
-  // SPLIT (f16s_t, common.h): 4 bytes per logical element in memory, [64 hi | 64 lo] half groups; the K loop walks the
-  // operands three times -- A_hi x B_lo, A_lo x B_hi, then (accumulators scaled by 2^-11) A_hi x B_hi -- each pass a plain
-  // half K loop whose loader picks the plane: LDS image, fragment reads and MFMAs are those of the f16 kernel.
+  // SPLIT (f16s_t, common.h): 4 bytes per logical element in memory, [32 hi | 32 lo] half groups, so the 128-byte line the loader
+  // stages per row and K-step holds BOTH planes of 32 logical elements: chunks 0-3 = hi, chunks 4-7 = lo.  What is the second
+  // 32-wide half of a K-step for the other formats is here the lo plane of the same 32 elements, and a K-step issues three MFMAs
+  // per fragment pair -- B_hi x A_hi when the hi fragments have landed, B_lo x A_hi and B_hi x A_lo when the lo ones have -- from
+  // one LDS image: two thirds of the LDS-DMA and fragment-read traffic per MFMA of the half formats.
   constexpr bool SPLIT = std::is_same<T, f16s_t>::value;
   constexpr bool F32 = std::is_same<T, float>::value;
   constexpr int EB = (int)sizeof(T);             // bytes per logical element in global memory
-  constexpr int BKE = F32 ? 32 : 64;             // elements per K-step (128 bytes of one plane)
-  constexpr int KSG = SPLIT ? 256 : 128;         // global bytes per K-step of a row
+  constexpr int BKE = (F32 || SPLIT) ? 32 : 64;  // logical elements per K-step (one 128-byte line per row)
+  constexpr int KSG = 128;                       // global bytes per K-step of a row
   constexpr int A_SLOTS = (BM * 8 + NT - 1) / NT, B_SLOTS = (BN * 8 + NT - 1) / NT;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr bool ASM_READS = GLDS && kAsmLdsReads && (NS > 2 || !(WM == 3 && FN == 4) || EPI == EPI_APPLY);
@@ -230,33 +231,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   const char* const rs_a2 = (const char*)p.A2;
   uint4 a_reg[A_SLOTS], b_reg[B_SLOTS];  // register staging (unused when GLDS)
 
-  // SPLIT: K-step kv of the 3 * nk_slice-step loop -> the operand K-step it reads and the plane offsets of A and B
-  // (pass 0: A_hi x B_lo, pass 1: A_lo x B_hi, pass 2: A_hi x B_hi); everything else: the identity
-  const int nk_real = nk_slice;
-  auto kmap = [&](int kv, int& a_plane, int& b_plane) {
-    a_plane = 0;
-    b_plane = 0;
-    if constexpr (SPLIT) {
-      const int pass = kv >= 2 * nk_real ? 2 : (kv >= nk_real ? 1 : 0);
-      a_plane = pass == 1 ? 128 : 0;
-      b_plane = pass == 0 ? 128 : 0;
-      return kv - pass * nk_real;
-    }
-    return kv;
-  };
-
-  auto issue_loads = [&](int kv, char* stage) {
+  auto issue_loads = [&](int kt, char* stage) {
     long a_koff;
-    int dy = 0, dx = 0, a_plane, b_plane;
-    const int kt = kmap(kv, a_plane, b_plane);
+    int dy = 0, dx = 0;
     if (kConvOk && p.conv) {
       const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       dy = ky * p.dil;
       dx = kx * p.dil;
-      a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB + a_plane;
+      a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB;
     } else {
-      a_koff = (long)kt * KSG + a_plane;
+      a_koff = (long)kt * KSG;
     }
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
@@ -283,9 +268,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     for (int i = 0; i < B_SLOTS; ++i) {
       if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
         if constexpr (GLDS) {
-          buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(kt * KSG + b_plane));
+          buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(kt * KSG));
         } else {
-          const char* src = Bb + ((long)b_off(i) + (long)kt * KSG + b_plane);
+          const char* src = Bb + ((long)b_off(i) + (long)kt * KSG);
           b_reg[i] = *reinterpret_cast<const uint4*>(src);
         }
       }
@@ -321,18 +306,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   float gcur[GN], gnext[GN];
   float gref[GN];  // per row: m* + log2(L), so that the block weight is g = 2^(m_t - gref)
   constexpr int STEPS_PER_BLOCK = 128 / BKE;  // K-steps per 128-key statistics block
-  const int nk = SPLIT ? 3 * nk_slice : nk_slice;
-  // SPLIT: the cross terms (passes 0 and 1) carry the lo planes' 2^11: one multiply per accumulator in front of the hi x hi pass
-  auto split_rescale = [&](int kv) {
-    if constexpr (SPLIT) {
-      if (kv == 2 * nk_real) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] *= kSplitInv;
-      }
-    }
-  };
+  const int nk = nk_slice;
   const int nblk = nk / STEPS_PER_BLOCK;
   // statistics row of fragment row i of this lane (rows past M read row M - 1: their outputs are never stored)
   auto stat_row = [&](int i) {
@@ -422,7 +396,6 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       char* cur = smem + (kt & 1) * STAGE_BYTES;
       char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
       const bool more = kt + 1 < nk;
-      split_rescale(kt);
       if constexpr (EPI == EPI_APPLY) {
         if (first) {
           if (kt + STEPS_PER_BLOCK < nk) {
@@ -463,6 +436,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
               if constexpr (EPI == EPI_APPLY) {
                 if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
                 else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
+              } else if constexpr (SPLIT) {
+                // kk = 0: the hi fragments have landed -> B_hi x A_hi; kk = 1: the lo fragments -> the two cross terms
+                if (kk == 0) {
+                  Mma<T>::template run<false>(wb[0][j], xa[0][i], acc[i][j]);
+                } else {
+                  Mma<T>::template run<false>(wb[1][j], xa[0][i], acc[i][j]);
+                  Mma<T>::template run<false>(wb[0][j], xa[1][i], acc[i][j]);
+                }
               } else {
                 Mma<T>::template run<false>(wb[kk][j], xa[kk][i], acc[i][j]);
               }
@@ -471,6 +452,25 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       } else {
         const char* a_base = cur + (wm * FM * 16 + frag_row) * 128;
         const char* b_base = cur + BM * 128 + (wn * FN * 16 + frag_row) * 128;
+        if constexpr (SPLIT) {
+          uint4 xa[2][FM], wb[2][FN];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xa[kk][i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * 128 + chunk);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wb[kk][j] = *reinterpret_cast<const uint4*>(b_base + j * 16 * 128 + chunk);
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              Mma<T>::template run<false>(wb[0][j], xa[0][i], acc[i][j]);
+              Mma<T>::template run<false>(wb[1][j], xa[0][i], acc[i][j]);
+              Mma<T>::template run<false>(wb[0][j], xa[1][i], acc[i][j]);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int chunk = ((kk * 4 + frag_grp) ^ swz) * 16;
@@ -490,6 +490,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
                 Mma<T>::template run<false>(wb[j], xa[i], acc[i][j]);
               }
             }
+        }
         }
       }
       if constexpr (EPI == EPI_APPLY) {
@@ -530,25 +531,26 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     static_assert(EPI != EPI_APPLY || STEPS_PER_BLOCK == 2, "the pipelined apply loop assumes 2 K-steps per block");
     constexpr int MIN_A = min_wave_loads(BM, NT);
     constexpr int NR = FM + FN, NM = FM * FN;
-    uint4 fa[2][FM], fb[2][FN];  // fragment sets: [0] = kk 0, [1] = kk 1
+    // fragment sets: [0] = kk 0, [1] = kk 1.  SPLIT: [0] = the hi plane, [1] = the lo plane; the B side keeps a third set, [2]: the
+    // next step's B_hi fragments are requested while this step's B_hi x A_lo terms still read the current ones and move into [0]
+    // at the top of the next step (an A_hi fragment is re-requested as soon as its row's B_lo x A_hi terms are issued)
+    uint4 fa[2][FM], fb[SPLIT ? 3 : 2][FN];
     long a_koff = 0;
     int dy = 0, dx = 0;  // conv: filter tap of the K-step being loaded
     int kt_load = 0;     // the K-step being loaded (second-segment products switch operand at k1_steps)
     int b_koff = 0;      // its byte offset in a B row
 
-    auto tap_of = [&](int kv) {
-      int a_plane, b_plane;
-      const int kt = kmap(kv, a_plane, b_plane);
+    auto tap_of = [&](int kt) {
       kt_load = kt;
-      b_koff = kt * KSG + b_plane;
+      b_koff = kt * KSG;
       if (kConvOk && p.conv) {
         const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
         dy = ky * p.dil;
         dx = kx * p.dil;
-        a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB + a_plane;
+        a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB;
       } else {
-        a_koff = (long)kt * KSG + a_plane;
+        a_koff = (long)kt * KSG;
       }
     };
     auto dma_a = [&](auto I, char* stage) {
@@ -583,8 +585,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #ifdef HVR_DBG_NOLDSREAD
       (void)soff;
 #else
-      if constexpr (r < FM) fa[kk][r] = lds_read128_off<r * 2048>((a_lane + soff) ^ (kk ? 64u : 0u));
-      else fb[kk][r - FM] = lds_read128_off<(r - FM) * 2048>((b_lane + soff) ^ (kk ? 64u : 0u));
+      if constexpr (r < FM) fa[kk == 1 ? 1 : 0][r] = lds_read128_off<r * 2048>((a_lane + soff) ^ (kk == 1 ? 64u : 0u));
+      else fb[kk][r - FM] = lds_read128_off<(r - FM) * 2048>((b_lane + soff) ^ (kk == 1 ? 64u : 0u));
 #endif
     };
 
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     // branch between its MFMAs), 2 = decided at run time from kt (loop tails).  NEXT: a K-step kt + 1 exists (its
     // first fragments are requested in half 1).  FIRST / LAST: position inside a 128-key block (EPI_APPLY).
     auto pipe_step = [&](int kt, auto LOAD, auto NEXT, auto FIRST, auto LAST) {
+      constexpr int HS = 0, HN = 2;  // SPLIT: this / the next step's B_hi set
       constexpr int lmode = decltype(LOAD)::value;
       constexpr bool next = decltype(NEXT)::value, first = decltype(FIRST)::value, last = decltype(LAST)::value;
       const bool load = lmode == 2 ? kt + NS - 1 < nk : lmode == 1;
@@ -630,15 +633,21 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         }
       }
       if (load) tap_of(kt + NS - 1);
-      split_rescale(kt);
       static_for<2>([&](auto KK) {
         constexpr int kk = decltype(KK)::value;
         constexpr int ND = kk == 0 ? A_SLOTS : B_SLOTS;
         constexpr bool reads = kk == 0 || next;  // half 1 requests the next step's first fragments
         constexpr int NF = (reads ? NR : 0) + ND;
-        constexpr int PER = (NF + NM - 1) / NM;  // fillers after each MFMA
+        constexpr int NMK = (SPLIT && kk == 1) ? 2 * NM : NM;   // SPLIT: half 1 issues the two cross terms of every fragment pair
+        constexpr int PER = (NF + NMK - 1) / NMK;  // fillers after each MFMA
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (SPLIT && kk == 0) {
+          if (kt > 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[0][j] = fb[2][j];
+          }
+        }
         if constexpr (kk == 1) {
           // loads that may stay in flight: the K-steps after kt + 1 (full groups), plus the A half of the group
           // this step is issuing; an apply block's g loads sit exactly that far back, hence one fewer there
@@ -657,17 +666,37 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
-        static_for<NM>([&](auto Q) {
-          constexpr int q = decltype(Q)::value, i = q / FN, j = q % FN;
+        static_for<NMK>([&](auto Q) {
+          constexpr int qq = decltype(Q)::value, q = qq % NM, i = q / FN, j = q % FN;
           if constexpr (EPI == EPI_APPLY) {
             if constexpr (first && kk == 0) Mma<T>::template run<true>(fb[kk][j], fa[kk][i], pacc[i][j]);
             else Mma<T>::template run<false>(fb[kk][j], fa[kk][i], pacc[i][j]);
+          } else if constexpr (SPLIT) {
+            if constexpr (kk == 0) Mma<T>::template run<false>(fb[HS][j], fa[0][i], acc[i][j]);     // B_hi x A_hi
+            else if constexpr (qq < NM) Mma<T>::template run<false>(fb[1][j], fa[0][i], acc[i][j]);  // B_lo x A_hi, row by row
+            else Mma<T>::template run<false>(fb[HS][j], fa[1][i], acc[i][j]);                       // B_hi x A_lo
           } else {
             Mma<T>::template run<false>(fb[kk][j], fa[kk][i], acc[i][j]);
           }
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (SPLIT && kk == 1) {
+            // one filler per slot: the slot behind a row's last B_lo x A_hi term re-requests that row's A_hi fragment (the next
+            // K-step's); every other slot takes the next of (the next step's B_hi fragments into the spare set, then the B DMA)
+            constexpr bool row_end = qq < NM && (qq + 1) % FN == 0;
+            constexpr int ends_before = (qq / FN) < FM ? (qq / FN) : FM;
+            constexpr int oi = qq - ends_before;            // index in the "other" list (only meaningful when !row_end)
+            constexpr int n_bhi = next ? FN : 0;
+            static_assert(2 * NM - FM >= FN + B_SLOTS, "half 1 has a slot for every filler");
+            if constexpr (row_end) {
+              if constexpr (next) read_frag(std::integral_constant<int, qq / FN>{}, std::integral_constant<int, 0>{}, (uint32_t)ns * STAGE_BYTES);
+            } else if constexpr (oi < n_bhi) {
+              read_frag(std::integral_constant<int, FM + oi>{}, std::integral_constant<int, HN>{}, (uint32_t)ns * STAGE_BYTES);
+            } else if constexpr (oi - n_bhi < B_SLOTS) {
+              if (load) dma_b(std::integral_constant<int, oi - n_bhi>{}, lstage);
+            }
+          } else
           static_for<PER>([&](auto U) {
-            constexpr int f = q * PER + decltype(U)::value;
+            constexpr int f = qq * PER + decltype(U)::value;
             constexpr int fr = reads ? f : f + NR;  // filler index in the (reads, DMA) order
             if constexpr (f < NF) {
               if constexpr (fr < NR) {
@@ -761,8 +790,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int j = 0; j < FN; ++j) {
             const int col = (wn * FN + j) * 16 + frag_grp * 4;
             f32x4 v = acc[i][j];
+            if constexpr (SPLIT) {
+              if (p.alpha != 0.f) v *= p.alpha;
+            }
             if (p.bias && n0 + col < p.N) {
-              const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
+              float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
+              if constexpr (SPLIT) {
+                if (p.beta != 0.f) { bv.x *= p.beta; bv.y *= p.beta; bv.z *= p.beta; bv.w *= p.beta; }
+              }
               v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
             }
             *reinterpret_cast<f32x4*>(ebuf + (i * 16 + frag_row) * LDW + col) = v;
@@ -790,7 +825,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         } else if constexpr (SPLIT) {
           if (p.resid) {  // (the C ABI admits split operands in whole 8-column chunks only: `full` holds)
             const char* rp = reinterpret_cast<const char*>(p.resid) + (long)m * p.ldr * 4 + split_col_bytes(n);
-            const uint4 th = *reinterpret_cast<const uint4*>(rp), tl = *reinterpret_cast<const uint4*>(rp + 128);
+            const uint4 th = *reinterpret_cast<const uint4*>(rp), tl = *reinterpret_cast<const uint4*>(rp + kSplitPlane);
             float rv[8];
             merge2(th.x, tl.x, rv[0], rv[1]); merge2(th.y, tl.y, rv[2], rv[3]);
             merge2(th.z, tl.z, rv[4], rv[5]); merge2(th.w, tl.w, rv[6], rv[7]);
@@ -831,7 +866,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y);
           split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
           *reinterpret_cast<uint4*>(cp) = h;
-          *reinterpret_cast<uint4*>(cp + 128) = l;
+          *reinterpret_cast<uint4*>(cp + kSplitPlane) = l;
         } else if constexpr (sizeof(T) == 2) {
           T* cp = reinterpret_cast<T*>(Cb) + (long)m * p.ldc + n;
           if (full && wide_c) {
@@ -903,6 +938,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         float e[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], sl2, -tmax[i]));  // masked keys: exp2(-inf) = 0
+        if constexpr (SPLIT) {
+          // probabilities are small numbers (1 / keys on average): stored x 2^12 so that their lo halves stay normal; the apply
+          // product takes the factor back (alpha, capi.hip), the statistics below are of the unscaled values
+        }
         if constexpr (sizeof(T) == 2) {
           // (the row sum is taken before rounding: the rounding errors of a tile's 128 values average out far below
           // the bf16 resolution of the output, and re-expanding the packed values costs as much VALU as the exponentials)
@@ -911,12 +950,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           *reinterpret_cast<uint2*>(pbuf + row * PITCH + col * 2) = make_uint2(lo, hi);
         } else if constexpr (SPLIT) {
           uint32_t h0, l0, h1, l1;
-          split2(e[0], e[1], h0, l0);
-          split2(e[2], e[3], h1, l1);
+          split2(e[0] * kSplitProbScale, e[1] * kSplitProbScale, h0, l0);
+          split2(e[2] * kSplitProbScale, e[3] * kSplitProbScale, h1, l1);
           sum += (e[0] + e[1]) + (e[2] + e[3]);
           char* dst = pbuf + row * PITCH + split_col_bytes(col);   // the staged row has the memory layout of the 128-key tile
           *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(dst + 128) = make_uint2(l0, l1);
+          *reinterpret_cast<uint2*>(dst + kSplitPlane) = make_uint2(l0, l1);
         } else {
           sum += (e[0] + e[1]) + (e[2] + e[3]);
           *reinterpret_cast<float2*>(pbuf + row * PITCH + col * 4) = make_float2(e[0], e[1]);

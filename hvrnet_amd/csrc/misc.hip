@@ -109,14 +109,14 @@ __global__ void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __
   }
 }
 
-// ---- casts between any two operand formats, 8 logical elements per thread (n % 8 == 0; split half: n % 64 == 0) ----
+// ---- casts between any two operand formats, 8 logical elements per thread (n % 8 == 0; split half: n % 32 == 0) ----
 template <typename T> __device__ __forceinline__ void load8(const char* base, long i, float v[8]) {
   if constexpr (std::is_same<T, float>::value) {
     load4(reinterpret_cast<const float*>(base) + i, v);
     load4(reinterpret_cast<const float*>(base) + i + 4, v + 4);
   } else if constexpr (std::is_same<T, f16s_t>::value) {
     const char* q = base + split_col_bytes(i);
-    const uint4 h = *reinterpret_cast<const uint4*>(q), l = *reinterpret_cast<const uint4*>(q + 128);
+    const uint4 h = *reinterpret_cast<const uint4*>(q), l = *reinterpret_cast<const uint4*>(q + kSplitPlane);
     merge2(h.x, l.x, v[0], v[1]); merge2(h.y, l.y, v[2], v[3]); merge2(h.z, l.z, v[4], v[5]); merge2(h.w, l.w, v[6], v[7]);
   } else {
     const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(base) + i);
@@ -132,17 +132,19 @@ template <typename T> __device__ __forceinline__ void store8(char* base, long i,
     uint4 h, l;
     split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
     *reinterpret_cast<uint4*>(q) = h;
-    *reinterpret_cast<uint4*>(q + 128) = l;
+    *reinterpret_cast<uint4*>(q + kSplitPlane) = l;
   } else {
     *reinterpret_cast<uint4*>(reinterpret_cast<T*>(base) + i) =
         make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
   }
 }
 template <typename TI, typename TO>
-__global__ void cast8_kernel(const char* __restrict__ in, char* __restrict__ out, long n) {
+__global__ void cast8_kernel(const char* __restrict__ in, char* __restrict__ out, long n, float scale) {
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
     float v[8];
     load8<TI>(in, i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= scale;   // (a power of two in every use: exact)
     store8<TO>(out, i, v);
   }
 }
@@ -270,19 +272,20 @@ __global__ __launch_bounds__(256) void transpose_pad_bf16x8_kernel(const bf16_t*
   }
 }
 
-// split half: a 64 x 64 logical tile is one [hi | lo] group per input row and one per output row -- two independent 64 x 64
-// transposes of 16-bit words (blockIdx.z = plane).  R, C, ldx, ldt in logical elements; C, ldx, ldt multiples of 64.
+// split half: the hi and the lo plane of a 64 x 64 logical tile are two independent 64 x 64 transposes of 16-bit words
+// (blockIdx.z = plane); only the addressing knows about the [32 hi | 32 lo] groups.  R, C, ldx, ldt in logical elements; C, ldx,
+// ldt multiples of 64 here (the relation's V^T: D and the padded key count).
 __global__ __launch_bounds__(256) void transpose_pad_split_kernel(const char* __restrict__ in, char* __restrict__ out, int R, int C,
                                                                   long ldx, long ldt) {
   constexpr int PITCH = 64 * 2 + 16;
   __shared__ __attribute__((aligned(16))) char tile[64 * PITCH];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x, plane = blockIdx.z * 128;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x, plane = blockIdx.z * kSplitPlane;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int s = it * 256 + tid, i = s >> 3, q = s & 7;
     const int r = r0 + i;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (r < R) v = *reinterpret_cast<const uint4*>(in + (long)r * ldx * 4 + (long)(c0 >> 6) * 256 + plane + q * 16);
+    if (r < R) v = *reinterpret_cast<const uint4*>(in + (long)r * ldx * 4 + split_col_bytes(c0 + q * 8) + plane);
     *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
   }
   __syncthreads();
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void transpose_pad_split_kernel(const char* __
       const uint32_t hi = *reinterpret_cast<const unsigned short*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
       w[e] = lo | (hi << 16);
     }
-    *reinterpret_cast<uint4*>(out + (long)c * ldt * 4 + (long)(r0 >> 6) * 256 + plane + q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(out + (long)c * ldt * 4 + split_col_bytes(r0 + q * 8) + plane) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void relation_normalize_kernel(T* __restrict__
 
 // the same on a split-half P (rows of ldp / 64 [hi | lo] groups): 8 logical columns per thread step
 __global__ __launch_bounds__(256) void relation_normalize_split_kernel(char* __restrict__ P, const float* __restrict__ mstat,
-                                                                       const float* __restrict__ lstat, int ntile, long ldp) {
+                                                                       const float* __restrict__ lstat, int ntile, long ldp, float post) {
   __shared__ float g[128];
   const int m = blockIdx.x, tid = threadIdx.x;
   if (tid < 64) {
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void relation_normalize_split_kernel(char* __r
     float l = 0.f;
     for (int t = tid; t < ntile; t += 64) l += lstat[(long)m * ntile + t] * exp2f(mstat[(long)m * ntile + t] - mx);
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
-    for (int t = tid; t < ntile; t += 64) g[t] = exp2f(mstat[(long)m * ntile + t] - mx) / l;
+    for (int t = tid; t < ntile; t += 64) g[t] = exp2f(mstat[(long)m * ntile + t] - mx) / l * post;
   }
   __syncthreads();
   char* row = P + (long)m * ldp * 4;
@@ -805,13 +808,15 @@ hipError_t run_det_loss(const float* logits, int ldl, int cls_off, int reg_off, 
   return hipGetLastError();
 }
 
-hipError_t run_relation_normalize(void* P, const float* mstat, const float* lstat, int Mq, int ntile, long ldp, int dtype, hipStream_t s) {
+// post (split half only): an extra factor on the probabilities -- the score pass stores them x kSplitProbScale; 1 keeps that
+// scale (the relation's own apply product takes it back), 1 / kSplitProbScale hands out true probabilities (hvr_relation_probs)
+hipError_t run_relation_normalize(void* P, const float* mstat, const float* lstat, int Mq, int ntile, long ldp, int dtype, float post, hipStream_t s) {
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(relation_normalize_kernel<bf16_t>, dim3(Mq), dim3(256), 0, s, (bf16_t*)P, mstat, lstat, ntile, ldp);
   else if (dtype == DT_F16)
     hipLaunchKernelGGL(relation_normalize_kernel<f16_t>, dim3(Mq), dim3(256), 0, s, (f16_t*)P, mstat, lstat, ntile, ldp);
   else if (dtype == DT_F16S)
-    hipLaunchKernelGGL(relation_normalize_split_kernel, dim3(Mq), dim3(256), 0, s, (char*)P, mstat, lstat, ntile, ldp);
+    hipLaunchKernelGGL(relation_normalize_split_kernel, dim3(Mq), dim3(256), 0, s, (char*)P, mstat, lstat, ntile, ldp, post);
   else
     hipLaunchKernelGGL(relation_normalize_kernel<float>, dim3(Mq), dim3(256), 0, s, (float*)P, mstat, lstat, ntile, ldp);
   return hipGetLastError();
@@ -840,7 +845,7 @@ hipError_t run_transpose_pad(const void* in, void* out, int R, int C, long ldx, 
   const bool wide = two && C % 8 == 0 && ldx % 8 == 0 && ldt % 8 == 0 &&
                     ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   if (dtype == DT_F16S) {
-    if (C % 64 || ldx % 64 || ldt % 64 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)) return hipErrorInvalidValue;
+    if (C % 64 || ldx % 32 || ldt % 64 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)) return hipErrorInvalidValue;
     grid.z = 2;
     hipLaunchKernelGGL(transpose_pad_split_kernel, grid, dim3(256), 0, s, (const char*)in, (char*)out, R, C, ldx, ldt);
   } else if (wide)
@@ -884,11 +889,11 @@ hipError_t run_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int 
   return hipGetLastError();
 }
 
-hipError_t run_cast(const void* in, void* out, long n, int from, int to, hipStream_t s) {
+hipError_t run_cast(const void* in, void* out, long n, int from, int to, float scale, hipStream_t s) {
   const int g = grid_for((n + 3) / 4, 256);
-  if (from == DT_F32 && to == DT_BF16)
+  if (scale == 1.f && from == DT_F32 && to == DT_BF16)
     hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(g), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
-  else if (from == DT_BF16 && to == DT_F32)
+  else if (scale == 1.f && from == DT_BF16 && to == DT_F32)
     hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(g), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
   else {
     // every other pair, 8 elements per thread (capi.hip checks n % 8 / n % 64 and the alignment)
@@ -896,7 +901,8 @@ hipError_t run_cast(const void* in, void* out, long n, int from, int to, hipStre
     const char* ip = (const char*)in;
     char* op = (char*)out;
 #define HVR_CAST8(FI, TI, FO, TO) \
-    if (from == FI && to == FO) { hipLaunchKernelGGL((cast8_kernel<TI, TO>), dim3(g8), dim3(256), 0, s, ip, op, n); return hipGetLastError(); }
+    if (from == FI && to == FO) { hipLaunchKernelGGL((cast8_kernel<TI, TO>), dim3(g8), dim3(256), 0, s, ip, op, n, scale); return hipGetLastError(); }
+    HVR_CAST8(DT_F32, float, DT_BF16, bf16_t) HVR_CAST8(DT_BF16, bf16_t, DT_F32, float) HVR_CAST8(DT_F32, float, DT_F32, float)
     HVR_CAST8(DT_F32, float, DT_F16, f16_t) HVR_CAST8(DT_F16, f16_t, DT_F32, float)
     HVR_CAST8(DT_F32, float, DT_F16S, f16s_t) HVR_CAST8(DT_F16S, f16s_t, DT_F32, float)
     HVR_CAST8(DT_BF16, bf16_t, DT_F16, f16_t) HVR_CAST8(DT_F16, f16_t, DT_BF16, bf16_t)

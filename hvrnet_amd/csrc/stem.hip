@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 }
 
 // The same stem on split-half operands (common.h: x ~ hi + lo * 2^-11): the input patch and the weights as two half planes each,
-// three MFMAs per product -- w_lo x a_hi and w_hi x a_lo into a cross accumulator (scaled 2^11), w_hi x a_hi into the main one --,
-// the conv pixels kept in f32 in the LDS (the pooling maximum does not act per plane), the pooled pixel written as one
-// [64 hi | 64 lo] group.  wpk: [2][64][7][32] half, plane 0 = hi(w), plane 1 = half((w - hi) * 2^11).  The weight fragments of
+// three MFMAs per product (w_hi x a_hi, w_lo x a_hi, w_hi x a_lo into one f32 accumulator),
+// the conv pixels kept in f32 in the LDS (the pooling maximum does not act per plane), the pooled pixel written as two
+// [32 hi | 32 lo] groups.  wpk: [2][64][7][32] half, plane 0 = hi(w), plane 1 = half(w - hi).  The weight fragments of
 // two 16-channel groups stay in registers at a time (both planes: 112 registers), the fragments are walked twice.
 constexpr int ST_CROWF = 68;                                // conv-out row pitch in f32
 constexpr int ST_PLANE_BYTES = (ST_IR + 3) * ST_PCOLS * 4 * 2;
@@ -202,17 +202,17 @@ __global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __re
       const int p = f * 16 + (lane & 15);
       const int cy = p / ST_CW, cx = p - cy * ST_CW;
       const int aoff = ((2 * cy) * ST_PCOLS + 2 * cx) * 8 + (lane >> 4) * 16;
-      f32x4 acc[2], accx[2];
+      f32x4 acc[2];
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf) { acc[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[nf] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int nf = 0; nf < 2; ++nf) acc[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) {
         const uint4 ah = *reinterpret_cast<const uint4*>(patch_hi + aoff + ky * ST_PCOLS * 8);
         const uint4 al = *reinterpret_cast<const uint4*>(patch_lo + aoff + ky * ST_PCOLS * 8);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-          accx[nf] = mfma_half<f16_t>(wl[nf][ky], ah, accx[nf]);
-          accx[nf] = mfma_half<f16_t>(wh[nf][ky], al, accx[nf]);
+          acc[nf] = mfma_half<f16_t>(wl[nf][ky], ah, acc[nf]);
+          acc[nf] = mfma_half<f16_t>(wh[nf][ky], al, acc[nf]);
           acc[nf] = mfma_half<f16_t>(wh[nf][ky], ah, acc[nf]);
         }
       }
@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __re
       for (int nf = 0; nf < 2; ++nf) {
         const int n = (half * 2 + nf) * 16 + (lane >> 4) * 4;
         const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        const float4 v = make_float4(fmaxf(fmaf(accx[nf][0], kSplitInv, acc[nf][0]) + bv.x, 0.f), fmaxf(fmaf(accx[nf][1], kSplitInv, acc[nf][1]) + bv.y, 0.f),
-                                     fmaxf(fmaf(accx[nf][2], kSplitInv, acc[nf][2]) + bv.z, 0.f), fmaxf(fmaf(accx[nf][3], kSplitInv, acc[nf][3]) + bv.w, 0.f));
+        constexpr float kInvW = 1.f / 64.f;   // the weights arrive x 2^6 (native.stem_split_weights: their lo halves stay normal numbers)
+        const float4 v = make_float4(fmaxf(fmaf(acc[nf][0], kInvW, bv.x), 0.f), fmaxf(fmaf(acc[nf][1], kInvW, bv.y), 0.f),
+                                     fmaxf(fmaf(acc[nf][2], kInvW, bv.z), 0.f), fmaxf(fmaf(acc[nf][3], kInvW, bv.w), 0.f));
         *reinterpret_cast<float4*>(cbuf + p * ST_CROWF + n) = v;
       }
     }
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __re
     uint4 h, l;
     split2(best[0], best[1], h.x, l.x); split2(best[2], best[3], h.y, l.y);
     split2(best[4], best[5], h.z, l.z); split2(best[6], best[7], h.w, l.w);
-    char* dst = out + (((long)b * PH + py) * PW + px) * 256 + ch * 16;   // one [64 hi | 64 lo] group per pixel
+    char* dst = out + (((long)b * PH + py) * PW + px) * 256 + split_col_bytes(ch * 8);   // 64 channels = two [32 hi | 32 lo] groups
     *reinterpret_cast<uint4*>(dst) = h;
-    *reinterpret_cast<uint4*>(dst + 128) = l;
+    *reinterpret_cast<uint4*>(dst + kSplitPlane) = l;
   }
 }
 

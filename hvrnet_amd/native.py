@@ -20,8 +20,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hvr_hip.h')
 
 HVR_F32, HVR_BF16, HVR_F16, HVR_F16S = 0, 1, 2, 3
 ABI_VERSION = 3
-# Split-half tensors (HVR_F16S, include/hvr_hip.h: [64 hi | 64 lo] half groups, 4 bytes per logical element) travel through
-# torch as int32 tensors of the LOGICAL shape: element size, strides, row / 64-column slicing, cat, clone and zeros all mean
+# Split-half tensors (HVR_F16S, include/hvr_hip.h: [32 hi | 32 lo] half groups, 4 bytes per logical element) travel through
+# torch as int32 tensors of the LOGICAL shape: element size, strides, row / 32-column slicing, cat, clone and zeros all mean
 # the right thing on the container, and nothing but this library ever interprets the bytes.  `SPLIT` is the dtype sentinel
 # (`set_compute_dtype(model, native.SPLIT)`).
 SPLIT = torch.int32
@@ -46,7 +46,7 @@ class GemmDesc(ctypes.Structure):
                 ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p), ('ldr', ctypes.c_int64),
                 ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
                 ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32),
-                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
+                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t), ('alpha', ctypes.c_float), ('beta', ctypes.c_float)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -58,7 +58,8 @@ class ConvDesc(ctypes.Structure):
                 ('bias', ctypes.c_void_p), ('resid', ctypes.c_void_p),
                 ('relu', ctypes.c_int32), ('out_f32', ctypes.c_int32),
                 ('dtype', ctypes.c_int32), ('staging', ctypes.c_int32), ('tile_hint', ctypes.c_int32),
-                ('zero', ctypes.c_void_p), ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t)]
+                ('zero', ctypes.c_void_p), ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_size_t), ('alpha', ctypes.c_float),
+                ('beta', ctypes.c_float)]
 
 
 class TailDesc(ctypes.Structure):
@@ -141,6 +142,7 @@ SYMBOLS = {
     'hvr_multiclass_nms_workspace_bytes': (_sz, [_i, _i]),
     'hvr_multiclass_nms': (_i, [_vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hvr_cast': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    'hvr_cast_scaled': (_i, [_vp, _vp, _i64, _i, _i, _f, _vp]),
     'hvr_permute_nchw_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'hvr_transpose_pad': (_i, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp]),
 }
@@ -289,17 +291,36 @@ def kstep(dtype):
     return 32 if dtype == torch.float32 else 64
 
 
+# A split-half value below 2^-3 keeps an absolute, not a relative, error bound (its lo half is then a half subnormal), so this
+# layer keeps split tensors SCALED by powers of two: weights x 2^6 (they are ~1e-2), activations x 2^4 (full precision from
+# 2^-7 up, range 4094).  cast() applies / removes the activation scale, as_operand() the weight scale, and gemm() / conv2d_nhwc()
+# hand the kernels the factors that keep every output in its convention: alpha on the accumulators, beta on the bias.  Every B
+# operand those two are given here is a weight matrix made by as_operand().  Nothing outside this file knows about the scales.
+SPLIT_WEIGHT_SCALE = 64.0
+SPLIT_ACT_SCALE = 16.0
+
+
+def _split_factors(out_is_f32, alpha):
+    """(alpha, beta) of a split-half product A(x ACT) . W(x WEIGHT)^T whose output is a scaled split tensor or true-valued f32."""
+    if alpha is not None:
+        return float(alpha), 1.0
+    if out_is_f32:
+        return 1.0 / (SPLIT_WEIGHT_SCALE * SPLIT_ACT_SCALE), 1.0
+    return 1.0 / SPLIT_WEIGHT_SCALE, SPLIT_ACT_SCALE
+
+
 def as_operand(t, dtype):
-    """An f32 tensor (weights at pack time) in the operand format `dtype`, contiguous."""
+    """An f32 WEIGHT tensor (pack time) in the operand format `dtype`, contiguous (split half: x SPLIT_WEIGHT_SCALE)."""
     t = t.contiguous()
     if dtype == SPLIT:
-        return cast(t.float(), SPLIT)
+        return cast(t.float(), SPLIT, scale=SPLIT_WEIGHT_SCALE)
     return t.to(dtype)
 
 
 # ----------------------------------------------------------------------------------------
-def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, staging=None, tile=None):
-    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + resid).  a / w / resid share one dtype."""
+def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, staging=None, tile=None, alpha=None):
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias + resid).  a / w / resid share one dtype.  alpha (split half only): the factor on
+    the accumulators (bias then unscaled); default: the factors of this layer's scaled split tensors (_split_factors)."""
     _need_cuda(a, w, bias, resid)
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
     assert a.stride(1) == 1 and w.stride(1) == 1
@@ -315,6 +336,8 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
                  relu=int(relu), out_f32=int(out.dtype == torch.float32 and a.dtype != torch.float32),
                  dtype=_dt(a), staging=STAGING if staging is None else staging,
                  tile_hint=TILE_HINT if tile is None else tile)
+    if a.dtype == SPLIT:
+        d.alpha, d.beta = _split_factors(out.dtype == torch.float32, alpha)
     nbytes = lib().hvr_gemm_fewrow_workspace_bytes(ctypes.byref(d)) if _fewrow[0] else 0   # few rows, long K: K slices + one reduce launch
     if nbytes:
         ws = _workspace(nbytes, a.device, 'gemm_fewrow')
@@ -342,7 +365,7 @@ def gemm_splitk(a, w, staging=None, tile=None):
     return out
 
 
-def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None, tile=None, out=None):
+def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1, out_f32=False, staging=None, tile=None, out=None, alpha=None):
     """x [B,H,W,Cin] (physical NHWC), w [Cout,KH,KW,Cin] -> [B,OH,OW,Cout]; out: a contiguous tensor of that shape and the
     output dtype to write into (the caller-allocates contract of the C ABI) instead of a fresh one."""
     _need_cuda(x, w, bias, resid)
@@ -364,6 +387,8 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  relu=int(relu), out_f32=int(out_f32 and x.dtype != torch.float32), dtype=_dt(x),
                  staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile,
                  zero=zero_page(x.device).data_ptr())
+    if x.dtype == SPLIT:
+        d.alpha, d.beta = _split_factors(bool(out_f32), alpha)
     # few-row problems (one frame through the stride-16 stages): the library cuts the K loop into slices when it is handed
     # scratch for the f32 partial tiles (per stream, like every other workspace here)
     nbytes = lib().hvr_conv2d_splitk_workspace_bytes(ctypes.byref(d)) if _fewrow[0] else 0
@@ -478,9 +503,9 @@ def im2col_stem(img, dtype, kp=192):
     assert img.dtype == torch.float32 and img.is_contiguous()
     B, _, H, W = img.shape
     OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    cols = torch.empty((B * OH * OW, kp), dtype=dtype, device=img.device)
+    cols = torch.empty((B * OH * OW, kp), dtype=torch.float32 if dtype == SPLIT else dtype, device=img.device)
     _check(lib().hvr_im2col_stem(_ptr(img), _ptr(cols), B, H, W, kp, _dt(cols), _stream()), 'hvr_im2col_stem')
-    return cols, OH, OW
+    return (cast(cols, SPLIT) if dtype == SPLIT else cols), OH, OW   # (split half: through cast(), which applies the activation scale)
 
 
 def stem_fused(img, wpk, bias):
@@ -500,10 +525,16 @@ def stem_fused(img, wpk, bias):
 
 
 def stem_split_weights(wf):
-    """f32 fused-stem weights [64, 7, 32] -> [2, 64, 7, 32] half: plane 0 = half(w), plane 1 = half((w - plane 0) * 2^11)."""
+    """f32 fused-stem weights [64, 7, 32] -> [2, 64, 7, 32] half planes (hi, lo) of the weights x 2^6 x the activation scale: the kernel
+    takes 2^6 back, so with the bias x SPLIT_ACT_SCALE (stem_split_bias) its output is a scaled split activation."""
+    wf = wf * (SPLIT_WEIGHT_SCALE * SPLIT_ACT_SCALE)
     hi = wf.half()
-    lo = ((wf - hi.float()) * 2048.0).half()
+    lo = (wf - hi.float()).half()
     return torch.stack([hi, lo], 0).contiguous()
+
+
+def stem_split_bias(b):
+    return (b * SPLIT_ACT_SCALE).contiguous()
 
 
 def maxpool3x3s2_nhwc(x):
@@ -587,6 +618,8 @@ def relation_fwd(q, k, v, scale, staging=None):
     o = torch.empty((Mq, D), dtype=q.dtype, device=q.device)
     nbytes = lib().hvr_relation_workspace_bytes(Mq, Mk, D, _dt(q))
     ws = _workspace(nbytes, q.device, 'relation')
+    if q.dtype == SPLIT:   # q, k arrive x SPLIT_ACT_SCALE each; v's scale carries over to the output
+        scale = float(scale) / (SPLIT_ACT_SCALE * SPLIT_ACT_SCALE)
     with _span('relation_full' if Mq == Mk else 'relation_key', 4.0 * Mq * Mk * D):
         _check(lib().hvr_relation_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
                                       Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging,
@@ -978,13 +1011,17 @@ def multiclass_nms(boxes, scores, score_thr, iou_thr, max_num):
     return dets, labels, n_out
 
 
-def cast(x, dtype):
+def cast(x, dtype, scale=None):
+    """x in the operand format `dtype`.  Split-half tensors are kept x SPLIT_ACT_SCALE (see the note at as_operand): casting
+    into the format applies the factor, casting out of it removes it; `scale` overrides that (as_operand: the weight scale)."""
     _need_cuda(x)
     if x.dtype == dtype:
         return x
     x = x.contiguous()
+    if scale is None:
+        scale = SPLIT_ACT_SCALE if dtype == SPLIT else (1.0 / SPLIT_ACT_SCALE if x.dtype == SPLIT else 1.0)
     out = torch.empty(x.shape, dtype=dtype, device=x.device)
-    _check(lib().hvr_cast(_ptr(x), _ptr(out), x.numel(), _dt(x), _dt(out), _stream()), 'hvr_cast')
+    _check(lib().hvr_cast_scaled(_ptr(x), _ptr(out), x.numel(), _dt(x), _dt(out), float(scale), _stream()), 'hvr_cast')
     return out
 
 

@@ -15,12 +15,12 @@
  *     weights; all accumulation, softmax, box and score arithmetic is f32) -- the precision ladder:
  *       HVR_BF16  bf16 operands, the benchmark dtype BASELINE.json names (v_mfma_f32_16x16x32_bf16);
  *       HVR_F16   IEEE half operands: the same rate and bytes, 8 x finer mantissa, range 65504;
- *       HVR_F16S  "split half": a logical element x is stored as hi = half(x), lo = half((x - hi) * 2^11)
- *                 (22 significant bits) and a product is three half MFMAs -- hi*lo + lo*hi, scaled by 2^-11, + hi*hi --
- *                 accumulated in f32: f32-grade results at 1/3 of the half MFMA rate.  Memory layout of a row of C
- *                 elements (C % 64 == 0): C / 64 groups of [64 hi halves][64 lo halves] = 4 bytes per logical element;
- *                 leading dimensions stay in logical elements, bases are 256-byte aligned, column offsets multiples
- *                 of 64.  hvr_cast converts to and from it.  Taken by hvr_gemm, hvr_conv2d_nhwc, hvr_relation_fwd,
+ *       HVR_F16S  "split half": a logical element x is stored as hi = half(x), lo = half(x - hi) (22 significant
+ *                 bits for |x| >= 2^-3, absolute error < 2^-24 below) and a product is three half MFMAs -- hi*hi + hi*lo +
+ *                 lo*hi -- accumulated in f32: f32-grade results at 1/3 of the half MFMA rate.  Memory layout of a row
+ *                 of C elements (C % 32 == 0): C / 32 groups of [32 hi halves][32 lo halves] = 4 bytes per logical
+ *                 element, both planes of a 32-element K-step in one 128-byte line; leading dimensions stay in logical
+ *                 elements, bases are 128-byte aligned, column offsets multiples of 32.  hvr_cast converts to and from it.  Taken by hvr_gemm, hvr_conv2d_nhwc, hvr_relation_fwd,
  *                 hvr_relation_probs, hvr_transpose_pad and hvr_cast; the other entry points return HVR_EUNSUPPORTED;
  *       HVR_F32   exact f32 (v_mfma_f32_16x16x4_f32, 1/16 of the half rate): the parity mode.
  *     The reference computes in f32 (no fp16 key in configs/faster_rcnn_r101_{selsa,hrnmp}_c5.py); its optional
@@ -74,6 +74,11 @@ typedef struct hvr_gemm_desc {
   int32_t staging;
   int32_t tile_hint;       /* 0 = library picks the tile shape; k > 0 forces shape k-1 (tuning) */
   void* ws; size_t ws_bytes;   /* hvr_gemm: few-row split-K scratch (hvr_gemm_fewrow_workspace_bytes) or NULL / 0 */
+  float alpha;             /* HVR_F16S only: C = act(alpha * (A . B^T) + bias + R), alpha a power of two (0 = 1).  A split-half
+                              value below 2^-3 keeps an absolute, not a relative, error bound (its lo half is a subnormal), so
+                              callers store small-magnitude operands scaled up -- this build's host layer keeps weights x 2^6 and
+                              activations x 2^4 (hvr_cast_scaled) -- and pass the inverse here */
+  float beta;              /* HVR_F16S only: factor on the bias (0 = 1): C = act(alpha * (A . B^T) + beta * bias + R) */
 } hvr_gemm_desc;
 /* Few-row products with an epilogue (one frame's 300 proposals through fc_new_1: 300 x 1024 x 12544 is 48 tiles of 128 x 64
  * walking 196 K-steps each): bytes of caller-owned scratch with which hvr_gemm cuts K into grid.y slices of f32 partial tiles
@@ -104,6 +109,7 @@ typedef struct hvr_conv_desc {
   int32_t relu, out_f32, dtype, staging, tile_hint;
   const void* zero;
   void* ws; size_t ws_bytes;   /* split-K workspace (see hvr_conv2d_splitk_workspace_bytes) or NULL / 0 */
+  float alpha, beta;       /* HVR_F16S only: factors on the accumulators / the bias, see hvr_gemm_desc (0 = 1) */
 } hvr_conv_desc;
 int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
 /* Few-row convolutions (one 600x1000 frame gives the stride-16 stages 2 394 output pixels: 76 tiles of 128 x 64 for 256 CUs,
@@ -171,7 +177,7 @@ int hvr_im2col_stem(const float* img, void* cols, int B, int H, int W, int KP, i
  * kx = 7); bias f32 [64]; out bf16 NHWC [B][PH][PW][64], PH = ((H-1)/2+1 - 1)/2 + 1. */
 int hvr_stem_fused(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, void* stream);
 /* the same in the other half formats: dtype HVR_BF16 / HVR_F16 (wpk and out in that format) or HVR_F16S -- split half: wpk is
- * [2][64][7][32] half, plane 0 = half(w), plane 1 = half((w - plane 0) * 2^11); out [B][PH][PW][64] in the split-half layout */
+ * [2][64][7][32] half of the weights x 2^6 (the kernel takes the factor back): plane 0 = half(64 w), plane 1 = half(64 w - plane 0); out [B][PH][PW][64] in the split-half layout */
 int hvr_stem_fused_dtype(const float* img, const void* wpk, const float* bias, void* out, int B, int H, int W, int dtype, void* stream);
 /* nn.MaxPool2d(3, 2, 1) on NHWC (resnet.py:466,526) */
 int hvr_maxpool3x3s2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
@@ -311,8 +317,11 @@ int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls,
 
 /* ---- layout / dtype plumbing at the API boundary ---- */
 /* any pair of the four dtypes; pairs other than f32 <-> bf16 move 8 elements per thread: n % 8 == 0 and 16-byte aligned buffers
- * (split half: n % 64 == 0 -- a contiguous tensor whose last dimension is a multiple of 64 -- and 256-byte alignment) */
+ * (split half: n % 32 == 0 -- a contiguous tensor whose last dimension is a multiple of 32 -- and 128-byte alignment) */
 int hvr_cast(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, void* stream);
+/* out = convert(in * scale), scale > 0 (a power of two for exact results): how the host layer moves between true values and the
+ * scaled split-half tensors it keeps (activations x 2^4, weights x 2^6: hvrnet_amd/native.py) */
+int hvr_cast_scaled(const void* in, void* out, int64_t n, int from_dtype, int to_dtype, float scale, void* stream);
 /* to_nhwc != 0: [B][C][HW] -> [B][HW][C]; else the inverse */
 int hvr_permute_nchw_nhwc(const void* in, void* out, int B, int C, int HW, int to_nhwc, int from_dtype,
                           int to_dtype, void* stream);

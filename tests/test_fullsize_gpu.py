@@ -103,12 +103,21 @@ def test_full_size_window_f32_matches_the_oracle(O, clip, head, dtype):
         got = model(x=c4, img=None, img_meta=clip['metas'], forward_feat=True, return_loss=False, rescale=True)
     assert c4_err < 1e-4 * c4_scale + 2e-3, (c4_err, c4_scale)
     assert [int(p.shape[0]) for p in w['proposals']] == [int(p.shape[0]) for p in inter['proposals']] == [N] * T
-    # proposals: same boxes in the same (score) order in every frame
+    # proposals: same boxes in the same (score) order in every frame -- up to the order of neighbours whose scores tie to 1e-5
+    # (two proposals of frame 11 score 0.8242 to six digits: which comes first is an f32 rounding matter)
     bad_frames = []
     for i in range(T):
-        d = (w['proposals'][i].cpu() - inter['proposals'][i]).abs()
-        if d[:, :4].max().item() > 2e-2 or d[:, 4].max().item() > 1e-3:
-            bad_frames.append(i)
+        a_, b_ = w['proposals'][i].cpu(), inter['proposals'][i]
+        for r in range(a_.shape[0]):
+            ok = False
+            for q in (r, r - 1, r + 1):
+                if 0 <= q < b_.shape[0] and (a_[r, :4] - b_[q, :4]).abs().max().item() <= 2e-2 and abs(float(a_[r, 4] - b_[q, 4])) <= 1e-3 \
+                        and (q == r or abs(float(b_[q, 4] - b_[r, 4])) <= 1e-5):
+                    ok = True
+                    break
+            if not ok:
+                bad_frames.append(i)
+                break
     stats = [parity.strict(g, r) for g, r in zip(_branches(head, got), _branches(head, want))]
     print('\n[full-size %s %s] C4 max err %.3g (scale %.3g); frames whose proposal list differs: %s; read-out: %s'
           % ('f32' if dtype == torch.float32 else 'f16x2', head, c4_err, c4_scale, bad_frames, stats))

@@ -29,8 +29,18 @@ def _rand(shape, seed, scale=1.0):
 
 
 def _to(x, dtype):
-    """f32 host tensor -> device operand in `dtype` (split half goes through hvr_cast)."""
+    """f32 host tensor -> device ACTIVATION operand in `dtype` (split half goes through hvr_cast, unscaled)."""
+    return native.cast(x.to(DEV).contiguous(), dtype)
+
+
+def _tow(x, dtype):
+    """f32 host tensor -> device WEIGHT operand (native.as_operand: split-half weights are stored x 2^6, gemm / conv2d pass alpha)."""
     return native.as_operand(x.to(DEV), dtype)
+
+
+def _backw(y):
+    """a weight operand back in f32 (split half: / SPLIT_WEIGHT_SCALE)."""
+    return native.cast(y, torch.float32, scale=1.0 / native.SPLIT_WEIGHT_SCALE).cpu() if y.dtype == SPLIT else _back(y)
 
 
 def _back(y):
@@ -38,19 +48,24 @@ def _back(y):
 
 
 def test_split_half_cast_round_trip_keeps_22_bits():
-    """f32 -> split half -> f32: |error| <= 2^-21 |x| for values in the half range, exact zeros stay zero, values beyond
-    65504 saturate (no inf - inf), tiny values keep an absolute error below 2^-35."""
+    """f32 -> split half -> f32, raw format (scale 1): |error| <= 2^-21 |x| for values in the half range (2^-24 absolute beneath
+    2^-3, where lo is a half subnormal), exact zeros stay zero, values beyond 65504 saturate (no inf - inf).  native.cast keeps
+    split ACTIVATIONS x 2^4: the same bounds hold from 2^-7 up, and the range ends at 4094."""
     x = _rand((37, 192), 1, 3.0)
     x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 1e5, -1e5, 1e-6])
     x[1, :4] = torch.tensor([6e-5, 3e-8, 1e-9, 1234.5678])
-    s = native.cast(x.to(DEV), SPLIT)
+    s = native.cast(x.to(DEV), SPLIT, scale=1.0)
     assert s.dtype == SPLIT and s.shape == x.shape
-    y = native.cast(s, torch.float32).cpu()
+    y = native.cast(s, torch.float32, scale=1.0).cpu()
     ok = x.abs() <= 65504
     err = (y - x).abs()
-    assert (err[ok] <= x.abs()[ok] * 2.0 ** -21 + 2.0 ** -35).all(), err[ok].max()
+    assert (err[ok] <= x.abs()[ok] * 2.0 ** -21 + 2.0 ** -24).all(), err[ok].max()
     assert y[0, 0] == 0 and y[0, 1] == 0 and y[0, 2] == 1 and y[0, 3] == -1
     assert y[0, 5] == 65504 and y[0, 6] == -65504 and torch.isfinite(y).all()
+    ya = native.cast(native.cast(x.to(DEV), SPLIT), torch.float32).cpu()     # the activation convention
+    oka = x.abs() <= 65504 / native.SPLIT_ACT_SCALE
+    assert ((ya - x).abs()[oka] <= x.abs()[oka] * 2.0 ** -21 + 2.0 ** -28).all()
+    assert ya[0, 4] == 65504 / native.SPLIT_ACT_SCALE and ya[0, 6] == -65504 / native.SPLIT_ACT_SCALE
     # the split form is what a half cast gives for values a half holds exactly
     h = _rand((8, 64), 2).half().float()
     assert torch.equal(native.cast(native.cast(h.to(DEV), SPLIT), torch.float32).cpu(), h)
@@ -60,7 +75,7 @@ def test_split_half_cast_round_trip_keeps_22_bits():
     assert torch.equal(native.cast(z.half().to(DEV), torch.float32).cpu(), z.half().float())
     assert torch.equal(native.cast(z.bfloat16().to(DEV), torch.float16).cpu(), z.bfloat16().float().half())
     with pytest.raises(native.HvrError):
-        native.cast(torch.zeros((3, 40), device=DEV), SPLIT)   # rows must be whole 64-element groups
+        native.cast(torch.zeros((3, 40), device=DEV), SPLIT)   # rows must be whole 32-element groups
 
 
 @pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
@@ -71,11 +86,11 @@ def test_every_tile_shape_on_half_and_split_operands(dtype, tile):
     against float64.  Ragged M and N."""
     M, N, K = 300, 328, 1024
     a, w, bias, resid = _rand((M, K), 11), _rand((N, K), 12, 0.05), _rand((N,), 13), _rand((M, 384), 14)
-    ad, wd, rd = _to(a, dtype), _to(w, dtype), _to(resid, dtype)
-    af, wf, rf = _back(ad).double(), _back(wd).double(), _back(rd).double()[:, :N]
+    ad, wd, rd = _to(a, dtype), _tow(w, dtype), _to(resid, dtype)
+    af, wf, rf = _back(ad).double(), _backw(wd).double(), _back(rd).double()[:, :N]
     ref = torch.relu(af @ wf.t() + bias.double() + rf)
     out = torch.zeros((M, 384), dtype=dtype, device=DEV)
-    # N = 328 is not a whole number of 64-column groups: split half takes N % 8 == 0 outputs inside a wider (ldc % 64 == 0) matrix
+    # N = 328 is not a whole number of 32-column groups: split half takes N % 8 == 0 outputs inside a wider (ldc % 32 == 0) matrix
     y = native.gemm(ad, wd, bias.to(DEV), rd[:, :N], relu=True, tile=tile, out=out[:, :N])
     scale = ref.abs().max().item()
     err = (_back(out)[:, :N].double() - ref).abs().max().item()
@@ -111,8 +126,8 @@ def test_conv_on_half_and_split_operands(cfg, dtype):
     x = _rand((B, cfg['Cin'], cfg['H'], cfg['W']), 21)
     w = _rand((cfg['Cout'], cfg['Cin'], cfg['k'], cfg['k']), 22, 0.05)
     bias = _rand((cfg['Cout'],), 23)
-    xn, wn = _to(x.permute(0, 2, 3, 1), dtype), _to(w.permute(0, 2, 3, 1), dtype)
-    xf, wf = _back(xn).permute(0, 3, 1, 2).double(), _back(wn).permute(0, 3, 1, 2).double()
+    xn, wn = _to(x.permute(0, 2, 3, 1), dtype), _tow(w.permute(0, 2, 3, 1), dtype)
+    xf, wf = _back(xn).permute(0, 3, 1, 2).double(), _backw(wn).permute(0, 3, 1, 2).double()
     ref = F.conv2d(xf, wf, bias.double(), stride=cfg['stride'], padding=cfg['pad'], dilation=cfg['dil'])
     resid = _rand(tuple(ref.shape), 24)
     rn = _to(resid.permute(0, 2, 3, 1), dtype)
@@ -201,9 +216,10 @@ def test_roi_align_and_pooling_on_half_and_split_maps():
 
 def test_split_half_rejects_what_it_cannot_address():
     a = native.cast(torch.zeros((64, 128), device=DEV), SPLIT)
-    w = native.cast(torch.zeros((64, 128), device=DEV), SPLIT)
-    with pytest.raises(native.HvrError):     # a column slice that does not start on a 64-element group
-        native.gemm(a[:, 32:96], w[:, :64])
+    w = native.as_operand(torch.zeros((64, 128), device=DEV), SPLIT)
+    with pytest.raises(native.HvrError):     # a column slice that does not start on a 32-element group
+        native.gemm(a[:, 16:80], w[:, :64])
+    native.gemm(a[:, 32:96], w[:, :64])      # one that does
     out = torch.zeros((64, 100), dtype=SPLIT, device=DEV)
     with pytest.raises(native.HvrError):     # output rows must be whole groups
         native.gemm(a, w, out=out[:, :64])
@@ -214,34 +230,33 @@ def test_stem_patch_rows_in_half_and_split_formats():
     rows equal hvr_cast of the f32 rows bit for bit, the half rows equal torch's cast."""
     img = _rand((2, 3, 61, 95), 71, 50.0).to(DEV)
     cols32, OH, OW = native.im2col_stem(img, torch.float32)
-    cols_s, _, _ = native.im2col_stem(img, SPLIT)
-    assert cols_s.dtype == SPLIT and cols_s.shape == cols32.shape == (2 * OH * OW, 192)
-    assert torch.equal(cols_s, native.cast(cols32, SPLIT))
+    cols_s = torch.empty((2 * OH * OW, 192), dtype=SPLIT, device=DEV)     # the C entry point writes the raw (unscaled) split format
+    assert native.lib().hvr_im2col_stem(native._ptr(img), native._ptr(cols_s), 2, 61, 95, 192, native.HVR_F16S, native._stream()) == 0
+    assert torch.equal(cols_s, native.cast(cols32, SPLIT, scale=1.0))
+    assert torch.equal(native.im2col_stem(img, SPLIT)[0], native.cast(cols32, SPLIT))   # the host wrapper: activation scale applied
     cols_h, _, _ = native.im2col_stem(img, torch.float16)
     assert torch.equal(cols_h, cols32.half())
 
 
-@pytest.mark.parametrize('dtype', [torch.float16, SPLIT])
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad,dil', [(15, 38, 63, 512, 512, 3, 1, 2, 2), (8, 38, 63, 1024, 512, 3, 1, 1, 1),
                                                               (13, 37, 61, 256, 256, 3, 1, 1, 1), (15, 38, 63, 2048, 512, 1, 1, 0, 1)])
-def test_big_tile_kernel_on_half_and_split_operands_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, pad, dil, dtype):
-    """bigtile.hip (288 x 256 tiles) instantiated on half and split-half operands: the same MFMA sequence per output element as
-    the tile engine (split half: the same three passes and the same 2^-11 rescale point), so the outputs are bit-identical --
-    tile=17 forces the kernel, tile=11 the engine's 144 x 256 shape."""
+def test_big_tile_kernel_on_half_operands_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, pad, dil):
+    """bigtile.hip (288 x 256 tiles) instantiated on half operands: the same MFMA sequence per output element as the tile engine,
+    so the outputs are bit-identical -- tile=17 forces the kernel, tile=11 the engine's 144 x 256 shape.  Split-half operands
+    stay on the tile engine (their fused K-step already has the lower LDS traffic per MFMA)."""
+    dtype = torch.float16
     x = _to(_rand((B, H, W, Cin), 81), dtype)
-    w = _to(_rand((Cout, k, k, Cin), 82, 0.03), dtype)
+    w = _tow(_rand((Cout, k, k, Cin), 82, 0.03), dtype)
     bias = _rand((Cout,), 83).to(DEV)
     big = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=17)
     eng = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=11)
     assert big.dtype == dtype and torch.equal(big, eng)
     tiles = ((B * H * W + 287) // 288) * (Cout // 256)     # (stride 1, same-size outputs)
     assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, k=k, stride=stride, pad=pad, dil=dil, dtype=dtype) == (3 if tiles >= 170 else 0)
-    if dtype == torch.float16:   # residual epilogue (half only; split half keeps residual convs on the tile engine)
-        r = _to(_rand((B, H, W, Cout), 84), dtype)
-        assert torch.equal(native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=17),
-                           native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=11))
-    else:
-        assert native.conv2d_path(B, H, W, Cin, Cout, resid=True, k=k, stride=stride, pad=pad, dil=dil, dtype=dtype) == 0
+    assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, k=k, stride=stride, pad=pad, dil=dil, dtype=SPLIT) == 0
+    r = _to(_rand((B, H, W, Cout), 84), dtype)
+    assert torch.equal(native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=17),
+                       native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=11))
 
 
 # ---- the dedicated bf16 kernels instantiated on half operands: each against the tile engine on the same operands ----
@@ -253,7 +268,7 @@ H16 = torch.float16
 def test_expand_panel_kernel_on_half_operands(Cin, Cout, H, W, B, with_res):
     """expand.hip on half operands (tile hint 13) against the tile engine (hint 1): same products, f32 sums in a different order,
     one half rounding -- and bit-exact one-hot rows (transposition detector)."""
-    x, w = _to(_rand((B, H, W, Cin), 91), H16), _to(_rand((Cout, 1, 1, Cin), 92, 0.05), H16)
+    x, w = _to(_rand((B, H, W, Cin), 91), H16), _tow(_rand((Cout, 1, 1, Cin), 92, 0.05), H16)
     bias = _rand((Cout,), 93).to(DEV)
     r = _to(_rand((B, H, W, Cout), 94), H16) if with_res else None
     forced = native.conv2d_nhwc(x, w, bias, r, relu=True, tile=13)
@@ -271,7 +286,7 @@ def test_expand_panel_kernel_on_half_operands(Cin, Cout, H, W, B, with_res):
 def test_layer1_3x3_stem_and_tails_on_half_operands():
     """conv3x3.hip (bit-identical to the tile engine), the fused stem (against the patch-matrix route in half), and the fused
     Bottleneck tails (hvr_bottleneck_tail / _tail_next) against the separate convs, all on half operands."""
-    x, w = _to(_rand((2, 37, 53, 64), 101), H16), _to(_rand((64, 3, 3, 64), 102, 0.05), H16)
+    x, w = _to(_rand((2, 37, 53, 64), 101), H16), _tow(_rand((64, 3, 3, 64), 102, 0.05), H16)
     bias = _rand((64,), 103).to(DEV)
     assert native.conv2d_path(2, 37, 53, 64, 64, k=3, pad=1, resid=False, dtype=H16) == 2
     assert torch.equal(native.conv2d_nhwc(x, w, bias, None, relu=True, pad=1), native.conv2d_nhwc(x, w, bias, None, relu=True, pad=1, tile=1))
@@ -336,7 +351,7 @@ def test_fused_stem_on_split_half_operands():
     bias = _rand((64,), 143)
     wf = torch.zeros((64, 7, 8, 4))
     wf[:, :, :7, :3] = w7.permute(0, 2, 3, 1)
-    y = native.stem_fused(img.to(DEV), native.stem_split_weights(wf.view(64, 7, 32).to(DEV)), bias.to(DEV))
+    y = native.stem_fused(img.to(DEV), native.stem_split_weights(wf.view(64, 7, 32).to(DEV)), native.stem_split_bias(bias.to(DEV)))
     ref = F.max_pool2d(torch.relu(F.conv2d(img.double(), w7.double(), bias.double(), stride=2, padding=3)), 3, 2, 1)
     assert y.dtype == SPLIT and tuple(y.shape) == (2, ref.shape[2], ref.shape[3], 64)
     got = _back(y).permute(0, 3, 1, 2).double()
@@ -344,5 +359,5 @@ def test_fused_stem_on_split_half_operands():
     wp = torch.zeros((64, 192))
     wp[:, :147] = w7.permute(0, 2, 3, 1).reshape(64, 147)
     cols, OH, OW = native.im2col_stem(img.to(DEV), SPLIT)
-    alt = native.maxpool3x3s2_nhwc(native.gemm(cols, _to(wp, SPLIT), bias.to(DEV), relu=True, out_f32=True).view(2, OH, OW, 64)).cpu()
+    alt = native.maxpool3x3s2_nhwc(native.gemm(cols, _tow(wp, SPLIT), bias.to(DEV), relu=True, out_f32=True).view(2, OH, OW, 64)).cpu()
     assert (_back(y) - alt).abs().max().item() < 3e-6 * alt.abs().max().item()

@@ -86,11 +86,16 @@ def main():
             got_inj = model(x=c4, img=None, img_meta=metas, proposals=props, forward_feat=True, return_loss=False, rescale=True)
         got = got if args.head == 'hvr' else [got]
         got_inj = got_inj if args.head == 'hvr' else [got_inj]
-        same_lists = 0
+        same_lists, list_diffs = 0, []
         for i in range(T):
             a, b = w['proposals'][i].cpu(), inter['proposals'][i]
             if a.shape == b.shape and (a[:, :4] - b[:, :4]).abs().max().item() <= 2e-2 and (a[:, 4] - b[:, 4]).abs().max().item() <= 1e-3:
                 same_lists += 1
+            elif a.shape == b.shape:
+                rows = ((a - b).abs().max(dim=1).values > 2e-2).nonzero().reshape(-1).tolist()
+                list_diffs.append(dict(frame=i, rows=rows[:6], n_rows=len(rows), max_box=float((a[:, :4] - b[:, :4]).abs().max()),
+                                       max_score=float((a[:, 4] - b[:, 4]).abs().max()),
+                                       first=[[round(v, 4) for v in a[rows[0]].tolist()], [round(v, 4) for v in b[rows[0]].tolist()]] if rows else None))
         po = parity.proposal_overlap([p.cpu().numpy() for p in w['proposals']], [p.numpy() for p in inter['proposals']])
         st = [parity.strict(g, r) for g, r in zip(got, want)]
         st_inj = [parity.strict(g, r) for g, r in zip(got_inj, want)]
@@ -108,7 +113,7 @@ def main():
         ms = 1e3 * sorted(ts[1:])[len(ts[1:]) // 2]
         row = dict(mode=mode, window_ms=round(ms, 3), frames_per_s=round(1e3 / ms, 2),
                    c4_rel_err=float((c4f - c4_ref).abs().max().item() / c4_scale),
-                   proposal_lists_equal='%d/%d' % (same_lists, T), proposal_overlap_mean=round(po['mean'], 4),
+                   proposal_lists_equal='%d/%d' % (same_lists, T), proposal_list_diffs=list_diffs[:3], proposal_overlap_mean=round(po['mean'], 4),
                    class_flips=[s['class_flips'] for s in st], detections=[s['n'] for s in st],
                    max_score_err=max(s['max_score_err'] for s in st), max_box_err_px=max(s['max_box_err'] for s in st),
                    tracked=dict(matched='%d/%d' % (tr['matched'], tr['n_ref']), max_score_err=tr['max_score_err'], max_box_err_px=tr['max_box_err']),

@@ -504,6 +504,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 
   GemmParams p;
   int rc;
+  static const int tile_scores_s = env_tile("HVR_TILE_SCORES_SPLIT"), tile_apply_s = env_tile("HVR_TILE_APPLY_SPLIT");   // tuning overrides
   if (dtype == HVR_F16S) {
     // split half: probabilities (scores pass + one normalising sweep, both in the split format), V^T, then O = P V as a plain
     // three-pass product -- no block weights inside a K loop whose accumulators change scale between passes
@@ -511,6 +512,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     if (rc) return rc;
     if (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
     p.N = Mk; p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
+    p.tile_hint = tile_scores_s;
     rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores (split half)");
     if (rc) return rc;
     rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, 1.f, s), "relation: normalise (split half)");
@@ -520,6 +522,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
     if (rc) return rc;
     p.alpha = 1.f / kSplitProbScale;   // the probabilities are stored x 2^12 (gemm_tile.h, EPI_SCORES)
+    p.tile_hint = tile_apply_s;
     return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half)");
   }
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;

@@ -140,10 +140,12 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 // three MFMAs per product (w_hi x a_hi, w_lo x a_hi, w_hi x a_lo into one f32 accumulator),
 // the conv pixels kept in f32 in the LDS (the pooling maximum does not act per plane), the pooled pixel written as two
 // [32 hi | 32 lo] groups.  wpk: [2][64][7][32] half, plane 0 = hi(w), plane 1 = half(w - hi).  The weight fragments of
-// two 16-channel groups stay in registers at a time (both planes: 112 registers), the fragments are walked twice.
-constexpr int ST_CROWF = 68;                                // conv-out row pitch in f32
+// two 16-channel groups stay in registers at a time (both planes: 112 registers); the tile is produced in two passes of 32 output
+// channels -- conv pixels to the LDS, pooled, written as one [32 hi | 32 lo] group per pixel -- so that the f32 conv buffer is
+// half as large and two workgroups share a CU.
+constexpr int ST_CROWF = 36;                                // conv-out row pitch in f32: 32 channels of one pass + 4
 constexpr int ST_PLANE_BYTES = (ST_IR + 3) * ST_PCOLS * 4 * 2;
-constexpr int ST_SPLIT_LDS = 2 * ST_PLANE_BYTES + ST_FRAGS * 16 * ST_CROWF * 4;
+constexpr int ST_SPLIT_LDS = 2 * ST_PLANE_BYTES + ST_FRAGS * 16 * ST_CROWF * 4;   // 74 KB: two workgroups per CU
 
 __global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __restrict__ img, const uint4* __restrict__ wpk,
                                                                const float* __restrict__ bias, char* __restrict__ out, int H, int W,
@@ -223,14 +225,13 @@ __global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __re
         constexpr float kInvW = 1.f / 64.f;   // the weights arrive x 2^6 (native.stem_split_weights: their lo halves stay normal numbers)
         const float4 v = make_float4(fmaxf(fmaf(acc[nf][0], kInvW, bv.x), 0.f), fmaxf(fmaf(acc[nf][1], kInvW, bv.y), 0.f),
                                      fmaxf(fmaf(acc[nf][2], kInvW, bv.z), 0.f), fmaxf(fmaf(acc[nf][3], kInvW, bv.w), 0.f));
-        *reinterpret_cast<float4*>(cbuf + p * ST_CROWF + n) = v;
+        *reinterpret_cast<float4*>(cbuf + p * ST_CROWF + nf * 16 + (lane >> 4) * 4) = v;
       }
     }
-  }
   __syncthreads();
 
-  for (int i = tid; i < ST_PH * ST_PW * 8; i += 256) {
-    const int ch = i & 7, q = i >> 3, qy = q / ST_PW, qx = q - qy * ST_PW;
+  for (int i = tid; i < ST_PH * ST_PW * 4; i += 256) {
+    const int ch = i & 3, q = i >> 2, qy = q / ST_PW, qx = q - qy * ST_PW;
     const int py = py0 + qy, px = px0 + qx;
     if (py >= PH || px >= PW) continue;
     float best[8];
@@ -253,9 +254,11 @@ __global__ __launch_bounds__(256) void stem_fused_split_kernel(const float* __re
     uint4 h, l;
     split2(best[0], best[1], h.x, l.x); split2(best[2], best[3], h.y, l.y);
     split2(best[4], best[5], h.z, l.z); split2(best[6], best[7], h.w, l.w);
-    char* dst = out + (((long)b * PH + py) * PW + px) * 256 + split_col_bytes(ch * 8);   // 64 channels = two [32 hi | 32 lo] groups
+    char* dst = out + (((long)b * PH + py) * PW + px) * 256 + half * 128 + ch * 16;   // this pass's 32 channels = one [32 hi | 32 lo] group
     *reinterpret_cast<uint4*>(dst) = h;
     *reinterpret_cast<uint4*>(dst + kSplitPlane) = l;
+  }
+  __syncthreads();   // the next pass overwrites the conv buffer
   }
 }
 

@@ -11,7 +11,10 @@ declare -A map=( [bench.json]=bench.json [bench_prof.json]=bench_profiled_run.js
   [relation_pmc_sq.txt]=relation_pmc_sq.txt [relation_traffic.json]=relation_traffic.json [rel_bench.txt]=relation_kernel_stats.txt
   [window_pmc_sq.txt]=window_pmc_sq.txt [hipblaslt_calibration.txt]=hipblaslt_calibration.txt [train_bench.json]=train_bench.json
   [train_bench_f32.json]=train_bench_f32.json [train_bench_hvr.json]=train_bench_hvr.json [train_kernel_stats.txt]=train_kernel_stats.txt
-  [ingest_bench.json]=ingest_bench.json [bench_selsa.json]=bench_selsa.json [bench_T21.json]=bench_T21.json )
+  [ingest_bench.json]=ingest_bench.json [bench_selsa.json]=bench_selsa.json [bench_T21.json]=bench_T21.json
+  [precision_ladder.json]=precision_ladder.json [window_f16_kernel_stats.txt]=window_f16_kernel_stats.txt
+  [window_f16x2_kernel_stats.txt]=window_f16x2_kernel_stats.txt [conv_layer3.txt]=conv_layer3.txt
+  [conv_hint_sweep_f16x2.txt]=conv_hint_sweep_f16x2.txt )
 for f in "${!map[@]}"; do
   if [ -s $src/$f ]; then cp $src/$f profiles/${r}_${map[$f]}; fi
 done

@@ -12,7 +12,7 @@ import sys
 
 def main(*paths):
     text = ''.join(open(p).read() for p in paths)
-    blocks = re.split(r'remark: Function Name: ', text)[1:]
+    blocks = re.split(r'remark: (?:\S+ )?Function Name: ', text)[1:]   # (with -save-temps the remarks carry file:line:col)
     bad, seen = [], 0
     for b in blocks:
         name = b.split()[0]
@@ -51,6 +51,8 @@ def main(*paths):
             seen += 1
             if spill:
                 bad.append('%s: %d VGPRs spilled' % (name, spill))
+    if not seen:
+        sys.exit('check_regs: no kernel recognised in the remarks (format change?)')
     if bad:
         sys.exit('check_regs: these kernels must not spill:\n  ' + '\n  '.join(bad))
     print('check_regs: %d kernels checked (untracked loads / serial sweeps / big accumulator tiles), none spills' % seen)

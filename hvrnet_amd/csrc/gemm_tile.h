@@ -398,10 +398,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       const bool more = kt + 1 < nk;
       if constexpr (EPI == EPI_APPLY) {
         if (first) {
-          if (kt + STEPS_PER_BLOCK < nk) {
+          // (unconditional -- the last block re-reads its own weight: a load under `if (a next block exists)` turns gnext into a
+          // value merged with its previous self, and the copies that merge costs are the compiler's to place, see pipe_step)
+          const int nb = kt / STEPS_PER_BLOCK + 1 < nblk ? kt / STEPS_PER_BLOCK + 1 : nblk - 1;
 #pragma unroll
-            for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + kt / STEPS_PER_BLOCK + 1);
-          }
+          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + nb);
           __builtin_amdgcn_sched_barrier(0);  // the g loads stay ahead of this step's DMA in the vmcnt queue
         }
       }
@@ -532,8 +533,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     constexpr int MIN_A = min_wave_loads(BM, NT);
     constexpr int NR = FM + FN, NM = FM * FN;
     // fragment sets: [0] = kk 0, [1] = kk 1.  SPLIT: [0] = the hi plane, [1] = the lo plane; the B side keeps a third set, [2]: the
-    // next step's B_hi fragments are requested while this step's B_hi x A_lo terms still read the current ones and move into [0]
-    // at the top of the next step (an A_hi fragment is re-requested as soon as its row's B_lo x A_hi terms are issued)
+    // next step's B_hi fragments are requested while this step's B_hi x A_lo terms still read the current ones, so B_hi lives in
+    // [0] on even and in [2] on odd K-steps (an A_hi fragment is re-requested as soon as its row's B_lo x A_hi terms are issued)
     uint4 fa[2][FM], fb[SPLIT ? 3 : 2][FN];
     long a_koff = 0;
     int dy = 0, dx = 0;  // conv: filter tap of the K-step being loaded
@@ -618,8 +619,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     // LOAD: this step issues the DMA of K-step kt + NS - 1: 1 / 0 at compile time (the steady-state loop must not
     // branch between its MFMAs), 2 = decided at run time from kt (loop tails).  NEXT: a K-step kt + 1 exists (its
     // first fragments are requested in half 1).  FIRST / LAST: position inside a 128-key block (EPI_APPLY).
-    auto pipe_step = [&](int kt, auto LOAD, auto NEXT, auto FIRST, auto LAST) {
-      constexpr int HS = 0, HN = 2;  // SPLIT: this / the next step's B_hi set
+    // PAR (SPLIT): parity of the K-step.  The B_hi fragments alternate between sets [0] and [2] -- even steps multiply out of [0]
+    // and request the next step's into [2], odd steps the other way round.  (Not "request into [2], move to [0] at the top of the
+    // next step": a value renamed across iterations is resolved by REGISTER COPIES the compiler places where it likes -- it put
+    // them at the loop header, in front of the lgkmcnt wait of half 0, reading fragments whose inline-asm ds_read it knows no
+    // latency for.  Alone the data had always landed by then; with another launch's workgroups keeping the LDS busy it had not.
+    // check_asm_waits.py now scans every build for reads of that kind.)
+    auto pipe_step = [&](int kt, auto LOAD, auto NEXT, auto FIRST, auto LAST, auto PAR) {
+      constexpr int HS = decltype(PAR)::value ? 2 : 0, HN = decltype(PAR)::value ? 0 : 2;  // SPLIT: this / the next step's B_hi set
       constexpr int lmode = decltype(LOAD)::value;
       constexpr bool next = decltype(NEXT)::value, first = decltype(FIRST)::value, last = decltype(LAST)::value;
       const bool load = lmode == 2 ? kt + NS - 1 < nk : lmode == 1;
@@ -627,10 +634,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       const int ns = cs + 1 == NS ? 0 : cs + 1;
       char* lstage = smem + (cs == 0 ? NS - 1 : cs - 1) * STAGE_BYTES;  // freed by the previous step's barrier
       if constexpr (EPI == EPI_APPLY && first) {
-        if (kt + STEPS_PER_BLOCK < nk) {
+        // every block requests a weight, the last one its own again (its waits are vmcnt(0)): loading only `if a next block
+        // exists` would make gnext a value merged with its previous self across iterations, and the register copies such a merge
+        // costs are placed by the compiler, which knows nothing of this load's latency (see PAR above, check_asm_waits.py)
+        const int nb = kt / STEPS_PER_BLOCK + 1 < nblk ? kt / STEPS_PER_BLOCK + 1 : nblk - 1;
 #pragma unroll
-          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + kt / STEPS_PER_BLOCK + 1);
-        }
+        for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + nb);
       }
       if (load) tap_of(kt + NS - 1);
       static_for<2>([&](auto KK) {
@@ -642,12 +651,6 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         constexpr int PER = (NF + NMK - 1) / NMK;  // fillers after each MFMA
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (SPLIT && kk == 0) {
-          if (kt > 0) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[0][j] = fb[2][j];
-          }
-        }
         if constexpr (kk == 1) {
           // loads that may stay in flight: the K-steps after kt + 1 (full groups), plus the A half of the group
           // this step is issuing; an apply block's g loads sit exactly that far back, hence one fewer there
@@ -729,22 +732,40 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     constexpr std::integral_constant<int, 1> L1{};
     constexpr std::integral_constant<int, 0> L0{};
     constexpr std::integral_constant<int, 2> LR{};
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
     if constexpr (EPI == EPI_APPLY) {  // nk is even: 128-key blocks of two K-steps
       int kt = 0;
       for (; kt + NS < nk; kt += 2) {  // both steps of the block load
-        pipe_step(kt, L1, Y, Y, N);
-        pipe_step(kt + 1, L1, Y, N, Y);
+        pipe_step(kt, L1, Y, Y, N, P0);
+        pipe_step(kt + 1, L1, Y, N, Y, P0);
       }
       for (; kt < nk; kt += 2) {  // the last NS / 2 blocks: the second step never loads
-        pipe_step(kt, LR, Y, Y, N);
-        if (kt + 2 < nk) pipe_step(kt + 1, L0, Y, N, Y);
-        else pipe_step(kt + 1, L0, N, N, Y);
+        pipe_step(kt, LR, Y, Y, N, P0);
+        if (kt + 2 < nk) pipe_step(kt + 1, L0, Y, N, Y, P0);
+        else pipe_step(kt + 1, L0, N, N, Y, P0);
+      }
+    } else if constexpr (SPLIT) {  // steps in (even, odd) pairs: the B_hi sets swap roles from one step to the next
+      int kt = 0;
+      for (; kt + NS < nk; kt += 2) {
+        pipe_step(kt, L1, Y, N, N, P0);
+        pipe_step(kt + 1, L1, Y, N, N, P1);
+      }
+      for (; kt + 2 < nk; kt += 2) {
+        pipe_step(kt, LR, Y, N, N, P0);
+        pipe_step(kt + 1, LR, Y, N, N, P1);
+      }
+      if (kt + 2 == nk) {
+        pipe_step(kt, L0, Y, N, N, P0);
+        pipe_step(kt + 1, L0, N, N, N, P1);
+      } else {  // kt + 1 == nk (nk >= 1)
+        pipe_step(kt, L0, N, N, N, P0);
       }
     } else {
       int kt = 0;
-      for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, L1, Y, N, N);
-      for (; kt + 1 < nk; ++kt) pipe_step(kt, L0, Y, N, N);
-      if (kt < nk) pipe_step(kt, L0, N, N, N);
+      for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, L1, Y, N, N, P0);
+      for (; kt + 1 < nk; ++kt) pipe_step(kt, L0, Y, N, N, P0);
+      pipe_step(kt, L0, N, N, N, P0);  // kt == nk - 1: a product has at least one K-step
     }
   }
 

@@ -361,3 +361,42 @@ def test_fused_stem_on_split_half_operands():
     cols, OH, OW = native.im2col_stem(img.to(DEV), SPLIT)
     alt = native.maxpool3x3s2_nhwc(native.gemm(cols, _tow(wp, SPLIT), bias.to(DEV), relu=True, out_f32=True).view(2, OH, OW, 64)).cpu()
     assert (_back(y) - alt).abs().max().item() < 3e-6 * alt.abs().max().item()
+
+
+@pytest.mark.parametrize('tile', [0, 8, 11, 12])
+def test_split_half_product_is_the_same_with_a_second_launch_keeping_the_lds_busy(tile):
+    """Two graph replays in flight on two streams, each an LDS-heavy kernel (the padded transpose) in front of a window-sized
+    split-half product: every output equals the product computed alone, bit for bit.  Round 3's pipelined split K loop renamed
+    its spare B_hi fragment set across iterations; the compiler resolved the rename with register copies at the loop header, in
+    front of the lgkmcnt wait, and a co-resident workgroup of the OTHER launch delayed the fragment reads past those copies --
+    garbage tiles only with two windows in flight (hvrnet_amd/csrc/check_asm_waits.py now scans every build for the pattern)."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    Mq, Mk, D = 4500, 4500, 1024
+    ldp = native.relation_ldp(Mk)
+    P = native.cast(torch.rand((Mq, ldp), device=DEV, generator=g), SPLIT)
+    V = native.cast(torch.randn((Mk, D), device=DEV, generator=g), SPLIT)
+    fn = lambda: native.gemm(P, native.transpose_pad(V, ldp), alpha=1.0, tile=tile)   # noqa: E731
+    ref = fn().clone()
+    torch.cuda.synchronize()
+    graphs = []
+    for _ in range(2):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+            st.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                out = fn()
+        torch.cuda.current_stream().wait_stream(st)
+        graphs.append((gr, out))
+    lanes = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(8):
+        for (gr, _), lane in zip(graphs, lanes):
+            with torch.cuda.stream(lane):
+                gr.replay()
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(out, ref) else 1 for _, out in graphs)
+    assert bad == 0, '%d of 16 concurrent replays differ from the product computed alone' % bad

@@ -44,6 +44,12 @@ for m in f16 f16x2; do
   rm -rf /tmp/m_$m; HVR_FRAME_GROUPS=1 rocprofv3 --kernel-trace --stats -d /tmp/m_$m -o w -- python tools/mode_window.py --mode $m --iters 3 > /dev/null 2>&1
   python tools/rocpd_stats.py $(find /tmp/m_$m -name "*.db" | head -1) > $out/window_${m}_kernel_stats.txt
 done
+rm -f $out/window_f16x2_pmc_sq.txt
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  rm -rf /tmp/ms; HVR_FRAME_GROUPS=1 rocprofv3 --kernel-trace --pmc $set -d /tmp/ms -o w -- python tools/mode_window.py --mode f16x2 --iters 1 > /dev/null 2>&1
+  echo "--- split-half window, pass: $set" >> $out/window_f16x2_pmc_sq.txt
+  python tools/pmc_dump.py $(find /tmp/ms -name "*.db" | head -1) tile_kernel >> $out/window_f16x2_pmc_sq.txt 2>&1
+done
 rm -f $out/conv_layer3.txt
 for d in bf16 f16 f16x2 f32; do python tools/probe/l3_block.py --dtype $d 2>/dev/null | grep "layer-3" >> $out/conv_layer3.txt; done
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do

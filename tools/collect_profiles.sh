@@ -30,6 +30,9 @@ done
 rm -rf /tmp/r_ks; rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --iters 10 > $out/rel_bench.txt 2>/dev/null
 python tools/rocpd_stats.py $(find /tmp/r_ks -name "*.db" | head -1) >> $out/rel_bench.txt
 python tools/probe/blaslt_ref.py > $out/hipblaslt_calibration.txt 2>/dev/null
+# (which macro tiles the vendor GEMM picks for these shapes: its kernel names carry them)
+rm -rf /tmp/bl_ks; rocprofv3 --kernel-trace --stats -d /tmp/bl_ks -o bl -- python tools/probe/blaslt_ref.py > /dev/null 2>&1
+python tools/rocpd_stats.py $(find /tmp/bl_ks -name "*.db" | head -1) > $out/hipblaslt_kernels.txt 2>&1
 # training step (SELSA, 1 key + 2 ref frames 600x1000, 300 proposals): throughput in both compute modes + kernel stats of the bf16 mode
 python tools/train_bench.py --steps 10 --warmup 2 > $out/train_bench.json 2>/dev/null
 python tools/train_bench.py --steps 5 --warmup 2 --dtype f32 > $out/train_bench_f32.json 2>/dev/null

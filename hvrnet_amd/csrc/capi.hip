@@ -471,7 +471,11 @@ static int apply_slices(int Mq, int Mk, int D) {
   const int nblk = (int)(rel_ldp(Mk) / 128);
   if (tiles >= 96 || nblk < 8 || D % 8) return 1;
   // a FIXED four blocks (512 keys) per slice: the partition -- and with it the order of the f32 sum -- depends on Mk only,
-  // so a query row's result does not depend on how many other rows are in the call
+  // so AMONG the calls that take this path (fewer than 96 output tiles: up to 1 536 query rows at D = 1024) a query row's result
+  // does not depend on how many other rows are in the call.  Whether the path is taken does depend on Mq: the same row computed
+  // in a 4 500-row call (unsplit, one running f32 sum over the 36 blocks) may differ from it in the last f32 bit.  The loops that
+  // are tested for batch invariance (cached / look-ahead stream) always call the stages with the shapes that ship -- 300 and
+  // 4 500 rows -- so each stage stays on one side of the threshold
   return (nblk + 3) / 4;
 }
 

@@ -59,6 +59,13 @@ constexpr int X_FJ = 4, X_BN = 16 * X_FJ, X_BM = 128, X_NT = 256;
 // ds_read_b128 group read rows {16 a + 4 j + r}: a = 0..3 (two of them per lane-group half), r = 0..3 -- the key
 // (2 a + (r >> 1)) makes the 8 lanes of either row parity land on 8 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int swz_key(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
+// The same for the NEXT conv's weight chunk (NX > 0), whose fragment reads take slot (2 g + v) ^ key -- the lane group g sits in
+// bits 1..2 of the slot there, not in bits 0..1.  A ds_read_b128 is served in groups of 16 lanes that hold every q = lane & 15 once,
+// with g & 1 = (q in 4..11) (xor the group's parity): the slot is c ^ 2 (q3 ^ q2) ^ key(q), and with swz_key's bits (q3, q2, q1)
+// that is (q3, q3, q1) -- four distinct slots for the eight lanes of a row parity, a 2-way bank conflict on every read (round 2's
+// SQ_LDS_BANK_CONFLICT: 2.3 - 4.6 M cycles in the NX > 0 kernels, 0 in the plain ones).  Key bits (q3, q3, q1) instead make it
+// (q3, q2, q1): eight slots.  q3 = bit 5 of the row (rows are 64 a + 16 (q >> 2) + 4 j + (q & 3)).
+__device__ __forceinline__ int nswz_key(int row) { return (((row >> 5) & 1) * 6) | ((row >> 1) & 1); }
 
 }  // namespace
 
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
 #pragma unroll
       for (int i = 0; i < NSLOTS; ++i) {
         const int s = i * NT + tid, row = s >> 3, pos = s & 7;
-        const int ch = pos ^ swz_key(row);
+        const int ch = pos ^ nswz_key(row);
         const char* src = (const char*)p.Wn + ((long)row * p.N * 2 + (long)c * 128 + ch * 16);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(nbuf + (i * NT + wave * 64) * 16), 16, 0, 0);
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
   }
   // Wn fragment of this lane: row 64 (jo >> 2) + 16 (q >> 2) + 4 (jo & 3) + (q & 3), 16-byte slot (2 g + v) ^ key
   const uint32_t n_lane = x_lds_off(smem) + 2 * CHUNK + NC * BN * 4 + ((q >> 2) * 16 + (q & 3)) * 128;
+  const int nkey = ((q >> 3) * 6) | ((q >> 1) & 1);   // nswz_key of that row
 
   static_for<NC>([&](auto U) {
     constexpr int u = decltype(U)::value;
@@ -296,8 +304,8 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
       static_for<NX>([&](auto JO) {
         constexpr int jo = decltype(JO)::value;
         constexpr int roff = (64 * (jo >> 2) + 4 * (jo & 3)) * 128;
-        const uint4 w0 = x_lds_read128<roff>(nb0 + ((((g << 1) | 0) ^ key) << 4));
-        const uint4 w1 = x_lds_read128<roff>(nb0 + ((((g << 1) | 1) ^ key) << 4));
+        const uint4 w0 = x_lds_read128<roff>(nb0 + ((((g << 1) | 0) ^ nkey) << 4));
+        const uint4 w1 = x_lds_read128<roff>(nb0 + ((((g << 1) | 1) ^ nkey) << 4));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

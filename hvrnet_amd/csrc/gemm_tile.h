@@ -802,8 +802,50 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     const int out_es = p.out_f32 ? 4 : EB;
     const bool wide_c = ((p.ldc * out_es) & 15) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 && (p.N & 7) == 0;
     const bool wide_r = p.resid && ((p.ldr * (long)EB) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0;
+    // The shifts of this wave's FN column fragments, fetched in ONE batch ahead of the staging passes (they depend on j only).  Left
+    // inside the (i, j) loop under its `if (p.bias && ...)` the compiler emitted one load + s_waitcnt vmcnt(0) per fragment: FM x FN
+    // serialised L2 round trips at the top of every tile's epilogue (18 for the 144 x 256 shape).  Columns past N (never stored)
+    // read the last valid float4.
+    float4 bvj[FN];
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int c = n0 + (wn * FN + j) * 16 + frag_grp * 4;
+        c = c < p.N ? c : p.N - 4;
+        bvj[j] = *reinterpret_cast<const float4*>(p.bias + c);
+      }
+      if constexpr (SPLIT) {
+        if (p.beta != 0.f) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) { bvj[j].x *= p.beta; bvj[j].y *= p.beta; bvj[j].z *= p.beta; bvj[j].w *= p.beta; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bvj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // split half: a pass's residual rows ([hi | lo] planes, two 16-byte pieces per 8 columns) are requested in one burst at the top
+    // of the pass, under the staging of the accumulators -- one overlapped round trip per pass instead of one per store-phase
+    // iteration (what RESPRE does for the 2-byte formats)
+    uint4 sres[SPLIT ? E_ITERS : 1][2];
 #pragma unroll
     for (int pass = 0; pass < WM; ++pass) {
+      if constexpr (SPLIT) {
+        if (p.resid) {
+#pragma unroll
+          for (int it = 0; it < E_ITERS; ++it) {
+            int c = it * NT + tid;
+            c = c < E_ROWS * E_CH ? c : E_ROWS * E_CH - 1;
+            const int r = c / E_CH, cc = c - r * E_CH;
+            int m = m0 + pass * E_ROWS + r, n = n0 + cc * 8;
+            m = m < p.M ? m : p.M - 1;
+            n = n < p.N ? n : p.N - 8;
+            const char* rp = reinterpret_cast<const char*>(p.resid) + (long)m * p.ldr * 4 + split_col_bytes(n);
+            sres[it][0] = *reinterpret_cast<const uint4*>(rp);
+            sres[it][1] = *reinterpret_cast<const uint4*>(rp + kSplitPlane);
+          }
+        }
+      }
       if (wm == pass) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -814,13 +856,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
             if constexpr (SPLIT) {
               if (p.alpha != 0.f) v *= p.alpha;
             }
-            if (p.bias && n0 + col < p.N) {
-              float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
-              if constexpr (SPLIT) {
-                if (p.beta != 0.f) { bv.x *= p.beta; bv.y *= p.beta; bv.z *= p.beta; bv.w *= p.beta; }
-              }
-              v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
+            v[0] += bvj[j].x; v[1] += bvj[j].y; v[2] += bvj[j].z; v[3] += bvj[j].w;
             *reinterpret_cast<f32x4*>(ebuf + (i * 16 + frag_row) * LDW + col) = v;
           }
       }
@@ -845,8 +881,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int e = 0; e < 8; ++e) v[e] += rv[e];
         } else if constexpr (SPLIT) {
           if (p.resid) {  // (the C ABI admits split operands in whole 8-column chunks only: `full` holds)
-            const char* rp = reinterpret_cast<const char*>(p.resid) + (long)m * p.ldr * 4 + split_col_bytes(n);
-            const uint4 th = *reinterpret_cast<const uint4*>(rp), tl = *reinterpret_cast<const uint4*>(rp + kSplitPlane);
+            const uint4 th = sres[it][0], tl = sres[it][1];
             float rv[8];
             merge2(th.x, tl.x, rv[0], rv[1]); merge2(th.y, tl.y, rv[2], rv[3]);
             merge2(th.z, tl.z, rv[4], rv[5]); merge2(th.w, tl.w, rv[6], rv[7]);

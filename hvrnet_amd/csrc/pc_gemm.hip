@@ -345,16 +345,26 @@ __global__ __launch_bounds__(PC_NT) void pc_tile_kernel(const GemmParams p) {
   constexpr int LDW = BN + 4, CH = BN / 8, CT = PC_CW * 64;
   float* ebuf = reinterpret_cast<float*>(smem);
   __builtin_amdgcn_s_barrier();  // every compute wave is done reading the ring
+  // the shifts of the wave's FN column fragments in one batch (inside the (i, j) loop each was a load + vmcnt(0): see gemm_tile.h)
+  float4 bvj[FN];
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      int c = n0 + (wn * FN + j) * 16 + frag_grp * 4;
+      c = c < p.N ? c : p.N - 4;
+      bvj[j] = *reinterpret_cast<const float4*>(p.bias + c);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bvj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int i = 0; i < PC_FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int col = (wn * FN + j) * 16 + frag_grp * 4;
       f32x4 v = acc[i][j];
-      if (p.bias && n0 + col < p.N) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + col);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
+      v[0] += bvj[j].x; v[1] += bvj[j].y; v[2] += bvj[j].z; v[3] += bvj[j].w;
       *reinterpret_cast<f32x4*>(ebuf + (i * 16 + frag_row) * LDW + col) = v;
     }
   __syncthreads();

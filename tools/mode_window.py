@@ -14,7 +14,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 import hvrnet_amd  # noqa: E402
-from hvrnet_amd import synthetic as S  # noqa: E402
+from hvrnet_amd import native, synthetic as S  # noqa: E402
+
+if os.environ.get('HVR_BENCH_LIB'):  # A/B a privately built library (tuning experiments only)
+    native.LIB_PATH = os.path.abspath(os.environ['HVR_BENCH_LIB'])
 from hvrnet_amd.config import hvr_config, selsa_config  # noqa: E402
 from precision_ladder import apply_mode  # noqa: E402
 

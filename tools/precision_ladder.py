@@ -92,10 +92,10 @@ def main():
             if a.shape == b.shape and (a[:, :4] - b[:, :4]).abs().max().item() <= 2e-2 and (a[:, 4] - b[:, 4]).abs().max().item() <= 1e-3:
                 same_lists += 1
             elif a.shape == b.shape:
-                rows = ((a - b).abs().max(dim=1).values > 2e-2).nonzero().reshape(-1).tolist()
-                list_diffs.append(dict(frame=i, rows=rows[:6], n_rows=len(rows), max_box=float((a[:, :4] - b[:, :4]).abs().max()),
+                bad = ((a - b).abs().max(dim=1).values > 2e-2).nonzero().reshape(-1).tolist()
+                list_diffs.append(dict(frame=i, rows=bad[:6], n_rows=len(bad), max_box=float((a[:, :4] - b[:, :4]).abs().max()),
                                        max_score=float((a[:, 4] - b[:, 4]).abs().max()),
-                                       first=[[round(v, 4) for v in a[rows[0]].tolist()], [round(v, 4) for v in b[rows[0]].tolist()]] if rows else None))
+                                       first=[[round(v, 4) for v in a[bad[0]].tolist()], [round(v, 4) for v in b[bad[0]].tolist()]] if bad else None))
         po = parity.proposal_overlap([p.cpu().numpy() for p in w['proposals']], [p.numpy() for p in inter['proposals']])
         st = [parity.strict(g, r) for g, r in zip(got, want)]
         st_inj = [parity.strict(g, r) for g, r in zip(got_inj, want)]

@@ -9,9 +9,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hvrnet_amd import native  # noqa: E402
 
+if os.environ.get('HVR_BENCH_LIB'):  # A/B a privately built library (tuning experiments only)
+    native.LIB_PATH = os.path.abspath(os.environ['HVR_BENCH_LIB'])
+
 ap = argparse.ArgumentParser()
 ap.add_argument('--dtype', default='f16x2')
 ap.add_argument('--frames', type=int, default=15)
+ap.add_argument('--hints', default=','.join(str(h) for h in range(1, 13)))
 args = ap.parse_args()
 DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16x2': native.SPLIT, 'f32': torch.float32}[args.dtype]
 B = args.frames
@@ -30,7 +34,7 @@ for name, H, W, Cin, Cout, k, st, pad, dil, res in SHAPES:
     OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
     r = native.as_operand(torch.randn((B, OH, OW, Cout), device='cuda', generator=g), DT) if res else None
     out = []
-    for hint in [0] + list(range(1, 13)):
+    for hint in [0] + [int(h) for h in args.hints.split(',') if h]:
         try:
             for _ in range(2):
                 native.conv2d_nhwc(x, w, bias, r, relu=True, stride=st, pad=pad, dil=dil, tile=hint)
@@ -44,5 +48,5 @@ for name, H, W, Cin, Cout, k, st, pad, dil, res in SHAPES:
             out.append((hint, s.elapsed_time(e) / 5 * 1e3))
         except native.HvrError:
             out.append((hint, float('nan')))
-    best = min((t, h) for h, t in out[1:] if t == t)
+    best = min([(t, h) for h, t in out[1:] if t == t] or [(out[0][1], 0)])
     print('%-26s auto %7.1f us | best hint %2d %7.1f us | %s' % (name, out[0][1], best[1], best[0], ' '.join('%d:%.0f' % (h, t) for h, t in out[1:])))

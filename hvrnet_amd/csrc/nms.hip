@@ -496,10 +496,20 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
     const int mcount = (n + 1023) >> 10;
     uint32_t uc[CE];
     if (cached) {
+      // all of a thread's logits are requested before the first is used (indices past n are clamped, not predicated): under
+      // `i < n ? load : 0` every one of the 29 strided 2-byte loads was its own round trip (load, s_waitcnt vmcnt(0), next)
+      float lg[CE];
+#pragma unroll
+      for (int m = 0; m < CE; ++m) {
+        int i = m * 1024 + (int)threadIdx.x;
+        i = i < n ? i : n - 1;
+        const int cell = i / A, a = i - cell * A;
+        lg[m] = ElemTraits<T>::load(c + (long)cell * cpitch + a);
+      }
 #pragma unroll
       for (int m = 0; m < CE; ++m) {
         const int i = m * 1024 + (int)threadIdx.x;
-        uc[m] = i < n ? float_key(score_of(i)) : 0u;
+        uc[m] = i < n ? float_key(1.f / (1.f + expf(-lg[m]))) : 0u;   // torch.sigmoid, as score_of
       }
     }
     int* wh = whist[wave & 15];
@@ -682,26 +692,46 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
 #endif
   // decode (delta2bbox, mmdet/core/bbox/transforms.py:78-110) in sorted order
   const int cnt = n > k ? k : n;
-  for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-    const int i = (int)(0xffffffffu - (uint32_t)comp[j]);
-    const int a = i % rp.A, cell = i / rp.A, x = cell % rp.W, y = cell / rp.W;
-    const float ax1 = rp.base[a][0] + x * rp.stride, ay1 = rp.base[a][1] + y * rp.stride;
-    const float ax2 = rp.base[a][2] + x * rp.stride, ay2 = rp.base[a][3] + y * rp.stride;
-    float d[4];
-    load4(r + (long)cell * rpitch + a * 4, d);
-    const float dx = d[0] * rp.s[0] + rp.m[0], dy = d[1] * rp.s[1] + rp.m[1];
-    float dw = d[2] * rp.s[2] + rp.m[2], dh = d[3] * rp.s[3] + rp.m[3];
-    dw = fminf(fmaxf(dw, -rp.max_ratio), rp.max_ratio);
-    dh = fminf(fmaxf(dh, -rp.max_ratio), rp.max_ratio);
-    const float px = (ax1 + ax2) * 0.5f, py = (ay1 + ay2) * 0.5f, pw = ax2 - ax1 + 1.0f, ph = ay2 - ay1 + 1.0f;
-    const float gw = pw * expf(dw), gh = ph * expf(dh), gx = px + pw * dx, gy = py + ph * dy;
-    float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f, x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
-    x1 = fminf(fmaxf(x1, 0.f), rp.img_w - 1.f);
-    y1 = fminf(fmaxf(y1, 0.f), rp.img_h - 1.f);
-    x2 = fminf(fmaxf(x2, 0.f), rp.img_w - 1.f);
-    y2 = fminf(fmaxf(y2, 0.f), rp.img_h - 1.f);
-    float* o = out + ((long)f * k + j) * 5;
-    o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = score_of(i);
+  // four proposals per thread and step: their deltas and logits are requested together (clamped slots, nothing predicated) -- one
+  // proposal per iteration made every one of a thread's six iterations a round trip of its own
+  constexpr int DU = 4;
+  for (int j0 = threadIdx.x; j0 < cnt; j0 += DU * blockDim.x) {
+    int ii[DU];
+    float d[DU][4], lgt[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      int j = j0 + u * (int)blockDim.x;
+      j = j < cnt ? j : cnt - 1;
+      ii[u] = (int)(0xffffffffu - (uint32_t)comp[j]);
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int a = ii[u] % rp.A, cell = ii[u] / rp.A;
+      load4(r + (long)cell * rpitch + a * 4, d[u]);
+      lgt[u] = ElemTraits<T>::load(c + (long)cell * cpitch + a);
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int j = j0 + u * (int)blockDim.x;
+      if (j >= cnt) continue;
+      const int i = ii[u];
+      const int a = i % rp.A, cell = i / rp.A, x = cell % rp.W, y = cell / rp.W;
+      const float ax1 = rp.base[a][0] + x * rp.stride, ay1 = rp.base[a][1] + y * rp.stride;
+      const float ax2 = rp.base[a][2] + x * rp.stride, ay2 = rp.base[a][3] + y * rp.stride;
+      const float dx = d[u][0] * rp.s[0] + rp.m[0], dy = d[u][1] * rp.s[1] + rp.m[1];
+      float dw = d[u][2] * rp.s[2] + rp.m[2], dh = d[u][3] * rp.s[3] + rp.m[3];
+      dw = fminf(fmaxf(dw, -rp.max_ratio), rp.max_ratio);
+      dh = fminf(fmaxf(dh, -rp.max_ratio), rp.max_ratio);
+      const float px = (ax1 + ax2) * 0.5f, py = (ay1 + ay2) * 0.5f, pw = ax2 - ax1 + 1.0f, ph = ay2 - ay1 + 1.0f;
+      const float gw = pw * expf(dw), gh = ph * expf(dh), gx = px + pw * dx, gy = py + ph * dy;
+      float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f, x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
+      x1 = fminf(fmaxf(x1, 0.f), rp.img_w - 1.f);
+      y1 = fminf(fmaxf(y1, 0.f), rp.img_h - 1.f);
+      x2 = fminf(fmaxf(x2, 0.f), rp.img_w - 1.f);
+      y2 = fminf(fmaxf(y2, 0.f), rp.img_h - 1.f);
+      float* o = out + ((long)f * k + j) * 5;
+      o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = 1.f / (1.f + expf(-lgt[u]));   // torch.sigmoid, as score_of
+    }
   }
 #ifdef HVR_DBG_SEL_CLK
   if (threadIdx.x == 0 && f == 0 && n > k)

@@ -325,6 +325,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       int rowo[FM];
 #pragma unroll
       for (int i = 0; i < FM; ++i) { mx[i] = -INFINITY; l[i] = 0.f; rowo[i] = stat_row(i); }
+      // the first block's maximum of every row, requested with the first batch below (fetched at its use -- after the
+      // combine -- the FM loads were FM serial round trips: each sat under its own s_waitcnt vmcnt(0))
+      float mfirst[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) mfirst[i] = p.mstat[rowo[i] + blk0];
       for (int t0 = lane >> 4; t0 < p.ntile; t0 += 4 * TB) {
         float mt[FM][TB], lt[FM][TB];
 #pragma unroll
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           m_ = mn;
         }
         gref[i] = m_ + __builtin_amdgcn_logf(l_);
-        gcur[i] = __builtin_amdgcn_exp2f(p.mstat[rowo[i] + blk0] - gref[i]);
+        gcur[i] = __builtin_amdgcn_exp2f(mfirst[i] - gref[i]);
         landed(gcur[i]);  // waited for here, ahead of the pipeline, not inside the K loop
         gnext[i] = 0.f;
       }

@@ -285,6 +285,18 @@ def allreduce_leg(dist, world, head, device, iters=5):
                 backend=dist.get_backend())
 
 
+def stream_side_measurement(head):
+    """The pipelined stream loop with the window graph on a stream confined to 96 CUs (GraphedStream(window_cus=96)), measured by
+    tools/stream_bench.py in a process of its own: where a HIP stream's launches queue depends on how many streams the process
+    has used before, and after this script's ladder of graph builds the confined window loses its gain (tools/stream_bench.py)."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stream_bench.py'), '--head', head], capture_output=True, text=True, timeout=300)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the headline down
+        sys.stderr.write('stream side measurement skipped: %r\n' % (exc,))
+        return None
+
+
 def lib_sha16():
     from hvrnet_amd import native
     return hashlib.sha256(open(native.LIB_PATH, 'rb').read()).hexdigest()[:16]
@@ -819,6 +831,11 @@ def main(argv=None):
                 best = max(ok, key=lambda r: (r.get('graph_replay') or r['single_lane'])['frames_per_s'])
                 out['precision_ladder']['fastest_mode_within_tolerance'] = dict(dtype=best['dtype'],
                                                                                 frames_per_s=(best.get('graph_replay') or best['single_lane'])['frames_per_s'])
+        if world == 1 and not args.no_graphs and args.inflight == 1 and out.get('graphed_stream'):
+            # (after everything else: the child shares the GPU with nothing of this process that is still running)
+            ss = stream_side_measurement(args.head)
+            if ss is not None:
+                out['graphed_stream']['pipelined_window_cus'] = ss
         if world == 1 and not args.no_train_step:
             ts = train_step_side_measurement(args.head)
             if ts is not None:

@@ -19,6 +19,7 @@ torch.cuda.CUDAGraph is the capture mechanism (hipStreamBeginCapture / hipGraphL
 build's own, launched through the C ABI on the capturing streams.  Results are identical to the eager path (same kernels,
 same order per stream): tests/test_graphs_gpu.py.
 """
+import contextlib
 import weakref
 
 import torch
@@ -35,6 +36,26 @@ _LIVE = weakref.WeakSet()
 def invalidate_all(reason):
     for g in list(_LIVE):
         g._stale = reason
+
+
+@contextlib.contextmanager
+def _capture(graph, **kw):
+    """torch.cuda.graph(graph, **kw) with Python's cyclic garbage collector held off for the duration.  A Graphed* object and its
+    pending windows reference each other, so a dropped one is freed by the collector, whenever that runs -- and when it ran in the
+    middle of ANOTHER object's capture (it is triggered by allocation counts: any ctypes launch can be the one), the dead
+    CUDAGraph's destructor called hipGraphExecDestroy while a stream was capturing in global mode: 'operation not permitted when
+    stream is capturing', from a destructor, i.e. std::terminate.  Collect first, then capture with the collector disabled."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
 
 
 def _check_live(g):
@@ -125,7 +146,7 @@ class GraphedClip(object):
             for k in range(max(1, n_out)):
                 outs = [_HostOut(b, c) for b, c, _ in per_window]   # pinned buffers exist before the capture (no host allocation inside it)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=self._stream, **(dict(pool=self._graphs[0].pool()) if self._graphs else {})):
+                with _capture(graph, stream=self._stream, **(dict(pool=self._graphs[0].pool()) if self._graphs else {})):
                     for out, (b2, c2, _) in zip(outs, self._enqueue()):
                         out.dev, out.counts_dev = [tuple(b) for b in b2], c2
                         out.enqueue_copies()
@@ -193,8 +214,17 @@ class GraphedStream(object):
     A frame may be pushed several times without recomputing it (`repeat_last()`): the reference pads the first and last
     windows of a video with copies of a frame (test.py:201-212, 257-300)."""
 
-    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1, fewrow_split=True):
+    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1, fewrow_split=True, window_cus=None):
         assert frame.is_cuda and frame.dim() == 4 and frame.shape[0] == 1
+        # window_cus = n (meant for the pipelined loop, push_async / commit / emit): everything that touches the window buffers --
+        # graph C, graph W, the padding / staging graphs -- is replayed on ONE stream confined to n of the chip's CUs
+        # (native.cu_masked_stream); the next frame's graph FC keeps its own unconfined stream.  That loop's critical path is the
+        # frame chain, ~150 small launches; the window's relation kernels are chip-filling launches of 150 KB-LDS workgroups, and
+        # every one of them that sits on a CU in front of a frame launch is 50 us of waiting.  With the window on 96 CUs (12 per
+        # XCD) the frame chain always finds free CUs: 333 -> 426 frames/s on one box (tools/probe/stream_cumask.py; 64 / 128 / 176
+        # CUs: 411 / 410 / 409).  Same graphs in the same order: same results.
+        self._wstream = None
+        self.window_cus = window_cus
         self.model, self.meta, self.rescale = model, meta, rescale
         self.lookahead = int(lookahead)
         # one frame gives the stride-16 stages 2 394 rows: its convs / fc_new_1 run split over K (native.fewrow_split) --
@@ -237,14 +267,14 @@ class GraphedStream(object):
             self._stream.synchronize()
             self._full = n
             self.graph_f = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_f, stream=self._stream):
+            with _capture(self.graph_f, stream=self._stream):
                 e = self._frame_entry()
                 self.last['f1'].copy_(e['f1'])
                 self.last['props'].copy_(e['props'])
                 self.last['count'].copy_(e['count'])
                 self._push_from(self.last)
             self.graph_p = torch.cuda.CUDAGraph()          # push the last computed frame again (padding)
-            with torch.cuda.graph(self.graph_p, stream=self._stream, pool=self.graph_f.pool()):
+            with _capture(self.graph_p, stream=self._stream, pool=self.graph_f.pool()):
                 self._push_from(self.last)
             # Look-ahead (offline video: the frames of a clip are all there): `lookahead` frames go through backbone / res5 / RPN /
             # RoIAlign / fc_new_1 in ONE batch -- a single 600x1000 frame gives the stride-16 stages 2 394 rows, 17-19 row tiles
@@ -259,13 +289,13 @@ class GraphedStream(object):
                     eb = self.model.frames_tensors(c4, metas)
                 self._stream.synchronize()
                 self.graph_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_fb, stream=self._stream, pool=self.graph_f.pool()):
+                with _capture(self.graph_fb, stream=self._stream, pool=self.graph_f.pool()):
                     c4 = self.model(img=self.batch, img_meta=metas, backbone_feat=True)[0]
                     eb = self.model.frames_tensors(c4, metas)
                 self._staged = eb   # static buffers of the batch graph: props [B,n,5], count [B], f1 [B * n, D]
                 for i in range(B):
                     gi = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gi, stream=self._stream, pool=self.graph_f.pool()):
+                    with _capture(gi, stream=self._stream, pool=self.graph_f.pool()):
                         self.last['f1'].copy_(eb['f1'][i * n:(i + 1) * n])
                         self.last['props'].copy_(eb['props'][i])
                         self.last['count'].copy_(eb['count'][i:i + 1])
@@ -276,7 +306,7 @@ class GraphedStream(object):
             for k in range(max(1, n_out)):
                 out = _HostOut(branches, counts)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=self._stream, pool=self.graph_f.pool()):
+                with _capture(graph, stream=self._stream, pool=self.graph_f.pool()):
                     b2, c2, _ = self._window()
                     out.dev, out.counts_dev = [tuple(b) for b in b2], c2
                     out.enqueue_copies()
@@ -296,19 +326,12 @@ class GraphedStream(object):
                 self._frame_entry(self.frame_nxt)
             self._fstream.synchronize()
             self.graph_fc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_fc, stream=self._fstream):
+            with _capture(self.graph_fc, stream=self._fstream):
                 e = self._frame_entry(self.frame_nxt)
                 self.nxt['f1'].copy_(e['f1'])
                 self.nxt['props'].copy_(e['props'])
                 self.nxt['count'].copy_(e['count'])
         self._stream.wait_stream(self._fstream)
-        with torch.no_grad(), torch.cuda.stream(self._stream):
-            self.graph_c = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_c, stream=self._stream, pool=self.graph_f.pool()):
-                self.last['f1'].copy_(self.nxt['f1'])
-                self.last['props'].copy_(self.nxt['props'])
-                self.last['count'].copy_(self.nxt['count'])
-                self._push_from(self.last)
         self._ev_fc, self._ev_commit, self._pending_frame = torch.cuda.Event(), None, None
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._hist = []  # the window's input frames (copies), for the exact re-run of a window that holds a short frame
@@ -352,13 +375,34 @@ class GraphedStream(object):
             return self.model.forward_feat(x=c4, img_meta=metas, rescale=self.rescale, speculate=False)
 
     # ---- the loop ----
+    @contextlib.contextmanager
+    def _window_stream(self, behind_caller=True):
+        """The stream the window buffers are worked on: the caller's current stream, or -- window_cus -- the CU-masked stream,
+        made current for the block and (behind_caller) ordered behind what the caller has enqueued so far.  emit() does not ask
+        for that order: what graph W reads was written by graphs on this very stream, and a wait on the caller's stream is a wait
+        on whatever shares its hardware queue -- HIP streams outnumber hardware queues (GPU_MAX_HW_QUEUES = 4), a queue is served
+        in order, and with the caller's stream on the frame stream's queue the event sat behind the ~150 launches of graph FC:
+        the window ran AFTER the frame it was meant to run beside (266 instead of 425 frames/s)."""
+        cur = torch.cuda.current_stream(self.frame.device)
+        if not self.window_cus:
+            yield cur
+            return
+        if self._wstream is None:
+            from . import native
+            self._wstream = native.cu_masked_stream(self.frame.device, 0, int(self.window_cus))
+        if behind_caller and cur != self._wstream:
+            self._wstream.wait_stream(cur)
+        with torch.cuda.stream(self._wstream):
+            yield self._wstream
+
     def push(self, frame=None):
         """A new frame arrives: graph F (its rows enter the window buffers)."""
-        if frame is not None:
-            self.frame.copy_(frame, non_blocking=True)
         _check_live(self)
-        self.graph_f.replay()
-        self._hist = (self._hist + [self.frame.clone()])[-self.T:]
+        with self._window_stream():
+            if frame is not None:
+                self.frame.copy_(frame, non_blocking=True)
+            self.graph_f.replay()
+            self._hist = (self._hist + [self.frame.clone()])[-self.T:]
 
     def push_async(self, frame):
         """A new frame arrives: its per-frame part (graph FC) starts on the frame stream and runs beside whatever the caller's
@@ -371,18 +415,18 @@ class GraphedStream(object):
         _check_live(self)
         with torch.cuda.stream(self._fstream):
             self.frame_nxt.copy_(frame, non_blocking=True)
+            self._pending_frame = self.frame_nxt.clone()   # (on the frame stream: nothing of the loop is enqueued on the caller's)
             self.graph_fc.replay()
             self._ev_fc.record(self._fstream)
-        self._pending_frame = frame.clone()
 
     def commit(self):
         """The frame started by push_async() enters the window buffers (graph C on the caller's stream, behind graph FC)."""
         assert self._pending_frame is not None, 'push_async() first'
-        cur = torch.cuda.current_stream(self.frame.device)
-        cur.wait_event(self._ev_fc)
-        self.graph_c.replay()
-        self._ev_commit = torch.cuda.Event()
-        self._ev_commit.record(cur)
+        with self._window_stream() as st:
+            st.wait_event(self._ev_fc)
+            self.graph_c.replay()
+            self._ev_commit = torch.cuda.Event()
+            self._ev_commit.record(st)
         self._hist = (self._hist + [self._pending_frame])[-self.T:]
         self._pending_frame = None
 
@@ -391,16 +435,20 @@ class GraphedStream(object):
         `advance(i)` to move frame i of the batch into the window buffers."""
         assert self.graph_fb is not None and frames.shape[0] == self.lookahead
         _check_live(self)
+        if self._wstream is not None:   # (the staging rows may still be read by advance() graphs on the window stream)
+            torch.cuda.current_stream(self.frame.device).wait_stream(self._wstream)
         self.batch.copy_(frames, non_blocking=True)
         self.graph_fb.replay()
         self._batch_frames = frames.clone()   # (the caller may reuse its decode buffer: a re-run of a short-frame window reads these)
 
     def advance(self, i):
-        self._stage_graphs[i].replay()
+        with self._window_stream():
+            self._stage_graphs[i].replay()
         self._hist = (self._hist + [self._batch_frames[i:i + 1]])[-self.T:]
 
     def repeat_last(self):
-        self.graph_p.replay()
+        with self._window_stream():
+            self.graph_p.replay()
         self._hist = (self._hist + [self._hist[-1]])[-self.T:]
 
     def emit(self):
@@ -410,9 +458,10 @@ class GraphedStream(object):
         if prev is not None and not prev.read:
             raise RuntimeError('emitting into output slot %d of %d before result() of its previous window was called' % (k, len(self._graphs_w)))
         self._turn += 1
-        self._graphs_w[k].replay()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.frame.device))
+        with self._window_stream(behind_caller=False) as st:
+            self._graphs_w[k].replay()
+            ev = torch.cuda.Event()
+            ev.record(st)
         hist = list(self._hist[-self.T:])   # this window's frames: later pushes must not change what a re-run sees
         pend = PendingGraphWindow(self, self._outs[k], ev, lambda: self._exact(hist))
         self._unread[k] = pend

@@ -586,6 +586,41 @@ def throughput_mode(on=True):
         TILE_HINT = prev
 
 
+_hip_rt = [None]
+_masked_streams = {}   # (device index, first, n) -> (raw handle, ExternalStream): ONE queue per mask, kept for the life of the process
+
+
+def cu_masked_stream(device, first_cu, n_cus, total_cus=256):
+    """A HIP stream whose launches -- direct ones and hipGraph replays issued ON it -- only use `n_cus` of the chip's CUs
+    (hipExtStreamCreateWithCUMask, mask bits [first_cu, first_cu + n_cus)).  On MI355X a contiguous range of mask bits is spread
+    over all eight XCDs (96 bits = 12 CUs in each; tools/probe/cumask), and the mask belongs to the stream a graph is replayed on,
+    not to the one it was captured on.  Every mask is a hardware queue of its own: a process that creates a dozen of them slows
+    every one down (queue oversubscription), so streams are cached per mask.  -> torch.cuda.ExternalStream"""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(first_cu), int(n_cus))
+    if key in _masked_streams:
+        return _masked_streams[key][1]
+    if _hip_rt[0] is None:
+        rt = ctypes.CDLL('libamdhip64.so')
+        rt.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        rt.hipExtStreamCreateWithCUMask.restype = ctypes.c_int
+        _hip_rt[0] = rt
+    if not (0 <= first_cu and n_cus > 0 and first_cu + n_cus <= total_cus):
+        raise HvrError('CU mask [%d, %d) outside [0, %d)' % (first_cu, first_cu + n_cus, total_cus))
+    words = (total_cus + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for cu in range(first_cu, first_cu + n_cus):
+        mask[cu // 32] |= 1 << (cu % 32)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(key[0]):
+        rc = _hip_rt[0].hipExtStreamCreateWithCUMask(ctypes.byref(handle), words, mask)
+    if rc != 0:
+        raise HvrError('hipExtStreamCreateWithCUMask failed (%d)' % rc)
+    st = torch.cuda.ExternalStream(handle.value, device=torch.device('cuda', key[0]))
+    _masked_streams[key] = (handle, st)
+    return st
+
+
 _ws_captured = set()   # keys whose current buffer was handed out during a stream capture
 _ws_retired = []       # replaced buffers a captured graph may still address: never freed
 

@@ -170,11 +170,13 @@ def test_graphed_stream_equals_the_cached_frame_loop(kind):
         _check(kind, got[off], want[off])
 
 
+@pytest.mark.parametrize('window_cus', [None, 96])
 @pytest.mark.parametrize('kind', ['hvr', 'selsa'])
-def test_pipelined_stream_equals_the_sequential_stream(kind):
+def test_pipelined_stream_equals_the_sequential_stream(kind, window_cus):
     """push_async / commit: frame i + 1's per-frame part (graph FC, own stream / pool / scratch) runs beside window i's
     relation stages and read-out (graph W).  Same kernels on the same rows: every emitted window equals the one the
-    sequential push() / emit() stream gives, bit for bit, over two passes of the video."""
+    sequential push() / emit() stream gives, bit for bit, over two passes of the video.  window_cus = 96: graph W replayed on a
+    stream confined to 96 CUs (native.cu_masked_stream) -- the same graph, ordered against commit() by events."""
     fi, n_prop = 2, 24
     T = 2 * fi + 1
     make = hvr_config if kind == 'hvr' else selsa_config
@@ -187,7 +189,7 @@ def test_pipelined_stream_equals_the_sequential_stream(kind):
         for f in frames:
             seq.push(f)
             want.append(seq.emit().result())
-    gs = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False)
+    gs = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False, window_cus=window_cus)
     order = frames + frames
     got, pend = [], None
     gs.push_async(order[0])

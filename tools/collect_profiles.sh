@@ -59,6 +59,7 @@ $T python tools/train_bench.py --steps 10 --warmup 2 --head hvr > $out/train_ben
 rm -rf /tmp/t_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/t_ks -o train -- python tools/train_bench.py --steps 3 --warmup 1 > /dev/null 2>&1
 $T python tools/rocpd_stats.py $(db /tmp/t_ks) > $out/train_kernel_stats.txt
 $T python tools/ingest_bench.py > $out/ingest_bench.json 2>/dev/null
+$T python tools/stream_bench.py > $out/stream_bench.json 2>/dev/null   # pipelined stream mode, window graph on a 96-CU stream (own process)
 fi
 
 if [[ $parts == *D* ]]; then
@@ -77,7 +78,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
 done
 rm -f $out/conv_layer3.txt
 for d in bf16 f16 f16x2 f32; do $T python tools/probe/l3_block.py --dtype $d 2>/dev/null | grep "layer-3" >> $out/conv_layer3.txt; done
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum"; do
   rm -rf /tmp/l3; $T rocprofv3 --kernel-trace --pmc $set -d /tmp/l3 -o l3 -- python tools/probe/l3_block.py --dtype bf16 --iters 3 > /dev/null 2>&1
   echo "--- bf16 layer-3 block, pass: $set (FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x 2 on gfx950)" >> $out/conv_layer3.txt
   $T python tools/pmc_dump.py $(db /tmp/l3) _kernel >> $out/conv_layer3.txt 2>&1

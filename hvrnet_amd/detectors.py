@@ -230,6 +230,8 @@ class _WindowDetector(TwoStageDetector):
             raise NotImplementedError('per-RoI shared head (feat_from_shared_head=False) is outside the hot path')
         return self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
 
+    rpn_side_stream = os.environ.get('HVR_RPN_SIDE', '1') != '0'
+
     def _side_stream(self, device):
         streams = self.__dict__.setdefault('_side_streams', {})
         key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # one RPN side stream per main stream
@@ -268,19 +270,24 @@ class _WindowDetector(TwoStageDetector):
         if proposals is None:
             # The RPN branch (3x3 conv, heads, select / NMS: a few latency-bound workgroups) and res5 both
             # depend only on C4: run the RPN on a second HIP stream underneath res5.
-            main, side = torch.cuda.current_stream(xc.device), self._side_stream(xc.device)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
+            if self.rpn_side_stream:
+                main, side = torch.cuda.current_stream(xc.device), self._side_stream(xc.device)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    rpn_outs = self.rpn_head([xc])
+                    props, counts = self.rpn_head.get_bboxes_batched(rpn_outs[0], rpn_outs[1], img_meta, self.test_cfg.rpn)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
+                main.wait_event(done)
+                props.record_stream(main)
+                counts.record_stream(main)
+            else:   # one chain (HVR_RPN_SIDE=0): no fork for a captured graph's replay to spread over further hardware queues
                 rpn_outs = self.rpn_head([xc])
                 props, counts = self.rpn_head.get_bboxes_batched(rpn_outs[0], rpn_outs[1], img_meta, self.test_cfg.rpn)
-                done = torch.cuda.Event()
-                done.record(side)
-            feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
-            main.wait_event(done)
-            props.record_stream(main)
-            counts.record_stream(main)
+                feats = [self.shared_head(xc)] if self.feat_from_shared_head else [xc]
             T, mx = props.shape[0], props.shape[1]
             counts_dev = counts if speculate else None
             counts_h = [mx] * T if speculate else counts.tolist()  # exact path: a mid-window host read of T integers

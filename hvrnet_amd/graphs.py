@@ -221,7 +221,7 @@ class GraphedStream(object):
         # (native.cu_masked_stream); the next frame's graph FC keeps its own unconfined stream.  That loop's critical path is the
         # frame chain, ~150 small launches; the window's relation kernels are chip-filling launches of 150 KB-LDS workgroups, and
         # every one of them that sits on a CU in front of a frame launch is 50 us of waiting.  With the window on 96 CUs (12 per
-        # XCD) the frame chain always finds free CUs: 333 -> 426 frames/s on one box (tools/probe/stream_cumask.py; 64 / 128 / 176
+        # XCD) the frame chain always finds free CUs: 333 -> 426 frames/s on one box (tools/stream_bench.py; 64 / 128 / 176
         # CUs: 411 / 410 / 409).  Same graphs in the same order: same results.
         self._wstream = None
         self.window_cus = window_cus
@@ -332,6 +332,13 @@ class GraphedStream(object):
                 self.nxt['props'].copy_(e['props'])
                 self.nxt['count'].copy_(e['count'])
         self._stream.wait_stream(self._fstream)
+        with torch.no_grad(), torch.cuda.stream(self._stream):
+            self.graph_c = torch.cuda.CUDAGraph()
+            with _capture(self.graph_c, stream=self._stream, pool=self.graph_f.pool()):
+                self.last['f1'].copy_(self.nxt['f1'])
+                self.last['props'].copy_(self.nxt['props'])
+                self.last['count'].copy_(self.nxt['count'])
+                self._push_from(self.last)
         self._ev_fc, self._ev_commit, self._pending_frame = torch.cuda.Event(), None, None
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._hist = []  # the window's input frames (copies), for the exact re-run of a window that holds a short frame

@@ -215,14 +215,32 @@ class GraphedStream(object):
     windows of a video with copies of a frame (test.py:201-212, 257-300)."""
 
     def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1, fewrow_split=True, window_cus=None):
+        # window_cus: every graph of this object is captured as ONE chain (the RPN branch behind res5, the second read-out branch
+        # behind the first).  A graph with parallel branches replayed on a CU-masked stream makes the runtime set its branch
+        # streams up from that stream -- hipGraphLaunch segfaulted (ROCm 7.2) when that was the process's first forked replay --
+        # and where the branch streams of the two graphs land among the hardware queues decides whether the window still runs
+        # beside the frame (frame graph forked, window graph not: 331 frames/s, no gain; both forked 425; neither 420).
+        undo = []
+        if window_cus:
+            for obj, attr in ((model, 'rpn_side_stream'), (model.bbox_head, 'readout_streams')):
+                if getattr(obj, attr, False):
+                    setattr(obj, attr, False)
+                    undo.append((obj, attr))
+        try:
+            self._build(model, frame, meta, rescale, warmup, n_out, lookahead, fewrow_split, window_cus)
+        finally:
+            for obj, attr in undo:
+                delattr(obj, attr)   # back to the class attribute
+
+    def _build(self, model, frame, meta, rescale, warmup, n_out, lookahead, fewrow_split, window_cus):
         assert frame.is_cuda and frame.dim() == 4 and frame.shape[0] == 1
         # window_cus = n (meant for the pipelined loop, push_async / commit / emit): everything that touches the window buffers --
         # graph C, graph W, the padding / staging graphs -- is replayed on ONE stream confined to n of the chip's CUs
         # (native.cu_masked_stream); the next frame's graph FC keeps its own unconfined stream.  That loop's critical path is the
         # frame chain, ~150 small launches; the window's relation kernels are chip-filling launches of 150 KB-LDS workgroups, and
         # every one of them that sits on a CU in front of a frame launch is 50 us of waiting.  With the window on 96 CUs (12 per
-        # XCD) the frame chain always finds free CUs: 333 -> 426 frames/s on one box (tools/stream_bench.py; 64 / 128 / 176
-        # CUs: 411 / 410 / 409).  Same graphs in the same order: same results.
+        # XCD) the frame chain always finds free CUs: 332 -> 420 frames/s on one box (tools/stream_bench.py; 64 / 128 / 176
+        # CUs: 411 / 410 / 409 with forked graphs).  Same graphs in the same order: same results.
         self._wstream = None
         self.window_cus = window_cus
         self.model, self.meta, self.rescale = model, meta, rescale

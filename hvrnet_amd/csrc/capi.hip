@@ -55,9 +55,14 @@ hipError_t run_roi_align_fwd(const void*, const float*, void*, int, int, int, in
                              hipStream_t);
 hipError_t run_roi_align_bwd(const float*, const float*, float*, int, int, int, int, int, int, float, int, int, hipStream_t);
 size_t nms_workspace_bytes(int P, int n);
-hipError_t run_nms_batched(const float*, int, int, float, int, int, int, long long*, int*, void*, hipStream_t);
+hipError_t run_nms_batched(const float*, int, int, float, int, int, int, long long*, int*, void*, hipStream_t, int band = 0,
+                           int* band_done = nullptr);
 hipError_t run_rpn_select(const void*, const void*, long, long, float*, const RpnParams&, int, hipStream_t);
-hipError_t run_rpn_gather(const float*, const long long*, const int*, int, int, int, int, float*, int*, hipStream_t);
+hipError_t run_rpn_select_wide(const void*, const void*, long, long, float*, const RpnParams&, void*, hipStream_t);
+size_t rpn_wide_workspace_bytes(int T, long n_anchor);
+int rpn_wide_max_frames(int set);
+int* rpn_wide_done_flags(void* wws, int T);
+hipError_t run_rpn_gather(const float*, const long long*, const int*, int, int, int, int, int, float*, int*, hipStream_t);
 hipError_t run_multiclass_nms(const float*, const float*, int, int, float, float, int, float*, long long*, int*, void*,
                               hipStream_t);
 size_t multiclass_nms_workspace_bytes(int R, int ncls);
@@ -860,8 +865,10 @@ static inline int rpn_npre(int H, int W, int A, int nms_pre) {
 size_t hvr_rpn_workspace_bytes(int T, int H, int W, int A, int nms_pre) {
   const int npre = rpn_npre(H, W, A, nms_pre);
   return align256((size_t)T * npre * 5 * 4) + align256((size_t)T * npre * 8) + align256((size_t)T * 4) +
-         nms_workspace_bytes(T, npre) + 256;
+         nms_workspace_bytes(T, npre) + rpn_wide_workspace_bytes(T, (long)H * W * A) + 256;
 }
+
+int hvr_rpn_wide_frames(int frames) { return rpn_wide_max_frames(frames); }
 
 int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* stream) {
   if (!d || !ws) return fail(HVR_EINVAL, "null pointer");
@@ -886,14 +893,22 @@ int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* st
   long long* keep = (long long*)w;   w += align256((size_t)d->T * npre * 8);
   int* n_keep = (int*)w;             w += align256((size_t)d->T * 4);
   hipStream_t s = (hipStream_t)stream;
-  int rc = check_launch(run_rpn_select(d->cls, d->reg, (long)d->H * d->W * rp.cls_pitch, (long)d->H * d->W * rp.reg_pitch, props, rp, HVR_F32, s), "rpn: select");
-  if (rc) return rc;
   const int presorted = n_anchor > npre ? 1 : 0;
+  // few frames (stream mode: one): the chip-wide kernels -- the same proposals, bit for bit (nms.hip, "the chip-wide form")
+  const bool wide = presorted && d->T <= rpn_wide_max_frames(-1) && d->nms_post > 0 && d->nms_post <= 1024;
+  void* wws = w + nms_workspace_bytes(d->T, npre);
+  int rc;
+  if (wide)
+    rc = check_launch(run_rpn_select_wide(d->cls, d->reg, (long)d->H * d->W * rp.cls_pitch, (long)d->H * d->W * rp.reg_pitch, props, rp, wws, s), "rpn: select (chip-wide)");
+  else
+    rc = check_launch(run_rpn_select(d->cls, d->reg, (long)d->H * d->W * rp.cls_pitch, (long)d->H * d->W * rp.reg_pitch, props, rp, HVR_F32, s), "rpn: select");
+  if (rc) return rc;
   // with score-sorted input the first nms_post survivors are known after nms_post keeps
-  rc = check_launch(run_nms_batched(props, d->T, npre, d->nms_thr, 1, presorted, presorted ? d->nms_post : 0, keep, n_keep, w, s),
+  rc = check_launch(run_nms_batched(props, d->T, npre, d->nms_thr, 1, presorted, presorted ? d->nms_post : 0, keep, n_keep, w, s,
+                                    wide ? 4096 : 0, wide ? rpn_wide_done_flags(wws, d->T) : nullptr),
                     "rpn: nms");
   if (rc) return rc;
-  return check_launch(run_rpn_gather(props, keep, n_keep, d->T, npre, d->nms_post, d->max_num, d->proposals, d->counts, s),
+  return check_launch(run_rpn_gather(props, keep, n_keep, d->T, npre, d->nms_post, d->max_num, presorted, d->proposals, d->counts, s),
                       "rpn: gather");
 }
 

@@ -337,9 +337,11 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long
 // the survivor set is the same bit for bit; 15 workgroups instead of a chip-filling mask launch: the chip stays with res5.
 __global__ __launch_bounds__(1024) void nms_greedy_kernel(const float* __restrict__ dets, const float4* __restrict__ boxes4,
                                                           const int* __restrict__ order, int n, float thr, int ge, int max_keep,
-                                                          long long* __restrict__ keep, int* __restrict__ n_keep, int keep_stride) {
+                                                          long long* __restrict__ keep, int* __restrict__ n_keep, int keep_stride,
+                                                          const int* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EXT = 4;  // words the front grows by
+  if (skip && skip[blockIdx.x]) return;  // (the band sweep below has already finished this problem)
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
   const int nb = (n + 63) >> 6;  // <= 128
@@ -451,6 +453,27 @@ __global__ __launch_bounds__(1024) void nms_greedy_kernel(const float* __restric
 // cls  [T][HW*A] logits in (y, x, anchor) order (NHWC conv output == permute(1,2,0))
 // reg  [T][HW*A][4]
 // out  [T][npre][5], sorted by score (desc) when HW*A > nms_pre, else original order
+
+// delta2bbox (mmdet/core/bbox/transforms.py:78-110) of anchor i (= cell * A + a, generated on the fly from the base anchors) with
+// its four deltas d and objectness logit lgt -> o[0..5) = clipped box + sigmoid score.  One body for the one-workgroup and the
+// chip-wide selection kernels: the same expressions, the same contractions, the same bits.
+__device__ __forceinline__ void rpn_decode_one(const RpnParams& rp, int i, const float d[4], float lgt, float* __restrict__ o) {
+  const int a = i % rp.A, cell = i / rp.A, x = cell % rp.W, y = cell / rp.W;
+  const float ax1 = rp.base[a][0] + x * rp.stride, ay1 = rp.base[a][1] + y * rp.stride;
+  const float ax2 = rp.base[a][2] + x * rp.stride, ay2 = rp.base[a][3] + y * rp.stride;
+  const float dx = d[0] * rp.s[0] + rp.m[0], dy = d[1] * rp.s[1] + rp.m[1];
+  float dw = d[2] * rp.s[2] + rp.m[2], dh = d[3] * rp.s[3] + rp.m[3];
+  dw = fminf(fmaxf(dw, -rp.max_ratio), rp.max_ratio);
+  dh = fminf(fmaxf(dh, -rp.max_ratio), rp.max_ratio);
+  const float px = (ax1 + ax2) * 0.5f, py = (ay1 + ay2) * 0.5f, pw = ax2 - ax1 + 1.0f, ph = ay2 - ay1 + 1.0f;
+  const float gw = pw * expf(dw), gh = ph * expf(dh), gx = px + pw * dx, gy = py + ph * dy;
+  float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f, x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
+  x1 = fminf(fmaxf(x1, 0.f), rp.img_w - 1.f);
+  y1 = fminf(fmaxf(y1, 0.f), rp.img_h - 1.f);
+  x2 = fminf(fmaxf(x2, 0.f), rp.img_w - 1.f);
+  y2 = fminf(fmaxf(y2, 0.f), rp.img_h - 1.f);
+  o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = 1.f / (1.f + expf(-lgt));   // torch.sigmoid, as score_of
+}
 
 template <typename T>
 __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ cls, const T* __restrict__ reg, long cls_stride,
@@ -714,23 +737,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
     for (int u = 0; u < DU; ++u) {
       const int j = j0 + u * (int)blockDim.x;
       if (j >= cnt) continue;
-      const int i = ii[u];
-      const int a = i % rp.A, cell = i / rp.A, x = cell % rp.W, y = cell / rp.W;
-      const float ax1 = rp.base[a][0] + x * rp.stride, ay1 = rp.base[a][1] + y * rp.stride;
-      const float ax2 = rp.base[a][2] + x * rp.stride, ay2 = rp.base[a][3] + y * rp.stride;
-      const float dx = d[u][0] * rp.s[0] + rp.m[0], dy = d[u][1] * rp.s[1] + rp.m[1];
-      float dw = d[u][2] * rp.s[2] + rp.m[2], dh = d[u][3] * rp.s[3] + rp.m[3];
-      dw = fminf(fmaxf(dw, -rp.max_ratio), rp.max_ratio);
-      dh = fminf(fmaxf(dh, -rp.max_ratio), rp.max_ratio);
-      const float px = (ax1 + ax2) * 0.5f, py = (ay1 + ay2) * 0.5f, pw = ax2 - ax1 + 1.0f, ph = ay2 - ay1 + 1.0f;
-      const float gw = pw * expf(dw), gh = ph * expf(dh), gx = px + pw * dx, gy = py + ph * dy;
-      float x1 = gx - gw * 0.5f + 0.5f, y1 = gy - gh * 0.5f + 0.5f, x2 = gx + gw * 0.5f - 0.5f, y2 = gy + gh * 0.5f - 0.5f;
-      x1 = fminf(fmaxf(x1, 0.f), rp.img_w - 1.f);
-      y1 = fminf(fmaxf(y1, 0.f), rp.img_h - 1.f);
-      x2 = fminf(fmaxf(x2, 0.f), rp.img_w - 1.f);
-      y2 = fminf(fmaxf(y2, 0.f), rp.img_h - 1.f);
-      float* o = out + ((long)f * k + j) * 5;
-      o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = 1.f / (1.f + expf(-lgt[u]));   // torch.sigmoid, as score_of
+      rpn_decode_one(rp, ii[u], d[u], lgt[u], out + ((long)f * k + j) * 5);
     }
   }
 #ifdef HVR_DBG_SEL_CLK
@@ -744,7 +751,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const T* __restrict__ 
 // (rpn_head.py:92-103).  props [T][npre][5]; keep [T][npre]; out [T][max_num][5]; rois [T][max_num][5]
 __global__ __launch_bounds__(256) void rpn_gather_kernel(const float* __restrict__ props, const long long* __restrict__ keep,
                                                          const int* __restrict__ n_keep, int npre, int nms_post, int max_num,
-                                                         float* __restrict__ out, int* __restrict__ counts) {
+                                                         int presorted, float* __restrict__ out, int* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int f = blockIdx.x;
   int cnt = n_keep[f];
@@ -754,16 +761,20 @@ __global__ __launch_bounds__(256) void rpn_gather_kernel(const float* __restrict
   uint32_t* idx = key + np2;
   const float* pf = props + (long)f * npre * 5;
   const long long* kf = keep + (long)f * npre;
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-    if (i < cnt) { key[i] = float_key(pf[kf[i] * 5 + 4]); idx[i] = (uint32_t)i; }
-    else { key[i] = 0u; idx[i] = 0xffffffffu; }
+  // props sorted by (score desc, anchor asc) and survivors listed by ascending position: the list IS in (score desc, position
+  // asc) order already, the network below would return the identity
+  if (!presorted) {
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+      if (i < cnt) { key[i] = float_key(pf[kf[i] * 5 + 4]); idx[i] = (uint32_t)i; }
+      else { key[i] = 0u; idx[i] = 0xffffffffu; }
+    }
+    __syncthreads();
+    bitonic_sort_pairs(key, idx, np2);
   }
-  __syncthreads();
-  bitonic_sort_pairs(key, idx, np2);
   const int num = cnt < max_num ? cnt : max_num;
   for (int j = threadIdx.x; j < num * 5; j += blockDim.x) {
     const int row = j / 5, col = j - row * 5;
-    out[((long)f * max_num + row) * 5 + col] = pf[kf[idx[row]] * 5 + col];
+    out[((long)f * max_num + row) * 5 + col] = pf[kf[presorted ? row : (int)idx[row]] * 5 + col];
   }
   if (threadIdx.x == 0) counts[f] = num;
 }
@@ -989,18 +1000,365 @@ __global__ __launch_bounds__(1024) void mc_nms_merge_kernel(const float* __restr
   if (threadIdx.x == 0) *n_out = nout;
 }
 
+// ---------------------------------------------------------------------------------
+// RPN proposals for FEW frames per call (stream mode: one new frame per output frame): the chip-wide form
+// ---------------------------------------------------------------------------------
+// The one-workgroup-per-frame kernels above leave 255 of the 256 CUs idle when a call brings one frame, and their time
+// (select 0.19 ms + greedy NMS 0.19 ms) sits on the critical path of every output frame (tools/test.py:214-250).  Same results,
+// bit for bit, from launches that cover the chip:
+//   rpn_wide_hist     keys (sigmoid -> sortable u32) of 1024 anchors per workgroup, histogram of their top 12 bits
+//   rpn_wide_scatter  every workgroup scans the 4096-bin histogram (suffix sums = where a bin's elements start in score order,
+//                     b0 = the bin that holds the nms_pre-th element) and scatters the elements of the bins >= b0 into their
+//                     bin's slot range (order inside a bin: arrival) -- a counting sort on the top 12 key bits
+//   rpn_wide_rank     rank of a candidate = start of its bin + the candidates of ITS BIN that come before it (higher key, or
+//                     equal key and lower anchor index: the tie rule of the bitonic network above); rank < nms_pre -> decode
+//                     (delta2bbox) and store at out[rank].  Work: sum over bins of size^2 instead of a sort.
+//   nms_band_mask     suppression bit mask of the first R0 <= 4096 score-sorted boxes, transposed (who suppresses box i)
+//   nms_band_sweep    one workgroup per frame, a pipeline of eight waves over the 64-box chunks (see the kernel); stops at
+//                     max_keep survivors.  A frame whose max_keep-th survivor lies behind box R0 is handed to
+//                     nms_greedy_kernel (skip flag clear).
+constexpr int WBINS = 4096, WSEL_THREADS = 256, WSEL_PER_WG = 1024;
+
+// Histogram bin of a score key (float_key of a sigmoid: a float in [0, 1]), monotone non-decreasing in the key -- all the counting
+// sort needs.  The key's top bits alone would give [0.5, 1) eight bins (one exponent), and that is where the nms_pre best scores
+// of a frame live: the upper 2048 bins split [0.5, 1] linearly (2^-12 each), the lower 2048 take the top 16 bits of the float
+// (128 steps per octave) from 0.5 down to 2^-17, everything below shares bin 0.
+__device__ __forceinline__ int wide_bin(uint32_t u) {
+  if (!(u & 0x80000000u)) return 0;   // (negative floats: no sigmoid is)
+  const uint32_t bits = u & 0x7fffffffu;
+  if (bits >= 0x3f000000u) return 2048 + (int)min((bits - 0x3f000000u) >> 12, 2047u);
+  const int b = (int)(bits >> 16) - (0x3f00 - 2048);
+  return b > 0 ? b : 0;
+}
+
+__device__ __forceinline__ void wave_hist_add(int* __restrict__ h, bool valid, int bin, int lane) {
+  unsigned long long todo = __ballot(valid);
+  for (int it = 0; it < 4 && todo; ++it) {   // lanes that hit the same bin are counted with a ballot and added once
+    const int leader = __builtin_ctzll(todo);
+    const int lb = __builtin_amdgcn_readlane(bin, leader);
+    const unsigned long long same = __ballot(valid && bin == lb);
+    if (lane == leader) atomicAdd(&h[lb], (int)__popcll(same));
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1ull) atomicAdd(&h[bin], 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(WSEL_THREADS) void rpn_wide_hist_kernel(const T* __restrict__ cls, long cls_stride, int n, int A,
+                                                                    int cpitch, int* __restrict__ hist0) {
+  __shared__ int lh[WBINS];
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  for (int b = tid; b < WBINS; b += WSEL_THREADS) lh[b] = 0;
+  const T* c = cls + (long)f * cls_stride;
+  const int base = blockIdx.x * WSEL_PER_WG;
+  constexpr int E = WSEL_PER_WG / WSEL_THREADS;
+  float lg[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    int i = base + e * WSEL_THREADS + tid;
+    i = i < n ? i : n - 1;
+    const int cell = i / A, a = i - cell * A;
+    lg[e] = ElemTraits<T>::load(c + (long)cell * cpitch + a);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = base + e * WSEL_THREADS + tid;
+    const uint32_t u = float_key(1.f / (1.f + expf(-lg[e])));   // torch.sigmoid, as rpn_select_kernel
+    wave_hist_add(lh, i < n, wide_bin(u), lane);
+  }
+  __syncthreads();
+  for (int b = tid; b < WBINS; b += WSEL_THREADS) {
+    const int v = lh[b];
+    if (v) atomicAdd(&hist0[(long)f * WBINS + b], v);
+  }
+}
+
+// meta[f] = {b0, candidates, 0, 0}
+template <typename T>
+__global__ __launch_bounds__(WSEL_THREADS) void rpn_wide_scatter_kernel(const T* __restrict__ cls, long cls_stride, int n, int A,
+                                                                       int cpitch, int k, const int* __restrict__ hist0,
+                                                                       int* __restrict__ gcount, int* __restrict__ binstart,
+                                                                       int* __restrict__ meta, unsigned long long* __restrict__ cand) {
+  __shared__ int start[WBINS];
+  __shared__ int lcnt[WBINS];
+  __shared__ int wtot[WSEL_THREADS / 64];
+  __shared__ int sh_b0;
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int BPT = WBINS / WSEL_THREADS;   // bins per thread
+  const int* hf = hist0 + (long)f * WBINS;
+  const T* c = cls + (long)f * cls_stride;
+  const int base = blockIdx.x * WSEL_PER_WG;
+  constexpr int E = WSEL_PER_WG / WSEL_THREADS;
+  float lg[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    int i = base + e * WSEL_THREADS + tid;
+    i = i < n ? i : n - 1;
+    const int cell = i / A, a = i - cell * A;
+    lg[e] = ElemTraits<T>::load(c + (long)cell * cpitch + a);
+  }
+  int h[BPT], sum = 0;
+#pragma unroll
+  for (int e = 0; e < BPT; ++e) { h[e] = hf[BPT * tid + e]; sum += h[e]; }
+  int suf = sum;   // elements in this thread's bins and in all higher ones
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_down(suf, o);
+    if (lane + o < 64) suf += v;
+  }
+  if (lane == 0) wtot[wave] = suf;
+#pragma unroll
+  for (int e = 0; e < BPT; ++e) lcnt[BPT * tid + e] = 0;
+  __syncthreads();
+  for (int w = wave + 1; w < WSEL_THREADS / 64; ++w) suf += wtot[w];
+  int run = suf - sum;   // elements in the bins above this thread's
+#pragma unroll
+  for (int e = BPT - 1; e >= 0; --e) {
+    start[BPT * tid + e] = run;
+    if (run < k && k <= run + h[e]) sh_b0 = BPT * tid + e;   // exactly one bin (n > k)
+    run += h[e];
+  }
+  __syncthreads();
+  const int b0 = sh_b0;
+  uint32_t u[E];
+  int loc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = base + e * WSEL_THREADS + tid;
+    u[e] = float_key(1.f / (1.f + expf(-lg[e])));
+    const int b = wide_bin(u[e]);
+    loc[e] = (i < n && b >= b0) ? atomicAdd(&lcnt[b], 1) : -1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < BPT; ++e) {
+    const int b = BPT * tid + e, cnt = lcnt[b];
+    if (cnt > 0) lcnt[b] = atomicAdd(&gcount[(long)f * WBINS + b], cnt);   // this workgroup's range inside the bin
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (loc[e] < 0) continue;
+    const int i = base + e * WSEL_THREADS + tid;
+    const int b = wide_bin(u[e]);
+    cand[(long)f * n + start[b] + lcnt[b] + loc[e]] = ((unsigned long long)u[e] << 32) | (0xffffffffu - (uint32_t)i);
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) binstart[(long)f * WBINS + BPT * tid + e] = start[BPT * tid + e];
+    if (tid == 0) { meta[f * 4 + 0] = b0; meta[f * 4 + 1] = start[b0] + hf[b0]; }
+  }
+}
+
+constexpr int WRANK_TILE = 2048;
+template <typename T>
+__global__ __launch_bounds__(256) void rpn_wide_rank_kernel(const T* __restrict__ cls, const T* __restrict__ reg, long cls_stride,
+                                                            long reg_stride, const int* __restrict__ hist0,
+                                                            const int* __restrict__ binstart, const int* __restrict__ meta,
+                                                            const unsigned long long* __restrict__ cand, float* __restrict__ out,
+                                                            const RpnParams rp) {
+  __shared__ unsigned long long tile[WRANK_TILE];
+  __shared__ int sh_we[4];
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = rp.n_anchor, k = rp.npre;
+  const int C = meta[f * 4 + 1];
+  const int p0 = blockIdx.x * 256;
+  if (p0 >= C) return;
+  const int p = p0 + tid;
+  const bool valid = p < C;
+  const unsigned long long* cf = cand + (long)f * n;
+  const unsigned long long comp = valid ? cf[p] : 0ull;
+  int s = 0, e = 0;
+  if (valid) {
+    const int b = wide_bin((uint32_t)(comp >> 32));
+    s = binstart[(long)f * WBINS + b];
+    e = s + hist0[(long)f * WBINS + b];
+    e = e < C ? e : C;   // (the threshold bin is the last one: its range ends at C by construction)
+  }
+  // Slots ascend with descending bins.  A wave's 64 candidates: everything in front of its first lane's bin is ahead of all
+  // of them, everything behind its last lane's bin behind all of them, so ONE range [ws, we) serves the wave -- rank = ws +
+  // the elements of that range that compare greater (higher key, or the same key and a lower anchor index).  Uniform loop
+  // bounds, every LDS read a broadcast.
+  if (lane == 0) sh_we[wave] = 0;
+  __syncthreads();
+  if (valid && (p == C - 1 || lane == 63)) sh_we[wave] = e;
+  __syncthreads();
+  const int ws = __builtin_amdgcn_readfirstlane(s), we = sh_we[wave];
+  int cnt = 0;
+  __shared__ int sh_lo;
+  if (tid == 0) sh_lo = s;
+  __syncthreads();
+  const int blo = sh_lo;
+  int bhi = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) bhi = max(bhi, sh_we[w]);
+  for (int t0 = blo; t0 < bhi; t0 += WRANK_TILE) {
+    const int tn = min(WRANK_TILE, bhi - t0);
+    for (int j = tid; j < tn; j += 256) tile[j] = cf[t0 + j];
+    __syncthreads();
+    const int js = max(ws, t0) - t0, je = min(we, t0 + tn) - t0;
+    int j = js;
+    for (; j + 8 <= je; j += 8) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tile[j + q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cnt += v[q] > comp ? 1 : 0;
+    }
+    for (; j < je; ++j) cnt += tile[j] > comp ? 1 : 0;
+    __syncthreads();
+  }
+  const int rank = ws + cnt;
+  if (!valid || rank >= k) return;
+  const int i = (int)(0xffffffffu - (uint32_t)comp);
+  const int a = i % rp.A, cell = i / rp.A;
+  const T* c = cls + (long)f * cls_stride;
+  const T* r = reg + (long)f * reg_stride;
+  float d[4];
+  load4(r + (long)cell * rp.reg_pitch + a * 4, d);
+  const float lgt = ElemTraits<T>::load(c + (long)cell * rp.cls_pitch + a);
+  rpn_decode_one(rp, i, d, lgt, out + ((long)f * k + rank) * 5);
+}
+
+// maskT [P][nb0 chunks][nb0 words][64] over the first R0 score-sorted boxes of dets [P][n][5], TRANSPOSED: word w of box i = the
+// boxes j of chunk w (j < i) that suppress box i.  Only words w <= i / 64 are written (and read).  IoU is symmetric in its arguments (box_iou_hits:
+// min / max and one commutative sum), so this is the bit matrix of nms_mask_kernel read by columns.
+__global__ __launch_bounds__(64) void nms_band_mask_kernel(const float* __restrict__ dets, int n, int R0, float thr, int ge,
+                                                           unsigned long long* __restrict__ maskT) {
+  // blockIdx.x = linear index of the (rb <= cb) block pairs: t = cb (cb + 1) / 2 + rb
+  const int p = blockIdx.y, t = blockIdx.x;
+  int cb = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+  while (cb * (cb + 1) / 2 > t) --cb;
+  const int rb = t - cb * (cb + 1) / 2;
+  const int nb0 = (R0 + 63) >> 6;
+  const float* d = dets + (long)p * n * 5;
+  __shared__ float4 rowbox[64];
+  __shared__ float rowarea[64];
+  const int rj = rb * 64 + (int)threadIdx.x;   // (< R0: rb <= cb and chunk cb starts inside the band)
+  const int rjc = min(rj, R0 - 1);
+  const float4 rbx = make_float4(d[rjc * 5 + 0], d[rjc * 5 + 1], d[rjc * 5 + 2], d[rjc * 5 + 3]);
+  rowbox[threadIdx.x] = rbx;
+  rowarea[threadIdx.x] = box_area_plus1(rbx);
+  const int i = cb * 64 + threadIdx.x;
+  const int ic = min(i, R0 - 1);
+  const float4 me = make_float4(d[ic * 5 + 0], d[ic * 5 + 1], d[ic * 5 + 2], d[ic * 5 + 3]);
+  const float my_area = box_area_plus1(me);
+  const float band_k = iou_band_k(thr);
+  __syncthreads();
+  if (i >= R0) return;
+  const int jend = (rb == cb) ? (int)threadIdx.x : 64;   // earlier boxes only (every box of an earlier chunk is)
+  unsigned long long bits = 0ull;
+#pragma unroll 4
+  for (int j = 0; j < 64; ++j) {
+    const bool hit = box_iou_hits(rowbox[j], rowarea[j], me, my_area, thr, band_k, ge);   // (row = the earlier box, as the sweeps above)
+    if (hit && j < jend) bits |= 1ull << j;
+  }
+  maskT[(((long)p * nb0 + cb) * nb0 + rb) * 64 + threadIdx.x] = bits;   // [chunk][word][box of the chunk]: coalesced for the sweep
+}
+
+// One workgroup of sixteen waves per problem, a pipeline over the 64-box chunks: wave w takes chunks w, w + 16, ...  A chunk's
+// verdict needs (a) for every box the survivors of the EARLIER chunks that suppress it -- (row of maskT) AND (survivor words), all
+// of it known except the last fifteen chunks' words when the wave starts (it published chunk cb - 16 itself), so those mask words
+// stream in while the chunks in between are being resolved by the other waves; (b) the chunk's own 64 x 64 block: the greedy rule
+// K_i = alive_i and no j < i in K suppresses i, iterated from K = alive until it stops changing (bit i is final once the bits
+// below it are; the fixed point is unique = the serial sweep's survivors) -- each round two ANDs and a ballot instead of a
+// scalar chain over the survivors.  Hand-over between waves through LDS (survivor word, running count, chunks-done counter).
+constexpr int SWEEP_WAVES = 16, SWEEP_FIN = 1 << 20;
+__global__ __launch_bounds__(64 * SWEEP_WAVES) void nms_band_sweep_kernel(const unsigned long long* __restrict__ maskT, int n, int R0,
+                                                                          int max_keep, long long* __restrict__ keep,
+                                                                          int* __restrict__ n_keep, int keep_stride,
+                                                                          int* __restrict__ done) {
+  __shared__ unsigned long long kept[64];
+  __shared__ int sh_done, sh_nkept;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb0 = (R0 + 63) >> 6;   // <= 64
+  const unsigned long long* mk = maskT + (long)p * nb0 * nb0 * 64;
+  long long* kp = keep + (long)p * keep_stride;
+  if (tid == 0) { sh_done = 0; sh_nkept = 0; }
+  __syncthreads();
+  auto chunks_done = [&]() { return __hip_atomic_load(&sh_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  for (int cb = wave; cb < nb0; cb += SWEEP_WAVES) {
+    const int i = cb * 64 + lane;
+    const bool inb = i < R0;
+    const unsigned long long* row = mk + (long)cb * nb0 * 64 + lane;   // word w of this lane's box: row[w * 64]
+    constexpr int TW = SWEEP_WAVES;   // tail words: the chunks that may still be open when the wave arrives
+    const int t0 = cb > TW - 1 ? cb - (TW - 1) : 0;
+    unsigned long long tailw[TW];   // words t0 .. cb (the last one: the chunk's own block)
+#pragma unroll
+    for (int q = 0; q < TW; ++q) tailw[q] = (t0 + q <= cb) ? row[(t0 + q) * 64] : 0ull;
+    unsigned long long sup = 0ull;
+    // words [0, t0): chunks resolved before this wave arrived here
+    for (int w0 = 0; w0 < t0; w0 += 16) {
+      unsigned long long r[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[q] = (w0 + q < t0) ? row[(w0 + q) * 64] : 0ull;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sup |= r[q] & kept[(w0 + q) & 63];
+    }
+    int d = 0;
+    unsigned long long cdiag = 0ull;
+#pragma unroll
+    for (int q = 0; q < TW; ++q) {
+      const int w = t0 + q;
+      if (w < cb) {
+        while ((d = chunks_done()) <= w) __builtin_amdgcn_s_sleep(1);
+        sup |= tailw[q] & kept[w];
+      } else if (w == cb) {
+        cdiag = tailw[q];
+      }
+    }
+    if (d >= SWEEP_FIN) break;
+    const unsigned long long alive = __ballot(inb && sup == 0ull);
+    unsigned long long K = alive;
+    while (true) {
+      const unsigned long long Kn = alive & ~__ballot((cdiag & K) != 0ull);
+      if (Kn == K) break;
+      K = Kn;
+    }
+    const int nk0 = cb > 0 ? *(volatile int*)&sh_nkept : 0;
+    bool fin = false;
+    int below = (int)__popcll(K & ((1ull << lane) - 1ull));
+    if (nk0 + (int)__popcll(K) >= max_keep) {   // the cap falls inside this chunk: its first max_keep - nk0 survivors count
+      K = __ballot(((K >> lane) & 1ull) && below < max_keep - nk0);
+      fin = true;
+    }
+    const int nk1 = nk0 + (int)__popcll(K);
+    const bool last = fin || cb == nb0 - 1;
+    // hand over FIRST: the release below waits for every store this wave has in flight (vmcnt(0)), and the next chunk's wave is
+    // spinning on it -- the survivor list's global stores go out behind it (an acknowledged store is most of a microsecond)
+    if (lane == 0) {
+      kept[cb] = K;
+      *(volatile int*)&sh_nkept = nk1;
+      __hip_atomic_store(&sh_done, last ? SWEEP_FIN : cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((K >> lane) & 1ull) kp[nk0 + below] = i;
+    if (lane == 0) {
+      if (last) {
+        const bool complete = fin || R0 >= n;
+        done[p] = complete ? 1 : 0;
+        if (complete) n_keep[p] = nk1;
+      }
+    }
+    if (last) break;
+  }
+}
+
 // ---------------- launchers ----------------
 size_t nms_workspace_bytes(int P, int n) {
   const size_t nb = (n + 63) / 64;
   size_t b = 0;
   b += ((size_t)P * n * sizeof(int) + 255) & ~(size_t)255;                    // order
   b += ((size_t)P * n * sizeof(float4) + 255) & ~(size_t)255;                 // sorted boxes
-  b += ((size_t)P * n * nb * sizeof(unsigned long long) + 255) & ~(size_t)255;  // mask
+  b += ((size_t)P * nb * 64 * nb * sizeof(unsigned long long) + 255) & ~(size_t)255;  // mask (whole 64-box chunks: the band form)
   return b;
 }
 
+// band > 0 (score-sorted input, a survivor cap): mask of the first `band` boxes chip-wide + a one-wave sweep per problem; the greedy
+// kernel then only runs the problems the sweep could not finish inside the band (done flags, `band_done` [P])
 hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, int presorted, int max_keep,
-                           long long* keep, int* n_keep, void* ws, hipStream_t s) {
+                           long long* keep, int* n_keep, void* ws, hipStream_t s, int band, int* band_done) {
   if (n <= 0 || P <= 0) return hipSuccess;
   if (n > 8192) return hipErrorInvalidValue;
   char* w = (char*)ws;
@@ -1028,9 +1386,16 @@ hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, i
       gattr = true;
     }
     if (!presorted) hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(1024), (size_t)np2 * 8, s, dets, n, 0, order, boxes4);
+    const int* skip = nullptr;
+    if (band > 0 && presorted && band_done) {
+      const int R0 = n < band ? n : (band < 4096 ? band : 4096), nb0 = (R0 + 63) / 64;
+      hipLaunchKernelGGL(nms_band_mask_kernel, dim3(nb0 * (nb0 + 1) / 2, P), dim3(64), 0, s, dets, n, R0, thr, ge, mask);
+      hipLaunchKernelGGL(nms_band_sweep_kernel, dim3(P), dim3(64 * SWEEP_WAVES), 0, s, mask, n, R0, max_keep, keep, n_keep, n, band_done);
+      skip = band_done;
+    }
     const size_t lds = (size_t)nb * 64 * 16 + (size_t)nb * 8 + 64 * 8 + ((n + 15) & ~15) + 128 + 2 * 1024;
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(P), dim3(1024), lds, s, presorted ? dets : nullptr, presorted ? nullptr : boxes4,
-                       presorted ? nullptr : order, n, thr, ge, max_keep, keep, n_keep, n);
+                       presorted ? nullptr : order, n, thr, ge, max_keep, keep, n_keep, n, skip);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(1024), (size_t)np2 * 8, s, dets, n, presorted, order, boxes4);
@@ -1060,12 +1425,55 @@ hipError_t run_rpn_select(const void* cls, const void* reg, long cls_stride, lon
   return hipGetLastError();
 }
 
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t rpn_wide_workspace_bytes(int T, long n_anchor) {
+  return al256((size_t)T * WBINS * 4 * 2) + al256((size_t)T * WBINS * 4) + al256((size_t)T * 16) + al256((size_t)T * 4) +
+         al256((size_t)T * n_anchor * 8);
+}
+// calls with at most this many frames take the chip-wide kernels (HVR_RPN_WIDE=<frames>, 0 = never)
+int rpn_wide_max_frames(int set) {
+  static int v = [] {
+    const char* e = std::getenv("HVR_RPN_WIDE");
+    return e ? std::atoi(e) : 4;
+  }();
+  const int prev = v;
+  if (set >= 0) v = set;
+  return prev;
+}
+int* rpn_wide_done_flags(void* wws, int T) {
+  return (int*)((char*)wws + al256((size_t)T * WBINS * 4 * 2) + al256((size_t)T * WBINS * 4) + al256((size_t)T * 16));
+}
+
+hipError_t run_rpn_select_wide(const void* cls, const void* reg, long cls_stride, long reg_stride, float* out, const RpnParams& rp,
+                               void* wws, hipStream_t s) {
+  const int T = rp.T, n = rp.n_anchor;
+  char* w = (char*)wws;
+  int* hist0 = (int*)w;                    // [T][WBINS]
+  int* gcount = hist0 + (size_t)T * WBINS; // [T][WBINS]  (zeroed with hist0)
+  w += al256((size_t)T * WBINS * 4 * 2);
+  int* binstart = (int*)w;  w += al256((size_t)T * WBINS * 4);
+  int* meta = (int*)w;      w += al256((size_t)T * 16);
+  w += al256((size_t)T * 4);               // done flags (rpn_wide_done_flags)
+  unsigned long long* cand = (unsigned long long*)w;
+  hipError_t e = hipMemsetAsync(hist0, 0, (size_t)T * WBINS * 4 * 2, s);
+  if (e != hipSuccess) return e;
+  const int G = (n + WSEL_PER_WG - 1) / WSEL_PER_WG;
+  const float* c = (const float*)cls;
+  const float* r = (const float*)reg;
+  hipLaunchKernelGGL(rpn_wide_hist_kernel<float>, dim3(G, T), dim3(WSEL_THREADS), 0, s, c, cls_stride, n, rp.A, rp.cls_pitch, hist0);
+  hipLaunchKernelGGL(rpn_wide_scatter_kernel<float>, dim3(G, T), dim3(WSEL_THREADS), 0, s, c, cls_stride, n, rp.A, rp.cls_pitch, rp.npre,
+                     hist0, gcount, binstart, meta, cand);
+  hipLaunchKernelGGL(rpn_wide_rank_kernel<float>, dim3((n + 255) / 256, T), dim3(256), 0, s, c, r, cls_stride, reg_stride, hist0, binstart,
+                     meta, cand, out, rp);
+  return hipGetLastError();
+}
+
 hipError_t run_rpn_gather(const float* props, const long long* keep, const int* n_keep, int T, int npre, int nms_post,
-                          int max_num, float* out, int* counts, hipStream_t s) {
+                          int max_num, int presorted, float* out, int* counts, hipStream_t s) {
   int np2 = 1;
   while (np2 < nms_post) np2 <<= 1;
   if (np2 > 4096) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rpn_gather_kernel, dim3(T), dim3(256), (size_t)np2 * 8, s, props, keep, n_keep, npre, nms_post, max_num, out, counts);
+  hipLaunchKernelGGL(rpn_gather_kernel, dim3(T), dim3(256), (size_t)np2 * 8, s, props, keep, n_keep, npre, nms_post, max_num, presorted, out, counts);
   return hipGetLastError();
 }
 

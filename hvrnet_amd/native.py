@@ -138,6 +138,7 @@ SYMBOLS = {
     'hvr_nms': (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     'hvr_rpn_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'hvr_rpn_proposals': (_i, [ctypes.POINTER(RpnDesc), _vp, _sz, _vp]),
+    'hvr_rpn_wide_frames': (_i, [_i]),
     'hvr_det_decode': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_multiclass_nms_workspace_bytes': (_sz, [_i, _i]),
     'hvr_multiclass_nms': (_i, [_vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -1011,6 +1012,11 @@ def rpn_proposals(cls, reg, base_anchors, anchor_stride, means, stds, img_shape,
     with _span('rpn_proposals', float(cls.numel() * 4 + reg.numel() * 4)):
         _check(lib().hvr_rpn_proposals(ctypes.byref(d), _ptr(ws), ws.numel(), _stream()), 'hvr_rpn_proposals')
     return props, counts
+
+
+def rpn_wide_frames(frames=-1):
+    """Calls of rpn_proposals with T <= frames take the chip-wide kernels (same proposals bit for bit); -> previous value."""
+    return int(lib().hvr_rpn_wide_frames(int(frames)))
 
 
 def det_decode(logits, cls_off, reg_off, ncls, rois, means, stds, img_shape, scale_factor, wh_ratio_clip=16 / 1000):

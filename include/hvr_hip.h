@@ -295,6 +295,10 @@ typedef struct hvr_rpn_desc {
 } hvr_rpn_desc;
 size_t hvr_rpn_workspace_bytes(int T, int H, int W, int A, int nms_pre);
 int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* stream);
+/* Calls with T <= frames take the chip-wide kernels (histogram / counting-sort selection, banded suppression mask + one-wave
+ * sweep: many workgroups per frame) instead of one workgroup per frame; the proposals are the same bit for bit.  Default 4
+ * (HVR_RPN_WIDE=<frames> in the environment overrides it; 0 = never).  frames < 0 only queries.  Returns the previous value. */
+int hvr_rpn_wide_frames(int frames);
 
 /* ------------------------------------------------------------------------------------
  * RCNN detection read-out for one key frame.  Replaces BBoxHead.get_det_bboxes

@@ -161,8 +161,17 @@ def test_nms_matches_reference_golden_vectors():
 
 
 # ------------------------------------------------------------------------------- RPN
+@pytest.fixture(params=[0, 4], ids=['one-workgroup-per-frame', 'chip-wide'])
+def rpn_form(request):
+    """Both forms of the proposal kernels (hvr_rpn_wide_frames): one workgroup per frame (what a 15-frame clip takes) and the
+    chip-wide kernels (what a call with few frames takes: stream mode) -- the same assertions against the oracle."""
+    prev = native.rpn_wide_frames(request.param)
+    yield request.param
+    native.rpn_wide_frames(prev)
+
+
 @pytest.mark.parametrize('H,W', [(38, 63), (10, 12)])
-def test_rpn_proposals_match_oracle(O, H, W):
+def test_rpn_proposals_match_oracle(O, H, W, rpn_form):
     """(38,63): 28 728 anchors > nms_pre -> top-k path; (10,12): 1 440 anchors -> no top-k, index-order NMS output."""
     T, A = 3, 12
     g = torch.Generator().manual_seed(21)
@@ -184,7 +193,7 @@ def test_rpn_proposals_match_oracle(O, H, W):
 
 
 @pytest.mark.parametrize('H,W', [(38, 63), (50, 84)])
-def test_rpn_proposals_with_tied_scores(O, H, W):
+def test_rpn_proposals_with_tied_scores(O, H, W, rpn_form):
     """Logits on a coarse grid (as bf16 conv outputs are): thousands of anchors share the score at the top-k cut, and the cut
     must take the lowest indices among them (the oracle's stable sort).  (38, 63): 28 728 anchors, the keys-in-registers path
     of the selection kernel; (50, 84): 50 400 anchors (a 1333 x 800 frame's C4 map), the recomputing path."""
@@ -206,7 +215,7 @@ def test_rpn_proposals_with_tied_scores(O, H, W):
         close(props[t, :n], want, 1e-5, 2e-3)
 
 
-def test_rpn_proposals_heavy_overlap_fewer_than_nms_post(O):
+def test_rpn_proposals_heavy_overlap_fewer_than_nms_post(O, rpn_form):
     """Frames 0 and 2: the largest anchors win everywhere and the deltas are small, so neighbours overlap by > 0.7, the
     sweep walks all 6 000 candidates and far fewer than nms_post boxes survive; frame 1 is ordinary (stops early after
     nms_post survivors) - both kinds in one launch."""
@@ -233,6 +242,41 @@ def test_rpn_proposals_heavy_overlap_fewer_than_nms_post(O):
         assert n == want.shape[0]
         close(props[t, :n], want, 1e-5, 2e-3)
     assert ns[0] < cfg['nms_post'] and ns[2] < cfg['nms_post'] and ns[1] == cfg['nms_post'], ns
+
+
+def test_rpn_proposals_chip_wide_equals_one_workgroup_per_frame():
+    """The two forms bit for bit on the cases that stress the chip-wide one: ordinary logits; one score for every anchor (one
+    histogram bin holds everything: the rank kernel orders 28 728 ties by anchor index); scores packed into a sliver of one bin;
+    the nms_post-th survivor behind the 4 096-box band of the suppression mask (hand-over to the greedy kernel) and exactly a
+    handful of survivors; a single frame."""
+    A, H, W = 12, 38, 63
+    g = torch.Generator().manual_seed(5)
+    gen = AnchorGenerator(16, [4, 8, 16, 32], [0.5, 1.0, 2.0])
+    cases = {}
+    cases['ordinary'] = (torch.randn((3, H, W, A), generator=g) * 1.5, torch.randn((3, H, W, 4 * A), generator=g) * 0.3)
+    cases['all equal'] = (torch.zeros((2, H, W, A)), torch.randn((2, H, W, 4 * A), generator=g) * 0.3)
+    cases['one bin'] = (0.3 + torch.randn((2, H, W, A), generator=g) * 1e-4, torch.randn((2, H, W, 4 * A), generator=g) * 0.3)
+    cls = torch.randn((2, H, W, A), generator=g) * 0.5 - 6.0
+    cls[..., [3, 7, 11]] += 12.0
+    cases['heavy overlap'] = (cls, torch.randn((2, H, W, 4 * A), generator=g) * 0.02)
+    cases['one frame'] = (torch.randn((1, H, W, A), generator=g), torch.randn((1, H, W, 4 * A), generator=g) * 0.1)
+    prev = native.rpn_wide_frames(-1)
+    try:
+        for name, (cls, reg) in cases.items():
+            got = {}
+            for form in (0, 4):
+                native.rpn_wide_frames(form)
+                p, c = native.rpn_proposals(cls.to(DEV), reg.to(DEV), gen.base_anchors, 16, (0., 0., 0., 0.), (1., 1., 1., 1.),
+                                            (600, 1000), 6000, 300, 300, 0.7)
+                got[form] = (p.cpu(), c.cpu())
+            assert torch.equal(got[0][1], got[4][1]), (name, got[0][1], got[4][1])
+            for t in range(cls.shape[0]):
+                n = int(got[0][1][t])
+                assert torch.equal(got[0][0][t, :n], got[4][0][t, :n]), (name, t)
+            if name == 'heavy overlap':
+                assert int(got[4][1].max()) < 300
+    finally:
+        native.rpn_wide_frames(prev)
 
 
 # ------------------------------------------------------------------------------- read-out

@@ -1325,8 +1325,11 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void nms_band_sweep_kernel(const 
     }
     const int nk1 = nk0 + (int)__popcll(K);
     const bool last = fin || cb == nb0 - 1;
-    // hand over FIRST: the release below waits for every store this wave has in flight (vmcnt(0)), and the next chunk's wave is
-    // spinning on it -- the survivor list's global stores go out behind it (an acknowledged store is most of a microsecond)
+    // hand over FIRST, survivor list's global stores behind it.  Observed: with the kp store in front, the compiler's release
+    // sequence is `s_waitcnt vmcnt(0) lgkmcnt(0)` + ds_write (build/nms-*.s) and the kernel took 34.6 us on the bench model's
+    // frame (41 chunks walked); with the store behind the release 23.6 us (one A/B, same box).  Likely reason: the next chunk's
+    // wave spins on sh_done while this one waits for the store's acknowledgement -- not isolated (the edit also moved the cap
+    // logic; a timing build without the store would tell), so no latency figure is claimed here.
     if (lane == 0) {
       kept[cb] = K;
       *(volatile int*)&sh_nkept = nk1;

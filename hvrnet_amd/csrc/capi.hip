@@ -471,6 +471,7 @@ static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
 // 3 x 8 output tile grid with a 72-step K loop -- 24 workgroups on 256 CUs): the 128-key blocks are dealt to `slices` workgroups
 // per output tile (at least 2 blocks each), every slice writes an f32 partial, one reduce launch sums and rounds them.  The
 // block weights g = 2^(m_t - m*) / L are global per row, so the partials simply add.  1 = no split.
+constexpr size_t kApplyTicketBytes = 1024;   // one int per output tile of a sliced apply pass (fewer than 96 tiles: apply_slices)
 static int apply_slices(int Mq, int Mk, int D) {
   const long tiles = (long)((Mq + 127) / 128) * ((D + 127) / 128);
   const int nblk = (int)(rel_ldp(Mk) / 128);
@@ -489,7 +490,7 @@ size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
   const size_t es = elem_size(dtype);
   const int slices = apply_slices(Mq, Mk, D);
   return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 2 * align256((size_t)Mq * nt * 4) +
-         (slices > 1 ? align256((size_t)slices * Mq * D * 4) : 0);
+         (slices > 1 ? align256((size_t)slices * Mq * D * 4) + kApplyTicketBytes : 0);
 }
 
 int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
@@ -589,8 +590,21 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     p.csplit_bytes = (long)Mq * D * 4;
     p.C = partial; p.ldc = D; p.out_f32 = two_byte ? 1 : 0;
     p.tile_hint = 1;  // 128 x 128 tiles; the slices are latency chains of 8 K-steps (the pipelined shapes measure the same)
+    // HVR_KEY_MERGE=1 (opt-in, two-byte operands): the slice that reaches an output tile last merges the partials inside the
+    // launch (gemm_tile.h, the ticket tail of EPI_APPLY: slice order, the reduce kernel's bits) instead of the reduce launch.
+    // Correct (bit-identical, tests/test_kernels_gpu.py) and SLOWER: the apply launch 24.4 -> 60.3 us, the 300 x 4 500 stage
+    // 49.3 -> 83.6 us (profiles/r03_key_stage_merge_ab.txt) against the 5.0 us reduce launch it saves.  Suspected, not isolated:
+    // the agent-scope fences (buffer_wbl2 sc1 / buffer_inv sc1 in every wave of 216 workgroups) that cross-XCD visibility needs.
+    static const int key_merge = std::getenv("HVR_KEY_MERGE") ? std::atoi(std::getenv("HVR_KEY_MERGE")) : 0;
+    const bool merge = key_merge && two_byte;
+    if (merge) {
+      int* tickets = (int*)((char*)partial + align256((size_t)slices * Mq * D * 4));
+      hipError_t e0 = hipMemsetAsync(tickets, 0, kApplyTicketBytes, s);
+      if (e0 != hipSuccess) return check_launch(e0, "relation: apply tickets");
+      p.tickets = tickets; p.merge_out = O; p.merge_ld = ldo;
+    }
     hipError_t e = run_tile_op(p, EPI_APPLY, s);
-    if (e == hipSuccess)
+    if (e == hipSuccess && !merge)
       e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s)
           : dtype == HVR_F16 ? run_splitk_reduce_f16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
     return check_launch(e, "relation: apply (key slices)");

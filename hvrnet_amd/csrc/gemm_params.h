@@ -56,6 +56,12 @@ struct GemmParams {
   // split-K (EPI_LINEAR, no conv): ksplit_count slices of ksplit_steps K-steps, partial s at C + s * csplit_bytes (0 = off)
   int ksplit_steps, ksplit_count;
   long csplit_bytes;
+  // EPI_APPLY split over key slices, merged inside the launch (null = the caller runs a reduce launch): one counter per output
+  // tile (zero before the launch); the slice that arrives last at a tile sums the ksplit_count f32 partials IN SLICE ORDER
+  // (the order and rounding of splitk_reduce_bf16_kernel: the same bits) and stores the tile to merge_out in the operand dtype
+  int* tickets;
+  void* merge_out;
+  long merge_ld;
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };

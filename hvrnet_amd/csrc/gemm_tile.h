@@ -940,6 +940,41 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       }
       __syncthreads();
     }
+    if constexpr (EPI == EPI_APPLY && sizeof(T) == 2 && !SPLIT) {
+      if (p.ksplit_steps > 0 && p.tickets) {
+        // In-launch merge of the key slices.  Every thread: its partial stores written back and visible device-wide (agent-scope
+        // fence: the eight XCDs' L2s are not coherent with each other) BEFORE the workgroup takes its ticket; the workgroup
+        // that draws the last ticket of a tile acquires (fence again: nothing stale from its own L2) and sums the slices'
+        // partials in slice order -- not in arrival order: the result must not depend on scheduling.
+        __threadfence();
+        __syncthreads();
+        int* sh_ticket = reinterpret_cast<int*>(smem);   // (the staging buffer is dead: the last pass ended with a barrier)
+        if (threadIdx.x == 0) *sh_ticket = atomicAdd(&p.tickets[blockIdx.x], 1);
+        __syncthreads();
+        const int S = (int)gridDim.y;
+        if (*sh_ticket == S - 1) {
+          __threadfence();
+          const float* part = reinterpret_cast<const float*>(p.C);   // slice s at + s * csplit_bytes
+          const long sstride = p.csplit_bytes / 4;
+          T* outp = reinterpret_cast<T*>(p.merge_out);
+          const int rows = min(BM, p.M - m0), segs = BN / 8;
+          for (int q = threadIdx.x; q < rows * segs; q += WM * WN * 64) {
+            const int r = q / segs, n = n0 + (q - r * segs) * 8;
+            if (n >= p.N) continue;
+            const float* src = part + (long)(m0 + r) * p.ldc + n;
+            float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+#pragma unroll 4
+            for (int sl = 1; sl < S; ++sl) {
+              const float4 u = *reinterpret_cast<const float4*>(src + sl * sstride), v = *reinterpret_cast<const float4*>(src + sl * sstride + 4);
+              a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+              b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+            }
+            *reinterpret_cast<uint4*>(outp + (long)(m0 + r) * p.merge_ld + n) =
+                make_uint4(pack2<T>(a.x, a.y), pack2<T>(a.z, a.w), pack2<T>(b.x, b.y), pack2<T>(b.z, b.w));
+          }
+        }
+      }
+    }
   } else {  // EPI_SCORES: per (row, 128-key tile) max / sum and P~ = exp(s - tilemax)
     static_assert(EPI != EPI_SCORES || BN == 128, "score tiles are 128 keys wide");
 #ifdef HVR_DBG_NOSCORE_EPI

@@ -8,6 +8,8 @@ f32 accumulation order (+ bf16 rounding of stored outputs, 2^-9 relative).
 import math
 import os
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -280,6 +282,27 @@ def test_relation_window_size_big_tile_path(Mq, Mk):
     # every output row is a convex combination of V rows
     ones = native.relation_fwd(qd, kd, torch.ones_like(vd), 1.0 / 32)
     torch.testing.assert_close(ones.float(), torch.ones_like(ones.float()), rtol=0, atol=8e-3)
+
+
+def test_key_stage_in_launch_merge_equals_the_reduce_launch(tmp_path):
+    """Key-frame-only stage (300 x 4 500, D = 1 024): the slice that reaches an output tile last merges the f32 partials inside the
+    apply launch (ticket per tile, slice order; opt-in HVR_KEY_MERGE=1 -- measured slower than the reduce launch, kept for the
+    record) -- the same bits as the separate reduce launch (HVR_KEY_MERGE=0, the default; the knob is read once per process:
+    two processes), and the same bits on every one of 200 repeats (a merge that ran ahead of another XCD's partial stores
+    would not be)."""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ('1', '0'):
+        path = str(tmp_path / ('key_%s.npy' % mode))
+        env = dict(os.environ, HVR_KEY_MERGE=mode)
+        r = subprocess.run([_sys.executable, os.path.join(root, 'tools', 'probe', 'key_bench.py'), '--dump', path, '--repeat',
+                            '200' if mode == '1' else '0', '--iters', '2'], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if mode == '1':
+            assert 'repeat 200: 0 differ' in r.stdout, r.stdout
+        outs[mode] = np.load(path)
+    assert outs['1'].shape == (300, 1024) and np.array_equal(outs['1'], outs['0'])
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -946,14 +946,18 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         // fence: the eight XCDs' L2s are not coherent with each other) BEFORE the workgroup takes its ticket; the workgroup
         // that draws the last ticket of a tile acquires (fence again: nothing stale from its own L2) and sums the slices'
         // partials in slice order -- not in arrival order: the result must not depend on scheduling.
+#ifndef HVR_DBG_MERGE_NOFENCE   // (timing-only ablation build, tools/build_dbg.sh: what the two fences cost; results not guaranteed)
         __threadfence();
+#endif
         __syncthreads();
         int* sh_ticket = reinterpret_cast<int*>(smem);   // (the staging buffer is dead: the last pass ended with a barrier)
         if (threadIdx.x == 0) *sh_ticket = atomicAdd(&p.tickets[blockIdx.x], 1);
         __syncthreads();
         const int S = (int)gridDim.y;
         if (*sh_ticket == S - 1) {
+#ifndef HVR_DBG_MERGE_NOFENCE
           __threadfence();
+#endif
           const float* part = reinterpret_cast<const float*>(p.C);   // slice s at + s * csplit_bytes
           const long sstride = p.csplit_bytes / 4;
           T* outp = reinterpret_cast<T*>(p.merge_out);

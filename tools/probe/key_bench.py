@@ -7,6 +7,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hvrnet_amd import native
+if os.environ.get('HVR_BENCH_LIB'): native.LIB_PATH = os.path.abspath(os.environ['HVR_BENCH_LIB'])
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--mq', type=int, default=300)

@@ -593,8 +593,10 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     // HVR_KEY_MERGE=1 (opt-in, two-byte operands): the slice that reaches an output tile last merges the partials inside the
     // launch (gemm_tile.h, the ticket tail of EPI_APPLY: slice order, the reduce kernel's bits) instead of the reduce launch.
     // Correct (bit-identical, tests/test_kernels_gpu.py) and SLOWER: the apply launch 24.4 -> 60.3 us, the 300 x 4 500 stage
-    // 49.3 -> 83.6 us (profiles/r03_key_stage_merge_ab.txt) against the 5.0 us reduce launch it saves.  Suspected, not isolated:
-    // the agent-scope fences (buffer_wbl2 sc1 / buffer_inv sc1 in every wave of 216 workgroups) that cross-XCD visibility needs.
+    // 49.3 -> 83.6 us (profiles/r03_key_stage_merge_ab.txt) against the 5.0 us reduce launch it saves.  Ablation (same file): with
+    // the two agent-scope fences compiled out (buffer_wbl2 sc1 / buffer_inv sc1 in every wave of 216 workgroups; cross-XCD
+    // visibility needs them, so that build is timing-only) the apply launch is 31.9 us -- the fences are 27.6 us of the 35, the
+    // merge tail itself 7.5, and even fence-free the form does not beat apply 24.4 + reduce 5.0.
     static const int key_merge = std::getenv("HVR_KEY_MERGE") ? std::atoi(std::getenv("HVR_KEY_MERGE")) : 0;
     const bool merge = key_merge && two_byte;
     if (merge) {

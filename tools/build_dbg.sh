@@ -15,6 +15,7 @@ N=$B/nms.o
 if [ -n "${NMS_DBG:-}" ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $defs -c hvrnet_amd/csrc/nms.hip -o dbg/$name/nms.o; N=dbg/$name/nms.o; fi
 X=$B/expand.o
 if [ -n "${EXPAND_DBG:-}" ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $defs -c hvrnet_amd/csrc/expand.hip -o dbg/$name/expand.o; X=dbg/$name/expand.o; fi
-hipcc --offload-arch=gfx950 -shared -fPIC dbg/$name/gemm.o $X $B/conv3x3.o dbg/$name/pc_gemm.o $B/misc.o $B/roi_align.o $N $B/stem.o $B/targets.o $B/ingest.o dbg/$name/relation_bt.o dbg/$name/capi.o -o dbg/libhvr_$name.so
+# (gemm_f16.o / bigtile.o: the product build's objects -- half-operand tile kernels and the 288 x 256 tiles are not what these builds probe)
+hipcc --offload-arch=gfx950 -shared -fPIC dbg/$name/gemm.o $B/gemm_f16.o $B/bigtile.o $X $B/conv3x3.o dbg/$name/pc_gemm.o $B/misc.o $B/roi_align.o $N $B/stem.o $B/targets.o $B/ingest.o dbg/$name/relation_bt.o dbg/$name/capi.o -o dbg/libhvr_$name.so
 rm -rf dbg/$name
 echo built dbg/libhvr_$name.so

@@ -3,11 +3,12 @@
 # the same command, PMC FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only), relation-core passes alone.
 # Every step runs under its own `timeout` (T): one profiled run that hangs must not eat the GPU budget of the rest (round 3 lost
 # 45 GPU-minutes to exactly that).  Parts:  A = bench lines + kernel stats of the bench command + relation-core passes,
-# B = window-wide PMC passes, C = training / ingest / vendor calibration, D = precision ladder + per-mode kernel stats + layer 3.
+# B = window-wide PMC passes, C = training / ingest / vendor calibration, D = precision ladder + per-mode kernel stats + layer 3,
+# E = stream mode: pipelined stream bench, per-kernel profile of one frame, the one-frame proposal call (chip-wide kernels), key-stage merge A/B.
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh A'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; mkdir -p $out
-parts=${1:-ABCD}
+parts=${1:-ABCDE}
 T="timeout 420"
 db() { find $1 -name "*.db" | head -1; }
 
@@ -86,3 +87,12 @@ done
 $T python tools/probe/conv_hint_sweep.py --dtype f16x2 > $out/conv_hint_sweep_f16x2.txt 2>/dev/null
 fi
 ls $out
+
+if [[ $parts == *E* ]]; then
+$T python tools/stream_bench.py --steps 60 2>/dev/null | tail -1 > $out/stream_bench.json
+rm -rf /tmp/f_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/f_ks -o fr -- python tools/probe/frame_profile.py 20 > $out/stream_frame.log 2>&1
+{ echo "# tools/probe/frame_profile.py under rocprofv3 --kernel-trace --stats: 23 frames (3 warm-up + 20), eager"; grep "one frame" $out/stream_frame.log; $T python tools/rocpd_stats.py $(db /tmp/f_ks) | head -45; } > $out/stream_frame_kernel_stats.txt
+rm -rf /tmp/rw_ks; HVR_RPN_WIDE=4 $T rocprofv3 --kernel-trace --stats -d /tmp/rw_ks -o rpn -- python tools/probe/rpn_probe.py > $out/rpn_wide_probe.txt 2>&1
+$T python tools/rocpd_stats.py $(db /tmp/rw_ks) | grep -i "rpn\|nms\|kernel \|dispatches" > $out/rpn_wide_kernel_stats.txt
+$T bash tools/probe/run_stream_ab.sh > /dev/null 2>&1; $T bash tools/probe/run_key.sh > /dev/null 2>&1   # -> gpurun_out/stream_ab.txt, gpurun_out/key_stage_ab.txt
+fi

@@ -14,7 +14,8 @@ declare -A map=( [bench.json]=bench.json [bench_prof.json]=bench_profiled_run.js
   [ingest_bench.json]=ingest_bench.json [bench_selsa.json]=bench_selsa.json [bench_T21.json]=bench_T21.json
   [precision_ladder.json]=precision_ladder.json [window_f16_kernel_stats.txt]=window_f16_kernel_stats.txt
   [window_f16x2_kernel_stats.txt]=window_f16x2_kernel_stats.txt [conv_layer3.txt]=conv_layer3.txt
-  [conv_hint_sweep_f16x2.txt]=conv_hint_sweep_f16x2.txt [window_f16x2_pmc_sq.txt]=window_f16x2_pmc_sq.txt [hipblaslt_kernels.txt]=hipblaslt_kernels.txt [stream_bench.json]=stream_bench.json )
+  [conv_hint_sweep_f16x2.txt]=conv_hint_sweep_f16x2.txt [window_f16x2_pmc_sq.txt]=window_f16x2_pmc_sq.txt [hipblaslt_kernels.txt]=hipblaslt_kernels.txt [stream_bench.json]=stream_bench.json
+  [stream_frame_kernel_stats.txt]=stream_frame_kernel_stats.txt [rpn_wide_kernel_stats.txt]=rpn_wide_kernel_stats.txt )
 for f in "${!map[@]}"; do
   if [ -s $src/$f ]; then cp $src/$f profiles/${r}_${map[$f]}; fi
 done

@@ -285,6 +285,46 @@ def test_rpn_proposals_chip_wide_equals_one_workgroup_per_frame():
         native.rpn_wide_frames(prev)
 
 
+@pytest.mark.parametrize('T,nms_post,max_num,thr', [(4, 300, 300, 0.7), (5, 300, 300, 0.7), (1, 1, 1, 0.7), (2, 64, 64, 0.7),
+                                                   (2, 1000, 1000, 0.7), (1, 1024, 300, 0.7), (1, 1025, 300, 0.7), (2, 300, 100, 0.7),
+                                                   (2, 300, 300, 0.5), (2, 300, 300, 0.9)])
+def test_rpn_proposals_forms_agree_across_caps_and_thresholds(T, nms_post, max_num, thr):
+    """Both forms of the proposal kernels, bit for bit, around the places where the chip-wide form switches behaviour: T at its
+    frame limit (4) and one past it (5: both calls take the one-workgroup kernels, a control), a survivor cap of 1 (met in the first
+    chunk), 64, 1 000 (more than survive the band: hand-over to the greedy kernel), 1 024 / 1 025 (the form's own limit and one
+    past it), max_num below nms_post (the gather's top-k on an already sorted list), IoU thresholds 0.5 and 0.9."""
+    A, H, W = 12, 38, 63
+    g = torch.Generator().manual_seed(100 * T + nms_post)
+    cls = torch.randn((T, H, W, A), generator=g) * 1.5
+    reg = torch.randn((T, H, W, 4 * A), generator=g) * 0.3
+    gen = AnchorGenerator(16, [4, 8, 16, 32], [0.5, 1.0, 2.0])
+    prev = native.rpn_wide_frames(-1)
+    got = {}
+    try:
+        for form in (0, 4):
+            native.rpn_wide_frames(form)
+            p, c = native.rpn_proposals(cls.to(DEV), reg.to(DEV), gen.base_anchors, 16, (0., 0., 0., 0.), (1., 1., 1., 1.), (600, 1000),
+                                        6000, nms_post, max_num, thr)
+            got[form] = (p.cpu(), c.cpu())
+    finally:
+        native.rpn_wide_frames(prev)
+    assert torch.equal(got[0][1], got[4][1]), (got[0][1], got[4][1])
+    assert int(got[0][1].max()) <= min(nms_post, max_num) and int(got[0][1].min()) >= 1
+    for t in range(T):
+        n = int(got[0][1][t])
+        assert torch.equal(got[0][0][t, :n], got[4][0][t, :n]), t
+
+
+def test_rpn_wide_frames_knob_round_trips():
+    prev = native.rpn_wide_frames(-1)
+    try:
+        assert native.rpn_wide_frames(7) == prev and native.rpn_wide_frames(-1) == 7
+        assert native.rpn_wide_frames(0) == 7 and native.rpn_wide_frames(-1) == 0
+    finally:
+        native.rpn_wide_frames(prev)
+    assert native.rpn_wide_frames(-1) == prev
+
+
 # ------------------------------------------------------------------------------- read-out
 def test_det_readout_matches_reference_golden():
     g = gold('g8_det')

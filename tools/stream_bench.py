@@ -75,11 +75,59 @@ def main():
     conf, res_c = loop(GraphedStream(model, frames[0:1], meta, rescale=True, window_cus=args.window_cus), args.steps)
     plain, res_p = loop(GraphedStream(model, frames[0:1], meta, rescale=True), args.steps)
     same = all(np.array_equal(a, b) for a, b in zip(flat(res_p), flat(res_c)))
+
+    def proposals_one_frame():
+        """hvr_rpn_proposals on the RPN outputs of one frame (what the frame graph holds on its critical path behind C4): us per
+        call, HIP events around 50 calls, in the chip-wide form a one-frame call takes by default and in the one-workgroup-per-frame
+        form (hvr_rpn_wide_frames(0)); the two outputs compared bit for bit."""
+        from hvrnet_amd import native
+        import hvrnet_amd.rpn_head as RH
+        cap, orig = {}, native.rpn_proposals
+
+        def spy(*a, **k):
+            cap['a'], cap['k'] = a, k
+            return orig(*a, **k)
+        RH.native.rpn_proposals = spy
+        try:
+            with torch.no_grad():
+                c4 = model(img=frames[0:1], img_meta=[meta], backbone_feat=True)[0]
+                model.frame_tensors(c4, meta)
+        finally:
+            RH.native.rpn_proposals = orig
+        a, k = cap['a'], cap['k']
+        res, outs = {}, {}
+        prev = native.rpn_wide_frames(-1)
+        try:
+            for name, frames_limit in (('chip_wide', max(prev, 1)), ('one_workgroup_per_frame', 0)):
+                native.rpn_wide_frames(frames_limit)
+                for _ in range(3):
+                    outs[name] = orig(*a, **k)
+                torch.cuda.synchronize()
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(50):
+                    orig(*a, **k)
+                s1.record()
+                torch.cuda.synchronize()
+                res[name + '_us'] = round(s0.elapsed_time(s1) / 50 * 1e3, 1)
+        finally:
+            native.rpn_wide_frames(prev)
+        n = int(outs['chip_wide'][1][0])
+        res['same_proposals'] = bool(torch.equal(outs['chip_wide'][1], outs['one_workgroup_per_frame'][1]) and
+                                     torch.equal(outs['chip_wide'][0][0, :n], outs['one_workgroup_per_frame'][0][0, :n]))
+        res['proposals'] = n
+        res['what'] = 'hvr_rpn_proposals, T = 1 (eager launches, HIP events around 50 calls): default form for one frame vs hvr_rpn_wide_frames(0)'
+        return res
+
+    try:
+        rpn1 = proposals_one_frame()
+    except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the stream numbers down
+        rpn1 = dict(error=repr(exc))
     gf = 650.0 if args.head == 'hvr' else 504.0
     print(json.dumps(dict(metric='stream mode, pipelined hipGraphs: output frames/s (one new frame per output frame, T = %d, %d proposals)' % (T, N),
                           window_on_the_callers_stream=round(plain, 2), window_cus=args.window_cus, window_on_confined_stream=round(conf, 2),
                           ms_per_frame=round(1e3 / conf, 3), tflops=round(conf * gf / 1e3, 1), frac_mfma_peak=round(conf * gf / 1e3 / 2500.0, 4),
-                          same_detections=bool(same), steps=args.steps, head=args.head)))
+                          same_detections=bool(same), steps=args.steps, head=args.head, rpn_proposals_one_frame=rpn1)))
 
 
 if __name__ == '__main__':

@@ -542,7 +542,11 @@ def main(argv=None):
                         max=round(world * args.steps / min(t_[0] for t_ in per_region), 2),
                         rel_spread=round((max(t_[0] for t_ in per_region) - min(t_[0] for t_ in per_region)) / elapsed, 4),
                         what='the headline region (K = %d steps, barrier + synchronize on both sides) timed %d times back to back; '
-                             '`value` / `ms_per_step` are the median region' % (args.steps, len(per_region)))
+                             '`value` / `ms_per_step` are the median region' % (args.steps, len(per_region)),
+                        scope='WITHIN this process only.  Measured on one box with one build (profiles/r03_lib_ab.txt): the two-lane '
+                              'graph-replay headline of two consecutive processes differed by 3.7 % (164.1 / 158.2 frames/s) while each '
+                              'process\'s regions agreed to < 1 % -- where the lanes\' streams land among the hardware queues is decided '
+                              'per process; the eager `single_lane` figure repeated to 0.2 %.  Box to box adds more (`device.note`).')
 
     # ---- the precision ladder: the same window in the other compute modes (rank 0, N = 1) ----
     ladder = {}

@@ -1271,6 +1271,9 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void nms_band_sweep_kernel(const 
                                                                           int* __restrict__ done) {
   __shared__ unsigned long long kept[64];
   __shared__ int sh_done, sh_nkept;
+#ifdef HVR_DBG_SWEEP_CLK   // (tools/build_dbg.sh, NMS_DBG=1: per-chunk clock stamps of the hand-over chain, printed for problem 0)
+  __shared__ long long dbg_clk[64][5];
+#endif
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb0 = (R0 + 63) >> 6;   // <= 64
   const unsigned long long* mk = maskT + (long)p * nb0 * nb0 * 64;
@@ -1309,13 +1312,26 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void nms_band_sweep_kernel(const 
       }
     }
     if (d >= SWEEP_FIN) break;
+#ifdef HVR_DBG_SWEEP_CLK
+    const long long c0 = clock64();
+#endif
     const unsigned long long alive = __ballot(inb && sup == 0ull);
     unsigned long long K = alive;
+#ifdef HVR_DBG_SWEEP_CLK
+    const long long c1 = clock64();
+    int rounds = 0;
+#endif
     while (true) {
       const unsigned long long Kn = alive & ~__ballot((cdiag & K) != 0ull);
+#ifdef HVR_DBG_SWEEP_CLK
+      ++rounds;
+#endif
       if (Kn == K) break;
       K = Kn;
     }
+#ifdef HVR_DBG_SWEEP_CLK
+    const long long c2 = clock64();
+#endif
     const int nk0 = cb > 0 ? *(volatile int*)&sh_nkept : 0;
     bool fin = false;
     int below = (int)__popcll(K & ((1ull << lane) - 1ull));
@@ -1336,6 +1352,16 @@ __global__ __launch_bounds__(64 * SWEEP_WAVES) void nms_band_sweep_kernel(const 
       __hip_atomic_store(&sh_done, last ? SWEEP_FIN : cb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef HVR_DBG_SWEEP_CLK
+    if (lane == 0) { dbg_clk[cb][0] = c0; dbg_clk[cb][1] = c1; dbg_clk[cb][2] = c2; dbg_clk[cb][3] = clock64(); dbg_clk[cb][4] = rounds; }
+    if (last && lane == 0 && p == 0) {
+      __builtin_amdgcn_s_sleep(100);
+      for (int c = 0; c <= cb; ++c)
+        printf("sweep chunk %2d: wait-end->alive %4lld  fixpoint %4lld (%lld rounds)  publish %4lld  | since previous publish %5lld\n", c,
+               dbg_clk[c][1] - dbg_clk[c][0], dbg_clk[c][2] - dbg_clk[c][1], dbg_clk[c][4], dbg_clk[c][3] - dbg_clk[c][2],
+               c ? dbg_clk[c][0] - dbg_clk[c - 1][3] : 0ll);
+    }
+#endif
     if ((K >> lane) & 1ull) kp[nk0 + below] = i;
     if (lane == 0) {
       if (last) {

@@ -414,8 +414,38 @@ class HRNMPBBoxHead(_RelationHead):
             out['loss_cls_%d' % (i + 1)], out['loss_bbox_%d' % (i + 1)], out['acc_%d' % (i + 1)] = d['total'][0], d['total'][1], d['acc']
         return out
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError('HRNMPBBoxHead.forward: use forward_test (inference) or forward_train (training, dynamic=False)')
+    def forward(self, bbox_feat_s, cur_range_s=None, key_dim=0, all_res=False, others=None, dynamic=False, all_labels=None,
+                post_sampler=None, bbox_targets_key=None):
+        """The reference's entry point, same signature and return (hrnmp_bbox_head.py:609-795; called at hnmb_rcnn.py:438 as
+        `self.bbox_head(feats, cur_range_s=cur_ranges, others=bbox_targets_key[0], all_labels=all_labels, dynamic=False)`):
+        -> ([cls_score_branch, cls_score], [bbox_pred_branch, bbox_pred], loss_additional, similarity_).
+        `others` (the key rows' labels) selects the training graph (forward_train: stages 1-3 per video, the inter-video stage 4
+        with hard-proposal mining and the triplet term in `loss_additional['loss_trip']`); without labels there is nothing to mine
+        and the call is the inference path (forward_test), with an empty loss dict.  `similarity_` is the reference's debugging
+        record (numpy copies of the affinities), None here.  Outside the envelope the reference itself asserts or leaves off:
+        `post_sampler` (asserted None at :636), `dynamic=True` (off in its own call, hnmb_rcnn.py:431) -- both raise."""
+        if post_sampler is not None:
+            raise NotImplementedError('HRNMPBBoxHead.forward: post_sampler is not implemented (the reference asserts it is None, hrnmp_bbox_head.py:636)')
+        if dynamic:
+            if all_labels is None:
+                raise AssertionError('`all_labels` should be specified when `dynamic` is `True`')   # hrnmp_bbox_head.py:639-640
+            raise NotImplementedError('HRNMPBBoxHead.forward: dynamic=True (per-video mining, hrnmp_bbox_head.py:416-606) is outside '
+                                      'the hot path: the reference calls the head with dynamic=False (hnmb_rcnn.py:431-438)')
+        assert cur_range_s is not None, 'Feature num range along axis needs specified'
+        nc = self.num_classes
+        if others is None:
+            cls, reg = self.forward_test(bbox_feat_s, cur_range_s, key_dim, all_res)
+            return cls, reg, dict(), None
+        logits, loss_additional = self.forward_train(bbox_feat_s, cur_range_s, others, key_dim)
+        return [l[:, :nc] for l in logits], [l[:, nc:nc + 4] for l in logits], loss_additional, None
+
+    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, reduction_override=None):
+        """HRNMPBBoxHead.loss with the reference's arguments (hrnmp_bbox_head.py:970-1007): the per-branch lists `forward`
+        returns -> dict(loss_cls_i, acc_i, loss_bbox_i).  The fused kernel (train_ops.det_loss) takes one [rows, classes + 4]
+        matrix per branch: the two column blocks are put side by side again (a copy of rows x 35 floats)."""
+        assert reduction_override is None, 'reduction_override is not used on the hot path'
+        fused = [torch.cat([c, b], dim=1) for c, b in zip(cls_score, bbox_pred)]
+        return self.loss_train(fused, labels, label_weights, bbox_targets, bbox_weights)
 
     readout_streams = os.environ.get('HVR_READOUT_STREAMS', '1') != '0'
 

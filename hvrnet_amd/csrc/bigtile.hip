@@ -42,7 +42,7 @@ template <typename T> __device__ __forceinline__ void bg_mma(const uint4& w, con
   // weights as the MFMA "A" operand: a lane ends up with 4 consecutive output channels of one pixel (see gemm.hip)
   if constexpr (std::is_same<T, bf16_t>::value)
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-  else
+  else   // f16_t, and the half planes of f16s_t
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
 }
 // 16 bytes per lane, global -> LDS, buffer addressing (see gemm.hip): offsets from 2^31 up read as zeros
@@ -61,11 +61,16 @@ __device__ __forceinline__ void bg_load_lds16(const void* base, char* lds, unsig
 // rows -- 9 + 9 = 288, or 5 + 4 = 144 (the one-round shape of a 35 910-pixel batch with N = 256: every SIMD carries one 5-fragment and
 // one 4-fragment wave, so the matrix work per SIMD is balanced; 0.45 / 0.5 LDS fragment reads per MFMA against the tile engine's 0.61
 // for the same 144 x 256 tile)
-// T: bf16_t or f16_t (the same kernel on the half MFMA); split-half operands stay on the tile engine, whose fused three-MFMA K-step
-// (gemm_tile.h) already halves the LDS traffic per MFMA this kernel exists to reduce
+// T: bf16_t, f16_t (the same kernel on the half MFMA) or f16s_t (split half, common.h: the 128-byte line of a row and K-step holds the
+// hi and the lo plane of 32 logical k, and a K-step is SIX phases instead of four -- the three terms B_hi x A_hi, B_lo x A_hi,
+// B_hi x A_lo, each over the two row-fragment groups -- issued from the one LDS image in the tile engine's order per accumulator, so
+// the outputs are bit-identical to gemm_tile.h's split K-step; the fragments of a term are re-read from the LDS, which has the
+// bandwidth to spare: 0.36 reads per MFMA as in the two-byte formats, for two thirds of their LDS-DMA per MFMA)
 template <typename T, int FM0, int FM1>
 __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
+  constexpr bool SPLIT = std::is_same<T, f16s_t>::value;
   constexpr int EB = (int)sizeof(T), KSG = 128;
+  constexpr int BKE = SPLIT ? 32 : 64;   // logical elements per K-step
   constexpr int BM = (FM0 + FM1) * 16;
   constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BG_BN * 128;
   constexpr int A_SLOTS = (BM * 8 + BG_NT - 1) / BG_NT;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   // second K segment (p.s2 > 0, plain products: a Bottleneck's projection shortcut folded into its closing 1x1, see gemm.hip):
   // K-steps from K1 / 64 on read the block input, an NHWC map [.][H2][W2][K - K1] sampled at stride s2, through a second resource
   const bool seg2 = p.s2 > 0;
-  const int k1_steps = seg2 ? p.K1 / 64 : 0x7fffffff;
+  const int k1_steps = seg2 ? p.K1 / BKE : 0x7fffffff;
   const char* const rs_a2 = (const char*)p.A2;
   int a_off2[A_SLOTS];
 #pragma unroll
@@ -123,12 +128,12 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   }
 
   int a_koff = 0, b_koff = 0, dy = 0, dx = 0, kt_load = 0;  // of the K-step being loaded
-  const int nk_real = p.K / 64;
+  const int nk_real = p.K / BKE;
   auto tap_of = [&](int kt) {
     kt_load = kt;
     b_koff = kt * KSG;
     if (p.conv) {
-      const int k = kt * 64, tap = k / p.Cin, cin0 = k - tap * p.Cin;
+      const int k = kt * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       dy = ky * p.dil;
       dx = kx * p.dil;
@@ -190,14 +195,18 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
       uint4 kb[BG_FN], qa[G0];
       tap_of(kn);
-      static_for<4>([&](auto PH) {
-        constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? FM - G0 : G0;
+      // phases: two per term.  Two-byte formats: term = K half (0 / 1) on both operands.  Split half: term 0 = B_hi x A_hi,
+      // 1 = B_lo x A_hi, 2 = B_hi x A_lo (the lo plane is the second 64 bytes of the line: the same address with bit 6 flipped)
+      constexpr int NPH = SPLIT ? 6 : 4;
+      static_for<NPH>([&](auto PH) {
+        constexpr int ph = decltype(PH)::value, term = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? FM - G0 : G0;
+        constexpr bool b_lo = term == 1, a_lo = SPLIT ? term == 2 : term == 1;
         // ---- L ----
         if constexpr ((ph & 1) == 0)
-          static_for<BG_FN>([&](auto J) { kb[decltype(J)::value] = bg_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+          static_for<BG_FN>([&](auto J) { kb[decltype(J)::value] = bg_read128<decltype(J)::value * 2048>(b_lo ? (b0 ^ 64u) : b0); });
         static_for<nr>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          qa[r] = bg_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+          qa[r] = bg_read128<(r0 + r) * 2048>(a_lo ? (a0 ^ 64u) : a0);
         });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph < 3) {
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
             });
           }
         }
-        if constexpr (ph == 3) {
+        if constexpr (ph == NPH - 1) {
           if (wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph == 3) {
+        if constexpr (ph == NPH - 1) {
           if (!wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -241,6 +250,96 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 
   // ---------------- epilogue: bias + ReLU, bf16, whole 128-byte row segments out through per-wave LDS staging ----------------
   // lane holds out[m0 + wrow0 + 16 i + frag_row][n0 + wn 64 + 16 j + 4 frag_grp + r] = acc[i][j][r]
+  if constexpr (SPLIT) {
+    // ---- split half: (alpha acc + beta bias) + resid in f32, ReLU, then the [hi | lo] pair -- the tile engine's order and roundings.
+    // A wave's 64 columns are two [32 hi | 32 lo] groups = 256 contiguous bytes of an output row: residual rows come in and output rows
+    // leave as whole 16-byte pieces through a per-wave staging image [16 rows][16 pieces], piece position XOR-ed with the row ----
+    int etid = threadIdx.x;
+    asm volatile("" : "+v"(etid));
+    const int el = etid & 63, erow = el & 15, egrp = el >> 4;
+    constexpr int SP = 256;
+    char* stg = smem + wave * (16 * SP);
+    float bias[BG_FN][4];
+#pragma unroll
+    for (int j = 0; j < BG_FN; ++j) {
+      const int n = n0 + wn * BG_WCOLS + j * 16 + egrp * 4;
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        bias[j][0] = b.x; bias[j][1] = b.y; bias[j][2] = b.z; bias[j][3] = b.w;
+        if (p.beta != 0.f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bias[j][r] *= p.beta;
+        }
+      } else {
+        bias[j][0] = bias[j][1] = bias[j][2] = bias[j][3] = 0.f;
+      }
+    }
+    // this lane's 8-byte slots of fragment column j in the staged row `erow`: columns c = 16 j + 4 egrp .. + 4 -> group c / 32, hi plane
+    // byte (c % 32) * 2; the lo plane is 64 bytes (four pieces) further
+    auto slot = [&](int j, int plane) {
+      const int piece = (j >> 1) * 8 + plane * 4 + 2 * (j & 1) + (egrp >> 1);
+      return stg + erow * SP + ((piece ^ erow) << 4) + (egrp & 1) * 8;
+    };
+    // store-phase mapping: piece q = it * 64 + el of the 16 x 16 block -> row q / 16, piece q % 16
+    const bool has_res = p.resid != nullptr;
+    const long col_bytes = split_col_bytes(n0 + wn * BG_WCOLS);
+    auto load_res = [&](int i, uint4 (&rv)[4]) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 64 + el, row = q >> 4, pc = q & 15;
+        int m = m0 + wrow0 + i * 16 + row;
+        m = m < p.M ? m : p.M - 1;
+        rv[it] = *reinterpret_cast<const uint4*>((const char*)p.resid + (long)m * p.ldr * 4 + col_bytes + pc * 16);
+      }
+    };
+    uint4 rnext[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    if (has_res) load_res(0, rnext);
+    __syncthreads();  // every wave is done reading the ring
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (has_res) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int q = it * 64 + el, row = q >> 4, pc = q & 15;
+          *reinterpret_cast<uint4*>(stg + row * SP + ((pc ^ row) << 4)) = rnext[it];
+        }
+        if (i + 1 < FM) load_res(i + 1, rnext);
+      }
+#pragma unroll
+      for (int j = 0; j < BG_FN; ++j) {
+        f32x4 v = acc[i][j];
+        if (p.alpha != 0.f) v *= p.alpha;
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = v[r] + bias[j][r];
+        char* sh = slot(j, 0);
+        char* sl = slot(j, 1);
+        if (has_res) {
+          const uint2 rh = *reinterpret_cast<const uint2*>(sh), rl = *reinterpret_cast<const uint2*>(sl);
+          float r0_, r1_, r2_, r3_;
+          merge2(rh.x, rl.x, r0_, r1_);
+          merge2(rh.y, rl.y, r2_, r3_);
+          e[0] += r0_; e[1] += r1_; e[2] += r2_; e[3] += r3_;
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = fmaxf(e[r], 0.f);
+        }
+        uint2 oh, ol;
+        split2(e[0], e[1], oh.x, ol.x);
+        split2(e[2], e[3], oh.y, ol.y);
+        *reinterpret_cast<uint2*>(sh) = oh;
+        *reinterpret_cast<uint2*>(sl) = ol;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 64 + el, row = q >> 4, pc = q & 15;
+        const int m = m0 + wrow0 + i * 16 + row;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SP + ((pc ^ row) << 4));
+        if (m < p.M) *reinterpret_cast<uint4*>((char*)p.C + (long)m * p.ldc * 4 + col_bytes + pc * 16) = v;
+      }
+    }
+  } else
   {
     int etid = threadIdx.x;
     asm volatile("" : "+v"(etid));  // lane-derived values re-derived here: nothing but the accumulators lives across the loop
@@ -326,22 +425,26 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 // 256-channel column tiles and whole 128-byte K-steps inside one filter tap.  `throughput`: the caller keeps the rest of the chip
 // busy with other launches (tile_hint kBigHint).
 bool bigtile_supported(const GemmParams& p, bool throughput) {
-  if ((p.dtype != DT_BF16 && p.dtype != DT_F16) || !p.staging || p.out_f32 || p.ksplit_steps > 0) return false;
-  if (p.s2 > 0 && (p.conv || p.K1 % 64 || (p.K - p.K1) % 64 || p.K1 < 64 || (reinterpret_cast<uintptr_t>(p.A2) & 15) ||
+  const bool split = p.dtype == DT_F16S;
+  if ((p.dtype != DT_BF16 && p.dtype != DT_F16 && !split) || !p.staging || p.out_f32 || p.ksplit_steps > 0) return false;
+  const int es = split ? 4 : 2, bke = split ? 32 : 64, row_al = split ? 32 : 8;   // bytes per element, elements per K-step, row pitch granule
+  if (p.s2 > 0 && (split || p.conv || p.K1 % 64 || (p.K - p.K1) % 64 || p.K1 < 64 || (reinterpret_cast<uintptr_t>(p.A2) & 15) ||
                    (long)p.M * (p.K - p.K1) * 2 >= (1L << 31))) return false;
-  if (p.N % BG_BN || p.K % 64 || p.ldc % 8 || p.lda % 8 || p.ldb % 8) return false;
-  if (p.resid && (p.ldr % 8 || (reinterpret_cast<uintptr_t>(p.resid) & 15))) return false;
+  if (p.N % BG_BN || p.K % bke || p.ldc % row_al || p.lda % row_al || p.ldb % row_al) return false;
+  if (p.resid && (p.ldr % row_al || (reinterpret_cast<uintptr_t>(p.resid) & (split ? 127 : 15)))) return false;
+  if (split && ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C)) & 127)) return false;
   // K >= 256: below that a tile is all prologue and epilogue and the row-panel kernel (expand.hip) is ahead -- layer 2's expand
   // 77 vs 76 us, layer 1's 139 vs 126; layer 3's (K = 256) 40 vs 43 and res5's (K = 512) 117 vs 138 go the other way
   static const int with_res = std::getenv("HVR_BIGTILE_RES") ? std::atoi(std::getenv("HVR_BIGTILE_RES")) : 1;
   // (with two windows in flight the panel kernel's expand convs, two small workgroups per CU, pack better beside the other
-  // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint)
-  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || throughput)))) return false;
-  if (p.conv && p.Cin % 64) return false;
+  // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint.
+  // Split half has no row-panel kernel for K >= 256: its residual convs take the big tiles in either mode.)
+  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || (throughput && !split))))) return false;
+  if (p.conv && p.Cin % bke) return false;
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                        reinterpret_cast<uintptr_t>(p.bias);
   if (al & 15) return false;
-  if ((long)p.N * p.ldb * 2 >= (1L << 31)) return false;
+  if ((long)p.N * p.ldb * es >= (1L << 31)) return false;
   // A grid that fills most of the chip by itself (N = 512: 250 tiles for a 15-frame batch) is faster than the 144-row shapes
   // outright (res5's 3x3 165 -> 136 us, the RPN's 312 -> 260); half a chip's worth (N = 256: 125 tiles, layer 3's 3x3 65 us
   // against 47 on twice the CUs) only pays in CU-time, i.e. for a caller that has other launches for the free half.
@@ -373,6 +476,7 @@ static hipError_t launch_bigtile(const GemmParams& p, hipStream_t stream) {
 }
 
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) {
+  if (p.dtype == DT_F16S) return launch_bigtile<f16s_t, 9, 9>(p, stream);
   if (p.dtype == DT_F16) return launch_bigtile<f16_t, 9, 9>(p, stream);
   return launch_bigtile<bf16_t, 9, 9>(p, stream);
 }

@@ -623,9 +623,11 @@ class HNMBRCNN(_WindowDetector):
         feats = list(torch.split(all_feats, rows, dim=0))
         targets = T.bbox_target(key_results, key_gtb, key_gtl, rcnn_cfg, target_means=self.bbox_head.target_means,
                                 target_stds=self.bbox_head.target_stds)
-        logits, losses = self.bbox_head.forward_train(feats, cur_ranges, targets[0], key_dim=self.key_dim)
-        losses = dict(losses)
-        losses.update(self.bbox_head.loss_train(logits, *targets))
+        # the head through the reference's own entry point and return (hnmb_rcnn.py:431-442, dynamic = False, no post sampler)
+        cls_scores, bbox_preds, loss_trip, _similarity = self.bbox_head(feats, cur_range_s=cur_ranges, others=targets[0],
+                                                                      all_labels=targets[0], dynamic=False)
+        losses = dict(loss_trip) if loss_trip is not None else dict()
+        losses.update(self.bbox_head.loss(cls_scores, bbox_preds, *targets))
         return losses
 
     def forward_feat_frames(self, entries, c4s=None, rescale=False, defer=False):

@@ -860,6 +860,76 @@ def test_hvr_head_training_step_matches_the_oracle(O):
     assert seen >= 30
 
 
+def test_hvr_head_forward_has_the_reference_signature_and_return(O):
+    """HRNMPBBoxHead.forward called exactly as HNMBRCNN.forward_train calls it (hnmb_rcnn.py:438:
+    `self.bbox_head(feats, cur_range_s=cur_ranges, others=bbox_targets_key[0], all_labels=all_labels, dynamic=False)`) returns the
+    reference's 4-tuple ([cls_branch, cls], [reg_branch, reg], loss_additional, similarity_) (hrnmp_bbox_head.py:795), equal to
+    the oracle's restatement of that method; `loss` takes those lists as the reference's does (hrnmp_bbox_head.py:970-1007) and
+    the gradients flow through both.  Without labels the same entry point is the inference path; the options the reference's own
+    call leaves off (dynamic=True, post_sampler) raise instead of approximating."""
+    sd = S.synth_state_dict('hvr')
+    n, V, F_ = 8, 3, 3
+    head = hvrnet_amd.HRNMPBBoxHead(sampler_num=n, t_dim=V * F_, imgs_per_video=F_, in_channels=256, num_classes=31,
+                                    reg_class_agnostic=True)
+    head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
+    head = hvrnet_amd.enable_training(head.to(DEV))
+    hvrnet_amd.set_compute_dtype(head, torch.float32)
+    g = torch.Generator().manual_seed(197)
+    lens = [7, 8, 5]
+    feats = [torch.randn((l + 2 * n - v, 256, 7, 7), generator=g).abs() for v, l in enumerate(lens)]
+    curs = [dict(start=0, length=l) for l in lens]
+    R = sum(lens)
+    labels = torch.randint(0, 4, (R,), generator=g)
+    labels[::3] = 0
+    lw, bt = torch.ones(R), torch.randn((R, 4), generator=g) * 0.8
+    bw = (labels > 0).float()[:, None].expand(-1, 4).contiguous()
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in sd if k.startswith('bbox_head.')}
+    cls_w, reg_w, extra = O.hvr_head_forward_train(feats, leaf, curs, labels, n, V * F_, F_)
+    want = O.hvr_head_loss(cls_w, reg_w, labels, lw, bt, bw)
+    want.update(extra)
+    sum(v for k, v in want.items() if 'loss' in k).backward()
+
+    dev_labels = labels.to(DEV)
+    out = head([f.to(DEV) for f in feats], cur_range_s=curs, others=dev_labels, all_labels=dev_labels, dynamic=False)
+    assert isinstance(out, tuple) and len(out) == 4
+    cls_scores, bbox_preds, loss_trip, similarity_ = out
+    assert similarity_ is None and isinstance(loss_trip, dict) and set(loss_trip) == {'loss_trip'}
+    assert len(cls_scores) == len(bbox_preds) == 2
+    for c, r, cw, rw in zip(cls_scores, bbox_preds, cls_w, reg_w):
+        assert tuple(c.shape) == (R, 31) and tuple(r.shape) == (R, 4)
+        close(c, cw.detach(), 2e-4, 2e-4)
+        close(r, rw.detach(), 2e-4, 2e-4)
+    got = head.loss(cls_scores, bbox_preds, dev_labels, lw.to(DEV), bt.to(DEV), bw.to(DEV))
+    got.update(loss_trip)
+    assert set(got) == set(want)
+    for k in want:
+        close(got[k], want[k].detach(), 2e-4, 1e-5)
+    sum(v for k, v in got.items() if 'loss' in k).backward()
+    for name in ('fc_new_1.weight', 'fc_new_4.weight', 'fc_cls.weight', 'fc_reg_2.weight', 'selsa_4.q_data_fc_4.weight'):
+        w, gp = leaf['bbox_head.' + name].grad, dict(head.named_parameters())[name].grad
+        assert gp is not None, name
+        want_abs = float(w.double().abs().sum())
+        assert abs(float(gp.double().abs().sum()) - want_abs) <= 2e-3 * want_abs + 1e-7, name
+
+    # no labels: the inference path through the same entry point
+    hvrnet_amd.set_compute_dtype(head, torch.float32)
+    head.sampler_num, head.t_dim = 16, 3
+    with torch.no_grad():
+        f = torch.randn((48, 256, 7, 7), generator=g).abs().to(DEV)
+        cur = [dict(start=16, length=16)]
+        c0, r0, extra0, sim0 = head(f, cur_range_s=cur)
+        c1, r1 = head.forward_test(f, cur)
+    assert extra0 == {} and sim0 is None
+    for a, b in zip(c0 + r0, c1 + r1):
+        assert torch.equal(a, b)
+    with pytest.raises(NotImplementedError):
+        head([f], cur_range_s=cur, others=dev_labels, all_labels=dev_labels, dynamic=True)
+    with pytest.raises(AssertionError):
+        head([f], cur_range_s=cur, others=dev_labels, dynamic=True)           # the reference's own assertion (:639-640)
+    with pytest.raises(NotImplementedError):
+        head([f], cur_range_s=cur, others=dev_labels, post_sampler=object())
+
+
 def test_hnmb_rcnn_forward_train_matches_the_oracle(O):
     """HNMBRCNN.forward_train through the detector's dispatch on five videos of three 128x192 frames (three of the key class,
     two others): video choice by res5 descriptors, proposals, per-frame sampling against each chosen video's key-frame ground

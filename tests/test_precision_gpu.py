@@ -238,13 +238,14 @@ def test_stem_patch_rows_in_half_and_split_formats():
     assert torch.equal(cols_h, cols32.half())
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, SPLIT], ids=['f16', 'f16x2'])
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad,dil', [(15, 38, 63, 512, 512, 3, 1, 2, 2), (8, 38, 63, 1024, 512, 3, 1, 1, 1),
                                                               (13, 37, 61, 256, 256, 3, 1, 1, 1), (15, 38, 63, 2048, 512, 1, 1, 0, 1)])
-def test_big_tile_kernel_on_half_operands_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, pad, dil):
-    """bigtile.hip (288 x 256 tiles) instantiated on half operands: the same MFMA sequence per output element as the tile engine,
-    so the outputs are bit-identical -- tile=17 forces the kernel, tile=11 the engine's 144 x 256 shape.  Split-half operands
-    stay on the tile engine (their fused K-step already has the lower LDS traffic per MFMA)."""
-    dtype = torch.float16
+def test_big_tile_kernel_on_half_operands_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, pad, dil, dtype):
+    """bigtile.hip (288 x 256 tiles) instantiated on half and on split-half operands: the same MFMA sequence per output element as
+    the tile engine (split half: B_hi x A_hi, B_lo x A_hi, B_hi x A_lo per K-step, six phases from one LDS image), so the outputs
+    are bit-identical -- tile=17 forces the kernel, tile=11 the engine's 144 x 256 shape.  The residual epilogue (merged f32 residual,
+    one rounding into the [hi | lo] pair) as well."""
     x = _to(_rand((B, H, W, Cin), 81), dtype)
     w = _tow(_rand((Cout, k, k, Cin), 82, 0.03), dtype)
     bias = _rand((Cout,), 83).to(DEV)
@@ -253,10 +254,19 @@ def test_big_tile_kernel_on_half_operands_equals_the_tile_engine(B, H, W, Cin, C
     assert big.dtype == dtype and torch.equal(big, eng)
     tiles = ((B * H * W + 287) // 288) * (Cout // 256)     # (stride 1, same-size outputs)
     assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, k=k, stride=stride, pad=pad, dil=dil, dtype=dtype) == (3 if tiles >= 170 else 0)
-    assert native.conv2d_path(B, H, W, Cin, Cout, resid=False, k=k, stride=stride, pad=pad, dil=dil, dtype=SPLIT) == 0
     r = _to(_rand((B, H, W, Cout), 84), dtype)
     assert torch.equal(native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=17),
                        native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=11))
+
+
+def test_big_tile_kernel_on_split_half_tracks_the_f64_product():
+    """The split-half big tiles against a float64 convolution of the un-rounded f32 inputs (res5's 3x3, dilation 2, ragged last
+    row tile): 22-bit operands, exact products, f32 sums -- 5e-6 of the output scale, like the tile engine's split K-step."""
+    B, H, W, Cin, Cout = 2, 38, 63, 256, 256
+    xf, wf, bf = _rand((B, H, W, Cin), 85), _rand((Cout, 3, 3, Cin), 86, 0.02), _rand((Cout,), 87)
+    got = _back(native.conv2d_nhwc(_to(xf, SPLIT), _tow(wf, SPLIT), bf.to(DEV), relu=True, pad=2, dil=2, tile=17))
+    want = F.relu(F.conv2d(xf.permute(0, 3, 1, 2).double(), wf.permute(0, 3, 1, 2).double(), bf.double(), padding=2, dilation=2)).permute(0, 2, 3, 1)
+    assert (got.double() - want).abs().max().item() < 5e-6 * want.abs().max().item()
 
 
 # ---- the dedicated bf16 kernels instantiated on half operands: each against the tile engine on the same operands ----

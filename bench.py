@@ -24,11 +24,13 @@ are identical to the eager ones (tests/test_graphs_gpu.py).  `--lanes 1 --no-gra
 GPU under torch.distributed.run, 127.0.0.1 rendezvous -- what tools/dist_test.sh:9-10 does for the reference) and refuses
 loudly when fewer than N devices are visible.
 
-Extra JSON keys: `roofline` (relation core, measured with HIP events inside the timed region), `kernel_classes`
-(per-class time / achieved rate from one extra instrumented window after the timed region), `f32_parity_mode` (the same
-window timed in the f32 compute mode, the mode whose outputs meet north_star's 1e-3), `parity` (this run's detections --
-headline dtype and f32 -- against the CPU oracle's on the same frames) and `cpu_baseline` (the CPU oracle timed on the
-whole window: 1 warm-up + median of 3, plus configs[0]; rank 0, N = 1); for N > 1 `per_rank`, `rccl_world_size` and
+JSON line (one line, numbers only; README.md "Reading the bench line" says what every key means).  After the contract keys:
+`within_tolerance` -- the fastest compute mode whose detections meet north_star's tolerance against the CPU oracle on the same
+frames (dtype, frames/s, its relation-core roofline, its parity); `single_lane` -- the eager one-window-in-flight figure with its
+own spread (the figure to compare builds with); `roofline` (relation core, HIP events inside the timed region); `cpu_baseline`
+(the CPU oracle on whole windows: 1 warm-up + median of 3, plus configs[0]; rank 0, N = 1); `precision_ladder` (one compact row per
+compute mode: eager / replayed throughput, roofline, parity, per-class kernel times); `kernel_classes` of the headline mode; side
+loops (`ref_loop`, `cached_loop`, `graphed_clip`, `graphed_stream`, `train_step`); for N > 1 `per_rank`, `rccl_world_size` and
 `train_allreduce` (the training step's one exchange: a flat f32 gradient buffer of the detector's trainable size).
 """
 import argparse
@@ -56,6 +58,10 @@ MODE_WHAT = {
     'f16x2': 'split half: every operand as hi + lo * 2^-11 halves (22 bits), three half MFMAs per product, f32 accumulation',
     'f32': 'f32 operands on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the half rate)'}
 HBM_PEAK_GBS = 8000.0
+# north_star's tolerance on a window's detections against oracle.clip_forward (same frames): class indices exact, scores within 1e-3,
+# box coordinates within 1e-3 px.  The box bar carries two f32 ulps at 1000 px (2 x 6.1e-5 = 1.2e-4): the oracle and the device
+# round the decode's f32 arithmetic in different orders, and coordinates reach 1000.  Nothing else is added.
+TOL_SCORE, TOL_BOX_PX = 1e-3, 1e-3 + 1.2e-4
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7           # per GPU, SURVEY.md section 5
 # trainable f32 parameters whose gradients one training step exchanges (176 MB HVR / 271 MB SELSA)
 TRAIN_GRAD_ELEMS = {'hvr': 44128768, 'selsa': 67700000}
@@ -171,10 +177,9 @@ def cpu_baseline_quick(head, T, n_prop, sd):
             O.get_det_bboxes(key_rois, c, r, (600, 1000, 3), 1.0, True, O.RCNN_TEST_CFG)
         t_head = time.time() - t0
     window_s = t_frames * (T / float(ns)) + t_head
-    return dict(value=1.0 / window_s, unit='frames/s', cores=cores, kind='port',
-                sample='--quick: %d of %d frames through backbone+res5+RPN+proposals+RoIAlign (%.2f s, scaled x%.1f) + full relation '
-                       'head M=%d and read-out (%.2f s); torch %d threads' % (ns, T, t_frames, T / float(ns), M, t_head, cores),
-                window_seconds=window_s), None
+    return dict(value=round(1.0 / window_s, 4), unit='frames/s', cores=cores, kind='port',
+                sample='--quick: %d of %d frames to RoIAlign (%.2f s, x%.1f) + full head M=%d (%.2f s)' % (ns, T, t_frames, T / float(ns), M, t_head),
+                window_seconds=round(window_s, 3)), None
 
 
 def cpu_baseline_full(head, T, n_prop, sd, frame_ids):
@@ -203,29 +208,28 @@ def cpu_baseline_full(head, T, n_prop, sd, frame_ids):
     runs = sorted(times[1:])
     window_s = runs[len(runs) // 2]
     c1 = sorted(t1[1:])[0]
-    out = dict(value=1.0 / window_s, unit='frames/s', cores=cores, kind='port',
-               sample='whole %d-frame clip-mode windows of the same synthetic clip (600x1000, %d proposals/frame, %s head) through '
-                      'oracle.clip_forward: 1 warm-up + median of 3 (%.2f / %.2f / %.2f s); torch %d threads'
-                      % (T, n_prop, head, runs[0], runs[1], runs[2], cores),
-               window_seconds=window_s, warmup_window_seconds=times[0],
-               config1=dict(what='configs[0]: 1 key + 2 reference frames, 32 proposals, one window (1 warm-up, best of 2)',
-                            window_seconds=c1, frames_per_s=1.0 / c1))
+    out = dict(value=round(1.0 / window_s, 4), unit='frames/s', cores=cores, kind='port',
+               sample='whole %d-frame windows of the same clip through oracle.clip_forward: 1 warm-up + median of 3 (%.2f / %.2f / %.2f s)'
+                      % (T, runs[0], runs[1], runs[2]),
+               window_seconds=round(window_s, 3), config1_window_seconds=round(c1, 3))
     return out, (res if head == 'hvr' else res[0])
 
 
 def parity_object(head, dtype_name, got, want):
-    """This run's detections against the CPU oracle's (same frames, same weights): position-by-position (class indices exact?)
-    and, for results that keep different boxes at the discontinuous steps, box-to-box matching."""
+    """This run's detections against the CPU oracle's (oracle.clip_forward, f32, same frames and weights, final branch): position by
+    position (class_flips, max_score_err, max_box_err in px) and, for results that keep different boxes at the discontinuous steps,
+    box-to-box matching (`matched`: oracle detections with score >= 0.05 that reappear with the same class and IoU > 0.9)."""
     from hvrnet_amd import parity
     g, w = (got[-1], want[-1]) if head == 'hvr' else (got, want)
     st, tr = parity.strict(g, w), parity.track(g, w)
-    return dict(dtype=dtype_name, against='oracle.clip_forward (CPU, f32) on the same %s window, final branch' % head,
-                class_flips=st['class_flips'], max_score_err=round(st['max_score_err'], 6), max_box_err=round(st['max_box_err'], 5),
-                detections=st['n'],
-                matched=dict(what='oracle detections with score >= 0.05 that reappear with the same class and IoU > 0.9',
-                             n_ref=tr['n_ref'], same_class_frac=round(tr['same_class_frac'], 4),
-                             max_score_err=round(tr['max_score_err'], 5), mean_score_err=round(tr['mean_score_err'], 5),
-                             max_box_err=round(tr['max_box_err'], 4)))
+    return dict(dtype=dtype_name, class_flips=st['class_flips'], max_score_err=round(st['max_score_err'], 6), max_box_err=round(st['max_box_err'], 5),
+                detections=st['n'], matched=dict(n_ref=tr['n_ref'], same_class_frac=round(tr['same_class_frac'], 4),
+                                                 max_score_err=round(tr['max_score_err'], 5), max_box_err=round(tr['max_box_err'], 4)))
+
+
+def within_tolerance(pr):
+    """north_star's bar on a parity object (TOL_SCORE / TOL_BOX_PX above; class indices exact)."""
+    return bool(pr is not None and pr['class_flips'] == 0 and pr['max_score_err'] < TOL_SCORE and pr['max_box_err'] < TOL_BOX_PX)
 
 
 def same_detections(a, b):
@@ -248,7 +252,7 @@ def train_step_side_measurement(head):
         line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
         d = json.loads(line)
         return dict(iterations_per_s=d['value'], ms_per_iteration=d['ms_per_step'], input_frames_per_s=d['frames_per_s'], dtype=d['dtype'],
-                    trainable_params=d['params'], what=d['metric'])
+                    trainable_params=d['params'])
     except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the headline down
         sys.stderr.write('train_step side measurement skipped: %r\n' % (exc,))
         return None
@@ -278,7 +282,7 @@ def allreduce_leg(dist, world, head, device, iters=5):
     ms = float(t.item())
     algbw = nbytes / (ms * 1e-3) / 1e9
     frac = 2.0 * (world - 1) / world
-    return dict(what='one flat f32 gradient all-reduce, %s training step (%.1f MB)' % (head.upper(), nbytes / 1e6), bytes=nbytes,
+    return dict(bytes=nbytes,
                 ms=round(ms, 4), algbw_gbs=round(algbw, 2), busbw_gbs=round(algbw * frac, 2),
                 est_ring_one_link_ms=round(frac * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3, 3),
                 est_direct_all_links_ms=round(frac * nbytes / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS * 1e9) * 1e3, 3),
@@ -493,25 +497,34 @@ def main(argv=None):
         del gcs
         return times, last
 
-    def roofline_of(mode, rel_spans, where):
+    def roofline_of(mode, rel_spans):
+        """The relation core's launches (hvr_relation_fwd with Mq = Mk = T x proposals, D = 1024: 4 Mq Mk D flops each; f16x2: three
+        half MFMAs per product, so its peak is the half peak / 3), HIP events around every call on the launch stream in the eager
+        single-lane region; `traffic`: HBM-side bytes per launch from the committed PMC passes of THIS library build, else null."""
         full = (rel_spans or {}).get('relation_full', dict(calls=0, ms=0.0, work=0.0))
         if not full['calls']:
             return None
         peak = MFMA_PEAK_TF[mode]
         ach = full['work'] / (full['ms'] * 1e-3) / 1e12
-        traffic, traffic_src = (relation_traffic() if T * n_prop == 4500 and mode == 'bf16' else (None, 'collected for the 4500-row bf16 problem only'))
-        return dict(kernel='relation core (the launches of hvr_relation_fwd), Mq=Mk=%d D=1024, %s operands' % (T * n_prop, mode), bound='mfma',
-                    achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic,
-                    traffic_source=traffic_src, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4),
-                    flops_per_launch=full['work'] / full['calls'],
-                    peak_note=dict(bf16='dense bf16 MFMA', f16='dense half MFMA', f32='exact-f32 MFMA (16x16x4)',
-                                   f16x2='dense half MFMA / 3: three MFMAs (hi*lo, lo*hi, hi*hi) per algorithmic product')[mode],
-                    measured_over=where)
+        traffic = relation_traffic()[0] if T * n_prop == 4500 and mode == 'bf16' else None
+        return dict(kernel='relation core', bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
+                    traffic=traffic, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4), flops_per_launch=full['work'] / full['calls'])
+
+    def class_times(mode):
+        """One extra instrumented window (outside every timed region): per kernel class [ms, fraction of the mode's MFMA peak or of the
+        HBM peak]."""
+        native.profile_begin(tags=('*',))
+        step().result()
+        out_c, peak_m = {}, MFMA_PEAK_TF[mode]
+        for tag, d in native.profile_end().items():
+            if d['ms'] <= 0:
+                continue
+            mfma = tag in ('gemm', 'conv', 'stem', 'relation_full', 'relation_key')
+            rate = d['work'] / (d['ms'] * 1e-3) / (1e12 if mfma else 1e9)
+            out_c[tag] = dict(calls=d['calls'], ms=round(d['ms'], 4), frac=round(rate / (peak_m if mfma else HBM_PEAK_GBS), 4), of='mfma' if mfma else 'hbm')
+        return out_c
 
     median = lambda xs: sorted(xs)[len(xs) // 2]   # noqa: E731
-    where_eager = ('the eager single-lane region (`single_lane`, the same K windows): HIP events on the launch stream around every '
-                   'hvr_relation_fwd call; a graph replay has no place for them, and with two windows sharing the chip an interval is '
-                   'not the kernel\'s own duration')
     # ---- region (1): the eager single-lane loop, relation launches tagged; timed `repeats` times (at least 3) ----
     sl_times, rel = [], {}
     for r in range(max(1, min(args.repeats, 3))):
@@ -521,10 +534,9 @@ def main(argv=None):
             e = rel.setdefault(tag, dict(calls=0, ms=0.0, work=0.0))
             e['calls'] += d['calls']; e['ms'] += d['ms']; e['work'] += d['work']
     mine = median(sl_times)
-    single_lane = dict(frames_per_s_per_gpu=round(args.steps / mine, 3), ms_per_step=round(mine / args.steps * 1e3, 3), steps=args.steps,
+    single_lane = dict(frames_per_s=round(args.steps / mine, 3), ms_per_step=round(mine / args.steps * 1e3, 3), steps=args.steps,
                        regions=[round(args.steps / t_, 2) for t_ in sl_times],
-                       what='eager launches, one window in flight per GPU (the round-1 headline loop), the region timed %d times (median '
-                            'reported): the region the roofline HIP events are taken in' % len(sl_times))
+                       rel_spread=round((max(sl_times) - min(sl_times)) / mine, 4))
     headline_mode = 'eager launches, %d window(s) in flight' % max(1, args.inflight)
     n_lanes = max(1, args.inflight)
     region_times = sl_times
@@ -538,15 +550,7 @@ def main(argv=None):
     order = sorted(range(len(per_region)), key=lambda i: per_region[i][0])
     elapsed, per_rank = per_region[order[len(order) // 2]]
     value_spread = dict(regions=len(per_region), frames_per_s=[round(world * args.steps / t_[0], 2) for t_ in per_region],
-                        min=round(world * args.steps / max(t_[0] for t_ in per_region), 2),
-                        max=round(world * args.steps / min(t_[0] for t_ in per_region), 2),
-                        rel_spread=round((max(t_[0] for t_ in per_region) - min(t_[0] for t_ in per_region)) / elapsed, 4),
-                        what='the headline region (K = %d steps, barrier + synchronize on both sides) timed %d times back to back; '
-                             '`value` / `ms_per_step` are the median region' % (args.steps, len(per_region)),
-                        scope='WITHIN this process only.  Measured on one box with one build (profiles/r03_lib_ab.txt): the two-lane '
-                              'graph-replay headline of two consecutive processes differed by 3.7 % (164.1 / 158.2 frames/s) while each '
-                              'process\'s regions agreed to < 1 % -- where the lanes\' streams land among the hardware queues is decided '
-                              'per process; the eager `single_lane` figure repeated to 0.2 %.  Box to box adds more (`device.note`).')
+                        rel_spread=round((max(t_[0] for t_ in per_region) - min(t_[0] for t_ in per_region)) / elapsed, 4))
 
     # ---- the precision ladder: the same window in the other compute modes (rank 0, N = 1) ----
     ladder = {}
@@ -555,23 +559,16 @@ def main(argv=None):
             hvrnet_amd.set_compute_dtype(model, MODES[mode])
             n_m = max(2, min(args.steps, 5 if mode == 'f32' else 10))
             el_m, res_m, spans_m = timed(n_m, 1, tags=('relation_full', 'relation_key'))
-            row = dict(dtype=mode, what=MODE_WHAT[mode], single_lane=dict(frames_per_s=round(n_m / el_m, 3), ms_per_step=round(el_m / n_m * 1e3, 3), steps=n_m),
-                       roofline=roofline_of(mode, spans_m, 'the eager single-lane windows of this mode'))
+            row = dict(dtype=mode, single_lane=dict(frames_per_s=round(n_m / el_m, 3), ms_per_step=round(el_m / n_m * 1e3, 3), steps=n_m),
+                       roofline=roofline_of(mode, spans_m), kernel_classes=class_times(mode))
             if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
                 tg, res_g = graph_regions(args.lanes, n_m, 2, 1)
-                row['graph_replay'] = dict(frames_per_s=round(n_m / tg[0], 3), ms_per_step=round(tg[0] / n_m * 1e3, 3), steps=n_m, lanes=args.lanes,
-                                           what='the headline\'s launch mode: hipGraph replay, %d windows in flight' % args.lanes)
+                row['graph_replay'] = dict(frames_per_s=round(n_m / tg[0], 3), ms_per_step=round(tg[0] / n_m * 1e3, 3), steps=n_m, lanes=args.lanes)
                 row['_res'] = res_g
             else:
                 row['_res'] = res_m
             ladder[mode] = row
         hvrnet_amd.set_compute_dtype(model, dt)
-    f32_leg = None
-    if 'f32' in ladder:
-        f32_leg = dict(frames_per_s=ladder['f32']['single_lane']['frames_per_s'], ms_per_step=ladder['f32']['single_lane']['ms_per_step'],
-                       steps=ladder['f32']['single_lane']['steps'], dtype='f32', roofline=ladder['f32']['roofline'],
-                       what='the same clip-mode window with f32 operands on the exact-f32 MFMA (eager, one lane): see precision_ladder')
-
     ref_loop_fps = cached_loop_fps = overlap2_fps = None
     n_loop = max(3, min(args.steps, 10))
     if not args.no_side_loops:
@@ -647,9 +644,7 @@ def main(argv=None):
         sync()
         el = time.perf_counter() - tg
         graphed_clip = dict(frames_per_s_per_gpu=round(ng / el, 3), ms_per_step=round(el / ng * 1e3, 3), steps=ng,
-                            same_detections=same_detections(res_graph, res),
-                            what='the headline window (clip mode, all T frames) replayed as ONE hipGraph per window, two graphs in turn '
-                                 'so that window i + 1 is enqueued before window i is read')
+                            same_detections=same_detections(res_graph, res))
         del gc
         # stream mode: one new frame per output frame, per-frame cache, graph F (frame arrives) + graph W (window emitted)
         gs = GraphedStream(model, frames[0:1], metas[0], rescale=True)
@@ -671,9 +666,7 @@ def main(argv=None):
         el = time.perf_counter() - tg
         gf = 650.0 if args.head == 'hvr' else 504.0
         graphed_stream = dict(frames_per_s_per_gpu=round(nsg / el, 2), ms_per_frame=round(el / nsg * 1e3, 3), steps=nsg,
-                              tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
-                              what='tools/test.py steady state with the per-frame cache as two hipGraphs: one new frame through backbone / '
-                                   'res5 / RPN / RoIAlign / fc_new_1 per output frame + relation stages and read-out on the T cached entries')
+                              tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4))
         # the same loop pipelined: frame i + 1's per-frame part (graph FC on a second stream) runs beside window i's relation
         # stages and read-out; one frame arrives per output frame, nothing is batched
         gs.push_async(frames[0:1])
@@ -696,10 +689,7 @@ def main(argv=None):
         sync()
         el = time.perf_counter() - tg
         graphed_stream['pipelined'] = dict(frames_per_s_per_gpu=round(nsg / el, 2), ms_per_frame=round(el / nsg * 1e3, 3), steps=nsg,
-                                           tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
-                                           what='the same loop with frame i + 1 going through backbone / res5 / RPN / RoIAlign / fc_new_1 on a '
-                                                'second HIP stream while window i runs its relation stages and read-out (push_async / commit; '
-                                                'identical detections, tests/test_graphs_gpu.py); still one new frame per output frame')
+                                           tflops=round(nsg / el * gf / 1e3, 1), frac_mfma_peak=round(nsg / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4))
         del gs
         # the same loop with look-ahead batches (offline video: T frames through the per-frame part at once, then one output frame
         # at a time): what a single 600x1000 frame cannot give the chip -- 2 394 stride-16 rows are 17-19 row tiles for 256 CUs
@@ -725,19 +715,15 @@ def main(argv=None):
         el = time.perf_counter() - tg
         graphed_stream['lookahead'] = dict(frames_per_s_per_gpu=round(nb * T / el, 2), ms_per_frame=round(el / (nb * T) * 1e3, 3), batch=T,
                                            steps=nb * T, tflops=round(nb * T / el * gf / 1e3, 1),
-                                           frac_mfma_peak=round(nb * T / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4),
-                                           what='the same loop with the per-frame part run on look-ahead batches of T frames (identical '
-                                                'detections, tests/test_graphs_gpu.py); one window emitted per frame')
+                                           frac_mfma_peak=round(nb * T / el * gf / 1e3 / MFMA_PEAK_TF[args.dtype], 4))
         del gl
         type(model).frame_groups = groups0
 
     # per-class breakdown from one extra, fully instrumented window (outside the timed region)
-    native.profile_begin(tags=('*',))
-    step()
-    classes = native.profile_end()
+    kc = class_times(args.dtype)
     if args.breakdown and rank == 0:
         native.profile_begin(tags=('*',), detail=True)
-        step()
+        step().result()
         for tag, d in sorted(native.profile_end().items(), key=lambda kv: -kv[1]['ms']):
             rate = d['work'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
             sys.stderr.write('%-44s calls %3d  %8.3f ms  %8.1f T(FLOP|B)/s\n' % (tag, d['calls'], d['ms'], rate))
@@ -745,20 +731,13 @@ def main(argv=None):
     ar = allreduce_leg(dist, world, args.head, dev) if world > 1 else None
 
     if rank == 0:
+        # The line is ordered for a reader of its first kilobytes: the contract keys, then the figure that carries north_star's tolerance
+        # (`within_tolerance`), the steering figure (`single_lane`), `roofline`, `cpu_baseline`, the ladder; side loops last.  What each
+        # key means is in README.md ("Reading the bench line"); the line itself carries numbers.
         branch = res[-1] if args.head == 'hvr' else res
         n_det = int(sum(len(r) for r in branch))
         peak = MFMA_PEAK_TF[args.dtype]
-        roofline = roofline_of(args.dtype, rel, where_eager)
-        kc = {}
-        for tag, d in classes.items():
-            e = dict(calls=d['calls'], ms=round(d['ms'], 4))
-            if tag in ('gemm', 'conv', 'stem', 'relation_full', 'relation_key') and d['ms'] > 0:
-                e['tflops'] = round(d['work'] / (d['ms'] * 1e-3) / 1e12, 2)
-                e['frac_mfma_peak'] = round(e['tflops'] / peak, 4)
-            elif d['ms'] > 0:
-                e['gbs'] = round(d['work'] / (d['ms'] * 1e-3) / 1e9, 1)
-                e['frac_hbm_peak'] = round(e['gbs'] / HBM_PEAK_GBS, 4)
-            kc[tag] = e
+        roofline = roofline_of(args.dtype, rel)
         out = dict(metric='VID frames/sec, R101 Faster-RCNN+%s, 1000x600, %d props, T=%d' % (args.head.upper(), n_prop, T),
                    value=round(world * args.steps / elapsed, 3), unit='frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
@@ -766,30 +745,80 @@ def main(argv=None):
                    config=dict(workload='configs[2]: faster_rcnn_r101_hrnmp_c5 inference, clip mode' if args.head == 'hvr'
                                else 'configs[1]: faster_rcnn_r101_selsa_c5 inference, clip mode',
                                frames_per_window=T, proposals_per_frame=n_prop, input='3x600x1000 padded to 608x1008',
-                               mode='clip (all T frames through backbone+res5+RPN+RoIAlign+head every step)',
                                parallelism='dp%d independent clips, no collectives' % world, windows_in_flight=n_lanes, launch=headline_mode,
-                               key_frame_detections=n_det),
-                   value_spread=value_spread, roofline=roofline, kernel_classes=kc, gpus_requested=args.gpus,
-                   per_rank=[dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)],
-                   rccl_world_size=(dist.get_world_size() if world > 1 else 1))
+                               key_frame_detections=n_det))
+        want = None
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, want = (cpu_baseline_quick(args.head, T, n_prop, sd) if args.quick else cpu_baseline_full(args.head, T, n_prop, sd, frame_ids))
+        # ---- the precision ladder: every compute mode's throughput next to how far its detections are from the CPU reference path ----
+        head_row = dict(dtype=args.dtype, headline=True, single_lane=dict(frames_per_s=single_lane['frames_per_s'], ms_per_step=single_lane['ms_per_step'],
+                                                                         steps=args.steps), roofline=roofline, kernel_classes=kc)
+        if headline_mode.startswith('hipGraph'):
+            head_row['graph_replay'] = dict(frames_per_s=out['value'], ms_per_step=out['ms_per_step'], steps=args.steps, lanes=n_lanes)
+        head_row['_res'] = res
+        rows = [head_row] + list(ladder.values())
+        for row in rows:
+            if want is not None:
+                row['parity'] = parity_object(args.head, row['dtype'], row.pop('_res'), want)
+                row['within_tolerance'] = within_tolerance(row['parity'])
+            else:
+                row.pop('_res', None)
+        ok = [r for r in rows if r.get('within_tolerance')]
+        if ok:
+            best = max(ok, key=lambda r: (r.get('graph_replay') or r['single_lane'])['frames_per_s'])
+            fig = best.get('graph_replay') or best['single_lane']
+            out['within_tolerance'] = dict(dtype=best['dtype'], frames_per_s=fig['frames_per_s'], ms_per_step=fig['ms_per_step'],
+                                           lanes=fig.get('lanes', 1), single_lane_frames_per_s=best['single_lane']['frames_per_s'],
+                                           roofline=best['roofline'],
+                                           parity=dict(class_flips=best['parity']['class_flips'], max_score_err=best['parity']['max_score_err'],
+                                                       max_box_err=best['parity']['max_box_err']),
+                                           tolerance=dict(class_flips=0, score=TOL_SCORE, box_px=round(TOL_BOX_PX, 6)))
+        elif want is not None:
+            out['within_tolerance'] = None
         out['single_lane'] = single_lane
+        out['roofline'] = roofline
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+        out['value_spread'] = value_spread
+        if want is not None:
+            pr = head_row['parity']
+            out['parity'] = dict(dtype=pr['dtype'], class_flips=pr['class_flips'], max_score_err=pr['max_score_err'], max_box_err=pr['max_box_err'],
+                                 detections=pr['detections'], same_class_frac=pr['matched']['same_class_frac'], within_tolerance=head_row['within_tolerance'])
+        if ladder or want is not None:
+            # one compact row per compute mode: eager = [frames/s, ms] of the single-lane loop, replay = [frames/s, ms, lanes] of the
+            # headline's launch mode, kernel_classes = class -> [ms, fraction of that mode's MFMA peak or of the HBM peak]
+            def compact(r):
+                c = dict(dtype=r['dtype'], eager=[r['single_lane']['frames_per_s'], r['single_lane']['ms_per_step']])
+                if r.get('headline'):
+                    c['headline'] = True
+                if 'graph_replay' in r:
+                    c['replay'] = [r['graph_replay']['frames_per_s'], r['graph_replay']['ms_per_step'], r['graph_replay']['lanes']]
+                rf = r.get('roofline')
+                c['roofline'] = dict(bound='mfma', achieved=rf['achieved'], peak=rf['peak'], unit=rf['unit'], frac=rf['frac'], avg_ms=rf['avg_ms']) if rf else None
+                if 'parity' in r:
+                    pr = r['parity']
+                    c['parity'] = dict(class_flips=pr['class_flips'], max_score_err=pr['max_score_err'], max_box_err=pr['max_box_err'],
+                                       same_class_frac=pr['matched']['same_class_frac'])
+                    c['within_tolerance'] = r['within_tolerance']
+                c['kernel_classes'] = {t: [e['ms'], e['frac']] for t, e in r['kernel_classes'].items()}
+                return c
+            out['precision_ladder'] = [compact(r) for r in rows]
+        out['kernel_classes'] = kc
+        out['gpus_requested'] = args.gpus
+        out['per_rank'] = [dict(rank=i, frames_per_s=round(args.steps / t_, 3)) for i, t_ in enumerate(per_rank)]
+        out['rccl_world_size'] = dist.get_world_size() if world > 1 else 1
         prop = torch.cuda.get_device_properties(dev)
-        out['device'] = dict(name=prop.name, cus=prop.multi_processor_count, hbm_gb=round(prop.total_memory / 2 ** 30, 1),
-                             note='boxes of this pool differ by up to 7 % on the same build (single_lane 137-149 frames/s)')
-        if f32_leg is not None:
-            out['f32_parity_mode'] = f32_leg
+        out['device'] = dict(name=prop.name, cus=prop.multi_processor_count, hbm_gb=round(prop.total_memory / 2 ** 30, 1))
+        out['lib_sha16'] = lib_sha16()
         if ref_loop_fps is not None:
-            out['ref_loop'] = dict(frames_per_s_per_gpu=round(ref_loop_fps, 2), steps=n_loop,
-                                   what='tools/test.py steady state: 1 new backbone frame + res5/RPN/RoIAlign/head on all T per output frame')
+            out['ref_loop'] = dict(frames_per_s_per_gpu=round(ref_loop_fps, 2), steps=n_loop)
             # ~650 GF (HVR) / 504 GF (SELSA) per output frame with the per-frame cache (SURVEY.md 8d "stream mode")
             gf = 650.0 if args.head == 'hvr' else 504.0
             out['cached_loop'] = dict(frames_per_s_per_gpu=round(cached_loop_fps, 2), steps=n_loop,
-                                      tflops=round(cached_loop_fps * gf / 1e3, 1), frac_mfma_peak=round(cached_loop_fps * gf / 1e3 / peak, 4),
-                                      what='the same loop with per-frame caching of res5/RPN/RoIAlign/fc_new_1 (identical detections); '
-                                           '%.0f GF per output frame' % gf)
+                                      tflops=round(cached_loop_fps * gf / 1e3, 1), frac_mfma_peak=round(cached_loop_fps * gf / 1e3 / peak, 4))
         if overlap2_fps is not None:
-            out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2),
-                                        what='clip mode, two independent windows in flight on two HIP streams (--inflight 2)')
+            out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2))
         if graphed_clip is not None:
             out['graphed_clip'] = graphed_clip
             out['graphed_stream'] = graphed_stream
@@ -800,51 +829,18 @@ def main(argv=None):
                                                       share_if_not_overlapped=round(ar['ms'] / (step_ms + ar['ms']), 4),
                                                       est_ring_share=round(ar['est_ring_one_link_ms'] / (step_ms + ar['est_ring_one_link_ms']), 4))
             out['train_allreduce'] = ar
-        if world == 1 and not args.no_cpu_baseline:
-            if args.quick:
-                out['cpu_baseline'], want = cpu_baseline_quick(args.head, T, n_prop, sd)
-            else:
-                out['cpu_baseline'], want = cpu_baseline_full(args.head, T, n_prop, sd, frame_ids)
-            if want is not None:
-                out['parity'] = parity_object(args.head, args.dtype, res, want)
-                for row in ladder.values():
-                    row['parity'] = parity_object(args.head, row['dtype'], row['_res'], want)
-                if f32_leg is not None:
-                    out['f32_parity_mode']['parity'] = ladder['f32']['parity']
-        # the precision ladder: every compute mode's throughput next to how far its detections are from the CPU reference path
-        # (north_star: class indices exact, scores / boxes within 1e-3)
-        if ladder or 'parity' in out:
-            head_row = dict(dtype=args.dtype, what=MODE_WHAT[args.dtype], single_lane=dict(frames_per_s=single_lane['frames_per_s_per_gpu'],
-                                                                                          ms_per_step=single_lane['ms_per_step'], steps=args.steps),
-                            roofline=roofline, headline=True)
-            if headline_mode.startswith('hipGraph'):
-                head_row['graph_replay'] = dict(frames_per_s=out['value'], ms_per_step=out['ms_per_step'], steps=args.steps, lanes=n_lanes)
-            if 'parity' in out:
-                head_row['parity'] = out['parity']
-            rows = [head_row] + [{k: v for k, v in row.items() if k != '_res'} for row in ladder.values()]
-            for row in rows:
-                pr = row.get('parity')
-                if pr is not None:
-                    row['meets_north_star_tolerance'] = bool(pr['class_flips'] == 0 and pr['max_score_err'] < 1e-3 and pr['max_box_err'] < 1e-3 + 1e-5 * 1000.0)
-            out['precision_ladder'] = dict(
-                tolerance='north_star: class indices exact (class_flips = 0), scores within 1e-3, box coordinates within 1e-3 px (+ 1e-5 '
-                          'relative: the f32 ulp at 1000 px is 6e-5) of oracle.clip_forward on the same frames, final branch',
-                rows=rows)
-            ok = [r for r in rows if r.get('meets_north_star_tolerance')]
-            if ok:
-                best = max(ok, key=lambda r: (r.get('graph_replay') or r['single_lane'])['frames_per_s'])
-                out['precision_ladder']['fastest_mode_within_tolerance'] = dict(dtype=best['dtype'],
-                                                                                frames_per_s=(best.get('graph_replay') or best['single_lane'])['frames_per_s'])
         if world == 1 and not args.no_graphs and args.inflight == 1 and out.get('graphed_stream'):
             # (after everything else: the child shares the GPU with nothing of this process that is still running)
             ss = stream_side_measurement(args.head)
             if ss is not None:
+                ss.pop('metric', None)
+                (ss.get('rpn_proposals_one_frame') or {}).pop('what', None)
                 out['graphed_stream']['pipelined_window_cus'] = ss
         if world == 1 and not args.no_train_step:
             ts = train_step_side_measurement(args.head)
             if ts is not None:
                 out['train_step'] = ts
-        print(json.dumps(out))
+        print(json.dumps(out, separators=(',', ':')))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -463,13 +463,11 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
 template <typename T, int FM0, int FM1>
 static hipError_t launch_bigtile(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = (FM0 + FM1) * 16, lds = 2 * (BM + BG_BN) * 128;
-  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr_set = attr_set_dev[current_device()];
   auto kern = big_tile_kernel<T, FM0, FM1>;
-  if (!attr_set) {
+  static std::atomic<unsigned> attr_set_dev{0};   // (the attribute is per device)
+  per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BG_BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(BG_NT), lds, stream, p);
   return hipGetLastError();

@@ -1,6 +1,7 @@
 // Shared device helpers for the hvr_hip kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <utility>
 #include <type_traits>
 #include <stdint.h>
@@ -171,12 +172,18 @@ __device__ __forceinline__ float quad_group_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// one-time per-device kernel attribute setup (hipFuncSetAttribute is per device: a process driving several GPUs needs it on each)
-constexpr int kMaxDevices = 16;
-inline int current_device() {
-  int d = 0;
+// One-time per-device kernel attribute setup (hipFuncSetAttribute is per device: a process driving several GPUs needs it on each).
+// `done` holds one bit per device 0..31; a device beyond that has no bit and runs the setup on every launch instead of borrowing
+// another device's (an aliased slot would leave it without its attribute).  Two threads that race on a fresh device both run the
+// setup (it is idempotent) -- neither launches before its own call has returned.
+constexpr int kMaxDevices = 32;
+template <typename F> inline void per_device_once(std::atomic<unsigned>& done, F&& setup) {
+  int d = -1;
   (void)hipGetDevice(&d);
-  return d >= 0 && d < kMaxDevices ? d : 0;
+  const bool slot = d >= 0 && d < kMaxDevices;
+  if (slot && (done.load(std::memory_order_acquire) & (1u << d))) return;
+  setup();
+  if (slot) done.fetch_or(1u << d, std::memory_order_release);
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})

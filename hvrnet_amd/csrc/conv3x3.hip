@@ -202,13 +202,11 @@ hipError_t run_conv3x3_c64(const GemmParams& g, hipStream_t stream) {
   p.H = g.H; p.W = g.W; p.B = g.M / (g.H * g.W); p.relu = g.relu;
   p.tiles_x = (g.W + C3_T - 1) / C3_T; p.tiles_y = (g.H + C3_T - 1) / C3_T;
   p.ntiles = p.B * p.tiles_x * p.tiles_y;
-  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr_set = attr_set_dev[current_device()];
-  if (!attr_set) {
+  static std::atomic<unsigned> attr_set_dev{0};   // (the attribute is per device)
+  per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
-    attr_set = true;
-  }
+  });
   const int grid = p.ntiles < 256 ? p.ntiles : 256;
   if (g.dtype == DT_F16) hipLaunchKernelGGL(conv3x3_c64_kernel<f16_t>, dim3(grid), dim3(C3_NT), C3_LDS, stream, p);
   else hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, dim3(grid), dim3(C3_NT), C3_LDS, stream, p);

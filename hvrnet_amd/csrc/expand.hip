@@ -376,13 +376,11 @@ static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
   constexpr int RF = KF > 8 ? 1 : 2;
   constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4 + 2 * NX * 16 * 128;  // two W chunks + shifts (+ two Wn chunks)
   static_assert(lds <= (RF == 2 ? 80 : 160) * 1024, "two workgroups per CU (one with 8 waves at K = 512)");
-  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr_set = attr_set_dev[current_device()];
   auto kern = expand_res_kernel<T, KF, RES, NC, RF, NX>;
-  if (!attr_set) {
+  static std::atomic<unsigned> attr_set_dev{0};   // (the attribute is per device)
+  per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(kern, dim3((p.M + X_BM - 1) / X_BM, p.N / X_BN / NC), dim3(64 * (X_BM / 16 / RF)), lds, stream, p);
   return hipGetLastError();
 }

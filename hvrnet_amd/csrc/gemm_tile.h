@@ -1112,12 +1112,10 @@ static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds = stage > epi ? stage : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = tile_kernel<T, WM, WN, FM, FN, EPI, GLDS, RESPRE, NS>;
-  static bool attr_set[kMaxDevices] = {};   // the attribute is per device
-  const int dev = current_device();
-  if (!attr_set[dev]) {
+  static std::atomic<unsigned> attr_set{0};   // (the attribute is per device)
+  per_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set[dev] = true;
-  }
+  });
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();

@@ -10,6 +10,7 @@
 // Integer / index work: bit-exact against the CPU reference semantics.  Tie rule (unspecified in the
 // reference, which relies on torch.sort/topk): higher score first, then lower index.
 #include <cstdlib>
+#include <atomic>
 #include "common.h"
 #include "gemm_params.h"
 
@@ -1399,21 +1400,17 @@ hipError_t run_nms_batched(const float* dets, int P, int n, float thr, int ge, i
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
   const int nb = (n + 63) / 64;
-  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr = attr_dev[current_device()];
-  if (!attr) {
+  static std::atomic<unsigned> attr_dev{0};   // (the attribute is per device)
+  per_device_once(attr_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
-    attr = true;
-  }
+  });
   // a small survivor cap (the RPN's nms_post): the greedy kernel prices max_keep x n IoUs instead of n^2 / 2
   static const bool no_greedy = std::getenv("HVR_NMS_MASK") != nullptr;
   if (max_keep > 0 && max_keep <= 1024 && !no_greedy) {
-    static bool gattr_dev[kMaxDevices] = {};
-    bool& gattr = gattr_dev[current_device()];
-    if (!gattr) {
+    static std::atomic<unsigned> gattr_dev{0};   // (the attribute is per device)
+    per_device_once(gattr_dev, [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      gattr = true;
-    }
+    });
     if (!presorted) hipLaunchKernelGGL(nms_sort_kernel, dim3(P), dim3(1024), (size_t)np2 * 8, s, dets, n, 0, order, boxes4);
     const int* skip = nullptr;
     if (band > 0 && presorted && band_done) {
@@ -1440,13 +1437,11 @@ hipError_t run_rpn_select(const void* cls, const void* reg, long cls_stride, lon
   while (kp2 < rp.npre) kp2 <<= 1;
   if (kp2 > 8192) return hipErrorInvalidValue;
   const size_t lds = (size_t)kp2 * 8;
-  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr = attr_dev[current_device()];
-  if (!attr) {
+  static std::atomic<unsigned> attr_dev{0};   // (the attribute is per device)
+  per_device_once(attr_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_select_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_select_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
-    attr = true;
-  }
+  });
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(rpn_select_kernel<bf16_t>, dim3(rp.T), dim3(1024), lds, s, (const bf16_t*)cls, (const bf16_t*)reg, cls_stride, reg_stride, out, rp);
   else
@@ -1461,13 +1456,13 @@ size_t rpn_wide_workspace_bytes(int T, long n_anchor) {
 }
 // calls with at most this many frames take the chip-wide kernels (HVR_RPN_WIDE=<frames>, 0 = never)
 int rpn_wide_max_frames(int set) {
-  static int v = [] {
+  // process-wide (include/hvr_hip.h says so): an atomic, so that a thread changing it never tears a concurrent call's read; a call
+  // reads it once, and a captured graph keeps the form that was selected at capture time
+  static std::atomic<int> v([] {
     const char* e = std::getenv("HVR_RPN_WIDE");
     return e ? std::atoi(e) : 4;
-  }();
-  const int prev = v;
-  if (set >= 0) v = set;
-  return prev;
+  }());
+  return set >= 0 ? v.exchange(set, std::memory_order_relaxed) : v.load(std::memory_order_relaxed);
 }
 int* rpn_wide_done_flags(void* wws, int T) {
   return (int*)((char*)wws + al256((size_t)T * WBINS * 4 * 2) + al256((size_t)T * WBINS * 4) + al256((size_t)T * 16));
@@ -1522,12 +1517,10 @@ hipError_t run_multiclass_nms(const float* boxes, const float* scores, int R, in
   if (max_num >= (ncls - 1) * R || (size_t)np2 * 8 + (size_t)sp2 * 8 > 160 * 1024 - 3072) sp2 = 0;
   const size_t lds = (size_t)np2 * 8 + (size_t)sp2 * 8;
   if (lds > 160 * 1024 - 3072) return hipErrorInvalidValue;
-  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr = attr_dev[current_device()];
-  if (!attr) {
+  static std::atomic<unsigned> attr_dev{0};   // (the attribute is per device)
+  per_device_once(attr_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mc_nms_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 3072);
-    attr = true;
-  }
+  });
   hipLaunchKernelGGL(mc_nms_merge_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, R, ncls, keepflag, kcount, max_num, sp2, dets, labels, n_out);
   return hipGetLastError();
 }

@@ -424,13 +424,11 @@ static hipError_t launch_pc(const GemmParams& p, hipStream_t stream) {
   constexpr size_t ring = EPI == EPI_APPLY ? (size_t)160 * 1024 : (size_t)NS * (PC_BM + BN) * 128, epi = (size_t)PC_BM * (BN + 4) * 4;
   constexpr size_t lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr_set = attr_set_dev[current_device()];
   auto kern = pc_tile_kernel<T, FN, EPI, NS>;
-  if (!attr_set) {
+  static std::atomic<unsigned> attr_set_dev{0};   // (the attribute is per device)
+  per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   const int tiles = ((p.M + PC_BM - 1) / PC_BM) * ((p.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(PC_NT), lds, stream, p);
   return hipGetLastError();

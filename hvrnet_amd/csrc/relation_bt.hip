@@ -463,13 +463,11 @@ bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, lo
 }
 
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
-  static bool attr_set_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr_set = attr_set_dev[current_device()];
-  if (!attr_set) {
+  static std::atomic<unsigned> attr_set_dev{0};   // (the attribute is per device)
+  per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
-    attr_set = true;
-  }
+  });
   const int ntiles = ((p.Mq + BT_BM - 1) / BT_BM) * (int)((p.ldp + BT_BN - 1) / BT_BN);
   ScoresBTParams q = p;
   for (int t0 = 0; t0 < ntiles; t0 += 256) {

@@ -266,21 +266,17 @@ hipError_t run_stem_fused(const float* img, const void* wpk, const float* bias, 
   const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
   const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
   constexpr int lds = ST_PATCH_BYTES + ST_CONV_BYTES;
-  static bool attr_dev[kMaxDevices] = {};  // (the attribute is per device)
-  bool& attr = attr_dev[current_device()];
-  if (!attr) {
+  static std::atomic<unsigned> attr_dev{0};   // (the attribute is per device)
+  per_device_once(attr_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
-  }
+  });
   dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
   if (dtype == DT_F16S) {
-    static bool sattr_dev[kMaxDevices] = {};
-    bool& sattr = sattr_dev[current_device()];
-    if (!sattr) {
+    static std::atomic<unsigned> sattr_dev{0};   // (the attribute is per device)
+    per_device_once(sattr_dev, [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fused_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_SPLIT_LDS);
-      sattr = true;
-    }
+    });
     hipLaunchKernelGGL(stem_fused_split_kernel, grid, dim3(256), ST_SPLIT_LDS, s, img, (const uint4*)wpk, bias, (char*)out, H, W, CH, CW, PH, PW);
     return hipGetLastError();
   }

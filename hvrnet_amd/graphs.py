@@ -423,9 +423,13 @@ class GraphedStream(object):
     def push(self, frame=None):
         """A new frame arrives: graph F (its rows enter the window buffers)."""
         _check_live(self)
-        with self._window_stream():
+        with self._window_stream() as st:
             if frame is not None:
                 self.frame.copy_(frame, non_blocking=True)
+                if frame.is_cuda and self.window_cus:
+                    # the copy runs on the confined window stream, not on the stream `frame` was made on: a temporary handed in
+                    # (push(decode())) must outlive it.  (A caller that REWRITES the same tensor must order that write itself.)
+                    frame.record_stream(st)
             self.graph_f.replay()
             self._hist = (self._hist + [self.frame.clone()])[-self.T:]
 
@@ -440,6 +444,8 @@ class GraphedStream(object):
         _check_live(self)
         with torch.cuda.stream(self._fstream):
             self.frame_nxt.copy_(frame, non_blocking=True)
+            if frame.is_cuda:
+                frame.record_stream(self._fstream)   # the caller may drop or recycle `frame` before the copy has run on the frame stream
             self._pending_frame = self.frame_nxt.clone()   # (on the frame stream: nothing of the loop is enqueued on the caller's)
             self.graph_fc.replay()
             self._ev_fc.record(self._fstream)

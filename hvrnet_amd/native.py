@@ -338,6 +338,10 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
                  dtype=_dt(a), staging=STAGING if staging is None else staging,
                  tile_hint=TILE_HINT if tile is None else tile)
     if a.dtype == SPLIT:
+        if resid is not None and out.dtype == torch.float32:
+            # a split residual is stored x SPLIT_ACT_SCALE and the epilogue adds it as it is: right for a scaled split output, 16 x
+            # too much beside a true-valued f32 one
+            raise HvrError('split-half gemm: a residual cannot be combined with an f32 output (the residual carries the activation scale)')
         d.alpha, d.beta = _split_factors(out.dtype == torch.float32, alpha)
     nbytes = lib().hvr_gemm_fewrow_workspace_bytes(ctypes.byref(d)) if _fewrow[0] else 0   # few rows, long K: K slices + one reduce launch
     if nbytes:
@@ -389,6 +393,8 @@ def conv2d_nhwc(x, w, bias=None, resid=None, relu=False, stride=1, pad=0, dil=1,
                  staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile,
                  zero=zero_page(x.device).data_ptr())
     if x.dtype == SPLIT:
+        if resid is not None and out_f32:
+            raise HvrError('split-half conv: a residual cannot be combined with an f32 output (the residual carries the activation scale)')
         d.alpha, d.beta = _split_factors(bool(out_f32), alpha)
     # few-row problems (one frame through the stride-16 stages): the library cuts the K loop into slices when it is handed
     # scratch for the f32 partial tiles (per stream, like every other workspace here)

@@ -25,7 +25,9 @@
  *       HVR_F32   exact f32 (v_mfma_f32_16x16x4_f32, 1/16 of the half rate): the parity mode.
  *     The reference computes in f32 (no fp16 key in configs/faster_rcnn_r101_{selsa,hrnmp}_c5.py); its optional
  *     mixed-precision islands are mmdet/core/fp16/decorators.py:9-160.
- *   - re-entrant, no global mutable state besides one-time kernel attribute setup.
+ *   - re-entrant; the only global mutable state is the one-time per-device kernel attribute setup (atomic, idempotent) and ONE
+ *     process-wide tuning knob, hvr_rpn_wide_frames (an atomic int: which of two bit-identical kernel forms hvr_rpn_proposals
+ *     launches; a captured graph keeps the form chosen at capture time).
  */
 #ifndef HVR_HIP_H_
 #define HVR_HIP_H_
@@ -297,7 +299,8 @@ size_t hvr_rpn_workspace_bytes(int T, int H, int W, int A, int nms_pre);
 int hvr_rpn_proposals(const hvr_rpn_desc* d, void* ws, size_t ws_bytes, void* stream);
 /* Calls with T <= frames take the chip-wide kernels (histogram / counting-sort selection, banded suppression mask + one-wave
  * sweep: many workgroups per frame) instead of one workgroup per frame; the proposals are the same bit for bit.  Default 4
- * (HVR_RPN_WIDE=<frames> in the environment overrides it; 0 = never).  frames < 0 only queries.  Returns the previous value. */
+ * (HVR_RPN_WIDE=<frames> in the environment overrides it; 0 = never).  frames < 0 only queries.  Returns the previous value.
+ * PROCESS-WIDE (an atomic): every thread and device of the process sees the new value from its next call on. */
 int hvr_rpn_wide_frames(int frames);
 
 /* ------------------------------------------------------------------------------------

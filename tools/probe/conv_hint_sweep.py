@@ -25,7 +25,9 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad, dil, resid
     ('l2.conv2 3x3 128', 76, 126, 128, 128, 3, 1, 1, 1, False), ('l2.conv3 128->512 +res', 76, 126, 128, 512, 1, 1, 0, 1, True),
     ('l3.conv1 1024->256', 38, 63, 1024, 256, 1, 1, 0, 1, False), ('l3.conv2 3x3 256', 38, 63, 256, 256, 3, 1, 1, 1, False),
     ('l3.conv3 256->1024 +res', 38, 63, 256, 1024, 1, 1, 0, 1, True), ('res5.conv2 3x3 512 d2', 38, 63, 512, 512, 3, 1, 2, 2, False),
-    ('res5.conv3 512->2048 +res', 38, 63, 512, 2048, 1, 1, 0, 1, True), ('rpn 3x3 1024->512', 38, 63, 1024, 512, 3, 1, 1, 1, False)]
+    ('res5.conv3 512->2048 +res', 38, 63, 512, 2048, 1, 1, 0, 1, True), ('rpn 3x3 1024->512', 38, 63, 1024, 512, 3, 1, 1, 1, False),
+    ('res5.conv1 2048->512', 38, 63, 2048, 512, 1, 1, 0, 1, False), ('res5.ds 1024->2048', 38, 63, 1024, 2048, 1, 1, 0, 1, False),
+    ('res5.ext 2048->256', 38, 63, 2048, 256, 1, 1, 0, 1, False)]
 g = torch.Generator(device='cuda').manual_seed(0)
 for name, H, W, Cin, Cout, k, st, pad, dil, res in SHAPES:
     x = native.as_operand(torch.randn((B, H, W, Cin), device='cuda', generator=g), DT)

@@ -180,6 +180,15 @@ class Bottleneck(nn.Module, PackedMixin):
             wn, bn = pn['c1'][0].reshape(pn['c1'][0].shape[0], -1), pn['c1'][1]
             if self.downsample is not None:
                 args = (out, x, None, p['tail'][0], p['tail'][1], self.stride) if self.fuse_tail else None
+                if x.dtype == native.SPLIT:
+                    # split half has no second-K-segment tail: the projection is its own conv and enters the fused closing 1x1 +
+                    # next conv1 as the residual (the identity form of hvr_bottleneck_tail_next)
+                    ident = native.conv2d_nhwc(x, p['ds'][0], p['ds'][1], relu=False, stride=self.stride)
+                    w3, b3 = p['c3'][0].reshape(p['c3'][0].shape[0], -1), p['c3'][1]
+                    if native.bottleneck_tail_next_supported(out, None, ident, w3, b3, 1, wn, bn):
+                        return native.bottleneck_tail_next(out, None, ident, w3, b3, wn, bn, out=dst)
+                    y = native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=ident, relu=True, out=dst)
+                    return y, None
             else:
                 args = (out, None, x, p['c3'][0].reshape(p['c3'][0].shape[0], -1), p['c3'][1], 1)
             if args is not None and native.bottleneck_tail_next_supported(*args, wn, bn):

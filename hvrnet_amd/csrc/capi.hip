@@ -96,7 +96,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" {
 
-int hvr_abi_version(void) { return 3; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S
+int hvr_abi_version(void) { return 4; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta
 const char* hvr_last_error(void) { return g_err.c_str(); }
 
 static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
@@ -298,7 +298,7 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
     q.tile_hint = 0;
     big_first = bigtile_supported(q, p.tile_hint == kBigHint);
   }
-  path = (pointwise && expand_supported(p) &&
+  path = (pointwise && (expand_supported(p) || expand_split_supported(p)) &&
           (p.tile_hint == kExpandHint || (hint0 && use_expand && p.resid && p.N >= 2 * p.K && !big_first))) ? 1 : 0;
   if (p.tile_hint == kExpandHint) p.tile_hint = 0;
   // layer 1's 3x3 (64 -> 64): persistent kernel with the weights resident in the LDS (conv3x3.hip)
@@ -321,7 +321,7 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   int path = 0;
   const int rc = conv_params(d, p, path);
   if (rc) return rc;
-  if (path == 1) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
+  if (path == 1) return check_launch(p.dtype == DT_F16S ? run_expand_split(p, (hipStream_t)stream) : run_expand(p, (hipStream_t)stream), "hvr_conv2d_nhwc(expand)");
   if (path == 2) return check_launch(run_conv3x3_c64(p, (hipStream_t)stream), "hvr_conv2d_nhwc(conv3x3_c64)");
   if (path == 0 && d->tile_hint == kBigForce) {
     if (!bigtile_supported(p, true)) return fail(HVR_EUNSUPPORTED, "the big-tile kernel takes bf16 convs with Cout %% 256 == 0 and Cin %% 64 == 0");
@@ -393,14 +393,19 @@ static int tail_next_params(const hvr_tail_next_desc* d, GemmParams& p) {
     const int rc = tail_params(&t, p);
     if (rc) return rc;
   } else {
-    if (t.dtype != HVR_BF16 && t.dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail_next takes bf16 or half operands");
+    if (t.dtype != HVR_BF16 && t.dtype != HVR_F16 && t.dtype != HVR_F16S)
+      return fail(HVR_EUNSUPPORTED, "hvr_bottleneck_tail_next takes bf16, half or (identity form) split-half operands");
     if (t.B <= 0 || t.OH <= 0 || t.OW <= 0) return fail(HVR_EINVAL, "empty tail problem");
     const long M = (long)t.B * t.OH * t.OW;
     if (M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output pixels");
     const int rc = fill_linear(p, t.h, t.w, t.y, (int)M, t.Cout, t.C1, t.C1, t.C1, t.Cout, t.dtype, 1);
     if (rc) return rc;
-    if (!d->resid || !aligned16(d->resid)) return fail(HVR_EINVAL, "an identity block needs its (16-byte aligned) residual map");
+    const bool split = t.dtype == HVR_F16S;
+    if (!d->resid || !(split ? aligned128(d->resid) : aligned16(d->resid)))
+      return fail(HVR_EINVAL, "an identity block needs its (16-byte aligned; split half: 128-byte aligned) residual map");
+    if (split && (t.Cout % 32 || !aligned128(t.y))) return fail(HVR_EINVAL, "split-half tail: Cout %% 32 == 0, 128-byte aligned y");
     p.bias = t.bias; p.relu = t.relu; p.resid = d->resid; p.ldr = t.Cout;
+    p.alpha = d->alpha; p.beta = d->beta;
   }
   if (!t.relu) return fail(HVR_EUNSUPPORTED, "the next block reads the activated output (relu = 1)");
   p.Wn = d->wn; p.bias_n = d->bias_n; p.Hn = d->hn; p.Cn = d->Cn;
@@ -410,13 +415,14 @@ static int tail_next_params(const hvr_tail_next_desc* d, GemmParams& p) {
 int hvr_bottleneck_tail_next_supported(const hvr_tail_next_desc* d) {
   GemmParams p;
   if (tail_next_params(d, p)) return 0;
-  return expand_next_supported(p) ? 1 : 0;
+  return (expand_next_supported(p) || expand_split_next_supported(p)) ? 1 : 0;
 }
 
 int hvr_bottleneck_tail_next(const hvr_tail_next_desc* d, void* stream) {
   GemmParams p;
   const int rc = tail_next_params(d, p);
   if (rc) return rc;
+  if (expand_split_next_supported(p)) return check_launch(run_expand_split(p, (hipStream_t)stream), "hvr_bottleneck_tail_next(split half)");
   if (!expand_next_supported(p))
     return fail(HVR_EUNSUPPORTED, "no fused tail + next conv kernel for C1=%d C2=%d Cout=%d Cn=%d", d->tail.C1, d->tail.C2, d->tail.Cout, d->Cn);
   return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail_next");

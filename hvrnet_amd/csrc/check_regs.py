@@ -16,7 +16,7 @@ def main(*paths):
     bad, seen = [], 0
     for b in blocks:
         name = b.split()[0]
-        if name.startswith('_ZN3hvr17expand_res_kernel'):   # expand.hip: sized for two workgroups per CU, a spill means it no longer fits
+        if name.startswith(('_ZN3hvr17expand_res_kernel', '_ZN3hvr19expand_split_kernel')):   # expand.hip: sized for two workgroups per CU, a spill means it no longer fits
             seen += 1
             spill = int(re.search(r'VGPRs Spill: (\d+)', b).group(1))
             scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', b).group(1))

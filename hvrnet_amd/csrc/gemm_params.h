@@ -80,6 +80,10 @@ bool conv3x3_c64_supported(const GemmParams& p);
 hipError_t run_conv3x3_c64(const GemmParams& p, hipStream_t stream);
 hipError_t run_expand(const GemmParams& p, hipStream_t stream);
 bool expand_next_supported(const GemmParams& p);
+// the same row-panel design on split-half operands (expand_split.hip): K = 64 / 128; with the next block's conv1 for stage 1 (N = 256, Cn = 64)
+bool expand_split_supported(const GemmParams& p);
+bool expand_split_next_supported(const GemmParams& p);
+hipError_t run_expand_split(const GemmParams& p, hipStream_t stream);
 // Producer / consumer tile kernel (pc_gemm.hip): 144 x 128 / 144 x 256 tiles, 4 compute + 4 DMA waves; EPI_LINEAR (plain
 // GEMM) and EPI_APPLY.  tile_hint kPcHint128 / kPcHint256 force it for a plain GEMM (tuning / tests)
 constexpr int kPcHint128 = kNumTileShapes + 2, kPcHint256 = kNumTileShapes + 3;

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, 'libhvr_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hvr_hip.h')
 
 HVR_F32, HVR_BF16, HVR_F16, HVR_F16S = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 # Split-half tensors (HVR_F16S, include/hvr_hip.h: [32 hi | 32 lo] half groups, 4 bytes per logical element) travel through
 # torch as int32 tensors of the LOGICAL shape: element size, strides, row / 32-column slicing, cat, clone and zeros all mean
 # the right thing on the container, and nothing but this library ever interprets the bytes.  `SPLIT` is the dtype sentinel
@@ -71,7 +71,7 @@ class TailDesc(ctypes.Structure):
 
 class TailNextDesc(ctypes.Structure):
     _fields_ = [('tail', TailDesc), ('resid', ctypes.c_void_p), ('wn', ctypes.c_void_p), ('bias_n', ctypes.c_void_p),
-                ('hn', ctypes.c_void_p), ('Cn', ctypes.c_int32)]
+                ('hn', ctypes.c_void_p), ('Cn', ctypes.c_int32), ('alpha', ctypes.c_float), ('beta', ctypes.c_float)]
 
 
 class RpnDesc(ctypes.Structure):
@@ -456,14 +456,20 @@ def _tail_next_desc(h, x, resid, w, bias, stride2, wn, bias_n, y, hn):
     else:
         t = TailDesc(h=h.data_ptr(), x=None, w=w.data_ptr(), y=y.data_ptr() if y is not None else ph, B=B, OH=OH, OW=OW, C1=C1,
                      H2=OH, W2=OW, C2=0, stride2=1, Cout=w.shape[0], bias=bias.data_ptr(), relu=1, dtype=_dt(h))
-    return TailNextDesc(tail=t, resid=resid.data_ptr() if resid is not None else None, wn=wn.data_ptr(), bias_n=bias_n.data_ptr(),
-                        hn=hn.data_ptr() if hn is not None else ph, Cn=wn.shape[0])
+    d = TailNextDesc(tail=t, resid=resid.data_ptr() if resid is not None else None, wn=wn.data_ptr(), bias_n=bias_n.data_ptr(),
+                     hn=hn.data_ptr() if hn is not None else ph, Cn=wn.shape[0])
+    if h.dtype == SPLIT:   # both products: scaled split activations x scaled split weights -> a scaled split activation
+        d.alpha, d.beta = _split_factors(False, None)
+    return d
 
 
 def bottleneck_tail_next_supported(h, x, resid, w, bias, stride2, wn, bias_n):
-    """True when hvr_bottleneck_tail_next runs these shapes: (Cout, Cn) = (256, 64) / (512, 128), bf16, contiguous maps."""
+    """True when hvr_bottleneck_tail_next runs these shapes: (Cout, Cn) = (256, 64) / (512, 128), bf16 / half, contiguous maps;
+    split half: the identity form (resid given, x None) with (Cout, Cn) = (256, 64)."""
     ts = [t for t in (h, x, resid) if t is not None]
-    if not all(t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.dtype == h.dtype and t.is_contiguous() for t in ts):
+    if not all(t.is_cuda and t.dtype in (torch.bfloat16, torch.float16, SPLIT) and t.dtype == h.dtype and t.is_contiguous() for t in ts):
+        return False
+    if h.dtype == SPLIT and (x is not None or wn.dtype != SPLIT or w.dtype != SPLIT):
         return False
     if (x is None) == (resid is None) or wn.dim() != 2 or wn.shape[1] != w.shape[0] or not wn.is_contiguous():
         return False

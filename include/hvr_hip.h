@@ -167,6 +167,8 @@ typedef struct hvr_tail_next_desc {
   const void* resid;
   const void* wn; const float* bias_n; void* hn;
   int32_t Cn;
+  float alpha, beta;   /* HVR_F16S only (identity form, tail.C2 == 0, (Cout, Cn) = (256, 64)): the factors of hvr_gemm_desc on BOTH
+                          products -- y = relu(alpha h W3^T + beta bias + resid), hn = relu(alpha y wn^T + beta bias_n); 0 = 1 */
 } hvr_tail_next_desc;
 int hvr_bottleneck_tail_next(const hvr_tail_next_desc* d, void* stream);
 int hvr_bottleneck_tail_next_supported(const hvr_tail_next_desc* d);

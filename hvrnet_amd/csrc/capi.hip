@@ -522,8 +522,10 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   int rc;
   static const int tile_scores_s = env_tile("HVR_TILE_SCORES_SPLIT"), tile_apply_s = env_tile("HVR_TILE_APPLY_SPLIT");   // tuning overrides
   if (dtype == HVR_F16S) {
-    // split half: probabilities (scores pass + one normalising sweep, both in the split format), V^T, then O = P V as a plain
-    // three-pass product -- no block weights inside a K loop whose accumulators change scale between passes
+    // split half: the scores pass (block-local maxima, P~ stored x 2^12 in the split format), V^T, then either one normalising sweep
+    // over P~ + a plain product, or the apply pass with the block weights g = 2^(m_t - m*) / L folded in per 128-key block
+    // (EPI_APPLY: a block is four split K-steps of three MFMAs, its un-scaled partial joins the running total by one FMA per
+    // accumulator register)
     rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
     if (rc) return rc;
     if (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
@@ -531,15 +533,25 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     p.tile_hint = tile_scores_s;
     rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores (split half)");
     if (rc) return rc;
-    rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, 1.f, s), "relation: normalise (split half)");
-    if (rc) return rc;
     rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose (split half)");
     if (rc) return rc;
     rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
     if (rc) return rc;
     p.alpha = 1.f / kSplitProbScale;   // the probabilities are stored x 2^12 (gemm_tile.h, EPI_SCORES)
+    p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
     p.tile_hint = tile_apply_s;
-    return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half)");
+    // Which form: measured on one MI355X (tools/rel_bench.py --dtype f16x2; profiles/r04_split_relation.txt): the folded form wins
+    // the key stage (300 x 4 500: 0.146 against 0.163 ms), the full stage goes the other way (4 500 x 4 500: 0.32-0.36 against
+    // 0.29 ms) -- the fold needs the double-buffered apply shapes (the pipelined loop is written for two K-steps per block), and one
+    // normalising sweep over P~ (22 us at 7.5 TB/s out of the Infinity Cache) + the pipelined plain product is cheaper than they are.
+    // HVR_SPLIT_NORMALIZE = 0 / 1 forces the folded / the swept form.
+    static const int split_normalize = std::getenv("HVR_SPLIT_NORMALIZE") ? std::atoi(std::getenv("HVR_SPLIT_NORMALIZE")) : -1;
+    if (split_normalize == 1 || (split_normalize < 0 && Mq >= 1024)) {
+      rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, 1.f, s), "relation: normalise (split half)");
+      if (rc) return rc;
+      return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half, plain product)");
+    }
+    return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply (split half)");
   }
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
   // tuning overrides, read once

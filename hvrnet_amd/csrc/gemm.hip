@@ -39,6 +39,7 @@ int choose_tile(const GemmParams& p, int epi) {
     if (epi == EPI_SCORES && kTileShapes[t].bn != 128) return 0;
     if (epi == EPI_APPLY && (t == 2 || t == 6 || t == 10)) return 3;
     if (epi == EPI_APPLY && t == 5) return 4;  // 256x128 with two accumulator sets has no room for the pipeline's registers
+    if (epi == EPI_APPLY && p.dtype == DT_F16S && t >= kNumBaseShapes) return 3;
     if (epi != EPI_LINEAR && t == 9) return 0;
     return t;
   }
@@ -62,6 +63,7 @@ int choose_tile(const GemmParams& p, int epi) {
                                                                        // 1 x 8 waves re-read the whole P~ tile per wave
     if (p.N <= 64 && s.bn > 64 && t != 0) continue;
     if (p.dtype == DT_F16S && t == 6) continue;   // (the 6-wave 144 x 256 ring has no registers for the split K-step's third B set)
+    if (p.dtype == DT_F16S && epi == EPI_APPLY && t >= kNumBaseShapes) continue;   // (split apply: the double-buffered shapes, gemm_tile.h)
     const long tiles = (long)((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
     const long slots = 256L * s.wg_per_cu;
     const long full = tiles / slots, rem = tiles % slots;

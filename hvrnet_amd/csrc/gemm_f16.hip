@@ -12,10 +12,9 @@ hipError_t run_tile_op_f16(const GemmParams& p, int epi, hipStream_t stream) {
     if (epi == EPI_SCORES) return dispatch_shape<f16_t, EPI_SCORES>(p, stream);
     return dispatch_shape<f16_t, EPI_APPLY>(p, stream);
   }
-  // split half: the relation's apply pass is a plain product of the normalised probabilities (capi.hip), not EPI_APPLY
   if (epi == EPI_LINEAR) return dispatch_shape<f16s_t, EPI_LINEAR>(p, stream);
   if (epi == EPI_SCORES) return dispatch_shape<f16s_t, EPI_SCORES>(p, stream);
-  return hipErrorInvalidValue;
+  return dispatch_shape<f16s_t, EPI_APPLY>(p, stream);   // (the double-buffered shapes: gemm.hip choose_tile)
 }
 
 }  // namespace hvr

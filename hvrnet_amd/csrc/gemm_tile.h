@@ -439,7 +439,16 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              if constexpr (EPI == EPI_APPLY) {
+              if constexpr (EPI == EPI_APPLY && SPLIT) {
+                // the block's un-scaled partial, three terms per K-step (four K-steps per 128-key block)
+                if (kk == 0) {
+                  if (first) Mma<T>::template run<true>(wb[0][j], xa[0][i], pacc[i][j]);
+                  else Mma<T>::template run<false>(wb[0][j], xa[0][i], pacc[i][j]);
+                } else {
+                  Mma<T>::template run<false>(wb[1][j], xa[0][i], pacc[i][j]);
+                  Mma<T>::template run<false>(wb[0][j], xa[1][i], pacc[i][j]);
+                }
+              } else if constexpr (EPI == EPI_APPLY) {
                 if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
                 else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
               } else if constexpr (SPLIT) {
@@ -472,9 +481,16 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              Mma<T>::template run<false>(wb[0][j], xa[0][i], acc[i][j]);
-              Mma<T>::template run<false>(wb[1][j], xa[0][i], acc[i][j]);
-              Mma<T>::template run<false>(wb[0][j], xa[1][i], acc[i][j]);
+              if constexpr (EPI == EPI_APPLY) {
+                if (first) Mma<T>::template run<true>(wb[0][j], xa[0][i], pacc[i][j]);
+                else Mma<T>::template run<false>(wb[0][j], xa[0][i], pacc[i][j]);
+                Mma<T>::template run<false>(wb[1][j], xa[0][i], pacc[i][j]);
+                Mma<T>::template run<false>(wb[0][j], xa[1][i], pacc[i][j]);
+              } else {
+                Mma<T>::template run<false>(wb[0][j], xa[0][i], acc[i][j]);
+                Mma<T>::template run<false>(wb[1][j], xa[0][i], acc[i][j]);
+                Mma<T>::template run<false>(wb[0][j], xa[1][i], acc[i][j]);
+              }
             }
         } else {
 #pragma unroll
@@ -1139,12 +1155,14 @@ static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t strea
       case 3: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS>(p, stream);
       case 4: return launch_tile<T, 4, 2, 4, 4, EPI, GLDS>(p, stream);
       case 5: if constexpr (EPI != EPI_APPLY) return launch_tile<T, 4, 2, 4, 4, EPI, GLDS, 3>(p, stream); break;
-      case 6: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
-      case 7: return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream);
-      case 8: return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream);
+      // (not for split half: the 6-wave 144 x 256 ring has no registers for the split K-step's fragment sets -- it would spill them)
+      case 6: if constexpr (EPI == EPI_LINEAR && !std::is_same<T, f16s_t>::value) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
+      // (the pipelined apply loop is written for two K-steps per 128-key block: split half has four and takes the double-buffered shapes)
+      case 7: if constexpr (!(EPI == EPI_APPLY && std::is_same<T, f16s_t>::value)) return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream); break;
+      case 8: if constexpr (!(EPI == EPI_APPLY && std::is_same<T, f16s_t>::value)) return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream); break;
       case 9: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS, 3>(p, stream); break;
       case 10: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 1, 8, 9, 2, EPI, GLDS, 3>(p, stream); break;
-      case 11: return launch_tile<T, 1, 8, 9, 1, EPI, GLDS, 4>(p, stream);
+      case 11: if constexpr (!(EPI == EPI_APPLY && std::is_same<T, f16s_t>::value)) return launch_tile<T, 1, 8, 9, 1, EPI, GLDS, 4>(p, stream); break;
       default: break;
     }
     return launch_tile<T, 2, 2, 4, 4, EPI, GLDS>(p, stream);

@@ -571,8 +571,19 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
     b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
     b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = dtype == HVR_F16;
+    // The apply pass that follows: when relation_apply.hip takes it (window-sized problems: whole 128-column output tiles, a K loop
+    // of whole register-ring rounds), the scores pass rounds its block maxima up to integers -- the block weights are then exact
+    // powers of two, which that kernel's producer waves apply on the exponent fields of P~ (HVR_APPLY_PC=0: the tile engine's apply)
+    static const int apply_pc = std::getenv("HVR_APPLY_PC") ? std::atoi(std::getenv("HVR_APPLY_PC")) : 1;
+    GemmParams pa;
+    rc = fill_linear(pa, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
+    if (rc) return rc;
+    pa.mstat = mstat; pa.lstat = lstat; pa.ntile = nt;
+    const bool pc_form = apply_pc && tile_apply == 0 && apply_slices(Mq, Mk, D) <= 1 && relation_apply_pc_supported(pa);
+    b.int_max = pc_form ? 1 : 0;
     rc = check_launch(run_scores_bt(b, s), "relation: scores (big tile)");
     if (rc) return rc;
+    if (pc_form) return check_launch(run_relation_apply_pc(pa, s), "relation: apply (producer-scaled)");
   } else {
     rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
     if (rc) return rc;

@@ -560,7 +560,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
   static const int no_bt = env_tile("HVR_NO_BT");  // force the tile-engine scores pass
   static const int no_pc = env_tile("HVR_NO_PC");  // force the tile-engine apply pass
-  static const int pc_apply = env_tile("HVR_PC_APPLY");
+  static const int pc_apply = std::getenv("HVR_PC_APPLY") ? std::atoi(std::getenv("HVR_PC_APPLY")) : 1;
 #ifdef HVR_DEBUG_KNOBS  // tuning builds only (tools/build_dbg.sh): alias every operand row to row 0 (no memory-system cost)
   static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
 #endif
@@ -571,19 +571,8 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
     b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
     b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = dtype == HVR_F16;
-    // The apply pass that follows: when relation_apply.hip takes it (window-sized problems: whole 128-column output tiles, a K loop
-    // of whole register-ring rounds), the scores pass rounds its block maxima up to integers -- the block weights are then exact
-    // powers of two, which that kernel's producer waves apply on the exponent fields of P~ (HVR_APPLY_PC=0: the tile engine's apply)
-    static const int apply_pc = std::getenv("HVR_APPLY_PC") ? std::atoi(std::getenv("HVR_APPLY_PC")) : 1;
-    GemmParams pa;
-    rc = fill_linear(pa, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
-    if (rc) return rc;
-    pa.mstat = mstat; pa.lstat = lstat; pa.ntile = nt;
-    const bool pc_form = apply_pc && tile_apply == 0 && apply_slices(Mq, Mk, D) <= 1 && relation_apply_pc_supported(pa);
-    b.int_max = pc_form ? 1 : 0;
     rc = check_launch(run_scores_bt(b, s), "relation: scores (big tile)");
     if (rc) return rc;
-    if (pc_form) return check_launch(run_relation_apply_pc(pa, s), "relation: apply (producer-scaled)");
   } else {
     rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
     if (rc) return rc;
@@ -640,9 +629,11 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
           : dtype == HVR_F16 ? run_splitk_reduce_f16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
     return check_launch(e, "relation: apply (key slices)");
   }
-  // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table): correct
-  // and tested, but 60 us against the tile engine's 57 on the 4 500-row window (DESIGN.md section 3 has the elimination
-  // builds: its DMA-only path runs at 26 B/clk/CU of the 52 the same pieces reach in isolation) -- opt-in, HVR_PC_APPLY=1.
+  // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table).  Round 2 measured
+  // it behind the tile engine (60 against 57 us) and left it opt-in; on round 4's boxes it is AHEAD, alone (tools/rel_bench.py: 0.1073 /
+  // 0.1102 ms per relation call against 0.1164 / 0.1200) and inside the window (three alternating runs of tools/window_breakdown.py:
+  // 109.4 / 110.3 / 110.5 us per call against 114.1 / 113.0 / 113.1) -- profiles/r04_relation_apply.txt -- so it is the default for
+  // window-sized problems; HVR_PC_APPLY=0 brings the tile engine's apply back.
   if (pc_apply && !no_pc && tile_apply == 0 && Mq >= 1024 && pc_supported(p, EPI_APPLY))
     return check_launch(run_pc(p, EPI_APPLY, 128, s), "relation: apply (pc)");
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");

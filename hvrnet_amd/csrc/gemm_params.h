@@ -95,8 +95,5 @@ constexpr int kBigHint = kNumTileShapes + 4, kBigForce = kNumTileShapes + 5;  //
 bool bigtile_supported(const GemmParams& p, bool throughput);
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream);
 hipError_t run_pc(const GemmParams& p, int epi, int bn, hipStream_t stream);
-// Relation apply pass with the block weights applied by the producer waves (relation_apply.hip): needs integer block maxima
-bool relation_apply_pc_supported(const GemmParams& p);
-hipError_t run_relation_apply_pc(const GemmParams& p, hipStream_t stream);
 
 }  // namespace hvr

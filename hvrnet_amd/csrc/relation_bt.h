@@ -18,8 +18,6 @@ struct ScoresBTParams {
   float sl2;        // scale * log2(e)
   int tile0, tiles_here;  // set by run_scores_bt per launch: this launch's slice of the tile grid
   int f16;                // operands are IEEE half (HVR_F16) instead of bf16
-  int int_max;            // block maxima rounded UP to integers (log2 units): P~ stays <= 1 and the weight of a block relative to the
-                          // row's largest block, 2^(m_t - M), is an exact power of two (relation_apply.hip applies it on the exponent)
 };
 
 // true when the one-round 352 x 256 tiling applies (bf16, aligned operands, a tile grid that fills most of the chip)

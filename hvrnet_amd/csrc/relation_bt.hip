@@ -402,10 +402,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i)
-  {
-    const float t_ = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * p.sl2;  // block max, log2 units
-    tmax[i] = p.int_max ? ceilf(t_) : t_;   // (any reference >= the block's maximum is a valid one: the statistics carry it)
-  }
+    tmax[i] = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * p.sl2;  // block max, log2 units
   const int st_row = lane >> 3, st_chunk = lane & 7;  // store phase: lane -> (row, 16-byte piece) of the staged block
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i) {

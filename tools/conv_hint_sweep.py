@@ -1,12 +1,12 @@
 """Tile-shape sweep of the window's convs in one operand format: does the cost model (fitted on bf16) pick well for half / split half?
-    python tools/probe/conv_hint_sweep.py --dtype f16x2"""
+    python tools/conv_hint_sweep.py --dtype f16x2"""
 import argparse
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hvrnet_amd import native  # noqa: E402
 
 if os.environ.get('HVR_BENCH_LIB'):  # A/B a privately built library (tuning experiments only)

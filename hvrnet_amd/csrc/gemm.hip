@@ -39,8 +39,10 @@ int choose_tile(const GemmParams& p, int epi) {
     if (epi == EPI_SCORES && kTileShapes[t].bn != 128) return 0;
     if (epi == EPI_APPLY && (t == 2 || t == 6 || t == 10)) return 3;
     if (epi == EPI_APPLY && t == 5) return 4;  // 256x128 with two accumulator sets has no room for the pipeline's registers
+    if (epi == EPI_APPLY && t == 8) return 7;  // (the 128 x 128 ring has no apply instantiation: the 144 x 128 ring)
     if (epi == EPI_APPLY && p.dtype == DT_F16S && t >= kNumBaseShapes) return 3;
     if (epi != EPI_LINEAR && t == 9) return 0;
+    if (p.conv && p.KH * p.KW > 32 && t >= kNumBaseShapes) return 0;   // (the pipelined loader keeps one out-of-image bit per filter tap)
     return t;
   }
   const bool full_menu = p.dtype != DT_F32 && p.staging == 1;
@@ -62,6 +64,7 @@ int choose_tile(const GemmParams& p, int epi) {
     if (epi == EPI_APPLY && (t == 2 || t == 6 || t >= 10)) continue;  // two accumulator sets do not fit 144x256;
                                                                        // 1 x 8 waves re-read the whole P~ tile per wave
     if (p.N <= 64 && s.bn > 64 && t != 0) continue;
+    if (p.conv && p.KH * p.KW > 32 && t >= kNumBaseShapes) continue;   // (one out-of-image bit per filter tap in the pipelined loader)
     if (p.dtype == DT_F16S && t == 6) continue;   // (the 6-wave 144 x 256 ring has no registers for the split K-step's third B set)
     if (p.dtype == DT_F16S && epi == EPI_APPLY && t >= kNumBaseShapes) continue;   // (split apply: the double-buffered shapes, gemm_tile.h)
     const long tiles = (long)((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);

@@ -557,43 +557,83 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     // next step's B_hi fragments are requested while this step's B_hi x A_lo terms still read the current ones, so B_hi lives in
     // [0] on even and in [2] on odd K-steps (an A_hi fragment is re-requested as soon as its row's B_lo x A_hi terms are issued)
     uint4 fa[2][FM], fb[SPLIT ? 3 : 2][FN];
-    long a_koff = 0;
-    int dy = 0, dx = 0;  // conv: filter tap of the K-step being loaded
     int kt_load = 0;     // the K-step being loaded (second-segment products switch operand at k1_steps)
     int b_koff = 0;      // its byte offset in a B row
 
-    auto tap_of = [&](int kt) {
+    // BRANCH-FREE state of the K-step being loaded.  A taken branch costs a wave ~100 cycles of instruction fetch (tools/
+    // kloop_probe.hip, profiles/r04_kloop_probe.txt: an MFMA loop of 36 MFMAs per iteration runs at 1.58 PF/s, unrolled twice at
+    // 1.89), and this loop used to take one or two around every DMA piece -- `if (conv)`, `if (second K segment)`, `if (this wave
+    // has a piece in the last slot)` as an exec-mask branch -- while every VALU operation squeezed between two 16-cycle MFMAs costs
+    // issue slots the matrix pipe then waits for.  So: ONE form for plain products and convs (the plain product is the conv formula
+    // with an unreachable channel count), the filter tap advances by scalar selects (no division, no branch), a piece's out-of-image
+    // test is a precomputed per-tap bit (two VALU operations: shift the lane's mask by the tap, OR the bit into bit 31 of the offset --
+    // offsets from 2^31 up are outside the buffer resource and read as zeros), the second K segment is scalar selects plus one
+    // v_cndmask, and the last-slot test is a scalar compare on the wave index.
+    const bool is_conv = kConvOk && p.conv;
+    const int cCin = is_conv ? p.Cin : 0x40000000, cKW = is_conv ? p.KW : 1, cDil = is_conv ? p.dil : 0;
+    const int cRowB = is_conv ? p.W * p.Cin * EB : 0, cPixB = is_conv ? p.Cin * EB : 0;   // bytes per input row / pixel (tensors < 2 GiB)
+    // bit t of oob[i]: filter tap t of slot i's pixel lies outside the image (<= 32 taps: run_tile_op keeps larger filters off this path)
+    unsigned oob[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) oob[i] = 0u;
+    if (is_conv) {
+      // (rows and columns tested separately: KH + KW compares per slot instead of KH x KW -- a tile of a 9-step conv notices)
+      unsigned colbad[A_SLOTS];
+#pragma unroll
+      for (int i = 0; i < A_SLOTS; ++i) colbad[i] = 0u;
+      for (int kx = 0, dx = 0; kx < p.KW; ++kx, dx += p.dil) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) colbad[i] |= (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W ? 0u : (1u << kx);
+      }
+      const unsigned all_kw = (1u << p.KW) - 1u;
+      for (int ky = 0, dy = 0, sh = 0; ky < p.KH; ++ky, dy += p.dil, sh += p.KW) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) oob[i] |= ((unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H ? colbad[i] : all_kw) << sh;
+      }
+    }
+    int t_cin0 = 0, t_kx = 0, t_ky = 0, t_tap = 0, a_koff32 = 0;
+    auto tap_set = [&](int kt) {   // (division form: once, behind the prologue)
       kt_load = kt;
       b_koff = kt * KSG;
-      if (kConvOk && p.conv) {
-        const int k = (kt + kt_base) * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        dy = ky * p.dil;
-        dx = kx * p.dil;
-        a_koff = (((long)dy * p.W + dx) * p.Cin + cin0) * (long)EB;
-      } else {
-        a_koff = (long)kt * KSG;
-      }
+      const int k = (kt + kt_base) * BKE;
+      t_tap = k / cCin;
+      t_cin0 = k - t_tap * cCin;
+      t_ky = t_tap / cKW;
+      t_kx = t_tap - t_ky * cKW;
+      a_koff32 = t_ky * cDil * cRowB + t_kx * cDil * cPixB + t_cin0 * EB;
+    };
+    auto tap_next = [&]() {        // the next K-step, by scalar selects
+      ++kt_load;
+      b_koff += KSG;
+      t_cin0 += BKE;
+      const bool w1 = t_cin0 >= cCin;
+      t_cin0 = w1 ? 0 : t_cin0;
+      t_tap += w1 ? 1 : 0;
+      t_kx += w1 ? 1 : 0;
+      const bool w2 = t_kx >= cKW;
+      t_kx = w2 ? 0 : t_kx;
+      t_ky += w2 ? 1 : 0;
+      const int wm = -(int)w1;   // both arms computed and masked: a select here comes back as two scalar branches per K-step
+      a_koff32 = ((t_ky * cDil * cRowB + t_kx * cDil * cPixB) & wm) | ((a_koff32 + KSG) & ~wm);
     };
     auto dma_a = [&](auto I, char* stage) {
       constexpr int i = decltype(I)::value;
-      if (A_SLOTS * NT == BM * 8 || i * NT + (tid & ~63) < BM * 8) {
-        unsigned voff = (unsigned)a_off[i];
-        if (kConvOk && p.conv) {
-          const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
-          voff = ok ? voff : kOob;
-        }
+      if (A_SLOTS * NT == BM * 8 || (i + 1) * NT <= BM * 8 || i * NT + wave * 64 < BM * 8) {   // (scalar: `wave` lives in an SGPR)
+        const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> t_tap) << 31);
 #ifndef HVR_DBG_NODMA
-        if (kt_load >= k1_steps) buffer_load_lds16(rs_a2, stage + (i * NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt_load - k1_steps) * KSG));
-        else buffer_load_lds16(rs_a, stage + (i * NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane((int)a_koff));
+        const bool s2 = kt_load >= k1_steps;
+        const char* const base = s2 ? rs_a2 : rs_a;
+        const unsigned vo = s2 ? (unsigned)a_off2[i] : voff;
+        const int so = s2 ? (kt_load - k1_steps) * KSG : a_koff32;
+        buffer_load_lds16(base, stage + (i * NT + wave * 64) * 16, vo, __builtin_amdgcn_readfirstlane(so));
 #else
         asm volatile("" ::"v"(voff), "v"(stage));
 #endif
       }
     };
-    auto dma_b = [&](auto I, char* stage) {   // (of the K-step tap_of() was last called for)
+    auto dma_b = [&](auto I, char* stage) {   // (of the K-step the tap state stands at)
       constexpr int i = decltype(I)::value;
-      if (B_SLOTS * NT == BN * 8 || i * NT + (tid & ~63) < BN * 8) {
+      if (B_SLOTS * NT == BN * 8 || (i + 1) * NT <= BN * 8 || i * NT + wave * 64 < BN * 8) {
 #ifndef HVR_DBG_NODMA
         buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(b_koff));
 #else
@@ -616,6 +656,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) issue_loads(s, smem + s * STAGE_BYTES);
+    tap_set(NS - 2);   // the last K-step requested: every loading pipe_step advances the state by one
     apply_prologue();
     if constexpr (RES_EARLY) {
 #pragma unroll
@@ -662,7 +703,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + nb);
       }
-      if (load) tap_of(kt + NS - 1);
+      if (load) tap_next();
       static_for<2>([&](auto KK) {
         constexpr int kk = decltype(KK)::value;
         constexpr int ND = kk == 0 ? A_SLOTS : B_SLOTS;
@@ -784,6 +825,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       }
     } else {
       int kt = 0;
+      for (; kt + NS < nk; kt += 2) {   // two K-steps per iteration: one loop branch per 4 x FM x FN MFMAs
+        pipe_step(kt, L1, Y, N, N, P0);
+        pipe_step(kt + 1, L1, Y, N, N, P0);
+      }
       for (; kt + NS - 1 < nk; ++kt) pipe_step(kt, L1, Y, N, N, P0);
       for (; kt + 1 < nk; ++kt) pipe_step(kt, L0, Y, N, N, P0);
       pipe_step(kt, L0, N, N, N, P0);  // kt == nk - 1: a product has at least one K-step
@@ -1159,7 +1204,9 @@ static hipError_t dispatch_tile(const GemmParams& p, int tile, hipStream_t strea
       case 6: if constexpr (EPI == EPI_LINEAR && !std::is_same<T, f16s_t>::value) return launch_tile<T, 3, 2, 3, 8, EPI, GLDS, 3>(p, stream); break;
       // (the pipelined apply loop is written for two K-steps per 128-key block: split half has four and takes the double-buffered shapes)
       case 7: if constexpr (!(EPI == EPI_APPLY && std::is_same<T, f16s_t>::value)) return launch_tile<T, 3, 2, 3, 4, EPI, GLDS, 4>(p, stream); break;
-      case 8: if constexpr (!(EPI == EPI_APPLY && std::is_same<T, f16s_t>::value)) return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream); break;
+      // (no apply pass on this shape: never chosen for it, and its untracked block-weight loads do not survive every register allocation --
+      // check_asm_waits.py flagged it after round 4's loop changes)
+      case 8: if constexpr (EPI != EPI_APPLY) return launch_tile<T, 2, 2, 4, 4, EPI, GLDS, 4>(p, stream); break;
       case 9: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 4, 1, 2, 4, EPI, GLDS, 3>(p, stream); break;
       case 10: if constexpr (EPI == EPI_LINEAR) return launch_tile<T, 1, 8, 9, 2, EPI, GLDS, 3>(p, stream); break;
       case 11: if constexpr (!(EPI == EPI_APPLY && std::is_same<T, f16s_t>::value)) return launch_tile<T, 1, 8, 9, 1, EPI, GLDS, 4>(p, stream); break;

@@ -75,7 +75,6 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BG_BN * 128;
   constexpr int A_SLOTS = (BM * 8 + BG_NT - 1) / BG_NT;
   constexpr int LAST_WAVES = (BM * 8 - (A_SLOTS - 1) * BG_NT) / 64;  // waves that carry a piece of the last A slot
-  constexpr unsigned kOob = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,40 +126,63 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     }
   }
 
-  int a_koff = 0, b_koff = 0, dy = 0, dx = 0, kt_load = 0;  // of the K-step being loaded
-  const int nk_real = p.K / BKE;
-  auto tap_of = [&](int kt) {
-    kt_load = kt;
-    b_koff = kt * KSG;
-    if (p.conv) {
-      const int k = kt * BKE, tap = k / p.Cin, cin0 = k - tap * p.Cin;
-      const int ky = tap / p.KW, kx = tap - ky * p.KW;
-      dy = ky * p.dil;
-      dx = kx * p.dil;
-      a_koff = ((dy * p.W + dx) * p.Cin + cin0) * EB;
-    } else {
-      a_koff = kt * KSG;
+  // BRANCH-FREE loader state (the form and the reasons: gemm_tile.h's pipelined K-step, profiles/r04_kloop_probe.txt -- a taken
+  // branch costs a wave ~100 cycles, and this loop's L sections are only hidden while they are shorter than the partner group's
+  // 16-20 MFMAs).  One form for plain products and convs: the plain product is the conv formula with an unreachable channel count;
+  // the filter tap advances by scalar selects; a piece's out-of-image test is bit `tap` of a per-slot mask built once per tile.
+  const bool is_conv = p.conv != 0;
+  const int cCin = is_conv ? p.Cin : 0x40000000, cKW = is_conv ? p.KW : 1, cDil = is_conv ? p.dil : 0;
+  const int cRowB = is_conv ? p.W * p.Cin * EB : 0, cPixB = is_conv ? p.Cin * EB : 0;   // bytes per input row / pixel (tensors < 2 GiB)
+  unsigned oob[A_SLOTS];   // bit t: filter tap t of slot i's pixel lies outside the image (<= 32 taps: bigtile_supported)
+#pragma unroll
+  for (int i = 0; i < A_SLOTS; ++i) oob[i] = 0u;
+  if (is_conv) {
+    unsigned colbad[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) colbad[i] = 0u;
+    for (int kx = 0, dx = 0; kx < p.KW; ++kx, dx += p.dil) {
+#pragma unroll
+      for (int i = 0; i < A_SLOTS; ++i) colbad[i] |= (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W ? 0u : (1u << kx);
     }
+    const unsigned all_kw = (1u << p.KW) - 1u;
+    for (int ky = 0, dy = 0, sh = 0; ky < p.KH; ++ky, dy += p.dil, sh += p.KW) {
+#pragma unroll
+      for (int i = 0; i < A_SLOTS; ++i) oob[i] |= ((unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H ? colbad[i] : all_kw) << sh;
+    }
+  }
+  int a_koff = 0, b_koff = 0, kt_load = 0, t_cin0 = 0, t_kx = 0, t_ky = 0, t_tap = 0;  // of the K-step being loaded (starts at step 0)
+  const int nk_real = p.K / BKE;
+  auto tap_next = [&](int adv) {   // adv = 1: the next K-step; 0: stay (the last step re-fetches itself into the idle stage)
+    kt_load += adv;
+    b_koff += adv * KSG;
+    t_cin0 += adv * BKE;
+    const bool w1 = t_cin0 >= cCin;
+    t_cin0 = w1 ? 0 : t_cin0;
+    t_tap += w1 ? 1 : 0;
+    t_kx += w1 ? 1 : 0;
+    const bool w2 = t_kx >= cKW;
+    t_kx = w2 ? 0 : t_kx;
+    t_ky += w2 ? 1 : 0;
+    const int wmask = -(int)w1;   // (both arms computed and masked: as a select this comes back as scalar branches)
+    a_koff = ((t_ky * cDil * cRowB + t_kx * cDil * cPixB) & wmask) | ((a_koff + adv * KSG) & ~wmask);
   };
   auto dma_a = [&](auto I, char* stage) {
     constexpr int i = decltype(I)::value;
-    if (i < A_SLOTS - 1 || wave < LAST_WAVES) {
-      unsigned voff = (unsigned)a_off[i];
-      if (p.conv) {
-        const bool ok = (unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H && (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W;
-        voff = ok ? voff : kOob;
-      }
-      if (kt_load >= k1_steps) bg_load_lds16(rs_a2, stage + (i * BG_NT + wave * 64) * 16, (unsigned)a_off2[i], __builtin_amdgcn_readfirstlane((kt_load - k1_steps) * KSG));
-      else bg_load_lds16(rs_a, stage + (i * BG_NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane(a_koff));
+    if (i < A_SLOTS - 1 || wave < LAST_WAVES) {   // (scalar: `wave` lives in an SGPR)
+      const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> t_tap) << 31);   // offsets from 2^31 up read as zeros
+      const bool s2 = kt_load >= k1_steps;
+      const char* const base = s2 ? rs_a2 : rs_a;
+      const unsigned vo = s2 ? (unsigned)a_off2[i] : voff;
+      const int so = s2 ? (kt_load - k1_steps) * KSG : a_koff;
+      bg_load_lds16(base, stage + (i * BG_NT + wave * 64) * 16, vo, __builtin_amdgcn_readfirstlane(so));
     }
   };
-  auto dma_b = [&](auto I, char* stage) {   // (of the K-step tap_of() was last called for)
+  auto dma_b = [&](auto I, char* stage) {   // (of the K-step the loader state stands at)
     constexpr int i = decltype(I)::value;
     bg_load_lds16(rs_b, stage + A_BYTES + (i * BG_NT + wave * 64) * 16, (unsigned)b_off[i], __builtin_amdgcn_readfirstlane(b_koff));
   };
 
   // first K-step into stage 0
-  tap_of(0);
   static_for<A_SLOTS>([&](auto I) { dma_a(I, smem); });
   static_for<BG_B_SLOTS>([&](auto I) { dma_b(I, smem); });
 
@@ -191,10 +213,9 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
       const uint32_t soff = (uint32_t)(kt & 1) * STAGE;
       char* nxt = smem + ((kt + 1) & 1) * STAGE;
-      const int kn = kt + 1 < nk ? kt + 1 : kt;  // (the last step re-fetches itself into the idle stage: one uniform stream)
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
       uint4 kb[BG_FN], qa[G0];
-      tap_of(kn);
+      tap_next(kt + 1 < nk ? 1 : 0);  // (the last step re-fetches itself into the idle stage: one uniform stream)
       // phases: two per term.  Two-byte formats: term = K half (0 / 1) on both operands.  Split half: term 0 = B_hi x A_hi,
       // 1 = B_lo x A_hi, 2 = B_hi x A_lo (the lo plane is the second 64 bytes of the line: the same address with bit 6 flipped)
       constexpr int NPH = SPLIT ? 6 : 4;
@@ -440,7 +461,7 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint.
   // Split half has no row-panel kernel for K >= 256: its residual convs take the big tiles in either mode.)
   if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || (throughput && !split))))) return false;
-  if (p.conv && p.Cin % bke) return false;
+  if (p.conv && (p.Cin % bke || p.KH * p.KW > 32)) return false;   // (the loader keeps a 32-bit tap mask per piece)
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                        reinterpret_cast<uintptr_t>(p.bias);
   if (al & 15) return false;

@@ -262,11 +262,13 @@ def profile_begin(tags=('*',), detail=False):
     _prof = dict(tags=set(tags), spans=[], detail=detail)
 
 
-def profile_end():
-    """-> {tag: dict(calls, ms, work)}; synchronises once."""
+def profile_end(raw=False):
+    """-> {tag: dict(calls, ms, work)}; synchronises once.  raw: the calls in issue order, [(tag, work, ms)]."""
     global _prof
     spans, _prof = _prof['spans'], None
     torch.cuda.synchronize()
+    if raw:
+        return [(tag, work, s.elapsed_time(e)) for tag, work, s, e in spans]
     out = {}
     for tag, work, s, e in spans:
         d = out.setdefault(tag, dict(calls=0, ms=0.0, work=0.0))

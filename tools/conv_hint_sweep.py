@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--dtype', default='f16x2')
 ap.add_argument('--frames', type=int, default=15)
 ap.add_argument('--hints', default=','.join(str(h) for h in range(1, 13)))
+ap.add_argument('--cold', type=int, default=0, help='MB written by a fill between the timed calls (0: back-to-back calls on the same operands)')
 args = ap.parse_args()
 DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16x2': native.SPLIT, 'f32': torch.float32}[args.dtype]
 B = args.frames
@@ -29,6 +30,7 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad, dil, resid
     ('res5.conv1 2048->512', 38, 63, 2048, 512, 1, 1, 0, 1, False), ('res5.ds 1024->2048', 38, 63, 1024, 2048, 1, 1, 0, 1, False),
     ('res5.ext 2048->256', 38, 63, 2048, 256, 1, 1, 0, 1, False)]
 g = torch.Generator(device='cuda').manual_seed(0)
+FLUSH = torch.empty(args.cold << 18, device='cuda') if args.cold else None
 for name, H, W, Cin, Cout, k, st, pad, dil, res in SHAPES:
     x = native.as_operand(torch.randn((B, H, W, Cin), device='cuda', generator=g), DT)
     w = native.as_operand(torch.randn((Cout, k, k, Cin), device='cuda', generator=g) * 0.05, DT)
@@ -42,6 +44,17 @@ for name, H, W, Cin, Cout, k, st, pad, dil, res in SHAPES:
                 native.conv2d_nhwc(x, w, bias, r, relu=True, stride=st, pad=pad, dil=dil, tile=hint)
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if args.cold:   # every timed call after a fill that evicts the operands from the L2 and the Infinity Cache
+                tot = 0.0
+                for _ in range(5):
+                    FLUSH.fill_(1.0)
+                    s.record()
+                    native.conv2d_nhwc(x, w, bias, r, relu=True, stride=st, pad=pad, dil=dil, tile=hint)
+                    e.record()
+                    torch.cuda.synchronize()
+                    tot += s.elapsed_time(e)
+                out.append((hint, tot / 5 * 1e3))
+                continue
             s.record()
             for _ in range(5):
                 native.conv2d_nhwc(x, w, bias, r, relu=True, stride=st, pad=pad, dil=dil, tile=hint)

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--sequence', action='store_true', help='also print the last window call by call, in issue order')
     args = ap.parse_args()
     T, N, dev = args.frames, 300, 'cuda:0'
     model = hvrnet_amd.build_model((hvr_config if args.head == 'hvr' else selsa_config)(frame_interval=T // 2, nms_post=N),
@@ -58,6 +59,11 @@ def main():
         for _ in range(args.iters):
             window()
         prof = native.profile_end()
+        seq = None
+        if args.sequence:
+            native.profile_begin(('*',), detail=True)
+            window()
+            seq = native.profile_end(raw=True)
     rows = sorted(((d['ms'] / args.iters, d['calls'] // args.iters, d['work'] / args.iters, tag) for tag, d in prof.items()), reverse=True)
     total = sum(r[0] for r in rows)
     print('mode %s: %.2f ms per window (wall, un-profiled); %.2f ms summed over the tagged calls' % (args.mode, wall, total))
@@ -66,6 +72,10 @@ def main():
         unit = 'GB/s' if tag.startswith(('conv_expand', 'roi_align', 'rpn_proposals')) else 'TF/s'
         rate = work / ms / (1e6 if unit == 'GB/s' else 1e9) if ms > 0 else 0.0
         print('%9.3f %6d %9.1f %7.0f %s  %s' % (ms, calls, ms * 1e3 / max(calls, 1), rate, unit, tag))
+    if seq:
+        print('\nthe window call by call (us):')
+        for tag, work, ms in seq:
+            print('%9.1f  %s' % (ms * 1e3, tag))
     if args.json:
         with open(args.json, 'w') as f:
             json.dump(dict(mode=args.mode, wall_ms=wall, tagged_ms=total,

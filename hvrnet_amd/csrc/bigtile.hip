@@ -207,9 +207,13 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   // MFMAs) with an s_barrier behind each; wave group 1 (waves 4..7, the SIMD partners of 0..3) runs one barrier behind group 0 ----
   {
     constexpr int G0 = (FM + 1) / 2;
-    const int dma_ph = wm ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
     constexpr int DMA_TOTAL = A_SLOTS + BG_B_SLOTS, DMA_FIRST = DMA_TOTAL / 2;
-    if (wm) __builtin_amdgcn_s_barrier();
+    // (the loop exists twice, once per wave group, behind one branch: which sections carry a wave's DMA pieces and its vmcnt wait
+    // depend on the group -- as run-time tests those were taken branches in every K-step, relation_bt.hip)
+    auto kloop = [&](auto WMC) __attribute__((always_inline)) {
+    constexpr int wmc = decltype(WMC)::value;
+    constexpr int dma_ph = wmc ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
+    if constexpr (wmc != 0) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const uint32_t soff = (uint32_t)(kt & 1) * STAGE;
       char* nxt = smem + ((kt + 1) & 1) * STAGE;
@@ -231,13 +235,13 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph < 3) {
-          if (dma_ph == ph) {
+          if constexpr (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
               constexpr int d = decltype(D)::value;
               if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt);
               else dma_b(std::integral_constant<int, d - A_SLOTS>{}, nxt);
             });
-          } else if (dma_ph + 1 == ph) {
+          } else if constexpr (dma_ph + 1 == ph) {
             static_for<DMA_TOTAL - DMA_FIRST>([&](auto D) {
               constexpr int d = DMA_FIRST + decltype(D)::value;
               if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt);
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
           }
         }
         if constexpr (ph == NPH - 1) {
-          if (wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
+          if constexpr (wmc != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -261,12 +265,15 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph == NPH - 1) {
-          if (!wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (wmc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
       });
     }
-    if (!wm) __builtin_amdgcn_s_barrier();
+    if constexpr (wmc == 0) __builtin_amdgcn_s_barrier();
+    };
+    if (wm) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
   }
 
   // ---------------- epilogue: bias + ReLU, bf16, whole 128-byte row segments out through per-wave LDS staging ----------------

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #ifndef HVR_DBG_NODMA
         buffer_load_lds16(rs_b, stage + BM * 128 + (i * NT + wave * 64) * 16, (unsigned)b_offr[i], __builtin_amdgcn_readfirstlane(b_koff));
 #else
-        asm volatile("" ::"v"(b_offr[i]), "v"(stage));
+        { const unsigned bo = (unsigned)b_offr[i]; asm volatile("" ::"v"(bo), "v"(stage)); }
 #endif
       }
     };

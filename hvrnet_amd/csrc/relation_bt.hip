@@ -258,13 +258,18 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   // the barrier that ends section 7, behind which group 0's first read of K-step kt + 1 sits.
   {
     constexpr int G0 = 6;  // row fragments of the first phase of a half (the second takes FM - G0)
-    const int dma_ph = wm ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
     constexpr int DMA_TOTAL = BT_A_SLOTS + BT_B_SLOTS, DMA_FIRST = DMA_TOTAL / 2;
 #ifdef HVR_DBG_BT_SEC
     long long sec_t[21];
     for (int q = 0; q < 21; ++q) sec_t[q] = 0;
 #endif
-    if (wm) __builtin_amdgcn_s_barrier();
+    // The loop exists TWICE, once per wave group, chosen by one branch in front of it: which sections carry a wave's DMA pieces
+    // and its vmcnt wait depend on the group, and as run-time tests those were three or four taken branches per K-step in every
+    // wave (a taken branch costs a wave ~100 cycles of instruction fetch: profiles/r04_kloop_probe.txt).
+    auto kloop = [&](auto WMC) __attribute__((always_inline)) {
+    constexpr int wmc = decltype(WMC)::value;
+    constexpr int dma_ph = wmc ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
+    if constexpr (wmc != 0) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
       char* nxt = smem + ((kt + 1) & 1) * BT_STAGE;
@@ -288,13 +293,13 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         frag_reads();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph < 3) {
-          if (dma_ph == ph) {
+          if constexpr (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
               constexpr int d = decltype(D)::value;
               if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
               else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
             });
-          } else if (dma_ph + 1 == ph) {
+          } else if constexpr (dma_ph + 1 == ph) {
             static_for<DMA_TOTAL - DMA_FIRST>([&](auto D) {
               constexpr int d = DMA_FIRST + decltype(D)::value;
               if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
           }
         }
         if constexpr (ph == 3) {
-          if (wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
+          if constexpr (wmc != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
         }
         __builtin_amdgcn_sched_barrier(0);
 #if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         if (kt == 8) sec_t[5 * ph + 4] = __builtin_readcyclecounter();
 #endif
         if constexpr (ph == 3) {
-          if (!wm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (wmc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
       });
@@ -344,7 +349,10 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       }
 #endif
     }
-    if (!wm) __builtin_amdgcn_s_barrier();
+    if constexpr (wmc == 0) __builtin_amdgcn_s_barrier();
+    };
+    if (wm) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
   }
 #endif
 

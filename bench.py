@@ -14,8 +14,10 @@ independent clips (no data-path collective): weak scaling, value = N * steps / m
 
 Two timed regions of the same K steps, each bracketed by barrier + synchronize: (1) the eager single-lane loop -- the
 region the `roofline` HIP events are taken in (a kernel's own duration: one window on the chip) and reported as
-`single_lane`; (2) the HEADLINE region: the same windows replayed from hipGraphs on `--lanes` (2) HIP streams in turn, so
-that two independent clips are in flight -- one window's latency-bound phases (proposals, read-out, the relation stages'
+`single_lane`; (2) the HEADLINE region: the same windows replayed from hipGraphs on `--lanes` (4) HIP streams in turn, so
+that four independent clips are in flight (measured, profiles/r04_lanes.txt: 2 lanes 162.7-165.5 frames/s, 4 lanes 171.5-174.4,
+6 / 8 the same as 4, odd counts no better than 2 -- the lanes' streams share the runtime's four hardware queues) -- one
+window's latency-bound phases (proposals, read-out, the relation stages'
 one-round kernels' prologues and epilogues) run beside the other's dense phases, one host call per window.  Every window of
 both regions is computed in full and its results are read on the host inside the region; the replayed windows' detections
 are identical to the eager ones (tests/test_graphs_gpu.py).  `--lanes 1 --no-graphs` makes region (1) the headline.
@@ -89,7 +91,7 @@ def parse(argv=None):
     ap.add_argument('--no-graphs', action='store_true', help='skip the hipGraph legs (graphed_clip / graphed_stream)')
     ap.add_argument('--inflight', type=int, default=int(os.environ.get('HVR_INFLIGHT', '1')),
                     help='independent windows enqueued on that many HIP streams in turn (throughput mode)')
-    ap.add_argument('--lanes', type=int, default=int(os.environ.get('HVR_LANES', '2')),
+    ap.add_argument('--lanes', type=int, default=int(os.environ.get('HVR_LANES', '4')),
                     help='headline region: windows replayed from hipGraphs on that many HIP streams in turn (1 with --no-graphs: the '
                          'eager single-lane loop is the headline, as in round 1)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')

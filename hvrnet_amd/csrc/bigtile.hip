@@ -479,11 +479,11 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   const long tiles = (long)((p.M + 287) / 288) * (p.N / BG_BN);
   static const int on = std::getenv("HVR_BIGTILE") ? std::atoi(std::getenv("HVR_BIGTILE")) : 1;
   static const int min_alone = std::getenv("HVR_BIGTILE_MIN") ? std::atoi(std::getenv("HVR_BIGTILE_MIN")) : 170;
-  // (half-chip grids under the throughput hint -- layer 3's 125 tiles -- were the idea behind the hint: 65 us on 125 CUs against 47
-  // on 250 is -31 % CU-time.  With two windows in flight it measures neutral (graph replay alone: 158.3 vs 158.1 frames/s) to
-  // -1.7 % (bench.py: 158.6 vs 161.4): the other window's launch is as often a full-chip grid that cannot use half a chip as a
-  // half-chip one that can.  The threshold is therefore the same; HVR_BIGTILE_MIN_SHARED=96 brings the half-chip launches back.)
-  static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 170;
+  // Half-chip grids under the throughput hint -- layer 3's 125 tiles: 63 us on 125 CUs against 43 on 250 is -27 % CU-time, if the
+  // other windows in flight have launches for the free half.  With two graph lanes that measured neutral to -1.7 % (round 3); with
+  // four (bench.py's default since round 4) it is +0.4 % in bf16 and +0.8 % in split half, twice each on one box
+  // (profiles/r04_lanes.txt) -- small, repeatable, so the shared threshold is 96 tiles.  HVR_BIGTILE_MIN_SHARED=170 restores the old one.
+  static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 96;
   if (p.tile_hint == kBigForce) return true;
   return on && tiles >= (throughput ? min_shared : min_alone) && tiles <= 4096;
 }

@@ -467,7 +467,8 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   // (with two windows in flight the panel kernel's expand convs, two small workgroups per CU, pack better beside the other
   // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint.
   // Split half has no row-panel kernel for K >= 256: its residual convs take the big tiles in either mode.)
-  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || (throughput && !split))))) return false;
+  static const int res_shared = std::getenv("HVR_BIGTILE_RES_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_RES_SHARED")) : 0;
+  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || (throughput && !split && !res_shared))))) return false;
   if (p.conv && (p.Cin % bke || p.KH * p.KW > 32)) return false;   // (the loader keeps a 32-bit tap mask per piece)
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                        reinterpret_cast<uintptr_t>(p.bias);

@@ -177,6 +177,40 @@ def test_big_tile_kernel_equals_the_tile_engine(B, H, W, Cin, Cout, k, stride, p
         assert torch.equal(g1, g0)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,pad,dil', [(2, 38, 63, 64, 256, 5, 1, 2, 1),     # 25 taps
+                                                              (2, 38, 63, 64, 256, 7, 1, 3, 1),     # 49 taps: more than a 32-bit tap mask holds
+                                                              (1, 23, 31, 128, 256, 3, 1, 6, 6),    # dilation 6: whole tap rows / columns off the image
+                                                              (2, 41, 59, 128, 256, 3, 2, 1, 1),    # stride 2, odd extents
+                                                              (1, 9, 11, 256, 256, 3, 1, 1, 1),     # fewer output pixels than one tile has rows
+                                                              (3, 38, 63, 64, 512, 6, 2, 2, 1)])    # 36 taps, even filter
+def test_conv_loader_tap_masks(B, H, W, Cin, Cout, k, stride, pad, dil):
+    """The pipelined K-step of the tile engine and the big tiles address a conv's A operand through per-piece out-of-image BIT MASKS
+    (bit t = filter tap t of this output pixel lies outside the image, built once per tile) and advance the tap by scalar selects
+    (gemm_tile.h, bigtile.hip).  Shapes that stress that form -- many taps (filters with more than 32 taps must be kept off the masked
+    loaders by the dispatcher and still come out right under every hint), dilations that push whole tap rows off the image, stride 2,
+    a map smaller than a tile -- against F.conv2d, and bit for bit against the double-buffered base shape (tile=1: the K order per output
+    element is the same in every shape)."""
+    x = _rand((B, H, W, Cin), torch.bfloat16, 171).to(DEV)
+    w = _rand((Cout, k, k, Cin), torch.bfloat16, 172, 0.02).to(DEV)
+    bias = _rand((Cout,), torch.float32, 173).to(DEV)
+    ref = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride=stride, padding=pad, dilation=dil))
+    base = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=1)
+    torch.testing.assert_close(base.float().permute(0, 3, 1, 2), ref, **_tol(torch.bfloat16))
+    for hint in (0, 7, 9, 11, 12):
+        got = native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=hint)
+        assert torch.equal(got, base), 'tile hint %d' % hint
+    if k * k <= 32:
+        assert torch.equal(native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=17), base)
+    else:   # the big tiles refuse what their loader cannot address instead of computing something else
+        with pytest.raises(native.HvrError):
+            native.conv2d_nhwc(x, w, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=17)
+    xs, ws = native.cast(x.float(), native.SPLIT), native.as_operand(w.float(), native.SPLIT)
+    sb = native.conv2d_nhwc(xs, ws, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=1)
+    for hint in (0, 11, 12):
+        assert torch.equal(native.conv2d_nhwc(xs, ws, bias, relu=True, stride=stride, pad=pad, dil=dil, tile=hint), sb), 'split half, tile hint %d' % hint
+    torch.testing.assert_close(native.cast(sb, torch.float32).permute(0, 3, 1, 2), ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize('M,N,K,with_res', [(300, 1024, 12544, False), (300, 1024, 1024, True), (37, 256, 4096, False)])
 def test_few_row_gemm_split_over_k(M, N, K, with_res):
     """hvr_gemm with the few-row scratch (one frame's 300 proposals through fc_new_1: 48 tiles walking 196 K-steps): K slices +

@@ -53,7 +53,7 @@ extern "C" {
 #define HVR_LAYOUT_NCHW 0 /* reference layout */
 #define HVR_LAYOUT_NHWC 1 /* native layout of this library */
 
-int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S */
+int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta (split-half operands) */
 const char* hvr_last_error(void);
 
 /* ------------------------------------------------------------------------------------

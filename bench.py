@@ -564,7 +564,7 @@ def main(argv=None):
             row = dict(dtype=mode, single_lane=dict(frames_per_s=round(n_m / el_m, 3), ms_per_step=round(el_m / n_m * 1e3, 3), steps=n_m),
                        roofline=roofline_of(mode, spans_m), kernel_classes=class_times(mode))
             if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
-                n_g = -(-max(n_m, 3 * args.lanes) // args.lanes) * args.lanes   # whole rounds of the lanes: a partial last round is idle lanes, not the mode
+                n_g = args.lanes * (3 if mode == 'f32' else 6)   # whole rounds of the lanes (a partial last round is idle lanes, not the mode), >= 0.3 s per region
                 tg, res_g = graph_regions(args.lanes, n_g, 2, 1)
                 row['graph_replay'] = dict(frames_per_s=round(n_g / tg[0], 3), ms_per_step=round(tg[0] / n_g * 1e3, 3), steps=n_g, lanes=args.lanes)
                 row['_res'] = res_g

@@ -574,10 +574,25 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     rc = check_launch(run_scores_bt(b, s), "relation: scores (big tile)");
     if (rc) return rc;
   } else {
-    rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
-    if (rc) return rc;
+    // few query rows (the key stage, 300 x 4 500: 108 score tiles on 256 CUs): V^T is written by workgroups of the SCORES launch that sit
+    // behind its tiles, on the CUs the score grid leaves idle -- one launch and ~8 us less than the transpose launch in front of it
+    // (GemmParams::tr_*, gemm_tile.h; HVR_KEY_VT_FOLD=0 restores the separate launch)
+    static const int vt_fold = std::getenv("HVR_KEY_VT_FOLD") ? std::atoi(std::getenv("HVR_KEY_VT_FOLD")) : 1;
+    const bool fold = vt_fold && two_byte && staging && Mq <= 1024 && D % 8 == 0 && ldv % 8 == 0 && aligned16(V) && aligned16(Vt);
+    if (!fold) {
+      rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
+      if (rc) return rc;
+    }
     rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
     if (rc) return rc;
+    if (fold) {
+      p.tr_in = V; p.tr_out = Vt; p.tr_R = Mk; p.tr_C = D; p.tr_ldx = ldv; p.tr_ldt = ldp;
+      const int score_tiles = ((Mq + 127) / 128) * ((Mk + 127) / 128);   // (the 128 x 128 shape below)
+      const int vt_tiles = ((D + 63) / 64) * (int)((ldp + 63) / 64);
+      int nb = 256 - score_tiles % 256;   // one workgroup per CU the last round of score tiles leaves free
+      if (nb < 64) nb += 256;
+      p.tr_blocks = nb < vt_tiles ? nb : vt_tiles;
+    }
     p.N = Mk;  // keys beyond Mk are masked inside the score epilogue
     p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
     // (few query rows -- the key stage, 300 x 4 500: 108 tiles walking 16 K-steps each -- are a latency chain: the 4-stage ring

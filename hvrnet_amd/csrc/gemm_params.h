@@ -62,6 +62,12 @@ struct GemmParams {
   int* tickets;
   void* merge_out;
   long merge_ld;
+  // EPI_SCORES, two-byte operands: tr_blocks > 0 workgroups behind the score tiles write tr_out[C][tr_ldt] = tr_in[R][tr_ldx]^T (zero for
+  // columns R .. tr_ldt - 1) -- the apply pass's V^T, made by the CUs a few-row score grid leaves idle instead of by a launch of its own
+  const void* tr_in;
+  void* tr_out;
+  int tr_R, tr_C, tr_blocks;
+  long tr_ldx, tr_ldt;
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };

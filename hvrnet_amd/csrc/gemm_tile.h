@@ -106,6 +106,39 @@ template <> struct Mma<float> {
 // drained at its bottom).  NS = 3 / 4 keep NS - 1 K-steps of LDS-DMA in flight: the waits are counted by hand
 // (`s_waitcnt vmcnt(n)` with n = the loads of the steps that may stay outstanding), which needs the inline-asm
 // fragment reads -- the compiler would otherwise drain every DMA in front of the first LDS read it can see.
+// out[C][ldt] = in[R][ldx]^T in 64 x 64 tiles of 16-bit elements, zero for columns R .. ldt - 1 (misc.hip's transpose_pad_bf16x8_kernel as a
+// device function: 16-byte global accesses on both sides); workgroup `b` of `nb` takes tiles b, b + nb, ...  C, ldx, ldt multiples of 8.
+template <int NT>
+__device__ __forceinline__ void transpose_pad_tiles16(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int R, int C,
+                                                      long ldx, long ldt, int b, int nb, char* tile) {
+  constexpr int PITCH = 64 * 2 + 16;
+  const int tiles_c = (C + 63) / 64, tiles_r = (int)((ldt + 63) / 64), tid = threadIdx.x;
+  for (int t = b; t < tiles_c * tiles_r; t += nb) {
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    for (int s = tid; s < 512; s += NT) {
+      const int i = s >> 3, q = s & 7, r = r0 + i, c = c0 + q * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (r < R && c < C) v = *reinterpret_cast<const uint4*>(in + (long)r * ldx + c);
+      *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
+    }
+    __syncthreads();
+    for (int s = tid; s < 512; s += NT) {
+      const int q = s >> 6, i = s & 63, c = c0 + i, r = r0 + q * 8;
+      if (c < C && r < ldt) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = *reinterpret_cast<const unsigned short*>(tile + (q * 8 + 2 * e) * PITCH + i * 2);
+          const uint32_t hi = *reinterpret_cast<const unsigned short*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+          w[e] = lo | (hi << 16);
+        }
+        *reinterpret_cast<uint4*>(out + (long)c * ldt + r) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T, int WM, int WN, int FM, int FN, int EPI, bool GLDS, bool RESPRE = false, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   constexpr int BM = WM * FM * 16, BN = WN * FN * 16, NT = WM * WN * 64;
@@ -134,6 +167,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
+  if constexpr (EPI == EPI_SCORES && sizeof(T) == 2) {
+    // the workgroups behind the score tiles transpose V for the apply pass (GemmParams::tr_*: a few-row score grid leaves most CUs idle)
+    if (p.tr_blocks > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
+      transpose_pad_tiles16<NT>((const unsigned short*)p.tr_in, (unsigned short*)p.tr_out, p.tr_R, p.tr_C, p.tr_ldx, p.tr_ldt,
+                                (int)blockIdx.x - tiles_m * tiles_n, p.tr_blocks, smem);
+      return;
+    }
+  }
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   int pid_m = tile / tiles_n, pid_n = tile % tiles_n;  // n fastest: the A panel is reused across the N tiles
   if (p.group_m > 1) {
@@ -1178,7 +1219,8 @@ static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
+  const int extra = (EPI == EPI_SCORES && sizeof(T) == 2 && p.tr_blocks > 0) ? p.tr_blocks : 0;   // (V^T workgroups: tile_kernel, GemmParams::tr_*)
+  hipLaunchKernelGGL(kern, dim3(tiles + extra, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
 }
 

@@ -330,7 +330,7 @@ def test_key_stage_in_launch_merge_equals_the_reduce_launch(tmp_path):
     for mode in ('1', '0'):
         path = str(tmp_path / ('key_%s.npy' % mode))
         env = dict(os.environ, HVR_KEY_MERGE=mode)
-        r = subprocess.run([_sys.executable, os.path.join(root, 'tools', 'probe', 'key_bench.py'), '--dump', path, '--repeat',
+        r = subprocess.run([_sys.executable, os.path.join(root, 'tools', 'key_bench.py'), '--dump', path, '--repeat',
                             '200' if mode == '1' else '0', '--iters', '2'], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         if mode == '1':

@@ -49,9 +49,9 @@ done
 fi
 
 if [[ $parts == *C* ]]; then
-$T python tools/probe/blaslt_ref.py > $out/hipblaslt_calibration.txt 2>/dev/null
+$T python tools/blaslt_ref.py > $out/hipblaslt_calibration.txt 2>/dev/null
 # (which macro tiles the vendor GEMM picks for these shapes: its kernel names carry them)
-rm -rf /tmp/bl_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/bl_ks -o bl -- python tools/probe/blaslt_ref.py > /dev/null 2>&1
+rm -rf /tmp/bl_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/bl_ks -o bl -- python tools/blaslt_ref.py > /dev/null 2>&1
 $T python tools/rocpd_stats.py $(db /tmp/bl_ks) > $out/hipblaslt_kernels.txt 2>&1
 # training step (SELSA, 1 key + 2 ref frames 600x1000, 300 proposals): throughput in both compute modes + kernel stats of the bf16 mode
 $T python tools/train_bench.py --steps 10 --warmup 2 > $out/train_bench.json 2>/dev/null
@@ -78,9 +78,9 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
   $T python tools/pmc_dump.py $(db /tmp/ms) tile_kernel >> $out/window_f16x2_pmc_sq.txt 2>&1
 done
 rm -f $out/conv_layer3.txt
-for d in bf16 f16 f16x2 f32; do $T python tools/probe/l3_block.py --dtype $d 2>/dev/null | grep "layer-3" >> $out/conv_layer3.txt; done
+for d in bf16 f16 f16x2 f32; do $T python tools/l3_block.py --dtype $d 2>/dev/null | grep "layer-3" >> $out/conv_layer3.txt; done
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum"; do
-  rm -rf /tmp/l3; $T rocprofv3 --kernel-trace --pmc $set -d /tmp/l3 -o l3 -- python tools/probe/l3_block.py --dtype bf16 --iters 3 > /dev/null 2>&1
+  rm -rf /tmp/l3; $T rocprofv3 --kernel-trace --pmc $set -d /tmp/l3 -o l3 -- python tools/l3_block.py --dtype bf16 --iters 3 > /dev/null 2>&1
   echo "--- bf16 layer-3 block, pass: $set (FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x 2 on gfx950)" >> $out/conv_layer3.txt
   $T python tools/pmc_dump.py $(db /tmp/l3) _kernel >> $out/conv_layer3.txt 2>&1
 done
@@ -90,9 +90,9 @@ ls $out
 
 if [[ $parts == *E* ]]; then
 $T python tools/stream_bench.py --steps 60 2>/dev/null | tail -1 > $out/stream_bench.json
-rm -rf /tmp/f_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/f_ks -o fr -- python tools/probe/frame_profile.py 20 > $out/stream_frame.log 2>&1
-{ echo "# tools/probe/frame_profile.py under rocprofv3 --kernel-trace --stats: 23 frames (3 warm-up + 20), eager; per-frame rows = call counts that are multiples of 23 (the rest is one-time weight packing)"; grep "one frame" $out/stream_frame.log; $T python tools/rocpd_stats.py $(db /tmp/f_ks) | head -45; } > $out/stream_frame_kernel_stats.txt
-rm -rf /tmp/rw_ks; HVR_RPN_WIDE=4 $T rocprofv3 --kernel-trace --stats -d /tmp/rw_ks -o rpn -- python tools/probe/rpn_probe.py > $out/rpn_wide_probe.txt 2>&1
+rm -rf /tmp/f_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/f_ks -o fr -- python tools/frame_profile.py 20 > $out/stream_frame.log 2>&1
+{ echo "# tools/frame_profile.py under rocprofv3 --kernel-trace --stats: 23 frames (3 warm-up + 20), eager; per-frame rows = call counts that are multiples of 23 (the rest is one-time weight packing)"; grep "one frame" $out/stream_frame.log; $T python tools/rocpd_stats.py $(db /tmp/f_ks) | head -45; } > $out/stream_frame_kernel_stats.txt
+rm -rf /tmp/rw_ks; HVR_RPN_WIDE=4 $T rocprofv3 --kernel-trace --stats -d /tmp/rw_ks -o rpn -- python tools/rpn_probe.py > $out/rpn_wide_probe.txt 2>&1
 $T python tools/rocpd_stats.py $(db /tmp/rw_ks) | grep -i "rpn\|nms\|kernel \|dispatches" > $out/rpn_wide_kernel_stats.txt
-$T bash tools/probe/run_stream_ab.sh > /dev/null 2>&1; $T bash tools/probe/run_key.sh > /dev/null 2>&1   # -> gpurun_out/stream_ab.txt, gpurun_out/key_stage_ab.txt
+$T bash tools/run_stream_ab.sh > /dev/null 2>&1; $T bash tools/run_key.sh > /dev/null 2>&1   # -> gpurun_out/stream_ab.txt, gpurun_out/key_stage_ab.txt
 fi

@@ -478,6 +478,10 @@ static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
 // per output tile (at least 2 blocks each), every slice writes an f32 partial, one reduce launch sums and rounds them.  The
 // block weights g = 2^(m_t - m*) / L are global per row, so the partials simply add.  1 = no split.
 constexpr size_t kApplyTicketBytes = 1024;   // one int per output tile of a sliced apply pass (fewer than 96 tiles: apply_slices)
+static int apply_slice_blocks() {   // 128-key blocks per slice of a sliced apply pass (HVR_KEY_SLICE_BLOCKS: tuning)
+  static const int per = std::getenv("HVR_KEY_SLICE_BLOCKS") ? std::atoi(std::getenv("HVR_KEY_SLICE_BLOCKS")) : 4;
+  return per >= 2 && per <= 8 ? per : 4;
+}
 static int apply_slices(int Mq, int Mk, int D) {
   const long tiles = (long)((Mq + 127) / 128) * ((D + 127) / 128);
   const int nblk = (int)(rel_ldp(Mk) / 128);
@@ -488,7 +492,8 @@ static int apply_slices(int Mq, int Mk, int D) {
   // in a 4 500-row call (unsplit, one running f32 sum over the 36 blocks) may differ from it in the last f32 bit.  The loops that
   // are tested for batch invariance (cached / look-ahead stream) always call the stages with the shapes that ship -- 300 and
   // 4 500 rows -- so each stage stays on one side of the threshold
-  return (nblk + 3) / 4;
+  const int per = apply_slice_blocks();
+  return (nblk + per - 1) / per;
 }
 
 size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
@@ -617,7 +622,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   const int slices = no_split ? 1 : apply_slices(Mq, Mk, D);
   if (slices > 1 && tile_apply == 0 && (!two_byte || (ldo % 8 == 0 && aligned16(O)))) {
     const int steps_per_blk = two_byte ? 2 : 4;
-    const int per = 4;  // apply_slices: four 128-key blocks per slice
+    const int per = apply_slice_blocks();  // apply_slices: 128-key blocks per slice
     p.ksplit_steps = per * steps_per_blk;
     p.ksplit_count = slices;
     p.csplit_bytes = (long)Mq * D * 4;

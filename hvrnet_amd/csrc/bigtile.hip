@@ -6,7 +6,7 @@
 //
 // Why a second shape next to gemm.hip's 144 x 256 tiles: with N = 256 .. 512 output channels every tile streams the whole
 // weight matrix, and a 144-row tile -- all that one round of 256 CUs leaves a 35 910-pixel batch -- pays 51 KB of L2 -> LDS
-// delivery per K-step of 1 152 MFMA cycles plus 0.61 LDS fragment reads per MFMA: 34 % MFMA-busy (the
+// delivery per K-step of 1 152 MFMA cycles plus 0.61 LDS fragment reads per MFMA: 34 % MFMA-busy (profiles/design_history.md section 10, the
 // K-loop ablations).  Here ONE workgroup per CU owns 288 x 256: 70 KB per K-step of 2 304 MFMA cycles (30 B/clk instead of
 // 44), 8 waves as 2 x 4 with 144 x 64 wave tiles (0.36 fragment reads per MFMA), and the loop is relation_bt.hip's
 // phase-staggered one (two wave groups one barrier apart: on every SIMD one wave runs a pure MFMA section while its partner

@@ -1468,6 +1468,11 @@ int* rpn_wide_done_flags(void* wws, int T) {
   return (int*)((char*)wws + al256((size_t)T * WBINS * 4 * 2) + al256((size_t)T * WBINS * 4) + al256((size_t)T * 16));
 }
 
+__global__ void rpn_wide_zero_kernel(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 hipError_t run_rpn_select_wide(const void* cls, const void* reg, long cls_stride, long reg_stride, float* out, const RpnParams& rp,
                                void* wws, hipStream_t s) {
   const int T = rp.T, n = rp.n_anchor;
@@ -1479,8 +1484,9 @@ hipError_t run_rpn_select_wide(const void* cls, const void* reg, long cls_stride
   int* meta = (int*)w;      w += al256((size_t)T * 16);
   w += al256((size_t)T * 4);               // done flags (rpn_wide_done_flags)
   unsigned long long* cand = (unsigned long long*)w;
-  hipError_t e = hipMemsetAsync(hist0, 0, (size_t)T * WBINS * 4 * 2, s);
-  if (e != hipSuccess) return e;
+  // (a kernel, not hipMemsetAsync: a captured graph whose chain holds a memset node, replayed again behind an ordinary launch on the
+  // same stream while its previous replay is still in flight, took a GPU memory fault on ROCm 7.2 -- profiles/r04_graph_memset_fault.txt)
+  hipLaunchKernelGGL(rpn_wide_zero_kernel, dim3((T * WBINS * 2 + 255) / 256), dim3(256), 0, s, hist0, T * WBINS * 2);
   const int G = (n + WSEL_PER_WG - 1) / WSEL_PER_WG;
   const float* c = (const float*)cls;
   const float* r = (const float*)reg;

@@ -322,3 +322,34 @@ def test_look_ahead_stream_also_takes_single_frames_and_guards_its_buffers():
         g.run()
     with pytest.raises(RuntimeError):
         one.push(frames[0:1])
+
+
+def test_one_chain_stream_graphs_survive_launches_between_replays():
+    """Stream-mode graph F captured as ONE chain (HVR_RPN_SIDE=0: the RPN branch in line, its one-frame proposal call in the chip-wide
+    form) replayed with ordinary launches between the replays and no host synchronisation -- the loop of GraphedStream.push().  With a
+    hipMemsetAsync node in that chain this sequence took a GPU memory fault on ROCm 7.2 (profiles/r04_graph_memset_fault.txt); the
+    zeroing is a kernel now.  In a child process: a fault kills the process that owns the queue."""
+    import os, subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import torch, sys
+sys.path.insert(0, %r)
+import hvrnet_amd
+from hvrnet_amd import synthetic as S
+from hvrnet_amd.config import hvr_config
+from hvrnet_amd.graphs import GraphedStream
+T, dev = 5, 'cuda:0'
+model = hvrnet_amd.build_model(hvr_config(frame_interval=T // 2, nms_post=64), S.synth_state_dict('hvr'), torch.bfloat16, dev)
+frames = torch.cat([S.synth_frame(i) for i in range(T)], 0).to(dev); meta = S.synth_meta()
+with torch.no_grad():
+    gs = GraphedStream(model, frames[0:1], meta, rescale=True)
+    scratch = torch.zeros(1024, device=dev)
+    for r in range(3):
+        for i in range(T):
+            gs.push(frames[i:i + 1]); scratch.add_(1)
+        res = gs.emit().result()
+    torch.cuda.synchronize()
+    print('OK', sum(len(c) for c in res))
+""" % root
+    r = subprocess.run([_sys.executable, '-c', code], env=dict(os.environ, HVR_RPN_SIDE='0'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -232,9 +232,30 @@ class _RelationHead(BBoxHead):
         b = torch.cat([fc_cls.bias, fc_reg.bias, fc_cls.bias.new_zeros(-(nc + 4) % 4)], 0)
         return TO.linear(h.contiguous(), w, b, out_f32=True)
 
-    def _stage(self, p, k, x, q_range=None):
-        """relu(Xq + relation_k(X)): rows `q_range` as queries (all rows when None), keys = X[:nongt_dim]."""
+    # bit-for-bit equality of a batched call (clips > 1) with the per-clip calls: native.relation_fwd_grouped(exact=True)
+    grouped_exact = False
+
+    def _stage(self, p, k, x, q_range=None, clips=1):
+        """relu(Xq + relation_k(X)): rows `q_range` as queries (all rows when None), keys = X[:nongt_dim].
+        clips = W > 1: x holds the rows of W independent clips back to back ([W * R, D]); projections and the output layer run on
+        all W * R rows as one product each, the relation core per clip in ONE grouped call (hvr_relation_fwd_grouped); q_range
+        addresses rows inside every clip -> [W * l, D], clip-major."""
         D = self.fc_feat_dim
+        if clips > 1:
+            R = x.shape[0] // clips
+            assert R * clips == x.shape[0] and self.nongt_dim >= R, 'batched clips: equal row counts, untruncated keys'
+            wqk, bqk = p['wqk%d' % k], p['bqk%d' % k]
+            scale = 1.0 / math.sqrt(float(self.dim[1]))
+            if q_range is None:
+                qk = native.gemm(x, wqk, bqk)
+                o = native.relation_fwd_grouped(qk[:, :D], qk[:, D:], x, scale, clips, exact=self.grouped_exact)
+                return native.gemm(o, p['wz%d' % k], p['bz%d' % k], resid=x, relu=True)
+            s, l = q_range
+            xq = x.view(clips, R, D)[:, s:s + l].reshape(clips * l, D)
+            q = native.gemm(xq, wqk[:D], bqk[:D])
+            kk = native.gemm(x, wqk[D:], bqk[D:])
+            o = native.relation_fwd_grouped(q, kk, x, scale, clips, exact=self.grouped_exact)
+            return native.gemm(o, p['wz%d' % k], p['bz%d' % k], resid=xq, relu=True)
         kv = x if self.nongt_dim >= x.shape[0] else x[:self.nongt_dim]
         wqk, bqk = p['wqk%d' % k], p['bqk%d' % k]
         if q_range is None and kv is x:
@@ -247,6 +268,14 @@ class _RelationHead(BBoxHead):
         o = native.relation_fwd(q, kk, kv, 1.0 / math.sqrt(float(self.dim[1])))
         return native.gemm(o, p['wz%d' % k], p['bz%d' % k], resid=xq, relu=True)
 
+    @staticmethod
+    def _key_rows(h, clips, s, l):
+        """rows s .. s + l of every clip of h [clips * R, D] -> [clips * l, D] (a view for one clip)."""
+        if clips == 1:
+            return h[s:s + l]
+        R = h.shape[0] // clips
+        return h.view(clips, R, h.shape[1])[:, s:s + l].reshape(clips * l, h.shape[1])
+
     def _readout(self, p, name, h):
         o = native.gemm(h, p[name][0], p[name][1], out_f32=True)
         nc = self.num_classes
@@ -257,25 +286,26 @@ class _RelationHead(BBoxHead):
 class SelsaBBoxHead(_RelationHead):
     NUM_STAGES = 2
 
-    def forward(self, bbox_feat, cur_range=None, key_dim=0, all_res=False):
+    def forward(self, bbox_feat, cur_range=None, key_dim=0, all_res=False, clips=1):
         """-> (cls_score, bbox_pred, None), selsa_bbox_head.py:203-261 (output_cur_only=False)."""
-        return self.forward_from_f1(self.fc1_rows(bbox_feat), cur_range, key_dim, all_res)
+        return self.forward_from_f1(self.fc1_rows(bbox_feat), cur_range, key_dim, all_res, clips=clips)
 
-    def forward_from_f1(self, f1, cur_range=None, key_dim=0, all_res=False):
-        """The head from the fc_new_1 rows on (rows are per-RoI: a video runner may cache them per frame)."""
+    def forward_from_f1(self, f1, cur_range=None, key_dim=0, all_res=False, clips=1):
+        """The head from the fc_new_1 rows on (rows are per-RoI: a video runner may cache them per frame).  clips = W > 1: f1 holds
+        W independent clips' rows back to back, cur_range addresses the key rows inside every clip; outputs are clip-major."""
         assert cur_range is not None, 'Feature num range along axis need specified'
         self.key_dim = key_dim
         self.nongt_dim = self.sampler_num * self.t_dim
         s, l = int(cur_range['start']), int(cur_range['length'])
         p = self.packed(f1.device)
-        h1 = self._stage(p, 1, f1)
+        h1 = self._stage(p, 1, f1, clips=clips)
         f2 = native.gemm(h1, p['fc2'], p['fcb2'])
         if all_res:
-            h2 = self._stage(p, 2, f2)
+            h2 = self._stage(p, 2, f2, clips=clips)
         elif self.dead_row_elimination:
-            h2 = self._stage(p, 2, f2, (s, l))
+            h2 = self._stage(p, 2, f2, (s, l), clips=clips)
         else:
-            h2 = self._stage(p, 2, f2)[s:s + l]
+            h2 = self._key_rows(self._stage(p, 2, f2, clips=clips), clips, s, l)
         cls, reg = self._readout(p, 'out1', h2)
         return cls, reg, None
 
@@ -323,32 +353,38 @@ class HRNMPBBoxHead(_RelationHead):
         anchors = torch.nonzero(labels != 0).reshape(-1)
         return [anchors, picks[anchors, 1], picks[anchors, 0]]
 
-    def forward_test(self, bbox_feat_s, cur_range_s=None, key_dim=0, all_res=False):
+    def forward_test(self, bbox_feat_s, cur_range_s=None, key_dim=0, all_res=False, clips=1):
         """-> ([cls_branch, cls], [reg_branch, reg]), hrnmp_bbox_head.py:800-909."""
-        return self.forward_from_f1(self.fc1_rows(bbox_feat_s), cur_range_s, key_dim, all_res)
+        return self.forward_from_f1(self.fc1_rows(bbox_feat_s), cur_range_s, key_dim, all_res, clips=clips)
 
-    def forward_from_f1(self, f1, cur_range_s=None, key_dim=0, all_res=False):
-        """The head from the fc_new_1 rows on (rows are per-RoI: a video runner may cache them per frame)."""
+    def forward_from_f1(self, f1, cur_range_s=None, key_dim=0, all_res=False, clips=1):
+        """The head from the fc_new_1 rows on (rows are per-RoI: a video runner may cache them per frame).  clips = W > 1: f1 holds
+        W independent clips' rows back to back, cur_range_s[0] addresses the key rows inside every clip; outputs are clip-major
+        ([W * l, .]: clip w's rows are w * l .. (w + 1) * l)."""
         assert cur_range_s is not None, 'Feature num range along axis need specified'
         self.key_dim = key_dim
         self.nongt_dim = self.sampler_num * self.t_dim
-        assert self.nongt_dim >= f1.shape[0]  # hrnmp_bbox_head.py:249
+        assert self.nongt_dim >= f1.shape[0] // clips  # hrnmp_bbox_head.py:249
         cur = cur_range_s[0]
         s, l = int(cur['start']), int(cur['length'])
         p = self.packed(f1.device)
-        h1 = self._stage(p, 1, f1)
+        h1 = self._stage(p, 1, f1, clips=clips)
         f2 = native.gemm(h1, p['fc2'], p['fcb2'])
         if self.dead_row_elimination:
-            h2_key = self._stage(p, 2, f2, (s, l))
+            h2_key = self._stage(p, 2, f2, (s, l), clips=clips)
         else:
-            h2_key = self._stage(p, 2, f2)[s:s + l]
+            h2_key = self._key_rows(self._stage(p, 2, f2, clips=clips), clips, s, l)
         cls_b, reg_b = self._readout(p, 'out1', h2_key)
         x3 = f1.clone()            # non-key rows fall back to the stage-1 pre-attention features (:865-868)
-        x3[s:s + l] = h2_key
+        if clips == 1:
+            x3[s:s + l] = h2_key
+        else:
+            R = f1.shape[0] // clips
+            x3.view(clips, R, -1)[:, s:s + l] = h2_key.view(clips, l, -1)
         f3 = native.gemm(x3, p['fc3'], p['fcb3'])
-        h3 = self._stage(p, 3, f3)
+        h3 = self._stage(p, 3, f3, clips=clips)
         f4 = native.gemm(h3, p['fc4'], p['fcb4'])
-        h4 = self._stage(p, 4, f4, (s, l))
+        h4 = self._stage(p, 4, f4, (s, l), clips=clips)
         cls, reg = self._readout(p, 'out2', h4)
         return [cls_b, cls], [reg_b, reg]
 

@@ -96,7 +96,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" {
 
-int hvr_abi_version(void) { return 4; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta
+int hvr_abi_version(void) { return 5; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta
 const char* hvr_last_error(void) { return g_err.c_str(); }
 
 static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
@@ -496,6 +496,70 @@ static int apply_slices(int Mq, int Mk, int D) {
   return (nblk + per - 1) / per;
 }
 
+// The apply pass of ONE problem on two-byte / f32 operands: O = sum_t g_t (P~_t V_t) from the scores pass's P~ and block statistics
+// (the tile engine's / pc_gemm.hip's EPI_APPLY, key slices for few query rows).  Shared by hvr_relation_fwd and the per-group leg of
+// hvr_relation_fwd_grouped.
+static int relation_apply_pass(const void* P, const void* Vt, float* mstat, float* lstat, float* partial, void* O, int64_t ldo,
+                               int Mq, int Mk, int D, long ldp, int nt, int dtype, int staging, hipStream_t s) {
+  const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
+  static const int tile_apply = env_tile("HVR_TILE_APPLY");
+  static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
+  static const int no_pc = env_tile("HVR_NO_PC");  // force the tile-engine apply pass
+  static const int pc_apply = std::getenv("HVR_PC_APPLY") ? std::atoi(std::getenv("HVR_PC_APPLY")) : 1;
+#ifdef HVR_DEBUG_KNOBS
+  static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
+#endif
+  GemmParams p;
+  int rc;
+  rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
+  if (rc) return rc;
+  p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+  p.tile_hint = tile_apply;
+  p.group_m = gm_apply;
+#ifdef HVR_DEBUG_KNOBS
+  if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
+#endif
+  static const int no_split = env_tile("HVR_NO_APPLY_SPLIT");
+  const int slices = no_split ? 1 : apply_slices(Mq, Mk, D);
+  if (slices > 1 && tile_apply == 0 && (!two_byte || (ldo % 8 == 0 && aligned16(O)))) {
+    const int steps_per_blk = two_byte ? 2 : 4;
+    const int per = apply_slice_blocks();  // apply_slices: 128-key blocks per slice
+    p.ksplit_steps = per * steps_per_blk;
+    p.ksplit_count = slices;
+    p.csplit_bytes = (long)Mq * D * 4;
+    p.C = partial; p.ldc = D; p.out_f32 = two_byte ? 1 : 0;
+    p.tile_hint = 1;  // 128 x 128 tiles; the slices are latency chains of 8 K-steps (the pipelined shapes measure the same)
+    // HVR_KEY_MERGE=1 (opt-in, two-byte operands): the slice that reaches an output tile last merges the partials inside the
+    // launch (gemm_tile.h, the ticket tail of EPI_APPLY: slice order, the reduce kernel's bits) instead of the reduce launch.
+    // Correct (bit-identical, tests/test_kernels_gpu.py) and SLOWER: the apply launch 24.4 -> 60.3 us, the 300 x 4 500 stage
+    // 49.3 -> 83.6 us (profiles/r03_key_stage_merge_ab.txt) against the 5.0 us reduce launch it saves.  Ablation (same file): with
+    // the two agent-scope fences compiled out (buffer_wbl2 sc1 / buffer_inv sc1 in every wave of 216 workgroups; cross-XCD
+    // visibility needs them, so that build is timing-only) the apply launch is 31.9 us -- the fences are 27.6 us of the 35, the
+    // merge tail itself 7.5, and even fence-free the form does not beat apply 24.4 + reduce 5.0.
+    static const int key_merge = std::getenv("HVR_KEY_MERGE") ? std::atoi(std::getenv("HVR_KEY_MERGE")) : 0;
+    const bool merge = key_merge && two_byte;
+    if (merge) {
+      int* tickets = (int*)((char*)partial + align256((size_t)slices * Mq * D * 4));
+      hipError_t e0 = hipMemsetAsync(tickets, 0, kApplyTicketBytes, s);
+      if (e0 != hipSuccess) return check_launch(e0, "relation: apply tickets");
+      p.tickets = tickets; p.merge_out = O; p.merge_ld = ldo;
+    }
+    hipError_t e = run_tile_op(p, EPI_APPLY, s);
+    if (e == hipSuccess && !merge)
+      e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s)
+          : dtype == HVR_F16 ? run_splitk_reduce_f16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
+    return check_launch(e, "relation: apply (key slices)");
+  }
+  // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table).  Round 2 measured
+  // it behind the tile engine (60 against 57 us) and left it opt-in; on round 4's boxes it is AHEAD, alone (tools/rel_bench.py: 0.1073 /
+  // 0.1102 ms per relation call against 0.1164 / 0.1200) and inside the window (three alternating runs of tools/window_breakdown.py:
+  // 109.4 / 110.3 / 110.5 us per call against 114.1 / 113.0 / 113.1) -- profiles/r04_relation_apply.txt -- so it is the default for
+  // window-sized problems; HVR_PC_APPLY=0 brings the tile engine's apply back.
+  if (pc_apply && !no_pc && tile_apply == 0 && Mq >= 1024 && pc_supported(p, EPI_APPLY))
+    return check_launch(run_pc(p, EPI_APPLY, 128, s), "relation: apply (pc)");
+  return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
+}
+
 size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
   const long ldp = rel_ldp(Mk), nt = ldp / 128;
   const size_t es = elem_size(dtype);
@@ -560,12 +624,9 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   }
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
   // tuning overrides, read once
-  static const int tile_scores = env_tile("HVR_TILE_SCORES"), tile_apply = env_tile("HVR_TILE_APPLY");
+  static const int tile_scores = env_tile("HVR_TILE_SCORES");
   static const int gm_scores = std::getenv("HVR_GM_SCORES") ? std::atoi(std::getenv("HVR_GM_SCORES")) : 8;
-  static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
   static const int no_bt = env_tile("HVR_NO_BT");  // force the tile-engine scores pass
-  static const int no_pc = env_tile("HVR_NO_PC");  // force the tile-engine apply pass
-  static const int pc_apply = std::getenv("HVR_PC_APPLY") ? std::atoi(std::getenv("HVR_PC_APPLY")) : 1;
 #ifdef HVR_DEBUG_KNOBS  // tuning builds only (tools/build_dbg.sh): alias every operand row to row 0 (no memory-system cost)
   static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
 #endif
@@ -576,6 +637,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
     b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
     b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = dtype == HVR_F16;
+    b.groups = 1; b.gs_q = b.gs_k = b.gs_v = b.gs_p = b.gs_vt = b.gs_stat = 0; b.int_max = 0;
     rc = check_launch(run_scores_bt(b, s), "relation: scores (big tile)");
     if (rc) return rc;
   } else {
@@ -610,53 +672,76 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
     rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores");
     if (rc) return rc;
   }
-  rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
-  if (rc) return rc;
-  p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
-  p.tile_hint = tile_apply;
-  p.group_m = gm_apply;
-#ifdef HVR_DEBUG_KNOBS
-  if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
-#endif
-  static const int no_split = env_tile("HVR_NO_APPLY_SPLIT");
-  const int slices = no_split ? 1 : apply_slices(Mq, Mk, D);
-  if (slices > 1 && tile_apply == 0 && (!two_byte || (ldo % 8 == 0 && aligned16(O)))) {
-    const int steps_per_blk = two_byte ? 2 : 4;
-    const int per = apply_slice_blocks();  // apply_slices: 128-key blocks per slice
-    p.ksplit_steps = per * steps_per_blk;
-    p.ksplit_count = slices;
-    p.csplit_bytes = (long)Mq * D * 4;
-    p.C = partial; p.ldc = D; p.out_f32 = two_byte ? 1 : 0;
-    p.tile_hint = 1;  // 128 x 128 tiles; the slices are latency chains of 8 K-steps (the pipelined shapes measure the same)
-    // HVR_KEY_MERGE=1 (opt-in, two-byte operands): the slice that reaches an output tile last merges the partials inside the
-    // launch (gemm_tile.h, the ticket tail of EPI_APPLY: slice order, the reduce kernel's bits) instead of the reduce launch.
-    // Correct (bit-identical, tests/test_kernels_gpu.py) and SLOWER: the apply launch 24.4 -> 60.3 us, the 300 x 4 500 stage
-    // 49.3 -> 83.6 us (profiles/r03_key_stage_merge_ab.txt) against the 5.0 us reduce launch it saves.  Ablation (same file): with
-    // the two agent-scope fences compiled out (buffer_wbl2 sc1 / buffer_inv sc1 in every wave of 216 workgroups; cross-XCD
-    // visibility needs them, so that build is timing-only) the apply launch is 31.9 us -- the fences are 27.6 us of the 35, the
-    // merge tail itself 7.5, and even fence-free the form does not beat apply 24.4 + reduce 5.0.
-    static const int key_merge = std::getenv("HVR_KEY_MERGE") ? std::atoi(std::getenv("HVR_KEY_MERGE")) : 0;
-    const bool merge = key_merge && two_byte;
-    if (merge) {
-      int* tickets = (int*)((char*)partial + align256((size_t)slices * Mq * D * 4));
-      hipError_t e0 = hipMemsetAsync(tickets, 0, kApplyTicketBytes, s);
-      if (e0 != hipSuccess) return check_launch(e0, "relation: apply tickets");
-      p.tickets = tickets; p.merge_out = O; p.merge_ld = ldo;
+  return relation_apply_pass(P, Vt, mstat, lstat, partial, O, ldo, Mq, Mk, D, ldp, nt, dtype, staging, s);
+}
+
+// ---- relation, G independent problems of one shape in one call (the windows a caller has in flight) ----
+size_t hvr_relation_grouped_workspace_bytes(int groups, int Mq, int Mk, int D, int dtype) {
+  return (size_t)(groups > 0 ? groups : 0) * align256(hvr_relation_workspace_bytes(Mq, Mk, D, dtype));
+}
+
+int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void* K, int64_t ldk, int64_t gsk, const void* V, int64_t ldv,
+                             int64_t gsv, void* O, int64_t ldo, int64_t gso, int groups, int Mq, int Mk, int D, float scale, int dtype,
+                             int staging, int exact, void* ws, size_t ws_bytes, void* stream) {
+  if (!Q || !K || !V || !O || !ws) return fail(HVR_EINVAL, "null pointer");
+  if (groups <= 0) return fail(HVR_EINVAL, "relation groups must be positive, got %d", groups);
+  if (Mq <= 0 || Mk <= 0) return fail(HVR_EINVAL, "empty relation Mq=%d Mk=%d", Mq, Mk);
+  if (!(scale > 0.f)) return fail(HVR_EINVAL, "relation scale must be positive (the reference uses 1/sqrt(D)), got %g", (double)scale);
+  if (gsq < 0 || gsk < 0 || gsv < 0 || gso < 0) return fail(HVR_EINVAL, "negative group stride");
+  const size_t per = align256(hvr_relation_workspace_bytes(Mq, Mk, D, dtype));
+  if (ws_bytes < per * (size_t)groups) return fail(HVR_EWORKSPACE, "grouped relation workspace %zu < %zu", ws_bytes, per * (size_t)groups);
+  const size_t es = elem_size(dtype);
+  hipStream_t s = (hipStream_t)stream;
+  // HVR_REL_GROUPED (tuning): 0 = one hvr_relation_fwd per group; 1 = the persistent scores launch over all groups, apply per group;
+  // 2 (default) = + the 288 x 256 apply launch over all groups where it applies (bf16, >= 3 window-sized groups)
+  static const int mode = std::getenv("HVR_REL_GROUPED") ? std::atoi(std::getenv("HVR_REL_GROUPED")) : 2;
+  const long ldp = rel_ldp(Mk);
+  const int nt = (int)(ldp / 128);
+  const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
+  // group 0's workspace laid out as hvr_relation_fwd lays out its own; group g's `per` bytes further
+  char* w = (char*)ws;
+  void* P = w;                w += align256((size_t)Mq * ldp * es);
+  void* Vt = w;               w += align256((size_t)D * ldp * es);
+  float* mstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
+  float* lstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
+  float* partial = (float*)w;
+  const bool strides_ok = two_byte && gsq % 8 == 0 && gsk % 8 == 0 && gsv % 8 == 0 && gso % 8 == 0;
+  if (groups == 1 || mode == 0 || !staging || !strides_ok ||
+      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, groups)) {
+    for (int g = 0; g < groups; ++g) {
+      const int rc = hvr_relation_fwd((const char*)Q + (size_t)g * gsq * es, ldq, (const char*)K + (size_t)g * gsk * es, ldk,
+                                      (const char*)V + (size_t)g * gsv * es, ldv, (char*)O + (size_t)g * gso * es, ldo, Mq, Mk, D, scale,
+                                      dtype, staging, (char*)ws + (size_t)g * per, per, stream);
+      if (rc) return rc;
     }
-    hipError_t e = run_tile_op(p, EPI_APPLY, s);
-    if (e == hipSuccess && !merge)
-      e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s)
-          : dtype == HVR_F16 ? run_splitk_reduce_f16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
-    return check_launch(e, "relation: apply (key slices)");
+    return HVR_OK;
   }
-  // The producer / consumer form of the apply pass (pc_gemm.hip, 144 x 128 tiles, block weights from an LDS table).  Round 2 measured
-  // it behind the tile engine (60 against 57 us) and left it opt-in; on round 4's boxes it is AHEAD, alone (tools/rel_bench.py: 0.1073 /
-  // 0.1102 ms per relation call against 0.1164 / 0.1200) and inside the window (three alternating runs of tools/window_breakdown.py:
-  // 109.4 / 110.3 / 110.5 us per call against 114.1 / 113.0 / 113.1) -- profiles/r04_relation_apply.txt -- so it is the default for
-  // window-sized problems; HVR_PC_APPLY=0 brings the tile engine's apply back.
-  if (pc_apply && !no_pc && tile_apply == 0 && Mq >= 1024 && pc_supported(p, EPI_APPLY))
-    return check_launch(run_pc(p, EPI_APPLY, 128, s), "relation: apply (pc)");
-  return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
+  // exact: every group's result is hvr_relation_fwd's bit for bit (one scores launch over all groups, its arithmetic per tile
+  // unchanged; the apply pass per group) -- what the batched head's equality tests run
+  const bool bt_apply = !exact && mode >= 2 && dtype == HVR_BF16 && apply_bt_supported(Mq, Mk, D, ldp, ldo, P, Vt, O, groups);
+  ScoresBTParams b;
+  b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
+  b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
+  b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = dtype == HVR_F16;
+  b.groups = groups; b.gs_q = gsq; b.gs_k = gsk; b.gs_v = gsv; b.gs_p = (long)(per / 2); b.gs_vt = (long)(per / 2); b.gs_stat = (long)(per / 4);
+  b.int_max = bt_apply ? 1 : 0;
+  int rc = check_launch(run_scores_bt(b, s), "relation (grouped): scores");
+  if (rc) return rc;
+  if (bt_apply) {
+    ApplyBTParams a;
+    a.P = (const bf16_t*)P; a.Vt = (const bf16_t*)Vt; a.mstat = mstat; a.lstat = lstat; a.O = (bf16_t*)O;
+    a.Mq = Mq; a.D = D; a.ntile = nt; a.ldp = ldp; a.ldo = ldo; a.groups = groups;
+    a.gs_p = b.gs_p; a.gs_vt = b.gs_vt; a.gs_stat = b.gs_stat; a.gs_o = gso;
+    return check_launch(run_apply_bt(a, s), "relation (grouped): apply");
+  }
+  for (int g = 0; g < groups; ++g) {
+    char* wg = (char*)ws + (size_t)g * per;
+    rc = relation_apply_pass(wg + ((char*)P - (char*)ws), wg + ((char*)Vt - (char*)ws), (float*)(wg + ((char*)mstat - (char*)ws)),
+                             (float*)(wg + ((char*)lstat - (char*)ws)), (float*)(wg + ((char*)partial - (char*)ws)),
+                             (char*)O + (size_t)g * gso * es, ldo, Mq, Mk, D, ldp, nt, dtype, staging, s);
+    if (rc) return rc;
+  }
+  return HVR_OK;
 }
 
 // ---- relation backward (attention backward of one stage) ----

@@ -1,10 +1,14 @@
-// Big-tile relation scores pass (relation_bt.hip); internal, the public ABI is include/hvr_hip.h.
+// Big-tile relation core (relation_bt.hip: scores pass; relation_apply_bt.hip: apply pass); internal, the public ABI is
+// include/hvr_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "common.h"
 
 namespace hvr {
 
+// One launch covers `groups` independent relation problems of the same shape (the windows a caller has in flight): group g's
+// operands sit gs_* ELEMENTS behind group 0's.  The 352 x 256 score tiles of all groups form one list that 256 persistent workgroups
+// walk (relation_bt.hip).
 struct ScoresBTParams {
   const bf16_t* Q;  // [Mq][ldq]
   const bf16_t* K;  // [Mk][ldk]
@@ -16,13 +20,33 @@ struct ScoresBTParams {
   int Mq, Mk, D, ntile;
   long ldq, ldk, ldv, ldp;
   float sl2;        // scale * log2(e)
-  int tile0, tiles_here;  // set by run_scores_bt per launch: this launch's slice of the tile grid
-  int f16;                // operands are IEEE half (HVR_F16) instead of bf16
+  int f16;          // operands are IEEE half (HVR_F16) instead of bf16
+  int groups;       // >= 1
+  long gs_q, gs_k, gs_v, gs_p, gs_vt, gs_stat;   // group strides in elements (0 with one group)
+  int int_max;      // block maxima rounded UP to integers (log2 units): a block's weight relative to the row's largest block is then an
+                    // exact power of two, which relation_apply_bt.hip applies on the exponent fields of the P~ fragments
 };
 
-// true when the one-round 352 x 256 tiling applies (bf16, aligned operands, a tile grid that fills most of the chip)
+// true when the 352 x 256 tiling applies to ONE group of this shape (two-byte operands, aligned, a tile grid that fills most of the
+// chip in whole rounds); with `groups` > 1 any tile count from 160 up qualifies -- the persistent workgroups take several tiles each
 bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, long ldp, const void* Q, const void* K,
-                         const void* V, const void* P, const void* Vt);
+                         const void* V, const void* P, const void* Vt, int groups = 1);
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream);
+
+// Apply pass on 288 x 256 tiles over the whole key axis (relation_apply_bt.hip), bf16 only, scores written with int_max = 1:
+//   O[g] = diag(1 / L) . (P~[g] with every 128-key block's exponent lowered by m* - m_block) . V^T[g]^T
+struct ApplyBTParams {
+  const bf16_t* P;      // [Mq][ldp]
+  const bf16_t* Vt;     // [D][ldp]
+  const float* mstat;   // [Mq][ntile] integer-valued block maxima
+  const float* lstat;   // [Mq][ntile]
+  bf16_t* O;            // [Mq][ldo]
+  int Mq, D, ntile;
+  long ldp, ldo;
+  int groups;
+  long gs_p, gs_vt, gs_stat, gs_o;
+};
+bool apply_bt_supported(int Mq, int Mk, int D, long ldp, long ldo, const void* P, const void* Vt, const void* O, int groups);
+hipError_t run_apply_bt(const ApplyBTParams& p, hipStream_t stream);
 
 }  // namespace hvr

@@ -21,7 +21,10 @@
 //     the scale folded into one FMA, bf16 pack, row segments staged per wave through LDS so that they leave as whole
 //     128-byte lines;
 //   * every workgroup also transposes its share of V into V^T[D][ldp] (64 x 64 tiles through LDS) while its first
-//     K-step is in flight, which removes the separate transpose launch in front of the apply pass.
+//     K-step is in flight, which removes the separate transpose launch in front of the apply pass;
+//   * the workgroups are PERSISTENT (round 5): a launch takes the score tiles of G independent problems of one shape -- the
+//     windows a caller has in flight -- as one list; from its second tile on a workgroup has its first K-step fetched under the
+//     previous tile's last K-step, and that tile's P~ stores drain under the new loop instead of in front of a kernel boundary.
 #include "common.h"
 #include "relation_bt.h"
 
@@ -36,14 +39,7 @@ constexpr int BT_A_BYTES = BT_BM * 128, BT_B_BYTES = BT_BN * 128, BT_STAGE = BT_
 constexpr int BT_A_SLOTS = (BT_BM * 8 + BT_NT - 1) / BT_NT;  // 6 (the last one: waves 0..3 only)
 constexpr int BT_B_SLOTS = BT_BN * 8 / BT_NT;                // 4
 constexpr int BT_LDS = 2 * BT_STAGE;                         // 155 648 B
-#ifndef HVR_BT_AHEAD
-#define HVR_BT_AHEAD 3
-#endif
-constexpr int BT_AHEAD = HVR_BT_AHEAD, BT_RING = BT_AHEAD + 2;  // query-fragment read-ahead distance / ring slots
-constexpr int BT_ITEMS = 2 * BT_FM;                          // (half, row fragment) items per K-step
-constexpr int BT_KB_AT = 2;                                  // the second half's key fragments are requested after this item
 static_assert(BT_LDS <= 160 * 1024, "LDS budget");
-static_assert(BT_A_SLOTS + BT_B_SLOTS <= BT_ITEMS / 2, "one DMA piece after every second item");
 
 __device__ __forceinline__ uint32_t lds_off(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
@@ -68,17 +64,6 @@ template <typename T> __device__ __forceinline__ void mma(const uint4& keys, con
 #endif
 }
 
-// LDS reads that may still be outstanding when item t's query fragment is needed: the fragments requested after it
-// (read-ahead, bounded by the end of the K-step) and, around BT_KB_AT, the four key fragments of the second half
-constexpr int pending_after(int t) {
-  int n = 0;
-  for (int u = t + 1; u <= t + BT_AHEAD - 1 && u < BT_ITEMS; ++u) ++n;  // q(t+1) .. q(t+AHEAD-1) exist at wait time
-  // the key fragments are issued after item BT_KB_AT's own read-ahead q(BT_KB_AT + AHEAD): they are younger than
-  // q(t) for t <= BT_KB_AT + AHEAD and already issued when item t > BT_KB_AT waits
-  if (t > BT_KB_AT && t <= BT_KB_AT + BT_AHEAD) n += BT_FN;
-  return n;
-}
-
 }  // namespace
 
 template <typename HT>   // bf16_t / f16_t: operands move as raw 16-bit words; the MFMA opcode and the P~ pack differ
@@ -89,31 +74,47 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   const int wm = wave / BT_WN, wn = wave % BT_WN;
   const int tiles_n = (int)((p.ldp + BT_BN - 1) / BT_BN);
   const int tiles_m = (p.Mq + BT_BM - 1) / BT_BM;
-  const int ntiles = tiles_m * tiles_n;
-  // Rounds of up to 256 tiles, one LAUNCH per round (one for the 4 500-row window: 234 tiles; two for the shipped T = 21
-  // window's 6 300 rows: 450 tiles): this launch holds tiles p.tile0 .. p.tile0 + p.tiles_here - 1
-  const bool has_tile = (int)blockIdx.x < p.tiles_here;
+  const int tpg = tiles_m * tiles_n;          // tiles per group
+  const int total = tpg * p.groups;
+  const int nwg = (int)gridDim.x;
+  // PERSISTENT workgroups: the tiles of all groups form one list, walked in rounds of `nwg` (256: one workgroup per CU); round r
+  // gives this workgroup tile r * nwg + xcd_remap(blockIdx.x, tiles of the round) -- n fastest inside an XCD's contiguous range, so
+  // that neighbouring tiles share their 352-row query panel in one L2.  One group of the 4 500-row window is 234 tiles = one round
+  // (every workgroup one tile, the launch of rounds 1-4); G windows in flight are G x 234 tiles, and from the second tile on a
+  // workgroup's first K-step is fetched under its previous tile's last K-step and that tile's P~ stores drain under the new loop.
+  auto tile_of = [&](int r) -> int {
+    const int left = total - r * nwg, here = left < nwg ? left : nwg;
+    return (int)blockIdx.x < here ? r * nwg + xcd_remap(blockIdx.x, here) : -1;
+  };
 #ifdef HVR_DBG_BT_CLK
-  long long dbg_t[5];
+  long long dbg_t[2 + 3 * 4];
+  for (int q = 0; q < 14; ++q) dbg_t[q] = 0;
   dbg_t[0] = wall_clock64();
 #endif
-  // n fastest inside an XCD's contiguous range: the 352-row query panel is shared by neighbouring tiles
-  const int tile = has_tile ? p.tile0 + xcd_remap(blockIdx.x, p.tiles_here) : 0;
-  const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;
-  const int m0 = pid_m * BT_BM, n0 = pid_n * BT_BN;
+  int cur = tile_of(0);
+  const bool has_tile = cur >= 0;
+  int g_cur = 0, m0 = 0, n0 = 0;
+  auto locate = [&](int t, int& g, int& tm0, int& tn0) {
+    g = t / tpg;
+    const int r = t - g * tpg, pm = r / tiles_n;
+    tm0 = pm * BT_BM;
+    tn0 = (r - pm * tiles_n) * BT_BN;
+  };
+  if (has_tile) locate(cur, g_cur, m0, n0);
 
   // ---- loader: a thread's 16-byte pieces sit 64 rows apart (slot s = i * 512 + tid -> row i * 64 + tid / 8), all in
-  // the same swizzled chunk; offsets are rebuilt at issue time (three VALU ops) instead of living in registers ----
+  // the same swizzled chunk; offsets are rebuilt at issue time (three VALU ops) instead of living in registers.  The tile a
+  // piece belongs to is an argument: the last K-step of a tile loads the NEXT tile's first K-step ----
   const int l_row = tid >> 3, l_chunk = ((tid & 7) ^ (l_row & 7)) * 16;
-  auto dma_a = [&](auto I, int kt, char* stage) {
+  auto dma_a = [&](auto I, int kt, char* stage, const char* qbase, int tm0) {
     constexpr int i = decltype(I)::value;
     if (i < BT_A_SLOTS - 1 || wave < (BT_BM * 8 - (BT_A_SLOTS - 1) * BT_NT) / 64) {
-      int m = m0 + i * 64 + l_row;
+      int m = tm0 + i * 64 + l_row;
       m = m < p.Mq ? m : p.Mq - 1;
 #ifdef HVR_DBG_BT_SAMEROW
       m &= 63;
 #endif
-      const char* src = (const char*)p.Q + ((long)m * p.ldq * 2 + l_chunk + kt * 128);
+      const char* src = qbase + ((long)m * p.ldq * 2 + l_chunk + kt * 128);
 #ifdef HVR_DBG_BT_NODMA
       if (kt == 0)
 #endif
@@ -121,52 +122,79 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
                                        (__attribute__((address_space(3))) void*)(stage + (i * BT_NT + wave * 64) * 16), 16, 0, 0);
     }
   };
-  auto dma_b = [&](auto I, int kt, char* stage) {
+  auto dma_b = [&](auto I, int kt, char* stage, const char* kbase, int tn0) {
     constexpr int i = decltype(I)::value;
-    int n = n0 + i * 64 + l_row;
+    int n = tn0 + i * 64 + l_row;
     n = n < p.Mk ? n : p.Mk - 1;
 #ifdef HVR_DBG_BT_SAMEROW
     n &= 63;
 #endif
-    const char* src = (const char*)p.K + ((long)n * p.ldk * 2 + l_chunk + kt * 128);
+    const char* src = kbase + ((long)n * p.ldk * 2 + l_chunk + kt * 128);
 #ifdef HVR_DBG_BT_NODMA
     if (kt == 0)
 #endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(stage + BT_A_BYTES + (i * BT_NT + wave * 64) * 16), 16, 0, 0);
   };
+  const char* q_cur = (const char*)(p.Q + (long)g_cur * p.gs_q);
+  const char* k_cur = (const char*)(p.K + (long)g_cur * p.gs_k);
 
-  // first K-step into stage 0; it lands while the workgroup transposes its share of V through stage 1's memory
+  // the first tile's first K-step into stage 0; it lands while the workgroup transposes its share of V through stage 1's memory
   if (has_tile) {
-    static_for<BT_A_SLOTS>([&](auto I) { dma_a(I, 0, smem); });
-    static_for<BT_B_SLOTS>([&](auto I) { dma_b(I, 0, smem); });
+    static_for<BT_A_SLOTS>([&](auto I) { dma_a(I, 0, smem, q_cur, m0); });
+    static_for<BT_B_SLOTS>([&](auto I) { dma_b(I, 0, smem, k_cur, n0); });
   }
 
-  // ---------------- V^T[D][ldp] = V[Mk][ldv]^T, zero-filled for keys Mk .. ldp - 1 ----------------
-  // 64 x 64 tiles, one per half workgroup (256 threads) and pass; 16-byte global accesses on both sides
+  // ---------------- V^T[g][D][ldp] = V[g][Mk][ldv]^T of every group, zero-filled for keys Mk .. ldp - 1 ----------------
+  // 64 x 64 tiles, one per half workgroup (256 threads) and pass, 16-byte global accesses on both sides, the next pass's loads in
+  // flight under this pass's LDS round trip (two LDS buffers per half: one barrier per pass).  WHO copies: when the last round of
+  // score tiles leaves workgroups without a tile (234 tiles of one 4 500-row window: 22; four windows, 936 tiles: 88 in the fourth
+  // round), those workgroups copy V^T beside the others' last tiles -- the copy (7 us per window when every workgroup carried
+  // its share in front of its first tile) leaves the critical path; with a full last round every workgroup takes its share first.
+  const int rounds = (total + nwg - 1) / nwg;
+  const int here_last = total - (rounds - 1) * nwg;   // tiles of the last round
+  const int n_idle = nwg - here_last;                 // workgroups without a tile in it
+  const bool vt_by_idle = n_idle >= 16;
+  auto vt_copy = [&](int first, int step) {           // 64 x 64 tiles first + half, first + half + step, ... of the list over all groups
 #ifndef HVR_DBG_BT_NOTRANSPOSE
-  if (p.tile0 == 0) {   // the first round's launch carries the V^T copy
-    constexpr int PITCH = 64 * 2 + 16;
+    constexpr int PITCH = 64 * 2 + 16, BUF = 64 * PITCH;
     const int half = tid >> 8, ht = tid & 255;
-    char* tbuf = smem + BT_STAGE + half * (64 * PITCH);
-    const int tr_c = p.D / 64, tr_r = (int)(p.ldp / 64), ntr = tr_c * tr_r;
-    const int per_pass = (int)gridDim.x * 2;
-    for (int base = 0; base < ntr; base += per_pass) {
-      const int tt = base + (int)blockIdx.x * 2 + half;
-      const bool live = tt < ntr;
+    char* const tb = smem + BT_STAGE + half * (2 * BUF);
+    const int tr_c = p.D / 64, ntr = tr_c * (int)(p.ldp / 64), ntr_all = ntr * p.groups;
+    auto fetch = [&](int tt_all, uint4 (&v)[2]) {     // (clamped addresses + selects: no predicated load, no per-element round trip)
+      const bool live = tt_all < ntr_all;
+      const int tc = live ? tt_all : ntr_all - 1;
+      const int tg = tc / ntr, tt = tc - tg * ntr;
       const int r0 = (tt / tr_c) * 64, c0 = (tt % tr_c) * 64;
-      if (live) {
+      const bf16_t* Vg = p.V + (long)tg * p.gs_v;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int s = it * 256 + ht, i = s >> 3, q = s & 7;
-          const int r = r0 + i, c = c0 + q * 8;
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if (r < p.Mk) v = *reinterpret_cast<const uint4*>(p.V + (long)r * p.ldv + c);
-          *reinterpret_cast<uint4*>(tbuf + i * PITCH + q * 16) = v;
-        }
+      for (int it = 0; it < 2; ++it) {
+        const int s = it * 256 + ht, i = s >> 3, q = s & 7;
+        const int r = r0 + i, rc = r < p.Mk ? r : p.Mk - 1;
+        const uint4 x = *reinterpret_cast<const uint4*>(Vg + (long)rc * p.ldv + c0 + q * 8);
+        const bool keep = live && r < p.Mk;
+        v[it] = make_uint4(keep ? x.x : 0u, keep ? x.y : 0u, keep ? x.z : 0u, keep ? x.w : 0u);
       }
-      __syncthreads();
+    };
+    uint4 cur[2], nxt[2];
+    fetch(first + half, cur);
+    int buf = 0;
+    for (int base = first; base < ntr_all; base += step) {
+      const int tt_all = base + half;
+      const bool live = tt_all < ntr_all;
+      char* const tbuf = tb + buf * BUF;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int s = it * 256 + ht, i = s >> 3, q = s & 7;
+        *reinterpret_cast<uint4*>(tbuf + i * PITCH + q * 16) = cur[it];
+      }
+      fetch(base + step + half, nxt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       if (live) {
+        const int tg = tt_all / ntr, tt = tt_all - tg * ntr;
+        const int r0 = (tt / tr_c) * 64, c0 = (tt % tr_c) * 64;
+        bf16_t* Vtg = p.Vt + (long)tg * p.gs_vt;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int s = it * 256 + ht, q = s >> 6, i = s & 63;
@@ -177,17 +205,32 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
             const uint32_t hi = *reinterpret_cast<const bf16_t*>(tbuf + (q * 8 + 2 * e + 1) * PITCH + i * 2);
             w[e] = lo | (hi << 16);
           }
-          *reinterpret_cast<uint4*>(p.Vt + (long)(c0 + i) * p.ldp + r0 + q * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+          *reinterpret_cast<uint4*>(Vtg + (long)(c0 + i) * p.ldp + r0 + q * 8) = make_uint4(w[0], w[1], w[2], w[3]);
         }
       }
-      __syncthreads();
+      cur[0] = nxt[0]; cur[1] = nxt[1];
+      buf ^= 1;
     }
-  }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the buffers are the first tile's stage 1
+#else
+    (void)first; (void)step;
 #endif
+  };
+  if (!vt_by_idle) vt_copy((int)blockIdx.x * 2, nwg * 2);
 #ifdef HVR_DBG_BT_CLK
   dbg_t[1] = wall_clock64();
 #endif
-  if (!has_tile) return;
+
+  const int nk = p.D / 64;   // even (scores_bt_supported): every tile starts in stage 0 and ends in stage 1
+  if (has_tile) for (int round = 0;; ++round) {
+  // the tile after this one (its first K-step is this tile's last prefetch)
+  const int nxt_tile = tile_of(round + 1);
+  const bool has_next = nxt_tile >= 0;
+  int g_nxt = g_cur, m0_nxt = m0, n0_nxt = n0;
+  if (has_next) locate(nxt_tile, g_nxt, m0_nxt, n0_nxt);
+  const char* q_nxt = (const char*)(p.Q + (long)g_nxt * p.gs_q);
+  const char* k_nxt = (const char*)(p.K + (long)g_nxt * p.gs_k);
 
   f32x4 acc[BT_FM][BT_FN];
 #pragma unroll
@@ -199,48 +242,14 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   const uint32_t a_lane = lds_off(smem) + (wm * BT_WROWS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
   const uint32_t b_lane = lds_off(smem) + BT_A_BYTES + (wn * BT_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
 
-  const int nk = p.D / 64;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the first K-step has landed: the first tile's was issued above (wait for it); a later tile's was waited for by the issuing
+  // waves inside the previous tile's last K-step -- no vmcnt wait here, which would also wait for that tile's P~ stores
+  if (round == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef HVR_DBG_BT_CLK
+  if (round < 4) dbg_t[2 + 3 * round] = wall_clock64();
+#endif
 
-#ifdef HVR_BT_LOCKSTEP
-  for (int kt = 0; kt < nk; ++kt) {
-    const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * BT_STAGE;
-    const int kn = kt + 1 < nk ? kt + 1 : kt;
-    const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
-    uint4 kb[2][BT_FN];  // key fragments: [half][column fragment]
-    uint4 qa[BT_RING];   // query-fragment ring: item t = half * FM + i lives in slot t % RING
-    auto read_q = [&](auto T) {
-      constexpr int t = decltype(T)::value, kk = t / BT_FM, i = t % BT_FM;
-      qa[t % BT_RING] = lds_read128<i * 2048>(kk ? (a0 ^ 64u) : a0);
-    };
-    static_for<BT_FN>([&](auto J) { kb[0][decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(b0); });
-    static_for<BT_AHEAD>([&](auto T) { read_q(T); });
-    static_for<BT_ITEMS>([&](auto T) {
-      constexpr int t = decltype(T)::value, kk = t / BT_FM, i = t % BT_FM;
-      __builtin_amdgcn_sched_barrier(0);
-      wait_lgkm<pending_after(t)>();
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<BT_FN>([&](auto J) { mma<HT>(kb[kk][decltype(J)::value], qa[t % BT_RING], acc[i][decltype(J)::value]); });
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (t + BT_AHEAD < BT_ITEMS) read_q(std::integral_constant<int, t + BT_AHEAD>{});
-      if constexpr (t == BT_KB_AT)
-        static_for<BT_FN>([&](auto J) { kb[1][decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(b0 ^ 64u); });
-      // the next K-step's DMA, one piece after every second item (the last step re-fetches its own K-step into the
-      // idle stage: one uniform instruction stream, no tail copy)
-      if constexpr (t % 2 == 1 && t / 2 < BT_A_SLOTS + BT_B_SLOTS) {
-        constexpr int d = t / 2;
-        if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
-        else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-#else
   // ---- phase-staggered K loop ----
   // The eight waves are two groups of four (wm = 0 / 1: waves w and w + 4 share SIMD w).  A K-step is four phases --
   // (K half h, row fragments 0..5) and (h, 6..10) for h = 0, 1 -- and a phase is two sections with an s_barrier behind each:
@@ -249,8 +258,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   // Group 1 runs ONE BARRIER behind group 0 (it takes one extra s_barrier before the loop, group 0 one after it), so on
   // every SIMD one wave is in a C section while its partner is in an L section: the matrix pipe always has a pure MFMA
   // stream to run and the LDS / DMA issue of the partner goes down the other ports beside it, instead of both waves of a
-  // SIMD asking for the LDS together and for the matrix pipe together (the lock-step loop, HVR_BT_LOCKSTEP, ran its
-  // MFMAs at ~0.6 of the pipe's rate).
+  // SIMD asking for the LDS together and for the matrix pipe together (a lock-step loop ran its MFMAs at ~0.6 of the pipe's rate).
   // Sections of K-step kt, numbered by barrier: group 0 reads its stage in sections 0, 2, 4, 6, group 1 in 1, 3, 5, 7 and
   // its last reads have returned at the top of section 8 (= section 0 of kt + 1).  The other stage -- read last during
   // K-step kt - 1 -- is therefore free from section 1 on: group 1 issues its DMA pieces in its L sections of phases 0 and 1
@@ -259,10 +267,6 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   {
     constexpr int G0 = 6;  // row fragments of the first phase of a half (the second takes FM - G0)
     constexpr int DMA_TOTAL = BT_A_SLOTS + BT_B_SLOTS, DMA_FIRST = DMA_TOTAL / 2;
-#ifdef HVR_DBG_BT_SEC
-    long long sec_t[21];
-    for (int q = 0; q < 21; ++q) sec_t[q] = 0;
-#endif
     // The loop exists TWICE, once per wave group, chosen by one branch in front of it: which sections carry a wave's DMA pieces
     // and its vmcnt wait depend on the group, and as run-time tests those were three or four taken branches per K-step in every
     // wave (a taken branch costs a wave ~100 cycles of instruction fetch: profiles/r04_kloop_probe.txt).
@@ -273,37 +277,37 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     for (int kt = 0; kt < nk; ++kt) {
       const uint32_t soff = (uint32_t)(kt & 1) * BT_STAGE;
       char* nxt = smem + ((kt + 1) & 1) * BT_STAGE;
-      const int kn = kt + 1 < nk ? kt + 1 : kt;  // (the last step re-fetches itself into the idle stage: one uniform stream)
+      // what this K-step prefetches into the other stage: K-step kt + 1 of this tile; from the last step the NEXT tile's first
+      // K-step (scalar selects: one uniform stream); with no tile left the last step re-fetches itself into the idle stage
+      const bool last = kt + 1 >= nk, pre = last && has_next;
+      const int kn = last ? (has_next ? 0 : kt) : kt + 1;
+      const char* lq = pre ? q_nxt : q_cur;
+      const char* lk = pre ? k_nxt : k_cur;
+      const int lm0 = pre ? m0_nxt : m0, ln0 = pre ? n0_nxt : n0;
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
       uint4 kb[BT_FN], qa[G0];
       static_for<4>([&](auto PH) {
         constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? BT_FM - G0 : G0;
-#ifdef HVR_DBG_BT_SEC
-        if (kt == 8) sec_t[5 * ph] = __builtin_readcyclecounter();
-#endif
         // ---- L ----
-        auto frag_reads = [&]() {
-          if constexpr ((ph & 1) == 0)
-            static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
-          static_for<nr>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            qa[r] = lds_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
-          });
-        };
-        frag_reads();
+        if constexpr ((ph & 1) == 0)
+          static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+        static_for<nr>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          qa[r] = lds_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+        });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph < 3) {
           if constexpr (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
               constexpr int d = decltype(D)::value;
-              if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
-              else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
+              if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt, lq, lm0);
+              else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt, lk, ln0);
             });
           } else if constexpr (dma_ph + 1 == ph) {
             static_for<DMA_TOTAL - DMA_FIRST>([&](auto D) {
               constexpr int d = DMA_FIRST + decltype(D)::value;
-              if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt);
-              else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt);
+              if constexpr (d < BT_A_SLOTS) dma_a(std::integral_constant<int, d>{}, kn, nxt, lq, lm0);
+              else dma_b(std::integral_constant<int, d - BT_A_SLOTS>{}, kn, nxt, lk, ln0);
             });
           }
         }
@@ -311,18 +315,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
           if constexpr (wmc != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
-        if (kt == 8) sec_t[5 * ph + 1] = __builtin_readcyclecounter();
-#endif
         __builtin_amdgcn_s_barrier();
-#ifdef HVR_DBG_BT_SEC
-        if (kt == 8) sec_t[5 * ph + 2] = __builtin_readcyclecounter();
-#endif
         // ---- C ----
         wait_lgkm<0>();
-#if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
-        if (kt == 8) sec_t[5 * ph + 3] = __builtin_readcyclecounter();
-#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         static_for<nr>([&](auto R) {
@@ -331,33 +326,20 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-#if defined(HVR_DBG_BT_SEC) && HVR_DBG_BT_SEC > 1
-        if (kt == 8) sec_t[5 * ph + 4] = __builtin_readcyclecounter();
-#endif
         if constexpr (ph == 3) {
           if constexpr (wmc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
       });
-#ifdef HVR_DBG_BT_SEC
-      if (kt == 8 && blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 4))
-      {
-        sec_t[20] = __builtin_readcyclecounter();
-        printf("BTSEC wg %d wave %d |", (int)blockIdx.x, wave);
-        for (int q = 1; q < 21; ++q) if (sec_t[q]) printf(" %lld%s", sec_t[q] - sec_t[0], q % 5 == 0 ? " |" : "");
-        printf("\n");
-      }
-#endif
     }
     if constexpr (wmc == 0) __builtin_amdgcn_s_barrier();
     };
     if (wm) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 0>{});
   }
-#endif
 
 #ifdef HVR_DBG_BT_CLK
-  dbg_t[2] = wall_clock64();
+  if (round < 4) dbg_t[3 + 3 * round] = wall_clock64();
 #endif
 #ifdef HVR_DBG_BT_NOEPI
   {
@@ -367,9 +349,8 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #pragma unroll
       for (int j = 0; j < BT_FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (t == 12345.f) p.mstat[0] = t;
-    return;
   }
-#endif
+#else
   {
   // ---------------- epilogue: block max / exp2 / pack / sums ----------------
   // (the lane-derived values are re-derived from a laundered copy of the thread index: nothing but the accumulators and the
@@ -377,40 +358,52 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   int etid = threadIdx.x;
   asm volatile("" : "+v"(etid));
   const int lane = etid & 63, frag_row = lane & 15, frag_grp = lane >> 4;
-  // LDS (the ring is idle): [8][176] maxima, [8][176] sums, then one 16-row x 64-key bf16 staging block per wave
-  float* red_max = reinterpret_cast<float*>(smem);
+  bf16_t* const Pg = p.P + (long)g_cur * p.gs_p;
+  float* const mst = p.mstat + (long)g_cur * p.gs_stat;
+  float* const lst = p.lstat + (long)g_cur * p.gs_stat;
+  // LDS scratch in STAGE 1 (the last K-step's stage: every wave is done reading it; stage 0 is receiving the next tile's first
+  // K-step): [8][176] maxima, [8][176] sums, then one 16-row x 64-key bf16 staging block per wave
+  float* red_max = reinterpret_cast<float*>(smem + BT_STAGE);
   float* red_sum = red_max + 8 * BT_WROWS;
   // staged rows are 128 bytes with no padding; bank-conflict-free on both sides (SQ_LDS_BANK_CONFLICT was 491 k cycles per
   // launch with 144-byte rows): the 16-byte piece index is XOR-ed with (row & 7) -- the 16 lanes of a ds_read_b128 group then
   // cover all 64 banks -- and rows 8..15 swap the two 8-byte halves of a piece, so that the 16 rows of a ds_write_b64 lane
   // group (same fragment column, rows r and r + 8 on the same piece) land on 32 distinct banks; the h = 1 read swaps them back
   constexpr int SPITCH = BT_WCOLS * 2;
-  char* stg = smem + 2 * 8 * BT_WROWS * 4 + wave * (16 * SPITCH);
+  char* stg = smem + BT_STAGE + 2 * 8 * BT_WROWS * 4 + wave * (16 * SPITCH);
   const int wr_lane = frag_row * SPITCH + (((frag_grp & 1) ^ (frag_row >> 3)) << 3);  // + ((2 j + (g >> 1)) ^ (row & 7)) * 16
   const int blk = wn >> 1;                                          // 128-key block of this wave inside the tile
   const bool blk_live = n0 + blk * 128 < p.ldp;                     // an odd block count leaves the last tile half empty
   const int ncol0 = n0 + wn * BT_WCOLS + frag_grp * 4;              // first key of this lane's fragment-0 columns
   float tmax[BT_FM];
+  if (n0 + BT_BN > p.Mk) {   // (only the last column tile holds keys past Mk: a scalar branch around 2 x 176 VALU operations)
+#pragma unroll
+    for (int i = 0; i < BT_FM; ++i)
+#pragma unroll
+      for (int j = 0; j < BT_FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[i][j][r] = (ncol0 + j * 16 + r < p.Mk) ? acc[i][j][r] : -INFINITY;  // keys past Mk never win the max and get weight 0
+  }
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i) {
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < BT_FN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = acc[i][j][r];
-        s = (ncol0 + j * 16 + r < p.Mk) ? s : -INFINITY;  // keys past Mk never win the max and get weight 0
-        acc[i][j][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
     mx = quad_group_max(mx);
     tmax[i] = mx;
     if (frag_grp == 0) red_max[wave * BT_WROWS + i * 16 + frag_row] = mx;
   }
-  __syncthreads();
+  // (raw barriers: __syncthreads() carries s_waitcnt vmcnt(0), which from the second tile on would wait for global stores)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < BT_FM; ++i)
+  for (int i = 0; i < BT_FM; ++i) {
     tmax[i] = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * p.sl2;  // block max, log2 units
+    if (p.int_max) tmax[i] = ceilf(tmax[i]);   // (relation_bt.h: exact power-of-two block weights for relation_apply_bt.hip)
+  }
   const int st_row = lane >> 3, st_chunk = lane & 7;  // store phase: lane -> (row, 16-byte piece) of the staged block
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i) {
@@ -433,10 +426,11 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
       if (h) v = make_uint4(v.z, v.w, v.x, v.y);
       if (m < p.Mq && blk_live)
-        *reinterpret_cast<uint4*>(p.P + (long)m * p.ldp + n0 + wn * BT_WCOLS + st_chunk * 8) = v;
+        *reinterpret_cast<uint4*>(Pg + (long)m * p.ldp + n0 + wn * BT_WCOLS + st_chunk * 8) = v;
     }
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   if ((wn & 1) == 0 && frag_grp == 0 && blk_live) {
     const int t = n0 / 128 + blk;
 #pragma unroll
@@ -444,30 +438,55 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       const int row = i * 16 + frag_row, m = m0 + wm * BT_WROWS + row;
       const float sum = red_sum[wave * BT_WROWS + row] + red_sum[(wave + 1) * BT_WROWS + row];
       if (m < p.Mq) {
-        p.mstat[(long)m * p.ntile + t] = tmax[i];
-        p.lstat[(long)m * p.ntile + t] = sum;
+        mst[(long)m * p.ntile + t] = tmax[i];
+        lst[(long)m * p.ntile + t] = sum;
       }
     }
   }
-#ifdef HVR_DBG_BT_CLK
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    dbg_t[3] = wall_clock64();
-    if (threadIdx.x == 0) printf("BTCLK %d %d %lld %lld %lld %lld\n", (int)blockIdx.x, (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) , dbg_t[0], dbg_t[1] - dbg_t[0], dbg_t[2] - dbg_t[0], dbg_t[3] - dbg_t[0]);
-#endif
   }
+#endif
+#ifdef HVR_DBG_BT_CLK
+  if (round < 4) dbg_t[4 + 3 * round] = wall_clock64();
+#endif
+  if (!has_next) break;
+  g_cur = g_nxt; m0 = m0_nxt; n0 = n0_nxt; q_cur = q_nxt; k_cur = k_nxt;
+  // the scratch reads above are done (their values went into the stores) before this wave reaches the next tile's first barrier,
+  // behind which the first DMA into stage 1 is issued
+  }
+  if (vt_by_idle && (int)blockIdx.x >= here_last) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the last tile's epilogue scratch shares the copy's LDS buffers
+    vt_copy(((int)blockIdx.x - here_last) * 2, n_idle * 2);
+  }
+#ifdef HVR_DBG_BT_CLK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const long long t_end = wall_clock64();
+    if (threadIdx.x == 0) {
+      printf("BTCLK wg %d xcc %d t0 %lld vt %lld |", (int)blockIdx.x, (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20), dbg_t[0], dbg_t[1] - dbg_t[0]);
+      for (int r = 0; r < 4; ++r)
+        if (dbg_t[2 + 3 * r]) printf(" tile%d loop %lld..%lld epi %lld |", r, dbg_t[2 + 3 * r] - dbg_t[0], dbg_t[3 + 3 * r] - dbg_t[0], dbg_t[4 + 3 * r] - dbg_t[0]);
+      printf(" drained %lld\n", t_end - dbg_t[0]);
+    }
+  }
+#endif
 }
 
 bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, long ldp, const void* Q, const void* K,
-                         const void* V, const void* P, const void* Vt) {
+                         const void* V, const void* P, const void* Vt, int groups) {
   const uintptr_t al = reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
                        reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Vt);
   if (al & 15) return false;
-  if (D % 64 || ldq % 8 || ldk % 8 || ldv % 8 || ldp % 128) return false;
+  // (D % 128: an even number of K-steps, so that every tile of a persistent workgroup starts in LDS stage 0)
+  if (D % 128 || ldq % 8 || ldk % 8 || ldv % 8 || ldp % 128 || groups < 1) return false;
   if ((long)Mq * ldq * 2 >= (1L << 31) || (long)Mk * ldk * 2 >= (1L << 31)) return false;
-  // the single-round shape only pays once the tile grid fills most of the chip
+  // the 352 x 256 shape only pays once the tile grid fills most of the chip
   const long tiles = (long)((Mq + BT_BM - 1) / BT_BM) * ((ldp + BT_BN - 1) / BT_BN);
-  // one round on most of the chip, or two rounds whose second is at least half full (the shipped T = 21 window: 450 tiles)
-  return ((tiles >= 160 && tiles <= 256) || (tiles >= 384 && tiles <= 512)) && Mk >= 128;
+  if (Mk < 128 || tiles * groups > (1L << 20)) return false;
+  // several groups: the persistent workgroups take tiles of all of them in turn, any per-group count from 160 up fills the rounds
+  if (groups > 1) return tiles >= 160;
+  // one group: one round on most of the chip, or two rounds whose second is at least half full (the shipped T = 21 window: 450 tiles)
+  return (tiles >= 160 && tiles <= 256) || (tiles >= 384 && tiles <= 512);
 }
 
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
@@ -476,15 +495,10 @@ hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
   });
-  const int ntiles = ((p.Mq + BT_BM - 1) / BT_BM) * (int)((p.ldp + BT_BN - 1) / BT_BN);
-  ScoresBTParams q = p;
-  for (int t0 = 0; t0 < ntiles; t0 += 256) {
-    q.tile0 = t0;
-    q.tiles_here = ntiles - t0 < 256 ? ntiles - t0 : 256;
-    // the first launch is a full grid: the workgroups without a tile still carry their share of the V^T copy
-    if (p.f16) hipLaunchKernelGGL(relation_scores_bt_kernel<f16_t>, dim3(t0 == 0 ? 256 : q.tiles_here), dim3(BT_NT), BT_LDS, stream, q);
-    else hipLaunchKernelGGL(relation_scores_bt_kernel<bf16_t>, dim3(t0 == 0 ? 256 : q.tiles_here), dim3(BT_NT), BT_LDS, stream, q);
-  }
+  // one launch of one workgroup per CU: persistent over the tile list of every group; the workgroups a short list leaves without a
+  // tile still carry their share of the V^T copies
+  if (p.f16) hipLaunchKernelGGL(relation_scores_bt_kernel<f16_t>, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
+  else hipLaunchKernelGGL(relation_scores_bt_kernel<bf16_t>, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
   return hipGetLastError();
 }
 

@@ -249,20 +249,31 @@ class _WindowDetector(TwoStageDetector):
             return torch.cat([t.permute(0, 2, 3, 1) for t in x], dim=0).permute(0, 3, 1, 2)
         return torch.cat(tuple(x), dim=0)
 
-    def window_tensors(self, x, img_meta, proposals=None, rescale=False, speculate=False):
+    def window_tensors(self, x, img_meta, proposals=None, rescale=False, speculate=False, clips=1):
         """Runs one window up to the head outputs; returns a dict of device tensors (used by forward_feat and tests).
         speculate: do not read the proposal counts; build the RoIs as if every frame kept all `nms_post` proposals and
-        return the counts tensor as `counts_dev` for the caller to check."""
+        return the counts tensor as `counts_dev` for the caller to check.
+        clips = W > 1 (speculative only): x / img_meta hold W independent clips of T frames back to back; res5, the RPN, its
+        proposals and RoIAlign take all W * T frames as one batch; `cur_range` addresses the key rows inside every clip and
+        `key_rois` is a list of W tensors."""
         xc = self._cat_frames(x)
-        assert xc.shape[0] == len(img_meta)
+        assert xc.shape[0] == len(img_meta) and len(img_meta) % clips == 0
+        if clips > 1 and not (speculate and proposals is None):
+            raise NotImplementedError('several clips per call run the speculative path (every frame keeps nms_post proposals); run the '
+                                      'exact path one clip at a time')
         feats, proposal_list, rois, counts_dev, counts_h = self._c5_and_rois(xc, img_meta, proposals, speculate)
         key = self.key_dim
         start = int(np.sum(counts_h[:key]))
         cur_range = dict(start=start, length=int(counts_h[key]))
         roi_feats = self.get_roi_feat(feats, rois.contiguous())
-        key_rois = rois[start:start + cur_range['length']].clone()
-        key_rois[:, 0] = 0  # the reference's rois carry batch index 0 (hnmb_rcnn.py:582-584)
-        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range, key_rois=key_rois,
+        per_clip = rois.shape[0] // clips
+        key_rois = []
+        for w in range(clips):
+            kr = rois[w * per_clip + start:w * per_clip + start + cur_range['length']].clone()
+            kr[:, 0] = 0  # the reference's rois carry batch index 0 (hnmb_rcnn.py:582-584)
+            key_rois.append(kr)
+        return dict(c5=feats[0], proposals=proposal_list, rois=rois, roi_feats=roi_feats, cur_range=cur_range,
+                    key_rois=key_rois[0] if clips == 1 else key_rois,
                     counts_dev=counts_dev, full_count=int(counts_h[0]) if counts_dev is not None else None)
 
     def _c5_and_rois(self, xc, img_meta, proposals=None, speculate=False):
@@ -336,25 +347,45 @@ class _WindowDetector(TwoStageDetector):
         return f1, cur_range, key_rois, counts_dev, mx
 
     # ---- device-only forms (no host read, no PendingWindow): what graphs.py captures into a hipGraph ----
-    def _head_branches(self, feats, from_f1, cur_range, key_rois, meta0, rescale):
-        """relation head + read-out -> list of (dets [max,5], labels [max], n [1]) device tensors, one per output branch."""
-        if type(self).__name__ == 'HNMBRCNN':
+    def _head_branches(self, feats, from_f1, cur_range, key_rois, meta0, rescale, clips=1):
+        """relation head + read-out -> list of (dets [max,5], labels [max], n [1]) device tensors, one per output branch; with
+        clips = W > 1 (key_rois a list of W tensors, meta0 a list of W metas) a list of W such lists."""
+        hvr = type(self).__name__ == 'HNMBRCNN'
+        if hvr:
             head = self.bbox_head.forward_from_f1 if from_f1 else self.bbox_head.forward_test
-            cls_score, bbox_pred = head(feats, [cur_range], key_dim=self.key_dim, all_res=False)
-            branches, _ = self.bbox_head.get_det_bboxes(key_rois, cls_score, bbox_pred, meta0['img_shape'], meta0['scale_factor'],
-                                                        rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
-            return list(branches)
-        head = self.bbox_head.forward_from_f1 if from_f1 else self.bbox_head
-        cls_score, bbox_pred = head(feats, cur_range, key_dim=self.key_dim, all_res=False)[:2]
-        branch, _ = self.bbox_head.get_det_bboxes(key_rois, cls_score, bbox_pred, meta0['img_shape'], meta0['scale_factor'],
-                                                  rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
-        return [branch]
+            cls_score, bbox_pred = head(feats, [cur_range], key_dim=self.key_dim, all_res=False, clips=clips)
+        else:
+            head = self.bbox_head.forward_from_f1 if from_f1 else self.bbox_head
+            cls_score, bbox_pred = head(feats, cur_range, key_dim=self.key_dim, all_res=False, clips=clips)[:2]
+        l = int(cur_range['length'])
+        out = []
+        for w in range(clips):
+            rows = slice(w * l, (w + 1) * l)
+            kr = key_rois if clips == 1 else key_rois[w]
+            meta = meta0 if clips == 1 else meta0[w]
+            if hvr:
+                cs, bp = ([c[rows] for c in cls_score], [b[rows] for b in bbox_pred]) if clips > 1 else (cls_score, bbox_pred)
+                branches, _ = self.bbox_head.get_det_bboxes(kr, cs, bp, meta['img_shape'], meta['scale_factor'],
+                                                            rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
+                out.append(list(branches))
+            else:
+                cs, bp = (cls_score[rows], bbox_pred[rows]) if clips > 1 else (cls_score, bbox_pred)
+                branch, _ = self.bbox_head.get_det_bboxes(kr, cs, bp, meta['img_shape'], meta['scale_factor'],
+                                                          rescale=rescale, cfg=self.test_cfg.rcnn, defer=True)
+                out.append([branch])
+        return out[0] if clips == 1 else out
 
-    def window_device_outputs(self, x, img_meta, rescale=False):
+    def window_device_outputs(self, x, img_meta, rescale=False, clips=1):
         """One speculative window (every frame assumed to keep nms_post proposals) up to its device-side results:
-        -> (branches, counts_dev [T] int32, full_count); the caller checks counts == full_count when it reads the results."""
-        w = self.window_tensors(x, img_meta, None, rescale, speculate=True)
-        return self._head_branches(w['roi_feats'], False, w['cur_range'], w['key_rois'], img_meta[0], rescale), w['counts_dev'], w['full_count']
+        -> (branches, counts_dev [T] int32, full_count); the caller checks counts == full_count when it reads the results.
+        clips = W > 1: W independent clips back to back in x / img_meta, every kernel up to the relation stages on all of them as one
+        batch, the relation core per clip in grouped calls -> a list of W such triples."""
+        w = self.window_tensors(x, img_meta, None, rescale, speculate=True, clips=clips)
+        if clips == 1:
+            return self._head_branches(w['roi_feats'], False, w['cur_range'], w['key_rois'], img_meta[0], rescale), w['counts_dev'], w['full_count']
+        T = len(img_meta) // clips
+        per = self._head_branches(w['roi_feats'], False, w['cur_range'], w['key_rois'], [img_meta[c * T] for c in range(clips)], rescale, clips=clips)
+        return [(per[c], w['counts_dev'][c * T:(c + 1) * T], w['full_count']) for c in range(clips)]
 
     def head_device_outputs(self, f1, cur_range, key_rois, counts_dev, meta0, rescale=False):
         """The window part of the per-frame-cache loop on assembled rows: f1 [T * n, 1024] (fc_new_1 rows of the T frames in

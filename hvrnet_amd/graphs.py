@@ -116,14 +116,19 @@ class GraphedClip(object):
     (or pass them to `run`) before replaying.  A replay must have been read (`result()`) before the next one is launched:
     the outputs are static buffers."""
 
-    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2, throughput=False, windows=1):
+    def __init__(self, model, frames, metas, rescale=True, warmup=2, n_out=2, throughput=False, windows=1, batch_head=True):
         assert frames.is_cuda and frames.dim() == 4 and frames.shape[0] == len(metas) and len(metas) % windows == 0
         self.model, self.metas, self.rescale = model, list(metas), rescale
         # windows = W > 1: `frames` holds W independent clips back to back; ONE graph takes all W * T frames through the backbone
         # in one batch -- 30 frames give layer 3's convs 250 of the 288 x 256 tiles (bigtile.hip) where 15 give 125 -- and then
         # runs res5 / RPN / RoIAlign / head / read-out per clip.  run() returns W pending windows.  Frames are independent through
-        # the backbone, so every clip's detections are the single-clip graph's
+        # the backbone, so every clip's detections are the single-clip graph's.  batch_head (round 5): res5, the RPN, its proposals,
+        # RoIAlign and every product of the head take the W clips as one batch too, and the relation core runs per clip in GROUPED
+        # calls (hvr_relation_fwd_grouped: persistent score tiles over the W windows, the 288 x 256 apply launch from W = 3 on in
+        # bf16) -- per clip the single-clip result up to the association of the relation core's f32 sums (bit for bit with
+        # bbox_head.grouped_exact = True)
         self.windows = int(windows)
+        self.batch_head = bool(batch_head) and self.windows > 1
         self.T = len(metas) // self.windows
         # throughput: the graph is one of several replayed side by side (bench.py's lanes) -- its launches prefer CU-time to
         # latency (native.throughput_mode: the 288 x 256 tiles on half the grid for layer 3's convs); same detections
@@ -161,6 +166,8 @@ class GraphedClip(object):
         T = self.T
         with native.throughput_mode(self.throughput):
             c4 = m(img=self.frames, img_meta=self.metas, backbone_feat=True)[0]
+            if self.batch_head:
+                return m.window_device_outputs(c4, self.metas, rescale=self.rescale, clips=self.windows)
             return [m.window_device_outputs(c4[w * T:(w + 1) * T], self.metas[w * T:(w + 1) * T], rescale=self.rescale)
                     for w in range(self.windows)]
 

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, 'libhvr_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hvr_hip.h')
 
 HVR_F32, HVR_BF16, HVR_F16, HVR_F16S = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 # Split-half tensors (HVR_F16S, include/hvr_hip.h: [32 hi | 32 lo] half groups, 4 bytes per logical element) travel through
 # torch as int32 tensors of the LOGICAL shape: element size, strides, row / 32-column slicing, cat, clone and zeros all mean
 # the right thing on the container, and nothing but this library ever interprets the bytes.  `SPLIT` is the dtype sentinel
@@ -108,6 +108,8 @@ SYMBOLS = {
     'hvr_stem_fused_dtype': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'hvr_relation_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_relation_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    'hvr_relation_grouped_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'hvr_relation_fwd_grouped': (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     'hvr_relation_probs_workspace_bytes': (_sz, [_i, _i]),
     'hvr_relation_probs': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     'hvr_relation_dscore': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _f, _i, _vp]),
@@ -674,6 +676,31 @@ def relation_fwd(q, k, v, scale, staging=None):
         _check(lib().hvr_relation_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(o), o.stride(0),
                                       Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging,
                                       _ptr(ws), ws.numel(), _stream()), 'hvr_relation_fwd')
+    return o
+
+
+def relation_fwd_grouped(q, k, v, scale, groups, staging=None, exact=False):
+    """`groups` independent relation problems of one shape in one call (the clips a batched head has in flight): q [G * Mq, D],
+    k / v [G * Mk, D] hold the groups' rows back to back (row-strided views are fine: group g starts g * rows * stride(0) elements
+    behind group 0) -> o [G * Mq, D], group g's rows = relation_fwd of group g's q / k / v (hvr_relation_fwd_grouped): up to the
+    association of the f32 sums by default, bit for bit with exact=True."""
+    _need_cuda(q, k, v)
+    G = int(groups)
+    assert G >= 1 and q.shape[0] % G == 0 and k.shape[0] % G == 0
+    Mq, Mk, D = q.shape[0] // G, k.shape[0] // G, q.shape[1]
+    assert k.shape[1] == D and v.shape == k.shape and q.dtype == k.dtype == v.dtype
+    if G == 1:
+        return relation_fwd(q, k, v, scale, staging)
+    o = torch.empty((G * Mq, D), dtype=q.dtype, device=q.device)
+    nbytes = lib().hvr_relation_grouped_workspace_bytes(G, Mq, Mk, D, _dt(q))
+    ws = _workspace(nbytes, q.device, 'relation_grouped')
+    if q.dtype == SPLIT:
+        scale = float(scale) / (SPLIT_ACT_SCALE * SPLIT_ACT_SCALE)
+    with _span('relation_full' if Mq == Mk else 'relation_key', 4.0 * G * Mq * Mk * D):
+        _check(lib().hvr_relation_fwd_grouped(_ptr(q), q.stride(0), Mq * q.stride(0), _ptr(k), k.stride(0), Mk * k.stride(0),
+                                              _ptr(v), v.stride(0), Mk * v.stride(0), _ptr(o), o.stride(0), Mq * o.stride(0), G,
+                                              Mq, Mk, D, float(scale), _dt(q), STAGING if staging is None else staging, int(bool(exact)),
+                                              _ptr(ws), ws.numel(), _stream()), 'hvr_relation_fwd_grouped')
     return o
 
 

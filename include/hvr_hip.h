@@ -53,7 +53,7 @@ extern "C" {
 #define HVR_LAYOUT_NCHW 0 /* reference layout */
 #define HVR_LAYOUT_NHWC 1 /* native layout of this library */
 
-int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta (split-half operands) */
+int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta (split-half operands); 5: hvr_relation_fwd_grouped */
 const char* hvr_last_error(void);
 
 /* ------------------------------------------------------------------------------------
@@ -196,6 +196,19 @@ size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype);
 int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                      void* O, int64_t ldo, int Mq, int Mk, int D, float scale, int dtype, int staging,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* The same for `groups` INDEPENDENT problems of one shape in one call -- the clips (windows) a caller has in flight, each with its
+ * own Q / K / V / O: group g's operands start gs* ELEMENTS behind group 0's (a batched head keeps the groups' rows back to back in
+ * one matrix: gs = rows x ld).  The reference runs one clip at a time (tools/test.py:214-250 -> hnmb_rcnn.py:195-222), so a stage of
+ * W clips is W calls of the lines above; here the 352 x 256 score tiles of all groups are one list walked by persistent workgroups
+ * (csrc/relation_bt.hip) and, for bf16 and >= 3 window-sized groups, the apply pass is one launch of 288 x 256 tiles over the whole
+ * key axis (csrc/relation_apply_bt.hip).  Per group the result is hvr_relation_fwd's up to the association of the f32 sums
+ * (exact != 0: bit for bit -- the scores launch stays grouped, the apply pass runs per group); shapes the grouped kernels do not take
+ * run as `groups` hvr_relation_fwd calls.  Workspace: hvr_relation_grouped_workspace_bytes. */
+size_t hvr_relation_grouped_workspace_bytes(int groups, int Mq, int Mk, int D, int dtype);
+int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void* K, int64_t ldk, int64_t gsk,
+                             const void* V, int64_t ldv, int64_t gsv, void* O, int64_t ldo, int64_t gso, int groups,
+                             int Mq, int Mk, int D, float scale, int dtype, int staging, int exact, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of the relation core (training path; the reference gets it from autograd through
  * torch.bmm / nn.Softmax / torch.mm, selsa_bbox_head.py:166-182).  Two pieces that are not plain GEMMs:

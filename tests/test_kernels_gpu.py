@@ -318,6 +318,40 @@ def test_relation_window_size_big_tile_path(Mq, Mk):
     torch.testing.assert_close(ones.float(), torch.ones_like(ones.float()), rtol=0, atol=8e-3)
 
 
+@pytest.mark.parametrize('G,Mq,Mk,dtype', [(4, 4500, 4500, torch.bfloat16), (2, 4500, 4500, torch.bfloat16), (3, 4321, 4100, torch.bfloat16),
+                                           (4, 4500, 4500, torch.float16), (2, 300, 4500, torch.bfloat16), (3, 96, 200, torch.float32)])
+def test_relation_grouped_equals_the_single_calls(G, Mq, Mk, dtype):
+    """hvr_relation_fwd_grouped: G independent problems of one shape (the windows a batched head has in flight) in one call --
+    persistent 352 x 256 score tiles over all groups (relation_bt.hip) and, for bf16 from three window-sized groups on, the
+    288 x 256 apply launch with the block weights applied on the exponent fields of P~ (relation_apply_bt.hip).
+      exact=True : every group's rows are hvr_relation_fwd's bit for bit;
+      default    : the same up to the association of the f32 sums (one bf16 output ulp), and against the f64 softmax on sampled rows;
+    spikes force block-weight shifts in an early and in the last 128-key block; shapes the grouped kernels do not take (key stage,
+    small problems, f32) run as G single calls and are equal trivially -- the plumbing of strides and workspaces is what they test."""
+    D = 1024
+    q, k, v = _rand((G * Mq, D), dtype, 51, 1.5), _rand((G * Mk, D), dtype, 52, 1.5), _rand((G * Mk, D), dtype, 53)
+    for g in range(G):
+        k[g * Mk + Mk - 2] = (q[g * Mq + 7].float() * 3).to(dtype)           # a late-block maximum ~ 96 above the rest of row 7
+        k[g * Mk + 5] = (q[g * Mq + Mq - 1].float() * 2).to(dtype)          # an early-block maximum for the last row
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else _tol(dtype)
+    exact = native.relation_fwd_grouped(qd, kd, vd, 1.0 / 32, G, exact=True)
+    fast = native.relation_fwd_grouped(qd, kd, vd, 1.0 / 32, G)
+    again = native.relation_fwd_grouped(qd, kd, vd, 1.0 / 32, G)
+    assert torch.isfinite(fast.float()).all() and torch.equal(fast, again)
+    rows = torch.cat([torch.arange(0, 16), torch.arange(min(280, Mq - 1), min(300, Mq)), torch.arange(max(Mq - 40, 0), Mq)]).unique()
+    for g in range(G):
+        single = native.relation_fwd(qd[g * Mq:(g + 1) * Mq], kd[g * Mk:(g + 1) * Mk], vd[g * Mk:(g + 1) * Mk], 1.0 / 32)
+        assert torch.equal(exact[g * Mq:(g + 1) * Mq], single), 'group %d: exact form differs from hvr_relation_fwd' % g
+        torch.testing.assert_close(fast[g * Mq:(g + 1) * Mq].float(), single.float(), **tol)
+        ref = _relation_ref(q[g * Mq + rows], k[g * Mk:(g + 1) * Mk], v[g * Mk:(g + 1) * Mk], 1.0 / 32)
+        torch.testing.assert_close(fast[g * Mq + rows.to(DEV)].float().cpu(), ref, **tol)
+    # strided operands: q / k as the two column halves of one projection output, as the heads pass them
+    if Mq == Mk:
+        qk = torch.cat([qd, kd], dim=1)
+        assert torch.equal(native.relation_fwd_grouped(qk[:, :D], qk[:, D:], vd, 1.0 / 32, G), fast)
+
+
 def test_key_stage_in_launch_merge_equals_the_reduce_launch(tmp_path):
     """Key-frame-only stage (300 x 4 500, D = 1 024): the slice that reaches an output tile last merges the f32 partials inside the
     apply launch (ticket per tile, slice order; opt-in HVR_KEY_MERGE=1 -- measured slower than the reduce launch, kept for the

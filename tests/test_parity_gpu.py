@@ -395,6 +395,36 @@ def _head(kind, dtype, sampler_num=32, t_dim=3):
     return h.to(DEV).eval()
 
 
+@pytest.mark.parametrize('kind,rows_per_frame,T', [('hvr', 300, 15), ('selsa', 300, 15), ('hvr', 24, 5)])
+def test_batched_clips_through_the_head_equal_the_per_clip_calls(kind, rows_per_frame, T):
+    """forward_from_f1(clips=W): the fc_new_1 rows of W independent clips back to back -- projections / fc layers / read-out as
+    one product each over all W * R rows, the relation core per clip in grouped calls (hvr_relation_fwd_grouped).  With
+    grouped_exact every clip's logits are the per-clip call's bit for bit (window-sized and small shapes); the default form differs
+    only by the relation core's f32 association."""
+    W, R = 4, rows_per_frame * T
+    h = _head(kind, torch.bfloat16, sampler_num=rows_per_frame, t_dim=T)
+    g = torch.Generator().manual_seed(5)
+    f1 = (torch.randn((W * R, 1024), generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    cur = dict(start=(T // 2) * rows_per_frame, length=rows_per_frame)
+    arg = [cur] if kind == 'hvr' else cur
+
+    def flat(out):
+        cls, reg = out[0], out[1]
+        return [t.float() for t in (list(cls) + list(reg) if isinstance(cls, list) else [cls, reg])]
+
+    with torch.no_grad():
+        per_clip = [flat(h.forward_from_f1(f1[w * R:(w + 1) * R].contiguous(), arg)) for w in range(W)]
+        h.grouped_exact = True
+        exact = flat(h.forward_from_f1(f1, arg, clips=W))
+        h.grouped_exact = False
+        fast = flat(h.forward_from_f1(f1, arg, clips=W))
+    l = rows_per_frame
+    for w in range(W):
+        for e, f, want in zip(exact, fast, per_clip[w]):
+            assert torch.equal(e[w * l:(w + 1) * l], want), 'clip %d: the exact batched form differs from the per-clip call' % w
+            close(f[w * l:(w + 1) * l], want.cpu().numpy(), 3e-2, 3e-2)
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
 def test_relation_stage_matches_reference_golden(dtype, tol):
     """G5: one stage from the reference's forward_single_selsa (all queries / key-only / truncated keys).

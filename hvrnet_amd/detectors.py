@@ -178,6 +178,27 @@ class TwoStageDetector(BaseDetector):
         return tuple(torch.cat([o[k].permute(0, 2, 3, 1) for o in outs], 0).permute(0, 3, 1, 2) for k in range(len(outs[0])))
 
     def extract_feat(self, img):
+        """backbone on a batch of frames.  The kernels address their operands with 32-bit byte offsets (tensors below 2 GiB): a batch
+        whose largest map would pass that -- W clips of 15 frames in a 4-byte mode: layer 1's output is 39 MB per 608 x 1008 frame, the
+        f32 mode's stem patch matrix 98 MB -- goes through in equal chunks, one after the other on the same stream, each writing its
+        slice of ONE C4 map (frames are independent through the backbone: the chunking changes no result)."""
+        bb = self.backbone
+        shape_of = getattr(bb, 'out_shape_nhwc', None)
+        if img.is_cuda and img.dim() == 4 and shape_of is not None and shape_of(img.shape[0], img.shape[2], img.shape[3]) is not None:
+            es = 2 if bb.compute_dtype in (torch.bfloat16, torch.float16) else 4
+            H, Wd = img.shape[2], img.shape[3]
+            per_frame = (H // 4) * (Wd // 4) * 256 * es
+            if bb.compute_dtype == torch.float32:
+                per_frame = max(per_frame, (H // 2) * (Wd // 2) * 192 * es)   # the generic stem's patch matrix
+            max_b = max(1, (2 ** 31 - 2 ** 20) // per_frame)
+            B = img.shape[0]
+            if B > max_b:
+                n = -(-B // max_b)
+                whole = torch.empty(shape_of(B, H, Wd), dtype=bb.compute_dtype, device=img.device)
+                bounds = [round(i * B / n) for i in range(n + 1)]
+                for a, b in zip(bounds[:-1], bounds[1:]):
+                    bb(img[a:b], out=whole[a:b])
+                return (whole.permute(0, 3, 1, 2),)
         return self._run_in_frame_groups(self.backbone, img)
 
     def simple_test_rpn(self, x, img_meta, rpn_test_cfg):
@@ -386,6 +407,26 @@ class _WindowDetector(TwoStageDetector):
         T = len(img_meta) // clips
         per = self._head_branches(w['roi_feats'], False, w['cur_range'], w['key_rois'], [img_meta[c * T] for c in range(clips)], rescale, clips=clips)
         return [(per[c], w['counts_dev'][c * T:(c + 1) * T], w['full_count']) for c in range(clips)]
+
+    def forward_feat_clips(self, x, img_meta, clips, rescale=False, defer=False):
+        """forward_feat for W = `clips` independent clips in ONE call: x [W * T, 1024, h, w] (or a sequence of C4 maps) and img_meta
+        hold the clips' frames back to back.  The reference runs one clip at a time (tools/test.py:214-250); here every kernel up to
+        the relation stages takes the W clips as one batch and the relation core runs per clip in grouped calls
+        (hvr_relation_fwd_grouped).  -> a list of W results (PendingWindow objects with defer=True), clip w's = forward_feat on its own
+        frames up to the association of the relation core's f32 sums.  A clip with a short frame (fewer than nms_post proposals) is
+        re-run alone through the exact path when its result is read."""
+        xc = self._cat_frames(x)
+        T = len(img_meta) // clips
+        outs = self.window_device_outputs(xc, img_meta, rescale=rescale, clips=clips)
+        if clips == 1:
+            outs = [outs]
+        single = type(self).__name__ == 'SelsaRCNN'
+
+        def exact(w):
+            return lambda: self.forward_feat(xc[w * T:(w + 1) * T], img_meta[w * T:(w + 1) * T], None, rescale, speculate=False)
+        pend = [PendingWindow(b if not single else b, c, full, self.bbox_head.num_classes, exact(w), single=single)
+                for w, (b, c, full) in enumerate(outs)]
+        return pend if defer else [p_.result() for p_ in pend]
 
     def head_device_outputs(self, f1, cur_range, key_rois, counts_dev, meta0, rescale=False):
         """The window part of the per-frame-cache loop on assembled rows: f1 [T * n, 1024] (fc_new_1 rows of the T frames in

@@ -133,6 +133,25 @@ def mining_case(mq=96, mk=288, d=64, ncls=6, seed=207):
     return labels, all_labels, aff_scale
 
 
+def hvr_train_case(videos=3, frames=3, n=16, ncls=31, seed=215):
+    """Inputs of the HVR head's TRAINING forward (hrnmp_bbox_head.py:609-795, dynamic=False): per video the RoI features of its
+    `frames` frames (key frame's n rows first), the key rows' labels of all videos (`others`: about a third background, a few
+    foreground classes so that every foreground row has same-label and different-label keys among the videos * n key rows) and
+    BBoxHead.loss targets for them.  -> (feats list, cur_range_s, labels, label_weights, bbox_targets, bbox_weights)."""
+    g = _gen(seed)
+    feats = [torch.randn((frames * n, 256, 7, 7), generator=g).abs() for _ in range(videos)]
+    cur = [dict(start=0, length=n) for _ in range(videos)]
+    m = videos * n
+    labels = torch.randint(1, 5, (m,), generator=g)
+    labels[torch.rand(m, generator=g) < 0.33] = 0
+    labels[1], labels[n + 2] = ncls - 1, ncls - 1     # a class carried by exactly two rows (in different videos)
+    label_weights = torch.ones(m)
+    bbox_targets = torch.randn((m, 4), generator=g) * 0.8
+    bbox_weights = (labels > 0).float()[:, None].expand(m, 4).contiguous()
+    bbox_targets = bbox_targets * bbox_weights
+    return feats, cur, labels, label_weights, bbox_targets, bbox_weights
+
+
 def eval_case(n_img=24, n_cls=5, seed=208):
     """Per-class detection arrays + annotations for the mAP evaluation: detections are jittered copies of the ground truth
     (some duplicated -> later claims of a covered box are false positives), background boxes, equal scores, images without

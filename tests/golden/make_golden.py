@@ -214,7 +214,12 @@ def _sub_state(sd, prefix):
     return {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + '.')}
 
 
+ONLY = [t for t in os.environ.get('HVR_GOLDEN_ONLY', '').split(',') if t]   # e.g. HVR_GOLDEN_ONLY=g15: rewrite only that fixture
+
+
 def save(name, **arrays):
+    if ONLY and not any(name.startswith(t) for t in ONLY):
+        return
     path = os.path.join(OUT, name + '.npz')
     np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
     print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
@@ -421,6 +426,53 @@ def main():
     a_idx, pos_idx, neg_idx = ref.HRNMPBBoxHead.hardest_proposal_mining(None, ml, mal, maff[None].clone(), None)
     top2 = maff.topk(3, dim=1).values
     save('g13_mining', anchor_idx=a_idx, hardest_pos_idx=pos_idx, hardest_neg_idx=neg_idx, min_gap=(top2[:, 0] - top2[:, 1]).min())
+
+    # ---- G15 the HVR head's TRAINING forward through the reference's own HRNMPBBoxHead.forward (hrnmp_bbox_head.py:609-795,
+    # dynamic=False, as hnmb_rcnn.py:438 calls it) + HRNMPBBoxHead.loss + backward().  TripletNonLocalLoss is absent from the
+    # reference tree: a stub in its place RECORDS the arguments the head hands it (q / k projections, labels, the mined index
+    # triple) and returns a zero that keeps the graph connected -- so the fixture pins everything around the triplet term,
+    # including that term's inputs, and nothing of the term itself ----
+    import mmdet.models.bbox_heads.hrnmp_bbox_head as hh_mod
+    calls15 = []
+
+    class RecordingTriplet(object):
+        def __init__(self, margin=None, **kw):
+            self.margin = margin
+
+        def compute_loss(self, q, k, labels, indices):
+            calls15.append(dict(margin=self.margin, q=q.detach().clone(), k=k.detach().clone(), labels=labels.clone(),
+                                indices=[i.clone() for i in indices]))
+            return q.sum() * 0.0
+
+    hh_mod.TripletNonLocalLoss = RecordingTriplet
+    V15, F15, n15 = 3, 3, 16
+    feats15, cur15, lab15, lw15, bt15, bw15 = C.hvr_train_case(V15, F15, n15)
+    hvr15 = ref.HRNMPBBoxHead(sampler_num=n15, t_dim=V15 * F15, imgs_per_video=F15, **common).train()
+    hvr15.load_state_dict(_sub_state(sd_hvr, 'bbox_head'), strict=True)
+    hvr15.zero_grad()
+    fg15 = [f.clone().requires_grad_(True) for f in feats15]
+    cls15, reg15, add15, _ = hvr15(fg15, cur_range_s=cur15, others=lab15, all_labels=lab15, dynamic=False)
+    loss15 = hvr15.loss(cls15, reg15, lab15, lw15, bt15, bw15)
+    total15 = sum(v for k_, v in loss15.items() if k_.startswith('loss')) + add15['loss_trip']
+    total15.backward()
+    assert len(calls15) == 1 and calls15[0]['margin'] == 10
+    g15 = dict(cls_branch=cls15[0].detach(), cls=cls15[1].detach(), reg_branch=reg15[0].detach(), reg=reg15[1].detach(),
+               trip_q_sum=calls15[0]['q'].double().sum(), trip_q_abs=calls15[0]['q'].double().abs().sum(), trip_q_shape=np.asarray(calls15[0]['q'].shape),
+               trip_k_sum=calls15[0]['k'].double().sum(), trip_k_abs=calls15[0]['k'].double().abs().sum(),
+               trip_anchor_idx=calls15[0]['indices'][0], trip_second_idx=calls15[0]['indices'][1], trip_third_idx=calls15[0]['indices'][2])
+    for k_, v in loss15.items():
+        g15[k_] = v.detach()
+    for v_i, f in enumerate(fg15):
+        g15['d_feats%d_sum' % v_i] = f.grad.double().sum()
+        g15['d_feats%d_abs' % v_i] = f.grad.double().abs().sum()
+    for name in ('fc_new_1.weight', 'selsa_1.q_data_fc_1.weight', 'selsa_2.k_data_fc_2.weight', 'fc_new_3.weight', 'selsa_3.linear_out_3.weight',
+                 'fc_new_4.weight', 'selsa_4.q_data_fc_4.weight', 'selsa_4.linear_out_4.weight', 'fc_cls.weight', 'fc_reg_2.weight', 'fc_new_2.bias'):
+        gr = dict(hvr15.named_parameters())[name].grad
+        key = name.replace('.', '__')
+        g15['sum__' + key] = gr.double().sum()
+        g15['abs__' + key] = gr.double().abs().sum()
+        g15['sample__' + key] = gr.reshape(-1)[::4099].clone()
+    save('g15_hvr_train', **g15)
 
     # ---- G14 mAP evaluation through the reference's own eval_map (mean_ap.py:475-586; the tools/vid_eval.py path) ----
     tt = _pkg('terminaltables')

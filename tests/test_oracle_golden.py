@@ -309,6 +309,59 @@ def test_g13_hard_proposal_mining(O):
     assert bg2.shape == (labels.numel(), 2) and bool((all_labels[bg2[labels == 0]] != 0).all())
 
 
+def test_g15_hvr_head_training_forward_and_backward(O):
+    """G15: the reference's own HRNMPBBoxHead.forward (training, dynamic=False, as hnmb_rcnn.py:438 calls it) + HRNMPBBoxHead.loss +
+    backward() on three videos of three frames, with a recording stub where its tree lacks TripletNonLocalLoss (the stub returns a
+    connected zero): both branches' logits and box deltas, the six loss outputs, what the head hands the triplet loss (q / k
+    projections, the mined index triple), the RoI-feature gradients and eleven parameter gradients (sum, abs-sum, strided sample)
+    pin oracle.hvr_head_forward_train / hvr_head_loss -- everything of the HVR training forward except the triplet term's value."""
+    g = gold('g15_hvr_train')
+    feats, cur, labels, lw, bt, bw = C.hvr_train_case()
+    sd = S.synth_state_dict('hvr')
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith('bbox_head.')}
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    rec = {}
+    cls, reg, extra = O.hvr_head_forward_train(fg, leaf, cur, labels, 16, 9, 3, record=rec)
+    for got, key in ((cls[0], 'cls_branch'), (cls[1], 'cls'), (reg[0], 'reg_branch'), (reg[1], 'reg')):
+        close(got.detach(), g[key], 1e-4, 1e-5)
+    losses = O.hvr_head_loss(cls, reg, labels, lw, bt, bw)
+    for k in ('loss_cls_1', 'loss_bbox_1', 'acc_1', 'loss_cls_2', 'loss_bbox_2', 'acc_2'):
+        close(losses[k].detach(), g[k], 1e-5, 1e-6)
+    # what the reference hands its triplet loss
+    assert tuple(rec['q'].shape) == tuple(int(x) for x in g['trip_q_shape'])
+    assert abs(float(rec['q'].double().abs().sum()) - float(g['trip_q_abs'])) <= 1e-4 * float(g['trip_q_abs'])
+    assert abs(float(rec['k'].double().abs().sum()) - float(g['trip_k_abs'])) <= 1e-4 * float(g['trip_k_abs'])
+    assert np.array_equal(rec['anchors'].numpy(), g['trip_anchor_idx'])
+    assert np.array_equal(rec['second'].numpy(), g['trip_second_idx']) and np.array_equal(rec['third'].numpy(), g['trip_third_idx'])
+    assert 'loss_trip' in extra          # (the stand-in's value: unpinned, and left out of the sum below as the stub's zero is)
+    sum(v for k, v in losses.items() if k.startswith('loss')).backward()
+    for v_i, f in enumerate(fg):
+        want_abs = float(g['d_feats%d_abs' % v_i])
+        assert abs(float(f.grad.double().abs().sum()) - want_abs) <= 1e-4 * want_abs, v_i
+        assert abs(float(f.grad.double().sum()) - float(g['d_feats%d_sum' % v_i])) <= 1e-4 * want_abs, v_i
+    seen = 0
+    for key in [k[len('abs__'):] for k in g.files if k.startswith('abs__')]:
+        gr = leaf['bbox_head.' + key.replace('__', '.')].grad
+        want_abs = float(g['abs__' + key])
+        assert abs(float(gr.double().abs().sum()) - want_abs) <= 1e-4 * want_abs + 1e-9, key
+        close(gr.reshape(-1)[::4099], g['sample__' + key], 1e-4, 1e-6 * max(1.0, want_abs / gr.numel()))
+        seen += 1
+    assert seen == 11
+
+
+def test_roi_align_f64_restatement_equals_the_c_restatement(O):
+    """oracle._roi_align_f64 (torch, float64: used by the f64 noise-floor run of the whole path) against oracle_ref.c on the same
+    boxes: interior, protruding, degenerate and out-of-image RoIs; the difference is f32 evaluation order only."""
+    g = torch.Generator().manual_seed(31)
+    feat = torch.randn((2, 6, 19, 31), generator=g)
+    rois = torch.tensor([[0, 10., 12., 200., 150.], [1, -30., -20., 90., 60.], [0, 400., 250., 520., 330.], [1, 37.5, 41.25, 37.5, 41.25],
+                         [0, 0., 0., 495., 303.], [1, 700., 700., 900., 900.], [0, 100., 50., 90., 40.]])
+    a = O.roi_align(feat, rois, 7, 1.0 / 16, 2)
+    b = O.roi_align(feat.double(), rois.double(), 7, 1.0 / 16, 2)
+    assert b.dtype == torch.float64 and a.shape == b.shape
+    close(a, b.float(), 1e-5, 1e-5)
+
+
 def test_ingest_oracle_closed_form_cases(O):
     """OpenCV is not in the image, so the resize restatement is pinned by cases with known answers: identity, an exact 2x
     reduction (every output = the rounded mean of a 2x2 block), constants under any scale, border replication when

@@ -17,6 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import hvrnet_amd  # noqa: E402
+from hvrnet_amd import parity  # noqa: E402
 from hvrnet_amd import native, ops, synthetic as S  # noqa: E402
 from hvrnet_amd.box_ops import AnchorGenerator, multiclass_nms  # noqa: E402
 from hvrnet_amd.config import ConfigDict, hvr_config, selsa_config  # noqa: E402
@@ -530,7 +531,7 @@ def test_config1_end_to_end_f32_matches_reference_golden():
         order = np.argsort(want_l, kind='stable')  # bbox2result groups by class, keeping in-class order
         assert labels.tolist() == want_l[order].tolist()                 # class indices exact
         close(boxes[:, 4], want_b[order][:, 4], 0, 1e-3)                 # scores within 1e-3
-        close(boxes[:, :4], want_b[order][:, :4], 1e-5, 1e-3)            # coords: 1e-3 px + 1e-5 relative (f32 ulp at 1000 px is 6e-5)
+        close(boxes[:, :4], want_b[order][:, :4], 0, parity.TOL_BOX_PX)  # coords: the one definition (hvrnet_amd/parity.py): 1e-3 px + two f32 ulps at 1000 px
     # SELSA detector on the same frames
     ms = hvrnet_amd.build_model(selsa_config(frame_interval=1, nms_post=32), S.synth_state_dict('selsa'), torch.float32, DEV)
     res = ms(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
@@ -540,7 +541,7 @@ def test_config1_end_to_end_f32_matches_reference_golden():
     assert labels.tolist() == want_l[order].tolist()
     got = np.concatenate(_per_class(res), 0)
     close(got[:, 4], want_b[order][:, 4], 0, 1e-3)
-    close(got[:, :4], want_b[order][:, :4], 1e-5, 1e-3)
+    close(got[:, :4], want_b[order][:, :4], 0, parity.TOL_BOX_PX)
 
 
 def test_config1_end_to_end_bf16_tracks_reference():
@@ -888,6 +889,42 @@ def test_hvr_head_training_step_matches_the_oracle(O):
         close(prm.grad.reshape(-1)[::4099], w.reshape(-1)[::4099], 5e-3, 5e-3 * want_abs / w.numel() + 1e-9)
         seen += 1
     assert seen >= 30
+
+
+def test_hvr_head_training_forward_matches_the_reference_golden_g15():
+    """G15 (the reference's own HRNMPBBoxHead.forward in training mode + loss + backward, triplet class stubbed to a recorded zero):
+    the HIP head called through the same entry point with the same arguments (hnmb_rcnn.py:438) gives both branches' logits /
+    deltas, the six loss outputs, the RoI-feature gradients and the eleven pinned parameter gradients; the triplet term's VALUE is
+    the stand-in's and stays out of the summed loss, as the stub's zero does in the fixture."""
+    g = gold('g15_hvr_train')
+    feats, cur, labels, lw, bt, bw = C.hvr_train_case()
+    sd = S.synth_state_dict('hvr')
+    head = hvrnet_amd.HRNMPBBoxHead(sampler_num=16, t_dim=9, imgs_per_video=3, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
+    head = hvrnet_amd.enable_training(head.to(DEV))
+    hvrnet_amd.set_compute_dtype(head, torch.float32)
+    fg = [f.to(DEV).requires_grad_(True) for f in feats]
+    lab = labels.to(DEV)
+    cls, reg, extra, sim = head(fg, cur_range_s=cur, others=lab, all_labels=lab, dynamic=False)
+    assert sim is None and 'loss_trip' in extra
+    for got, key in ((cls[0], 'cls_branch'), (cls[1], 'cls'), (reg[0], 'reg_branch'), (reg[1], 'reg')):
+        close(got.detach(), g[key], 2e-4, 2e-5)
+    losses = head.loss(cls, reg, lab, lw.to(DEV), bt.to(DEV), bw.to(DEV))
+    for k in ('loss_cls_1', 'loss_bbox_1', 'acc_1', 'loss_cls_2', 'loss_bbox_2', 'acc_2'):
+        close(losses[k].detach(), g[k], 2e-4, 1e-5)
+    sum(v for k, v in losses.items() if k.startswith('loss')).backward()
+    for v_i, f in enumerate(fg):
+        want_abs = float(g['d_feats%d_abs' % v_i])
+        assert abs(float(f.grad.double().abs().sum()) - want_abs) <= 2e-3 * want_abs, v_i
+    params = dict(head.named_parameters())
+    seen = 0
+    for key in [k[len('abs__'):] for k in g.files if k.startswith('abs__')]:
+        gr = params[key.replace('__', '.')].grad
+        want_abs = float(g['abs__' + key])
+        assert gr is not None and abs(float(gr.double().abs().sum()) - want_abs) <= 2e-3 * want_abs + 1e-7, key
+        close(gr.reshape(-1)[::4099], g['sample__' + key], 5e-3, 5e-3 * want_abs / gr.numel() + 1e-9)
+        seen += 1
+    assert seen == 11
 
 
 def test_hvr_head_forward_has_the_reference_signature_and_return(O):

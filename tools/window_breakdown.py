@@ -34,17 +34,23 @@ def main():
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--clips', type=int, default=1, help='W independent clips per call (the batched window: detectors.window_device_outputs(clips=W)); rows are per CALL, i.e. for W windows')
     ap.add_argument('--sequence', action='store_true', help='also print the last window call by call, in issue order')
     args = ap.parse_args()
     T, N, dev = args.frames, 300, 'cuda:0'
     model = hvrnet_amd.build_model((hvr_config if args.head == 'hvr' else selsa_config)(frame_interval=T // 2, nms_post=N),
                                    S.synth_state_dict(args.head), None, dev)
     apply_mode(model, args.mode)
-    fr = torch.cat([S.synth_frame(i) for i in range(T)], 0).to(dev)
-    metas = [S.synth_meta() for _ in range(T)]
+    W = args.clips
+    fr = torch.cat([S.synth_frame(i) for i in range(T * W)], 0).to(dev)
+    metas = [S.synth_meta() for _ in range(T * W)]
 
     def window():
         c4 = model(img=fr, img_meta=metas, backbone_feat=True)[0]
+        if W > 1:
+            out = model.window_device_outputs(c4, metas, rescale=True, clips=W)
+            torch.cuda.synchronize()
+            return out
         return model(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
 
     with torch.no_grad():
@@ -66,7 +72,7 @@ def main():
             seq = native.profile_end(raw=True)
     rows = sorted(((d['ms'] / args.iters, d['calls'] // args.iters, d['work'] / args.iters, tag) for tag, d in prof.items()), reverse=True)
     total = sum(r[0] for r in rows)
-    print('mode %s: %.2f ms per window (wall, un-profiled); %.2f ms summed over the tagged calls' % (args.mode, wall, total))
+    print('mode %s, %d clip(s) per call: %.2f ms per call (wall, un-profiled) = %.2f ms per window; %.2f ms summed over the tagged calls' % (args.mode, W, wall, wall / W, total))
     print('%9s %6s %9s %9s  %s' % ('ms', 'calls', 'us/call', 'work/s', 'call'))
     for ms, calls, work, tag in rows:
         unit = 'GB/s' if tag.startswith(('conv_expand', 'roi_align', 'rpn_proposals')) else 'TF/s'

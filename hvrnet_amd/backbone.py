@@ -13,8 +13,6 @@ forward pass runs on packed device buffers:
 Inference only: BN layers are always treated as frozen (both configs set norm_eval=True,
 requires_grad=False).  There is no CPU path (native.py raises on CPU tensors).
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -205,8 +203,8 @@ class Bottleneck(nn.Module, PackedMixin):
             identity = native.conv2d_nhwc(x, p['ds'][0], p['ds'][1], relu=False, stride=self.stride)
         return native.conv2d_nhwc(out, p['c3'][0], p['c3'][1], resid=identity, relu=True, out=dst)
 
-    fuse_next = os.environ.get('HVR_FUSE_NEXT', '1') != '0'
-    fuse_tail = os.environ.get('HVR_FUSE_TAIL', '1') != '0'
+    fuse_next = True   # class attributes (tests flip them to compare the fused kernels with the per-conv path); no environment switch
+    fuse_tail = True
 
     def forward(self, x):
         return as_logical(self.forward_nhwc(as_nhwc(x, self.compute_dtype)))

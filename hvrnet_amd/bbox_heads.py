@@ -18,8 +18,6 @@ triplet loss) is not part of this round.
 """
 import math
 
-import os
-
 import torch
 import torch.nn as nn
 from torch.nn.modules.utils import _pair
@@ -483,7 +481,7 @@ class HRNMPBBoxHead(_RelationHead):
         fused = [torch.cat([c, b], dim=1) for c, b in zip(cls_score, bbox_pred)]
         return self.loss_train(fused, labels, label_weights, bbox_targets, bbox_weights)
 
-    readout_streams = os.environ.get('HVR_READOUT_STREAMS', '1') != '0'
+    readout_streams = True   # the second branch's read-out on a side stream (class attribute; no environment switch)
 
     def get_det_bboxes(self, rois, cls_scores, bbox_preds, img_shape, scale_factor, rescale=False, cfg=None, defer=False):
         """Per-branch read-out -> (list of det_bboxes, list of det_labels), hrnmp_bbox_head.py:1009-1052."""

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < A_SLOTS; ++i) colbad[i] |= (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W ? 0u : (1u << kx);
     }
-    const unsigned all_kw = (1u << p.KW) - 1u;
+    const unsigned all_kw = p.KW >= 32 ? ~0u : (1u << p.KW) - 1u;   // (a 1 x 32 filter passes the <= 32 taps gate: no shift by 32)
     for (int ky = 0, dy = 0, sh = 0; ky < p.KH; ++ky, dy += p.dil, sh += p.KW) {
 #pragma unroll
       for (int i = 0; i < A_SLOTS; ++i) oob[i] |= ((unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H ? colbad[i] : all_kw) << sh;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   auto dma_a = [&](auto I, char* stage) {
     constexpr int i = decltype(I)::value;
     if (i < A_SLOTS - 1 || wave < LAST_WAVES) {   // (scalar: `wave` lives in an SGPR)
-      const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> t_tap) << 31);   // offsets from 2^31 up read as zeros
+      const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> (t_tap & 31)) << 31);   // offsets from 2^31 up read as zeros
       const bool s2 = kt_load >= k1_steps;
       const char* const base = s2 ? rs_a2 : rs_a;
       const unsigned vo = s2 ? (unsigned)a_off2[i] : voff;
@@ -463,12 +463,11 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   if (split && ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C)) & 127)) return false;
   // K >= 256: below that a tile is all prologue and epilogue and the row-panel kernel (expand.hip) is ahead -- layer 2's expand
   // 77 vs 76 us, layer 1's 139 vs 126; layer 3's (K = 256) 40 vs 43 and res5's (K = 512) 117 vs 138 go the other way
-  static const int with_res = std::getenv("HVR_BIGTILE_RES") ? std::atoi(std::getenv("HVR_BIGTILE_RES")) : 1;
   // (with two windows in flight the panel kernel's expand convs, two small workgroups per CU, pack better beside the other
-  // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint.
-  // Split half has no row-panel kernel for K >= 256: its residual convs take the big tiles in either mode.)
-  static const int res_shared = std::getenv("HVR_BIGTILE_RES_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_RES_SHARED")) : 0;
-  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && (!with_res || (throughput && !split && !res_shared))))) return false;
+  // window's launches: 160.8 vs 158.1 frames/s; alone on the chip the big tiles win, 139.7 vs 137.5 -- so not under the hint
+  // (forcing them there measured -0.7 %, round 4).  Split half has no row-panel kernel for K >= 256: its residual convs take the
+  // big tiles in either mode.)
+  if (p.tile_hint != kBigForce && (p.K < 256 || (p.resid && throughput && !split))) return false;
   if (p.conv && (p.Cin % bke || p.KH * p.KW > 32)) return false;   // (the loader keeps a 32-bit tap mask per piece)
   const uintptr_t al = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                        reinterpret_cast<uintptr_t>(p.bias);
@@ -479,12 +478,12 @@ bool bigtile_supported(const GemmParams& p, bool throughput) {
   // against 47 on twice the CUs) only pays in CU-time, i.e. for a caller that has other launches for the free half.
   const long tiles = (long)((p.M + 287) / 288) * (p.N / BG_BN);
   static const int on = std::getenv("HVR_BIGTILE") ? std::atoi(std::getenv("HVR_BIGTILE")) : 1;
-  static const int min_alone = std::getenv("HVR_BIGTILE_MIN") ? std::atoi(std::getenv("HVR_BIGTILE_MIN")) : 170;
+  constexpr int min_alone = 170;
   // Half-chip grids under the throughput hint -- layer 3's 125 tiles: 63 us on 125 CUs against 43 on 250 is -27 % CU-time, if the
   // other windows in flight have launches for the free half.  With two graph lanes that measured neutral to -1.7 % (round 3); with
   // four (bench.py's default since round 4) it is +0.4 % in bf16 and +0.8 % in split half, twice each on one box
-  // (profiles/r04_lanes.txt) -- small, repeatable, so the shared threshold is 96 tiles.  HVR_BIGTILE_MIN_SHARED=170 restores the old one.
-  static const int min_shared = std::getenv("HVR_BIGTILE_MIN_SHARED") ? std::atoi(std::getenv("HVR_BIGTILE_MIN_SHARED")) : 96;
+  // (profiles/r04_lanes.txt) -- small, repeatable, so the shared threshold is 96 tiles.
+  constexpr int min_shared = 96;
   if (p.tile_hint == kBigForce) return true;
   return on && tiles >= (throughput ? min_shared : min_alone) && tiles <= 4096;
 }

@@ -15,6 +15,7 @@
 
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
+hipError_t run_zero_fill(void*, size_t, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_f16(const float*, void*, int, int, long, int, hipStream_t);
@@ -128,9 +129,7 @@ static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int
 // the launch to ~1.5 workgroups per CU, at least 4 K-steps each
 static int fewrow_slices(const GemmParams& p) {
   static const int on = std::getenv("HVR_CONV_SPLITK") ? std::atoi(std::getenv("HVR_CONV_SPLITK")) : 1;
-  static const int target = std::getenv("HVR_CONV_SPLITK_WGS") ? std::atoi(std::getenv("HVR_CONV_SPLITK_WGS")) : 512;
-  static const int mink = std::getenv("HVR_CONV_SPLITK_MINK") ? std::atoi(std::getenv("HVR_CONV_SPLITK_MINK")) : 8;
-  static const int minper = std::getenv("HVR_CONV_SPLITK_PER") ? std::atoi(std::getenv("HVR_CONV_SPLITK_PER")) : 4;
+  constexpr int target = 512, mink = 8, minper = 4;
   if (!on || p.dtype != DT_BF16 || !p.staging || p.out_f32 || p.tile_hint != 0) return 1;
   if (p.N % 8 || p.ldc % 8 || (p.resid && p.ldr % 8) || !aligned16(p.C) || (p.resid && !aligned16(p.resid)) || (p.bias && !aligned16(p.bias))) return 1;
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
@@ -359,8 +358,7 @@ static int tail_params(const hvr_tail_desc* d, GemmParams& p) {
 // the tile engine's form of the fused tail (K too long for the row-panel kernel: stage 3's 256 + 512 and res5's 512 + 1024):
 // one GEMM over K = C1 + C2 whose A operand switches from h to the sampled block input at K-step C1 / 64
 static bool tail_on_tile_engine(const GemmParams& p) {
-  static const int on = std::getenv("HVR_TAIL_TILE") ? std::atoi(std::getenv("HVR_TAIL_TILE")) : 1;
-  return on && (p.dtype == DT_BF16 || p.dtype == DT_F16) && p.K1 % 64 == 0 && (p.K - p.K1) % 64 == 0 && p.K1 >= 64 && p.K - p.K1 >= 64 && p.N % 8 == 0 && p.ldc % 8 == 0 &&
+  return (p.dtype == DT_BF16 || p.dtype == DT_F16) && p.K1 % 64 == 0 && (p.K - p.K1) % 64 == 0 && p.K1 >= 64 && p.K - p.K1 >= 64 && p.N % 8 == 0 && p.ldc % 8 == 0 &&
          (long)p.M * (p.K - p.K1) * 2 < (1L << 31);
 }
 
@@ -376,10 +374,8 @@ int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream) {
   if (rc) return rc;
   if (expand_supported(p)) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail");
   if (tail_on_tile_engine(p)) {
-    // (the 288 x 256 tiles take the second K segment too, but measure slightly behind the tile engine here -- 144.7 vs 145.7
-    // frames/s on the single-lane window: opt-in, HVR_TAIL_BIG=1)
-    static const int big = std::getenv("HVR_TAIL_BIG") ? std::atoi(std::getenv("HVR_TAIL_BIG")) : 0;
-    if (big && bigtile_supported(p, false)) return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_bottleneck_tail(big tile)");
+    // (the 288 x 256 tiles take the second K segment too, but measured slightly behind the tile engine here -- 144.7 vs 145.7
+    // frames/s on the single-lane window, round 3: not taken)
     return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_bottleneck_tail(tile engine)");
   }
   return fail(HVR_EUNSUPPORTED, "no fused tail kernel for C1=%d C2=%d Cout=%d", d->C1, d->C2, d->Cout);
@@ -405,7 +401,7 @@ static int tail_next_params(const hvr_tail_next_desc* d, GemmParams& p) {
       return fail(HVR_EINVAL, "an identity block needs its (16-byte aligned; split half: 128-byte aligned) residual map");
     if (split && (t.Cout % 32 || !aligned128(t.y))) return fail(HVR_EINVAL, "split-half tail: Cout %% 32 == 0, 128-byte aligned y");
     p.bias = t.bias; p.relu = t.relu; p.resid = d->resid; p.ldr = t.Cout;
-    p.alpha = d->alpha; p.beta = d->beta;
+    if (t.dtype == HVR_F16S) { p.alpha = d->alpha; p.beta = d->beta; }   // (documented as split-half only: include/hvr_hip.h)
   }
   if (!t.relu) return fail(HVR_EUNSUPPORTED, "the next block reads the activated output (relu = 1)");
   p.Wn = d->wn; p.bias_n = d->bias_n; p.Hn = d->hn; p.Cn = d->Cn;
@@ -477,11 +473,7 @@ static inline long rel_ldp(int Mk) { return ((long)Mk + 127) / 128 * 128; }
 // 3 x 8 output tile grid with a 72-step K loop -- 24 workgroups on 256 CUs): the 128-key blocks are dealt to `slices` workgroups
 // per output tile (at least 2 blocks each), every slice writes an f32 partial, one reduce launch sums and rounds them.  The
 // block weights g = 2^(m_t - m*) / L are global per row, so the partials simply add.  1 = no split.
-constexpr size_t kApplyTicketBytes = 1024;   // one int per output tile of a sliced apply pass (fewer than 96 tiles: apply_slices)
-static int apply_slice_blocks() {   // 128-key blocks per slice of a sliced apply pass (HVR_KEY_SLICE_BLOCKS: tuning)
-  static const int per = std::getenv("HVR_KEY_SLICE_BLOCKS") ? std::atoi(std::getenv("HVR_KEY_SLICE_BLOCKS")) : 4;
-  return per >= 2 && per <= 8 ? per : 4;
-}
+static int apply_slice_blocks() { return 4; }   // 128-key blocks per slice of a sliced apply pass
 static int apply_slices(int Mq, int Mk, int D) {
   const long tiles = (long)((Mq + 127) / 128) * ((D + 127) / 128);
   const int nblk = (int)(rel_ldp(Mk) / 128);
@@ -502,10 +494,7 @@ static int apply_slices(int Mq, int Mk, int D) {
 static int relation_apply_pass(const void* P, const void* Vt, float* mstat, float* lstat, float* partial, void* O, int64_t ldo,
                                int Mq, int Mk, int D, long ldp, int nt, int dtype, int staging, hipStream_t s) {
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
-  static const int tile_apply = env_tile("HVR_TILE_APPLY");
-  static const int gm_apply = std::getenv("HVR_GM_APPLY") ? std::atoi(std::getenv("HVR_GM_APPLY")) : 1;
-  static const int no_pc = env_tile("HVR_NO_PC");  // force the tile-engine apply pass
-  static const int pc_apply = std::getenv("HVR_PC_APPLY") ? std::atoi(std::getenv("HVR_PC_APPLY")) : 1;
+  constexpr int tile_apply = 0, gm_apply = 1;
 #ifdef HVR_DEBUG_KNOBS
   static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
 #endif
@@ -519,8 +508,7 @@ static int relation_apply_pass(const void* P, const void* Vt, float* mstat, floa
 #ifdef HVR_DEBUG_KNOBS
   if (dbg_ld0 & 2) { p.lda = 0; p.ldb = 0; }
 #endif
-  static const int no_split = env_tile("HVR_NO_APPLY_SPLIT");
-  const int slices = no_split ? 1 : apply_slices(Mq, Mk, D);
+  const int slices = apply_slices(Mq, Mk, D);
   if (slices > 1 && tile_apply == 0 && (!two_byte || (ldo % 8 == 0 && aligned16(O)))) {
     const int steps_per_blk = two_byte ? 2 : 4;
     const int per = apply_slice_blocks();  // apply_slices: 128-key blocks per slice
@@ -529,23 +517,11 @@ static int relation_apply_pass(const void* P, const void* Vt, float* mstat, floa
     p.csplit_bytes = (long)Mq * D * 4;
     p.C = partial; p.ldc = D; p.out_f32 = two_byte ? 1 : 0;
     p.tile_hint = 1;  // 128 x 128 tiles; the slices are latency chains of 8 K-steps (the pipelined shapes measure the same)
-    // HVR_KEY_MERGE=1 (opt-in, two-byte operands): the slice that reaches an output tile last merges the partials inside the
-    // launch (gemm_tile.h, the ticket tail of EPI_APPLY: slice order, the reduce kernel's bits) instead of the reduce launch.
-    // Correct (bit-identical, tests/test_kernels_gpu.py) and SLOWER: the apply launch 24.4 -> 60.3 us, the 300 x 4 500 stage
-    // 49.3 -> 83.6 us (profiles/r03_key_stage_merge_ab.txt) against the 5.0 us reduce launch it saves.  Ablation (same file): with
-    // the two agent-scope fences compiled out (buffer_wbl2 sc1 / buffer_inv sc1 in every wave of 216 workgroups; cross-XCD
-    // visibility needs them, so that build is timing-only) the apply launch is 31.9 us -- the fences are 27.6 us of the 35, the
-    // merge tail itself 7.5, and even fence-free the form does not beat apply 24.4 + reduce 5.0.
-    static const int key_merge = std::getenv("HVR_KEY_MERGE") ? std::atoi(std::getenv("HVR_KEY_MERGE")) : 0;
-    const bool merge = key_merge && two_byte;
-    if (merge) {
-      int* tickets = (int*)((char*)partial + align256((size_t)slices * Mq * D * 4));
-      hipError_t e0 = hipMemsetAsync(tickets, 0, kApplyTicketBytes, s);
-      if (e0 != hipSuccess) return check_launch(e0, "relation: apply tickets");
-      p.tickets = tickets; p.merge_out = O; p.merge_ld = ldo;
-    }
+    // (an in-launch merge of the partials by the slice that reaches an output tile last -- tickets, agent-scope fences -- was built in
+    // round 3 and measured SLOWER than the 5 us reduce launch it saved: 49.3 -> 83.6 us for the stage, 27.6 us of it fences
+    // (profiles/r03_key_stage_merge_ab.txt); removed in round 5)
     hipError_t e = run_tile_op(p, EPI_APPLY, s);
-    if (e == hipSuccess && !merge)
+    if (e == hipSuccess)
       e = dtype == HVR_BF16 ? run_splitk_reduce_bf16(partial, O, Mq, D, ldo, slices, s)
           : dtype == HVR_F16 ? run_splitk_reduce_f16(partial, O, Mq, D, ldo, slices, s) : run_splitk_reduce(partial, (float*)O, Mq, D, ldo, slices, s);
     return check_launch(e, "relation: apply (key slices)");
@@ -554,8 +530,8 @@ static int relation_apply_pass(const void* P, const void* Vt, float* mstat, floa
   // it behind the tile engine (60 against 57 us) and left it opt-in; on round 4's boxes it is AHEAD, alone (tools/rel_bench.py: 0.1073 /
   // 0.1102 ms per relation call against 0.1164 / 0.1200) and inside the window (three alternating runs of tools/window_breakdown.py:
   // 109.4 / 110.3 / 110.5 us per call against 114.1 / 113.0 / 113.1) -- profiles/r04_relation_apply.txt -- so it is the default for
-  // window-sized problems; HVR_PC_APPLY=0 brings the tile engine's apply back.
-  if (pc_apply && !no_pc && tile_apply == 0 && Mq >= 1024 && pc_supported(p, EPI_APPLY))
+  // window-sized problems.
+  if (Mq >= 1024 && pc_supported(p, EPI_APPLY))
     return check_launch(run_pc(p, EPI_APPLY, 128, s), "relation: apply (pc)");
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
 }
@@ -565,7 +541,7 @@ size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
   const size_t es = elem_size(dtype);
   const int slices = apply_slices(Mq, Mk, D);
   return align256((size_t)Mq * ldp * es) + align256((size_t)D * ldp * es) + 2 * align256((size_t)Mq * nt * 4) +
-         (slices > 1 ? align256((size_t)slices * Mq * D * 4) + kApplyTicketBytes : 0);
+         (slices > 1 ? align256((size_t)slices * Mq * D * 4) : 0);
 }
 
 int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
@@ -589,7 +565,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 
   GemmParams p;
   int rc;
-  static const int tile_scores_s = env_tile("HVR_TILE_SCORES_SPLIT"), tile_apply_s = env_tile("HVR_TILE_APPLY_SPLIT");   // tuning overrides
+  constexpr int tile_scores_s = 0, tile_apply_s = 0;
   if (dtype == HVR_F16S) {
     // split half: the scores pass (block-local maxima, P~ stored x 2^12 in the split format), V^T, then either one normalising sweep
     // over P~ + a plain product, or the apply pass with the block weights g = 2^(m_t - m*) / L folded in per 128-key block
@@ -624,13 +600,11 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   }
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
   // tuning overrides, read once
-  static const int tile_scores = env_tile("HVR_TILE_SCORES");
-  static const int gm_scores = std::getenv("HVR_GM_SCORES") ? std::atoi(std::getenv("HVR_GM_SCORES")) : 8;
-  static const int no_bt = env_tile("HVR_NO_BT");  // force the tile-engine scores pass
+  constexpr int tile_scores = 0, gm_scores = 8;
 #ifdef HVR_DEBUG_KNOBS  // tuning builds only (tools/build_dbg.sh): alias every operand row to row 0 (no memory-system cost)
   static const int dbg_ld0 = env_tile("HVR_DBG_LD0");
 #endif
-  const bool bt = two_byte && staging && !no_bt && scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt);
+  const bool bt = two_byte && staging && scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt);
   if (bt) {
     // window-sized problems: one 336 x 256 score tile per CU, V^T written by the same launch (relation_bt.hip)
     ScoresBTParams b;
@@ -643,9 +617,8 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
   } else {
     // few query rows (the key stage, 300 x 4 500: 108 score tiles on 256 CUs): V^T is written by workgroups of the SCORES launch that sit
     // behind its tiles, on the CUs the score grid leaves idle -- one launch and ~8 us less than the transpose launch in front of it
-    // (GemmParams::tr_*, gemm_tile.h; HVR_KEY_VT_FOLD=0 restores the separate launch)
-    static const int vt_fold = std::getenv("HVR_KEY_VT_FOLD") ? std::atoi(std::getenv("HVR_KEY_VT_FOLD")) : 1;
-    const bool fold = vt_fold && two_byte && staging && Mq <= 1024 && D % 8 == 0 && ldv % 8 == 0 && aligned16(V) && aligned16(Vt);
+    // (GemmParams::tr_*, gemm_tile.h)
+    const bool fold = two_byte && staging && Mq <= 1024 && D % 8 == 0 && ldv % 8 == 0 && aligned16(V) && aligned16(Vt);
     if (!fold) {
       rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose");
       if (rc) return rc;
@@ -972,7 +945,7 @@ int hvr_nms(const float* dets, int n, float thr, int ge_semantics, int64_t* keep
             size_t ws_bytes, void* stream) {
   if (!n_keep) return fail(HVR_EINVAL, "null n_keep");
   if (n == 0) {
-    (void)hipMemsetAsync(n_keep, 0, sizeof(int32_t), (hipStream_t)stream);
+    (void)run_zero_fill(n_keep, sizeof(int32_t), (hipStream_t)stream);
     return HVR_OK;
   }
   if (!dets || !keep || !ws) return fail(HVR_EINVAL, "null pointer");
@@ -987,7 +960,7 @@ int hvr_nms_first(const float* dets, int n, float thr, int ge_semantics, int max
   if (max_keep <= 0) return fail(HVR_EINVAL, "hvr_nms_first needs max_keep > 0 (hvr_nms keeps every survivor)");
   if (!n_keep) return fail(HVR_EINVAL, "null n_keep");
   if (n == 0) {
-    (void)hipMemsetAsync(n_keep, 0, sizeof(int32_t), (hipStream_t)stream);
+    (void)run_zero_fill(n_keep, sizeof(int32_t), (hipStream_t)stream);
     return HVR_OK;
   }
   if (!dets || !keep || !ws) return fail(HVR_EINVAL, "null pointer");
@@ -1071,7 +1044,7 @@ int hvr_multiclass_nms(const float* boxes, const float* scores, int R, int ncls,
                        float* dets, int64_t* labels, int32_t* n_out, void* ws, size_t ws_bytes, void* stream) {
   if (!n_out) return fail(HVR_EINVAL, "null n_out");
   if (R == 0) {
-    (void)hipMemsetAsync(n_out, 0, sizeof(int32_t), (hipStream_t)stream);
+    (void)run_zero_fill(n_out, sizeof(int32_t), (hipStream_t)stream);
     return HVR_OK;
   }
   if (!boxes || !scores || !dets || !labels || !ws) return fail(HVR_EINVAL, "null pointer");

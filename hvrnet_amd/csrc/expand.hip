@@ -345,10 +345,8 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
 // chunks per workgroup: 8 when that still gives the chip two workgroups per CU, else 4, else 2
 static int expand_nc(int M, int N) {
   const int panels = (M + X_BM - 1) / X_BM, nchunks = N / X_BN;
-  static const int env_nc = std::getenv("HVR_EXPAND_NC") ? std::atoi(std::getenv("HVR_EXPAND_NC")) : 0;
-  if ((env_nc == 2 || env_nc == 4 || env_nc == 8 || env_nc == 16) && nchunks % env_nc == 0) return env_nc;
   // (16 = one workgroup per panel at N = 1024: measured SLOWER at layer 3 / 15 frames, 51 us against 42 -- 281 workgroups do
-  // not keep enough loads in flight; kept as an override for experiments)
+  // not keep enough loads in flight)
   if (nchunks % 8 == 0 && (long)panels * (nchunks / 8) >= 512) return 8;
   if (nchunks % 4 == 0) return 4;
   if (nchunks % 2 == 0) return 2;

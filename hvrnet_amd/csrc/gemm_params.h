@@ -56,12 +56,6 @@ struct GemmParams {
   // split-K (EPI_LINEAR, no conv): ksplit_count slices of ksplit_steps K-steps, partial s at C + s * csplit_bytes (0 = off)
   int ksplit_steps, ksplit_count;
   long csplit_bytes;
-  // EPI_APPLY split over key slices, merged inside the launch (null = the caller runs a reduce launch): one counter per output
-  // tile (zero before the launch); the slice that arrives last at a tile sums the ksplit_count f32 partials IN SLICE ORDER
-  // (the order and rounding of splitk_reduce_bf16_kernel: the same bits) and stores the tile to merge_out in the operand dtype
-  int* tickets;
-  void* merge_out;
-  long merge_ld;
   // EPI_SCORES, two-byte operands: tr_blocks > 0 workgroups behind the score tiles write tr_out[C][tr_ldt] = tr_in[R][tr_ldx]^T (zero for
   // columns R .. tr_ldt - 1) -- the apply pass's V^T, made by the CUs a few-row score grid leaves idle instead of by a launch of its own
   const void* tr_in;

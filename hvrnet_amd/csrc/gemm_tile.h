@@ -626,7 +626,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) colbad[i] |= (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W ? 0u : (1u << kx);
       }
-      const unsigned all_kw = (1u << p.KW) - 1u;
+      const unsigned all_kw = p.KW >= 32 ? ~0u : (1u << p.KW) - 1u;   // (a 1 x 32 filter passes the <= 32 taps gate: no shift by 32)
       for (int ky = 0, dy = 0, sh = 0; ky < p.KH; ++ky, dy += p.dil, sh += p.KW) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) oob[i] |= ((unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H ? colbad[i] : all_kw) << sh;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
     auto dma_a = [&](auto I, char* stage) {
       constexpr int i = decltype(I)::value;
       if (A_SLOTS * NT == BM * 8 || (i + 1) * NT <= BM * 8 || i * NT + wave * 64 < BM * 8) {   // (scalar: `wave` lives in an SGPR)
-        const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> t_tap) << 31);
+        const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> (t_tap & 31)) << 31);
 #ifndef HVR_DBG_NODMA
         const bool s2 = kt_load >= k1_steps;
         const char* const base = s2 ? rs_a2 : rs_a;
@@ -1041,45 +1041,6 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         }
       }
       __syncthreads();
-    }
-    if constexpr (EPI == EPI_APPLY && sizeof(T) == 2 && !SPLIT) {
-      if (p.ksplit_steps > 0 && p.tickets) {
-        // In-launch merge of the key slices.  Every thread: its partial stores written back and visible device-wide (agent-scope
-        // fence: the eight XCDs' L2s are not coherent with each other) BEFORE the workgroup takes its ticket; the workgroup
-        // that draws the last ticket of a tile acquires (fence again: nothing stale from its own L2) and sums the slices'
-        // partials in slice order -- not in arrival order: the result must not depend on scheduling.
-#ifndef HVR_DBG_MERGE_NOFENCE   // (timing-only ablation build, tools/build_dbg.sh: what the two fences cost; results not guaranteed)
-        __threadfence();
-#endif
-        __syncthreads();
-        int* sh_ticket = reinterpret_cast<int*>(smem);   // (the staging buffer is dead: the last pass ended with a barrier)
-        if (threadIdx.x == 0) *sh_ticket = atomicAdd(&p.tickets[blockIdx.x], 1);
-        __syncthreads();
-        const int S = (int)gridDim.y;
-        if (*sh_ticket == S - 1) {
-#ifndef HVR_DBG_MERGE_NOFENCE
-          __threadfence();
-#endif
-          const float* part = reinterpret_cast<const float*>(p.C);   // slice s at + s * csplit_bytes
-          const long sstride = p.csplit_bytes / 4;
-          T* outp = reinterpret_cast<T*>(p.merge_out);
-          const int rows = min(BM, p.M - m0), segs = BN / 8;
-          for (int q = threadIdx.x; q < rows * segs; q += WM * WN * 64) {
-            const int r = q / segs, n = n0 + (q - r * segs) * 8;
-            if (n >= p.N) continue;
-            const float* src = part + (long)(m0 + r) * p.ldc + n;
-            float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-#pragma unroll 4
-            for (int sl = 1; sl < S; ++sl) {
-              const float4 u = *reinterpret_cast<const float4*>(src + sl * sstride), v = *reinterpret_cast<const float4*>(src + sl * sstride + 4);
-              a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-              b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
-            }
-            *reinterpret_cast<uint4*>(outp + (long)(m0 + r) * p.merge_ld + n) =
-                make_uint4(pack2<T>(a.x, a.y), pack2<T>(a.z, a.w), pack2<T>(b.x, b.y), pack2<T>(b.z, b.w));
-          }
-        }
-      }
     }
   } else {  // EPI_SCORES: per (row, 128-key tile) max / sum and P~ = exp(s - tilemax)
     static_assert(EPI != EPI_SCORES || BN == 128, "score tiles are 128 keys wide");

@@ -943,4 +943,29 @@ hipError_t run_det_decode(const float* logits, int ldl, int cls_off, int reg_off
   return hipGetLastError();
 }
 
+// ---- zero fill ----
+// Every zeroing inside a capturable C-ABI path goes through this kernel, not hipMemsetAsync: a captured one-chain graph holding a memset
+// node took a GPU memory fault when replayed behind ordinary launches without host synchronisation (ROCm 7.2;
+// profiles/r04_graph_memset_fault.txt).  `bytes` a multiple of 4, p 4-byte aligned; 16-byte stores once p is 16-byte aligned.
+__global__ void zero_fill_kernel(uint32_t* __restrict__ p, long words) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const long n4 = words >> 2;
+    for (long j = i; j < n4; j += stride) q[j] = make_uint4(0u, 0u, 0u, 0u);
+    for (long j = (n4 << 2) + i; j < words; j += stride) p[j] = 0u;
+  } else {
+    for (; i < words; i += stride) p[i] = 0u;
+  }
+}
+hipError_t run_zero_fill(void* p, size_t bytes, hipStream_t s) {
+  if (!p || bytes == 0) return hipSuccess;
+  const long words = (long)((bytes + 3) / 4);
+  long blocks = (words / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words);
+  return hipGetLastError();
+}
+
 }  // namespace hvr

@@ -12,6 +12,7 @@
 #include <cstdint>
 
 namespace hvr {
+hipError_t run_zero_fill(void*, size_t, hipStream_t);   // misc.hip: a kernel, not a memset node (captured graphs)
 
 namespace {
 
@@ -434,8 +435,8 @@ hipError_t run_triplet_margin(const void* q, long ldq, const void* k, long ldk, 
                               const long long* n_, int n, float margin, int bf16, float* ws, float* out2, float* dq, float* dk,
                               hipStream_t s) {
   hipError_t e = hipSuccess;
-  if (dq) e = hipMemsetAsync(dq, 0, (size_t)Mq * D * 4, s);
-  if (e == hipSuccess && dk) e = hipMemsetAsync(dk, 0, (size_t)Mk * D * 4, s);
+  if (dq) e = run_zero_fill(dq, (size_t)Mq * D * 4, s);
+  if (e == hipSuccess && dk) e = run_zero_fill(dk, (size_t)Mk * D * 4, s);
   if (e != hipSuccess) return e;
   return bf16 ? launch_triplet<__hip_bfloat16>(q, ldq, k, ldk, D, a, p, n_, n, margin, ws, out2, dq, dk, s)
               : launch_triplet<float>(q, ldq, k, ldk, D, a, p, n_, n, margin, ws, out2, dq, dk, s);
@@ -448,7 +449,7 @@ hipError_t run_max_iou_assign(const float* boxes, int ldb, int n, const float* g
                               float neg_lo, float neg_hi, float min_pos, long long* gt_inds, float* max_ov, void* ws, hipStream_t s) {
   int* argmax = (int*)ws;
   unsigned* gt_max = (unsigned*)(argmax + n);
-  hipError_t e = hipMemsetAsync(gt_max, 0, (size_t)k * 4, s);
+  hipError_t e = run_zero_fill(gt_max, (size_t)k * 4, s);
   if (e != hipSuccess) return e;
   const int blocks = (n + 255) / 256;
   hipLaunchKernelGGL(assign_max_kernel, dim3(blocks), dim3(256), 0, s, boxes, ldb, n, gts, k, valid, max_ov, argmax, gt_max);
@@ -467,10 +468,10 @@ hipError_t run_box_targets(const float* boxes, int ldb, int n, const float* gts,
                            const long long* inds, const int* counts, int num, const float* means, const float* stds, float pos_weight,
                            int scatter, long long* labels, float* label_w, float* bbox_t, float* bbox_w, hipStream_t s) {
   const size_t rows = scatter ? (size_t)n : (size_t)num;
-  hipError_t e = hipMemsetAsync(labels, 0, rows * 8, s);
-  if (e == hipSuccess) e = hipMemsetAsync(label_w, 0, rows * 4, s);
-  if (e == hipSuccess) e = hipMemsetAsync(bbox_t, 0, rows * 16, s);
-  if (e == hipSuccess) e = hipMemsetAsync(bbox_w, 0, rows * 16, s);
+  hipError_t e = run_zero_fill(labels, rows * 8, s);
+  if (e == hipSuccess) e = run_zero_fill(label_w, rows * 4, s);
+  if (e == hipSuccess) e = run_zero_fill(bbox_t, rows * 16, s);
+  if (e == hipSuccess) e = run_zero_fill(bbox_w, rows * 16, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(box_targets_kernel, dim3((num + 255) / 256), dim3(256), 0, s, boxes, ldb, gts, gt_labels, gt_inds, inds, counts,
                      make_float4(means[0], means[1], means[2], means[3]), make_float4(stds[0], stds[1], stds[2], stds[3]), pos_weight,
@@ -480,7 +481,7 @@ hipError_t run_box_targets(const float* boxes, int ldb, int n, const float* gts,
 
 hipError_t run_rpn_loss(const float* o, int ldo, int A, int rows, const long long* labels, const float* label_w, const float* bbox_t,
                         const float* bbox_w, const int* counts, float beta, float* out2, float* d_o, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(d_o, 0, (size_t)rows * ldo * 4, s);
+  hipError_t e = run_zero_fill(d_o, (size_t)rows * ldo * 4, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, s, o, ldo, A, rows, labels, label_w, bbox_t, bbox_w, counts, beta, out2,
                      d_o);

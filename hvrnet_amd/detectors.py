@@ -118,70 +118,13 @@ class TwoStageDetector(BaseDetector):
             self.bbox_roi_extractor.init_weights()
             self.bbox_head.init_weights()
 
-    # Frames are independent through the backbone.  With `frame_groups` = G > 1 a batch of frames is cut into G
-    # contiguous groups that run on G HIP streams.  The idea -- a bottleneck alternates MFMA-bound (3x3) and HBM-bound
-    # (1x1 + residual) convolutions, so two groups out of step would overlap one kind with the other -- does NOT pay on
-    # this chip: two hipGraph chains of layer-3 blocks on two streams (8 + 7, 9 + 6, 10 + 5 frames) take exactly the time
-    # of one 15-frame chain (114.6 vs 114.7 us per block, tools/probe/two_stream_l3.py), the work is conserved, not
-    # overlapped; and in eager mode the second group's launches queue behind the first's on the host.  One group (the
-    # default since round 2) keeps every launch at the full 15-frame size, where the 3x3 tile grid is one round of the
-    # chip (250 tiles of 144 x 256 on 256 CUs), and halves the launch count.  G > 1 stays as a knob.
-    frame_groups = int(os.environ.get('HVR_FRAME_GROUPS', '1'))
-    group_first = int(os.environ.get('HVR_GROUP_FIRST', '0'))
-
-    def _group_streams(self, device, n):
-        pool = self.__dict__.setdefault('_gstreams', {})
-        key = (str(device), torch.cuda.current_stream(device).cuda_stream)  # helper streams belong to one main stream
-        while len(pool.setdefault(key, [])) < n:
-            pool[key].append(torch.cuda.Stream(device=device))
-        return pool[key][:n]
-
-    def _run_in_frame_groups(self, fn, x):
-        """fn(frames [b,...]) -> tuple of logical [b,C,H,W] maps (physically NHWC); groups run on separate streams and
-        the per-group results are concatenated along the frame axis."""
-        G = min(self.frame_groups, x.shape[0])
-        if G <= 1 or not x.is_cuda:
-            return fn(x)
-        main = torch.cuda.current_stream(x.device)
-        sides = self._group_streams(x.device, G - 1)
-        whole = None
-        shape_of = getattr(fn, 'out_shape_nhwc', None)
-        if shape_of is not None and x.dim() == 4 and shape_of(x.shape[0], x.shape[2], x.shape[3]) is not None and os.environ.get('HVR_GROUP_CAT') != '1':
-            # every group writes its frames' slice of ONE map: no concatenation (a 147 MB copy at 15 frames) at the join
-            whole = torch.empty(shape_of(x.shape[0], x.shape[2], x.shape[3]), dtype=fn.compute_dtype, device=x.device)
-        bounds = [round(i * x.shape[0] / G) for i in range(G + 1)]
-        if G == 2 and x.shape[0] >= 5:
-            # two UNEQUAL groups (9 + 6 of 15 frames): equal ones run the same kernel sequence in step and meet at every
-            # HBM-bound conv; a 3 : 2 split keeps them out of step (measured 133.6 vs 131.4 frames/s for 8 + 7, either
-            # order; 10 + 5 is back at 131).  Frames are independent through the backbone: the split changes no result.
-            first = self.group_first if 0 < self.group_first < x.shape[0] else int(round(0.6 * x.shape[0]))
-            bounds[1] = first
-        start = torch.cuda.Event()
-        start.record(main)
-        outs = [None] * G
-        for g in range(1, G):
-            with torch.cuda.stream(sides[g - 1]):
-                sides[g - 1].wait_event(start)
-                if whole is not None:
-                    whole.record_stream(sides[g - 1])
-                    outs[g] = fn(x[bounds[g]:bounds[g + 1]], out=whole[bounds[g]:bounds[g + 1]])
-                else:
-                    outs[g] = fn(x[bounds[g]:bounds[g + 1]])
-        outs[0] = fn(x[bounds[0]:bounds[1]], out=whole[bounds[0]:bounds[1]]) if whole is not None else fn(x[bounds[0]:bounds[1]])
-        for g in range(1, G):
-            main.wait_stream(sides[g - 1])
-            for t in outs[g]:
-                t.record_stream(main)
-        if whole is not None:
-            return (whole.permute(0, 3, 1, 2),)
-        # concatenate in the physical (NHWC) layout, frames outermost
-        return tuple(torch.cat([o[k].permute(0, 2, 3, 1) for o in outs], 0).permute(0, 3, 1, 2) for k in range(len(outs[0])))
-
     def extract_feat(self, img):
         """backbone on a batch of frames.  The kernels address their operands with 32-bit byte offsets (tensors below 2 GiB): a batch
         whose largest map would pass that -- W clips of 15 frames in a 4-byte mode: layer 1's output is 39 MB per 608 x 1008 frame, the
         f32 mode's stem patch matrix 98 MB -- goes through in equal chunks, one after the other on the same stream, each writing its
-        slice of ONE C4 map (frames are independent through the backbone: the chunking changes no result)."""
+        slice of ONE C4 map (frames are independent through the backbone: the chunking changes no result).  (Rounds 1-4 could also
+        cut a batch into groups on several HIP streams; it stopped paying in round 2 -- 114.6 vs 114.7 us per layer-3 block -- and was
+        removed in round 5.)"""
         bb = self.backbone
         shape_of = getattr(bb, 'out_shape_nhwc', None)
         if img.is_cuda and img.dim() == 4 and shape_of is not None and shape_of(img.shape[0], img.shape[2], img.shape[3]) is not None:
@@ -199,7 +142,7 @@ class TwoStageDetector(BaseDetector):
                 for a, b in zip(bounds[:-1], bounds[1:]):
                     bb(img[a:b], out=whole[a:b])
                 return (whole.permute(0, 3, 1, 2),)
-        return self._run_in_frame_groups(self.backbone, img)
+        return self.backbone(img)
 
     def simple_test_rpn(self, x, img_meta, rpn_test_cfg):
         """test_mixins.py:9-13."""

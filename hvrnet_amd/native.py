@@ -30,9 +30,10 @@ DTYPE_NAMES = {torch.bfloat16: 'bf16', torch.float16: 'f16', SPLIT: 'f16x2', tor
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
 # default operand staging of the MFMA tile engine (0 register-staged, 1 global->LDS DMA)
-STAGING = int(os.environ.get('HVR_STAGING', '1'))
+STAGING = 1   # operand loader of the tile engine: 1 = LDS-DMA (the product path); 0 = register staging, kept as the second loader the
+              # kernel tests cross-check (3 x slower); an argument of the C ABI, not an environment switch
 # 0 = the library's cost model picks the tile shape; k > 0 forces shape k-1 (tools/kernel_bench.py sweeps)
-TILE_HINT = int(os.environ.get('HVR_TILE', '0'))
+TILE_HINT = 0
 
 
 class HvrError(RuntimeError):
@@ -610,7 +611,7 @@ _masked_streams = {}   # (device index, first, n) -> (raw handle, ExternalStream
 def cu_masked_stream(device, first_cu, n_cus, total_cus=256):
     """A HIP stream whose launches -- direct ones and hipGraph replays issued ON it -- only use `n_cus` of the chip's CUs
     (hipExtStreamCreateWithCUMask, mask bits [first_cu, first_cu + n_cus)).  On MI355X a contiguous range of mask bits is spread
-    over all eight XCDs (96 bits = 12 CUs in each; tools/probe/cumask), and the mask belongs to the stream a graph is replayed on,
+    over all eight XCDs (96 bits = 12 CUs in each: measured in round 3 with a per-CU occupancy probe, profiles/r03_stream_bench.json), and the mask belongs to the stream a graph is replayed on,
     not to the one it was captured on.  Every mask is a hardware queue of its own: a process that creates a dozen of them slows
     every one down (queue oversubscription), so streams are cached per mask.  -> torch.cuda.ExternalStream"""
     dev = torch.device(device)

@@ -28,6 +28,20 @@
  *   - re-entrant; the only global mutable state is the one-time per-device kernel attribute setup (atomic, idempotent) and ONE
  *     process-wide tuning knob, hvr_rpn_wide_frames (an atomic int: which of two bit-identical kernel forms hvr_rpn_proposals
  *     launches; a captured graph keeps the form chosen at capture time).
+ *   - environment switches, read once per process (round 5 retired the tuning knobs of rounds 1-4: tile-shape hints, slice sizes,
+ *     group sizes, thresholds and the variants that measured slower are gone).  What is left selects between kernels that compute
+ *     the same thing, for A/B runs and for the tests that compare them:
+ *       HVR_BIGTILE=0         no 288 x 256 tiles (csrc/bigtile.hip): the tile engine's shapes everywhere (bit-identical)
+ *       HVR_EXPAND=0          no row-panel expand kernel (csrc/expand.hip): tile engine / big tiles
+ *       HVR_CONV3=0           no weights-resident 3x3 kernel for Cin = 64 (csrc/conv3x3.hip): tile engine (bit-identical)
+ *       HVR_CONV_SPLITK=0     no K slices for few-row tile-engine products (stream mode's one-frame launches)
+ *       HVR_SPLIT_NORMALIZE   split-half relation: 0 = block weights folded into the apply pass, 1 = one normalising sweep + plain
+ *                             product (default: by query-row count)
+ *       HVR_REL_GROUPED       hvr_relation_fwd_grouped: 0 = one hvr_relation_fwd per group, 1 = grouped scores + per-group apply,
+ *                             2 (default) = + the grouped apply launch
+ *       HVR_NMS_MASK          (set) hvr_nms always takes the bit-mask kernels, never the greedy small-cap kernel
+ *       HVR_RPN_WIDE=<frames> initial value of hvr_rpn_wide_frames
+ *     and, in the Python host layer, HVR_RPN_SIDE=0 (RPN branch on the caller's stream instead of a side stream).
  */
 #ifndef HVR_HIP_H_
 #define HVR_HIP_H_

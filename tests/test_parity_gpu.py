@@ -531,7 +531,7 @@ def test_config1_end_to_end_f32_matches_reference_golden():
         order = np.argsort(want_l, kind='stable')  # bbox2result groups by class, keeping in-class order
         assert labels.tolist() == want_l[order].tolist()                 # class indices exact
         close(boxes[:, 4], want_b[order][:, 4], 0, 1e-3)                 # scores within 1e-3
-        close(boxes[:, :4], want_b[order][:, :4], 0, parity.TOL_BOX_PX)  # coords: the one definition (hvrnet_amd/parity.py): 1e-3 px + two f32 ulps at 1000 px
+        close(boxes[:, :4], want_b[order][:, :4], 0, parity.box_bar(1000.0))  # coords: the one definition (hvrnet_amd/parity.py): 1e-3 px + 1.3e-6 x the 1000 px extent
     # SELSA detector on the same frames
     ms = hvrnet_amd.build_model(selsa_config(frame_interval=1, nms_post=32), S.synth_state_dict('selsa'), torch.float32, DEV)
     res = ms(x=c4, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
@@ -541,7 +541,7 @@ def test_config1_end_to_end_f32_matches_reference_golden():
     assert labels.tolist() == want_l[order].tolist()
     got = np.concatenate(_per_class(res), 0)
     close(got[:, 4], want_b[order][:, 4], 0, 1e-3)
-    close(got[:, :4], want_b[order][:, :4], 0, parity.TOL_BOX_PX)
+    close(got[:, :4], want_b[order][:, :4], 0, parity.box_bar(1000.0))
 
 
 def test_config1_end_to_end_bf16_tracks_reference():
@@ -577,22 +577,6 @@ def test_config1_end_to_end_bf16_tracks_reference():
     # projection-shortcut tail, which rounds LESS than the two-conv path) moves a detection or two across it; the full-size
     # statistics of the benchmarked window are in tests/test_fullsize_gpu.py.
     assert tot > 0 and hit >= 0.90 * tot, (hit, tot)
-
-
-def test_frame_groups_on_separate_streams_change_nothing():
-    """The backbone may cut a batch of frames into groups that run on separate HIP streams: same C4 maps."""
-    model = hvrnet_amd.build_model(hvr_config(frame_interval=1, nms_post=32), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
-    frames = torch.cat([S.synth_frame(i) for i in range(5)], 0).to(DEV)
-    metas = [S.synth_meta() for _ in range(5)]
-    outs = []
-    for groups in (1, 2, 3):
-        model.frame_groups = groups
-        outs.append(model(img=frames, img_meta=metas, backbone_feat=True)[0].float())
-        torch.cuda.synchronize()
-    assert outs[0].shape[0] == 5
-    for o in outs[1:]:
-        assert o.shape == outs[0].shape and o.permute(0, 2, 3, 1).is_contiguous()
-        torch.testing.assert_close(o, outs[0], rtol=0, atol=0)
 
 
 def _same_results(a, b):

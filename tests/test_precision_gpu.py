@@ -10,6 +10,8 @@ Tolerances, each stated where it is used:
     the result tracks the f64 product of the UN-rounded f32 inputs to ~1e-6 of the output scale.
 """
 import math
+import os
+import sys
 
 import pytest
 import torch
@@ -174,6 +176,43 @@ def test_relation_split_half_peaky_rows():
     o = _back(native.relation_fwd(qd, kd, vd, 1.0 / math.sqrt(D))).double()
     assert torch.isfinite(o).all()
     assert (o - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+def test_split_half_relation_folded_and_swept_forms_agree(tmp_path):
+    """The split-half relation core picks its apply form by the query-row count (capi.hip: block weights folded into the apply pass
+    below 1 024 rows, one normalising sweep + a plain product from there) and HVR_SPLIT_NORMALIZE = 0 / 1 forces one; the switch is
+    read once per process, so each form runs in a child: the key stage (300 x 4 500) and a window-sized problem (1 100 x 4 500)
+    in BOTH forms against the f64 softmax of the operands as the kernel sees them, and against each other."""
+    import subprocess
+    import sys
+    code = r'''
+import math, sys, torch
+sys.path.insert(0, %r)
+from hvrnet_amd import native
+D, outs = 1024, []
+for Mq, Mk, seed in ((300, 4500, 61), (1100, 4500, 71)):
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = (torch.randn((m, D), generator=g) * sc for m, sc in ((Mq, 0.5), (Mk, 0.5), (Mk, 1.0)))
+    k[4000] = q[3] * 6.0          # a late-block maximum far above the rest of row 3
+    qd, kd, vd = (native.cast(t.cuda().contiguous(), native.SPLIT) for t in (q, k, v))
+    back = lambda t: native.cast(t, torch.float32).cpu()
+    ref = torch.softmax(back(qd).double() @ back(kd).double().t() / math.sqrt(D), dim=1) @ back(vd).double()
+    o = back(native.relation_fwd(qd, kd, vd, 1.0 / math.sqrt(D))).double()
+    err = (o - ref).abs().max().item()
+    assert err < 2e-5 * ref.abs().max().item(), (Mq, err)
+    outs.append(o)
+torch.save(outs, sys.argv[1])
+print('ok')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form in ('0', '1'):
+        path = str(tmp_path / ('split_%s.pt' % form))
+        r = subprocess.run([sys.executable, '-c', code % root, path], capture_output=True, text=True, timeout=300, env=dict(os.environ, HVR_SPLIT_NORMALIZE=form))
+        assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-1500:]
+        res[form] = torch.load(path)
+    for a, b in zip(res['0'], res['1']):
+        assert (a - b).abs().max().item() < 2e-5 * b.abs().max().item()
 
 
 @pytest.mark.parametrize('R,C', [(300, 1024), (4500, 1024), (65, 64)])

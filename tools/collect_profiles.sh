@@ -42,7 +42,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VA
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/w_$i
-  HVR_FRAME_GROUPS=1 $T rocprofv3 --kernel-trace --pmc $set -d /tmp/w_$i -o w -- python bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-train-step --no-side-loops --no-graphs --no-f32-leg > /dev/null 2>&1
+  $T rocprofv3 --kernel-trace --pmc $set -d /tmp/w_$i -o w -- python bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline --no-train-step --no-side-loops --no-graphs --no-f32-leg > /dev/null 2>&1
   echo "--- pass $i: $set" >> $out/window_pmc_sq.txt
   $T python tools/pmc_dump.py $(db /tmp/w_$i) _kernel >> $out/window_pmc_sq.txt 2>&1
 done
@@ -68,12 +68,12 @@ if [[ $parts == *D* ]]; then
 # windows, and the three convs of a layer-3 Bottleneck alone (timings per format; FETCH / WRITE / SQ passes of the bf16 block)
 timeout 900 python tools/precision_ladder.py --modes bf16,f16,f16x2,f32,trunk_f16x2+head_f16 --out $out/precision_ladder.json > /dev/null 2>&1
 for m in f16 f16x2; do
-  rm -rf /tmp/m_$m; HVR_FRAME_GROUPS=1 $T rocprofv3 --kernel-trace --stats -d /tmp/m_$m -o w -- python tools/mode_window.py --mode $m --iters 3 > /dev/null 2>&1
+  rm -rf /tmp/m_$m; $T rocprofv3 --kernel-trace --stats -d /tmp/m_$m -o w -- python tools/mode_window.py --mode $m --iters 3 > /dev/null 2>&1
   $T python tools/rocpd_stats.py $(db /tmp/m_$m) > $out/window_${m}_kernel_stats.txt
 done
 rm -f $out/window_f16x2_pmc_sq.txt
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
-  rm -rf /tmp/ms; HVR_FRAME_GROUPS=1 $T rocprofv3 --kernel-trace --pmc $set -d /tmp/ms -o w -- python tools/mode_window.py --mode f16x2 --iters 1 > /dev/null 2>&1
+  rm -rf /tmp/ms; $T rocprofv3 --kernel-trace --pmc $set -d /tmp/ms -o w -- python tools/mode_window.py --mode f16x2 --iters 1 > /dev/null 2>&1
   echo "--- split-half window, pass: $set" >> $out/window_f16x2_pmc_sq.txt
   $T python tools/pmc_dump.py $(db /tmp/ms) tile_kernel >> $out/window_f16x2_pmc_sq.txt 2>&1
 done

@@ -1,7 +1,6 @@
 """Key-frame-only relation stage (Mq = 300 queries against Mk = 4 500 keys, D = 1 024; hrnmp_bbox_head.py:269-278,888-891): time per
-hvr_relation_fwd call and, with --dump PATH, the output of seeded operands (uint16 view of the bf16 tensor) -- the in-launch slice
-merge (default) against the reduce launch (HVR_KEY_MERGE=0) are compared bit for bit from two processes (tests/test_kernels_gpu.py).
---repeat N: the call repeated N times, every output compared with the first (a merge that read a stale partial would differ)."""
+hvr_relation_fwd call and, with --dump PATH, the output of seeded operands (uint16 view of the bf16 tensor).
+--repeat N: the call repeated N times, every output compared with the first."""
 import argparse, os, sys
 import numpy as np
 import torch
@@ -38,4 +37,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(a.iters): native.relation_fwd(q, k, v, 1.0 / 32)
 e.record(); torch.cuda.synchronize()
-print('Mq %d Mk %d: %.1f us per call (HVR_KEY_MERGE=%s)' % (a.mq, a.mk, s.elapsed_time(e) / a.iters * 1000, os.environ.get('HVR_KEY_MERGE', 'default')))
+print('Mq %d Mk %d: %.1f us per call' % (a.mq, a.mk, s.elapsed_time(e) / a.iters * 1000))

@@ -16,6 +16,8 @@
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_zero_fill(void*, size_t, hipStream_t);
+hipError_t run_im2col_t(const void*, void*, int, int, int, int, int, int, int, int, int, int, long, hipStream_t);
+hipError_t run_relu_bwd_t(const void*, const void*, void*, void*, int, int, long, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_f16(const float*, void*, int, int, long, int, hipStream_t);
@@ -758,6 +760,23 @@ int hvr_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int
   const int OH = H + 2 * pad - dil * (KH - 1), OW = W + 2 * pad - dil * (KW - 1);
   if (OH <= 0 || OW <= 0) return fail(HVR_EINVAL, "empty im2col output");
   return check_launch(run_im2col_nhwc(x, cols, B, H, W, Cin, KH, KW, pad, dil, OH, OW, dtype, (hipStream_t)stream), "hvr_im2col_nhwc");
+}
+
+int hvr_im2col_t(const void* x, void* colsT, int64_t ldt, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int dtype, void* stream) {
+  if (!x || !colsT || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 8 || KH <= 0 || KW <= 0 || pad < 0 || dil <= 0)
+    return fail(HVR_EINVAL, "bad im2col_t arguments (Cin %% 8 == 0 required)");
+  if (dtype != HVR_BF16 && dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "hvr_im2col_t takes bf16 / half maps (f32: hvr_im2col_nhwc + hvr_transpose_pad)");
+  const int OH = H + 2 * pad - dil * (KH - 1), OW = W + 2 * pad - dil * (KW - 1);
+  if (OH <= 0 || OW <= 0) return fail(HVR_EINVAL, "empty im2col output");
+  if (ldt % 8 || ldt < (int64_t)B * OH * OW || !aligned16(x) || !aligned16(colsT)) return fail(HVR_EINVAL, "im2col_t: ldt a multiple of 8 >= B*OH*OW, 16-byte aligned buffers");
+  return check_launch(run_im2col_t(x, colsT, B, H, W, Cin, KH, KW, pad, dil, OH, OW, (long)ldt, (hipStream_t)stream), "hvr_im2col_t");
+}
+
+int hvr_relu_bwd_t(const void* dY, const void* Y, void* dZ, void* dZt, int64_t ldt, int R, int C, int dtype, void* stream) {
+  if (!dY || !Y || !dZ || !dZt || R <= 0 || C <= 0 || C % 8 || ldt % 8 || ldt < R) return fail(HVR_EINVAL, "bad relu_bwd_t arguments (C %% 8 == 0, ldt %% 8 == 0, ldt >= R)");
+  if (dtype != HVR_BF16 && dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "hvr_relu_bwd_t takes bf16 / half maps (f32: hvr_relu_bwd + hvr_transpose_pad)");
+  if (!aligned16(dY) || !aligned16(Y) || !aligned16(dZ) || !aligned16(dZt)) return fail(HVR_EINVAL, "relu_bwd_t: 16-byte aligned buffers");
+  return check_launch(run_relu_bwd_t(dY, Y, dZ, dZt, R, C, (long)ldt, (hipStream_t)stream), "hvr_relu_bwd_t");
 }
 
 int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t C, int dtype, void* stream) {

@@ -272,6 +272,94 @@ __global__ __launch_bounds__(256) void transpose_pad_bf16x8_kernel(const bf16_t*
   }
 }
 
+// ---- training: the two K-contiguous operands of a conv's weight-gradient product dW = dZ^T . cols, written in one pass each ----
+// (round 4's step built them as relu_bwd -> transpose_pad and im2col -> transpose_pad: 291 transposes per iteration, 13 % of its kernel
+// time, each re-reading what the kernel before it had just written.)  16-bit operands (bf16 / half as raw words), 64 x 64 tiles, 16-byte
+// global accesses on both sides, as transpose_pad_bf16x8_kernel.
+//
+// colsT[(tap * Cin + c)][p] = x[b][oy - pad + ky dil][ox - pad + kx dil][c] (zero outside the image and for p >= P), p = (b OH + oy) OW + ox,
+// tap = ky KW + kx = blockIdx.z: the transposed patch matrix of a stride-1 KH x KW conv, without the row-major patch matrix in between.
+__global__ __launch_bounds__(256) void im2col_t_x8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H, int W, int Cin,
+                                                           int KW, int pad, int dil, int OH, int OW, long ldt) {
+  constexpr int PITCH = 64 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char tile[64 * PITCH];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x, tap = blockIdx.z;
+  const int ky = tap / KW, kx = tap - ky * KW;
+  const long P = (long)B * OH * OW;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, i = s >> 3, q = s & 7;
+    const long p = (long)r0 + i;
+    const int c = c0 + q * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (p < P && c < Cin) {
+      const int ox = (int)(p % OW);
+      const long t = p / OW;
+      const int oy = (int)(t % OH), b = (int)(t / OH);
+      const int iy = oy - pad + ky * dil, ix = ox - pad + kx * dil;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const uint4*>(x + (((long)b * H + iy) * W + ix) * Cin + c);
+    }
+    *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, q = s >> 6, i = s & 63;
+    const int c = c0 + i;
+    const long r = (long)r0 + q * 8;
+    if (c >= Cin || r >= ldt) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e) * PITCH + i * 2);
+      const uint32_t hi = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+      w[e] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(out + ((long)tap * Cin + c) * ldt + r) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// dZ = dY where Y > 0 else 0 ([R][C], row-major) AND dZ^T [C][ldt] (columns R .. ldt - 1 zero) from one read of dY and Y.  A 16-bit float
+// (bf16 or half) is positive when its sign bit is clear and the rest is not zero.
+__global__ __launch_bounds__(256) void relu_bwd_t_x8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ dz,
+                                                             bf16_t* __restrict__ dzt, int R, int C, long ldt) {
+  constexpr int PITCH = 64 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char tile[64 * PITCH];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  auto mask2 = [](uint32_t g, uint32_t a) -> uint32_t {   // two 16-bit lanes of gradient g gated by activation a
+    const uint32_t lo = ((a & 0x7fffu) != 0u && !(a & 0x8000u)) ? 0x0000ffffu : 0u;
+    const uint32_t hi = ((a & 0x7fff0000u) != 0u && !(a & 0x80000000u)) ? 0xffff0000u : 0u;
+    return g & (lo | hi);
+  };
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, i = s >> 3, q = s & 7;
+    const int r = r0 + i, c = c0 + q * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R && c < C) {
+      const uint4 g = *reinterpret_cast<const uint4*>(dy + (long)r * C + c), a = *reinterpret_cast<const uint4*>(y + (long)r * C + c);
+      v = make_uint4(mask2(g.x, a.x), mask2(g.y, a.y), mask2(g.z, a.z), mask2(g.w, a.w));
+      *reinterpret_cast<uint4*>(dz + (long)r * C + c) = v;
+    }
+    *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int s = it * 256 + tid, q = s >> 6, i = s & 63;
+    const int c = c0 + i, r = r0 + q * 8;
+    if (c >= C || r >= ldt) continue;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e) * PITCH + i * 2);
+      const uint32_t hi = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+      w[e] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(dzt + (long)c * ldt + r) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // split half: the hi and the lo plane of a 64 x 64 logical tile are two independent 64 x 64 transposes of 16-bit words
 // (blockIdx.z = plane); only the addressing knows about the [32 hi | 32 lo] groups.  R, C, ldx, ldt in logical elements; C, ldx,
 // ldt multiples of 64 here (the relation's V^T: D and the padded key count).
@@ -940,6 +1028,19 @@ hipError_t run_det_decode(const float* logits, int ldl, int cls_off, int reg_off
   hipLaunchKernelGGL(det_decode_kernel, dim3((R + 63) / 64), dim3(64), 0, s, logits, ldl, cls_off, reg_off, ncls, rois, R,
                      means[0], means[1], means[2], means[3], stds[0], stds[1], stds[2], stds[3], max_ratio, img_h, img_w,
                      scale_factor, scores, boxes);
+  return hipGetLastError();
+}
+
+hipError_t run_im2col_t(const void* x, void* out, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int OH, int OW, long ldt, hipStream_t s) {
+  const long P = (long)B * OH * OW;
+  dim3 grid((unsigned)((Cin + 63) / 64), (unsigned)((ldt + 63) / 64), (unsigned)(KH * KW));
+  (void)P;
+  hipLaunchKernelGGL(im2col_t_x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, Cin, KW, pad, dil, OH, OW, ldt);
+  return hipGetLastError();
+}
+hipError_t run_relu_bwd_t(const void* dy, const void* y, void* dz, void* dzt, int R, int C, long ldt, hipStream_t s) {
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((ldt + 63) / 64));
+  hipLaunchKernelGGL(relu_bwd_t_x8_kernel, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dz, (bf16_t*)dzt, R, C, ldt);
   return hipGetLastError();
 }
 

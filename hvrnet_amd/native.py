@@ -116,6 +116,8 @@ SYMBOLS = {
     'hvr_relation_dscore': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i64, _i, _f, _i, _vp]),
     'hvr_relu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     'hvr_im2col_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'hvr_im2col_t': (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'hvr_relu_bwd_t': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'hvr_scale_rows': (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
     'hvr_sgd_workspace_bytes': (_sz, []),
     'hvr_sgd_step': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _sz, _i, _vp]),
@@ -774,6 +776,28 @@ def relu_bwd(dy, y):
     dz = torch.empty_like(dy)
     _check(lib().hvr_relu_bwd(_ptr(dy), _ptr(y), _ptr(dz), dy.numel(), _dt(dy), _stream()), 'hvr_relu_bwd')
     return dz
+
+
+def relu_bwd_t(dy, y, ldt):
+    """(dz, dzt): dz = dy where y > 0 ([R, C]) and its transpose [C, ldt] (columns R.. zero) from one pass (bf16 / half)."""
+    _need_cuda(dy, y)
+    dy, y = dy.contiguous(), y.contiguous()
+    assert dy.dim() == 2 and dy.shape == y.shape and dy.dtype == y.dtype
+    R, C = dy.shape
+    dz = torch.empty_like(dy)
+    dzt = torch.empty((C, ldt), dtype=dy.dtype, device=dy.device)
+    _check(lib().hvr_relu_bwd_t(_ptr(dy), _ptr(y), _ptr(dz), _ptr(dzt), ldt, R, C, _dt(dy), _stream()), 'hvr_relu_bwd_t')
+    return dz, dzt
+
+
+def im2col_t(x, KH, KW, pad, dil, ldt):
+    """x [B,H,W,Cin] (NHWC, bf16 / half) -> the TRANSPOSED patch matrix [KH*KW*Cin, ldt] of a stride-1 conv (columns B*OH*OW.. zero)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    B, H, W, Cin = x.shape
+    out = torch.empty((KH * KW * Cin, ldt), dtype=x.dtype, device=x.device)
+    _check(lib().hvr_im2col_t(_ptr(x), _ptr(out), ldt, B, H, W, Cin, KH, KW, pad, dil, _dt(x), _stream()), 'hvr_im2col_t')
+    return out
 
 
 def colsum(dy):

@@ -59,6 +59,23 @@ def _pad_cols(t, n):
     return out
 
 
+def _two_byte(dtype):
+    return dtype in (torch.bfloat16, torch.float16)
+
+
+# Weight gradients of convs go STRAIGHT into the parameter's gradient buffer when it has one (dist_train.FlatParams gives every
+# parameter a view of the flat gradient buffer, zeroed at the start of the step): the f32 product is scaled, permuted and ADDED in
+# place by hvr_unpack_conv_wgrad and autograd is handed no gradient for the weight -- no temporary, no AccumulateGrad add per layer
+# (151 torch launches per iteration in round 4).  Same values: one f32 addition to a zeroed buffer.
+_direct = dict(on=True)
+
+
+def wgrad_direct(flag):
+    prev = _direct['on']
+    _direct['on'] = bool(flag)
+    return prev
+
+
 class LinearFunction(Function):
     """y = act(x @ w^T + b (+ resid)); x [M, K], w [N, K], b [N]; N a multiple of 4, K a multiple of the K-step.
     x's dtype is the compute dtype: with bf16 activations the f32 master weight is rounded to bf16 on the way in, products
@@ -82,16 +99,20 @@ class LinearFunction(Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         dy = native.cast(dy.contiguous(), x.dtype)
-        dz = native.relu_bwd(dy, y) if ctx.relu else dy
         M, K = x.shape
         N = w.shape[0]
         step = native.kstep(x.dtype)
         ldn, ldm = (N + step - 1) // step * step, (M + step - 1) // step * step
+        dzt = None
+        if ctx.relu and _two_byte(x.dtype) and N % 8 == 0 and ctx.needs_input_grad[1]:
+            dz, dzt = native.relu_bwd_t(dy, y, ldm)      # the ReLU mask and dz^T (the weight gradient's K-contiguous operand) in one pass
+        else:
+            dz = native.relu_bwd(dy, y) if ctx.relu else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = native.gemm(_pad_cols(dz, ldn), native.transpose_pad(w, ldn))           # [M, K] = dz [M, N] W [N, K]
         if ctx.needs_input_grad[1]:
-            dw = native.gemm_splitk(native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))       # [N, K] = dz^T x, f32
+            dw = native.gemm_splitk(dzt if dzt is not None else native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))   # [N, K] = dz^T x, f32
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = native.colsum(dz)
         dr = dz if (ctx.has_resid and ctx.needs_input_grad[3]) else None
@@ -251,13 +272,19 @@ class ConvFunction(Function):
         xs, w_eff, s, y = ctx.saved_tensors
         relu, stride, pad, dil, has_resid, x_shape = ctx.cfg
         dy = native.cast(dy.contiguous(), xs.dtype)
-        dz = native.relu_bwd(dy, y) if relu else dy
         Cout, KH, KW, Cin = w_eff.shape
-        B, OH, OW, _ = dz.shape
+        B, OH, OW, _ = dy.shape
         P = B * OH * OW
-        step = native.kstep(dz.dtype)
+        step = native.kstep(dy.dtype)
         ldp = (P + step - 1) // step * step
-        dz2 = dz.view(P, Cout)
+        fast = _two_byte(dy.dtype) and Cout % 8 == 0 and Cin % 8 == 0     # the one-pass K-contiguous operands (hvr_relu_bwd_t / hvr_im2col_t)
+        dzt = None
+        if relu and fast and ctx.needs_input_grad[1]:
+            dz2, dzt = native.relu_bwd_t(dy.view(P, Cout), y.view(P, Cout), ldp)
+            dz = dz2.view(B, OH, OW, Cout)
+        else:
+            dz = native.relu_bwd(dy, y) if relu else dy
+            dz2 = dz.view(P, Cout)
         dx = dw = None
         side_reads_dz = False
         if ctx.needs_input_grad[0]:
@@ -274,12 +301,20 @@ class ConvFunction(Function):
                 dx = dxs
         if ctx.needs_input_grad[1]:
             def weight_gradient(into=None):
-                cols = xs.view(P, Cin) if (KH, KW) == (1, 1) else native.im2col_nhwc(xs, KH, KW, pad, dil)   # [P, KH*KW*Cin]
-                dw_eff = native.gemm_splitk(native.transpose_pad(dz2, ldp), native.transpose_pad(cols, ldp))   # [Cout, KH*KW*Cin], f32
+                if (KH, KW) == (1, 1):
+                    colsT = native.transpose_pad(xs.view(P, Cin), ldp)
+                elif fast:
+                    colsT = native.im2col_t(xs, KH, KW, pad, dil, ldp)                  # [KH*KW*Cin, ldp]: no row-major patch matrix in between
+                else:
+                    colsT = native.transpose_pad(native.im2col_nhwc(xs, KH, KW, pad, dil), ldp)
+                dw_eff = native.gemm_splitk(dzt if dzt is not None else native.transpose_pad(dz2, ldp), colsT)   # [Cout, KH*KW*Cin], f32
                 return native.unpack_conv_wgrad(dw_eff, s, (Cout, Cin, KH, KW), accumulate_into=into)   # * s, parameter layout
 
             wp = ctx.w_param
-            if _overlap['on'] and wp is not None and wp.grad is not None and wp.grad.is_contiguous() and wp.grad.dtype == torch.float32:
+            has_grad_buf = wp is not None and wp.grad is not None and wp.grad.is_contiguous() and wp.grad.dtype == torch.float32
+            if _direct['on'] and not _overlap['on'] and has_grad_buf:
+                weight_gradient(into=wp.grad)     # added in place on this stream; autograd gets no gradient for the weight
+            elif _overlap['on'] and has_grad_buf:
                 main, side = torch.cuda.current_stream(dz.device), _side_stream(dz.device)
                 ready = torch.cuda.Event()
                 ready.record(main)

@@ -258,6 +258,12 @@ int hvr_det_loss(const float* logits, int ldl, int cls_off, int reg_off, int ncl
  * hvr_scale_rows multiplies row r of a [R][C] matrix by scale[r]: the frozen BatchNorm scale folded into the weights on
  * the way in and into their gradient on the way out. */
 int hvr_im2col_nhwc(const void* x, void* cols, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int dtype, void* stream);
+/* The K-contiguous operands of the weight-gradient product in one pass each (bf16 / half; round 5): colsT [KH*KW*Cin][ldt] = the
+ * TRANSPOSED patch matrix (row tap*Cin + c holds that input channel of every output pixel, columns B*OH*OW .. ldt-1 zero), and
+ * dZ = dY where Y > 0 together with dZt [C][ldt] = dZ^T -- instead of hvr_im2col_nhwc / hvr_relu_bwd each followed by
+ * hvr_transpose_pad. */
+int hvr_im2col_t(const void* x, void* colsT, int64_t ldt, int B, int H, int W, int Cin, int KH, int KW, int pad, int dil, int dtype, void* stream);
+int hvr_relu_bwd_t(const void* dY, const void* Y, void* dZ, void* dZt, int64_t ldt, int R, int C, int dtype, void* stream);
 int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t C, int dtype, void* stream);
 /* The two layout + scale passes of a trainable conv in one kernel each: the f32 master weight [Cout][Cin][KH][KW] times the
  * frozen BatchNorm scale, permuted to the conv kernel's [Cout][KH][KW][Cin] and rounded to the compute dtype; and the way back

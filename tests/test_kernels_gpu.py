@@ -740,3 +740,33 @@ def test_bottleneck_tail_says_when_it_does_not_apply():
     assert not native.bottleneck_tail_supported(h, x, w, b, 1)
     hb, xb = h.bfloat16(), torch.zeros((1, 8, 16, 96), device=DEV, dtype=torch.bfloat16)
     assert not native.bottleneck_tail_supported(hb, xb, torch.zeros((256, 160), device=DEV, dtype=torch.bfloat16), b, 1)  # 64 + 96: no whole K-step
+
+
+# ------------------------------------------------------------------------------- training: one-pass K-contiguous operands of the weight gradient
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W,Cin,k,pad,dil', [(2, 19, 31, 64, 3, 1, 1), (3, 38, 63, 256, 3, 2, 2), (1, 9, 14, 128, 3, 1, 1), (2, 7, 9, 72, 5, 2, 1)])
+def test_im2col_t_equals_im2col_then_transpose(B, H, W, Cin, k, pad, dil, dtype):
+    """hvr_im2col_t writes the TRANSPOSED patch matrix of a stride-1 conv directly (the weight-gradient product's K-contiguous operand):
+    bit for bit hvr_transpose_pad(hvr_im2col_nhwc(x)), ragged pixel counts, dilation and zero padding included."""
+    x = _rand((B, H, W, Cin), dtype, 91).to(DEV)
+    OH, OW = H + 2 * pad - dil * (k - 1), W + 2 * pad - dil * (k - 1)
+    P = B * OH * OW
+    ldt = (P + 63) // 64 * 64
+    got = native.im2col_t(x, k, k, pad, dil, ldt)
+    want = native.transpose_pad(native.im2col_nhwc(x, k, k, pad, dil), ldt)
+    assert got.shape == want.shape == (k * k * Cin, ldt) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('R,C', [(7182, 256), (300, 1024), (65, 72), (4500, 36 + 4)])
+def test_relu_bwd_t_equals_relu_bwd_then_transpose(R, C, dtype):
+    """hvr_relu_bwd_t: the ReLU mask and the transposed masked gradient from one read -- bit for bit hvr_relu_bwd and hvr_transpose_pad of
+    its output (negative, zero and negative-zero activations gate the gradient off)."""
+    dy, y = _rand((R, C), dtype, 92).to(DEV), _rand((R, C), dtype, 93).to(DEV)
+    y[::7] = 0.0
+    y[1::11] = -0.0
+    ldt = (R + 63) // 64 * 64
+    dz, dzt = native.relu_bwd_t(dy, y, ldt)
+    want = native.relu_bwd(dy, y)
+    assert torch.equal(dz, want) and torch.equal(dzt, native.transpose_pad(want, ldt))
+    assert torch.equal(dz, torch.where(y.float() > 0, dy, torch.zeros_like(dy)))

@@ -351,14 +351,14 @@ def relation_traffic(units=1):
     libhvr_hip.so and whose `groups` is `units`; None (stale) otherwise."""
     import glob
     sha = lib_sha16()
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_relation_traffic.json')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_relation_traffic*.json')), reverse=True):
         try:
             d = json.load(open(path))
         except ValueError:
             continue
         if d.get('lib_sha16') == sha and int(d.get('groups', 1)) == int(units):
             return d.get('traffic_bytes_per_launch'), os.path.basename(path)
-    return None, 'no profiles/r*_relation_traffic.json was collected for this build (lib %s): tools/collect_profiles.sh' % sha
+    return None, 'no profiles/r*_relation_traffic*.json was collected for this build (lib %s) with groups = %d: tools/collect_profiles.sh' % (sha, units)
 
 
 # ------------------------------------------------------------------------------------------ stub (CPU host-logic self-test)

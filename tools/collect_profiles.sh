@@ -13,22 +13,31 @@ T="timeout 420"
 db() { find $1 -name "*.db" | head -1; }
 
 if [[ $parts == *A* ]]; then
+# the relation core alone: one window per call (hvr_relation_fwd) and the product's four windows per call (hvr_relation_fwd_grouped)
+for G in 1 4; do
+  sfx=$([ $G = 1 ] && echo "" || echo "_g$G")
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/r_$c; $T rocprofv3 --kernel-trace --pmc $c -d /tmp/r_$c -o rel -- python tools/rel_bench.py --iters 5 --groups $G > /dev/null 2>&1
+    $T python tools/rocpd_pmc.py $(db /tmp/r_$c) $c > $out/rel_pmc_$(echo $c | tr A-Z a-z)$sfx.txt
+  done
+  $T python tools/make_traffic_json.py $(db /tmp/r_FETCH_SIZE) $(db /tmp/r_WRITE_SIZE) $out/relation_traffic$sfx.json $G
+  rm -f $out/relation_pmc_sq$sfx.txt; REL_GROUPS=$G $T bash tools/rel_pmc.sh $out/relation_pmc_sq$sfx.txt
+  rm -rf /tmp/r_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --iters 10 --groups $G > $out/rel_bench$sfx.txt 2>/dev/null
+  $T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench$sfx.txt
+done
+# (the traffic files are keyed to this build: put them where bench.py looks before the bench lines are taken)
+r=${ROUND:-r05}; cp $out/relation_traffic.json profiles/${r}_relation_traffic.json; cp $out/relation_traffic_g4.json profiles/${r}_relation_traffic_g4.json
 $T python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
 $T python bench.py --head selsa --steps 20 --warmup 3 --no-train-step > $out/bench_selsa.json 2>/dev/null
 $T python bench.py --frames 21 --steps 10 --warmup 2 --no-train-step --no-f32-leg --no-side-loops --quick > $out/bench_T21.json 2>/dev/null   # the shipped window length (frame_interval = 10)
 # kernel stats of the bench command (the eager single-lane region is where bench.py takes the relation core's HIP events; the
 # graph legs are skipped under the profiler: a kernel-trace of two graph lanes replaying did not come back in round 3)
-rm -rf /tmp/p_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o bench -- python bench.py --steps 5 --warmup 2 --repeats 2 --no-graphs --no-f32-leg --no-cpu-baseline --no-train-step > $out/bench_prof.json 2> $out/bench_prof.err
+rm -rf /tmp/p_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o bench -- python bench.py --steps 8 --warmup 4 --repeats 2 --no-graphs --no-f32-leg --no-cpu-baseline --no-train-step > $out/bench_prof.json 2> $out/bench_prof.err
 $T python tools/rocpd_stats.py $(db /tmp/p_ks) > $out/bench_kernel_stats.txt
 $T python tools/rocpd_phases.py $(db /tmp/p_ks) 4 > $out/bench_window_phases.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/r_$c; $T rocprofv3 --kernel-trace --pmc $c -d /tmp/r_$c -o rel -- python tools/rel_bench.py --iters 5 > /dev/null 2>&1
-  $T python tools/rocpd_pmc.py $(db /tmp/r_$c) $c > $out/rel_pmc_$(echo $c | tr A-Z a-z).txt
-done
-$T python tools/make_traffic_json.py $(db /tmp/r_FETCH_SIZE) $(db /tmp/r_WRITE_SIZE) $out/relation_traffic.json
-rm -f $out/relation_pmc_sq.txt; $T bash tools/rel_pmc.sh $out/relation_pmc_sq.txt
-rm -rf /tmp/r_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --iters 10 > $out/rel_bench.txt 2>/dev/null
-$T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench.txt
+$T python tools/window_breakdown.py --mode bf16 --iters 3 > $out/window_breakdown_bf16.txt 2>/dev/null
+$T python tools/window_breakdown.py --mode bf16 --iters 3 --clips 4 > $out/window_breakdown_bf16_w4.txt 2>/dev/null
+$T python tools/window_breakdown.py --mode f16x2 --iters 2 --clips 4 > $out/window_breakdown_f16x2_w4.txt 2>/dev/null
 fi
 
 if [[ $parts == *B* ]]; then

@@ -15,7 +15,11 @@ declare -A map=( [bench.json]=bench.json [bench_prof.json]=bench_profiled_run.js
   [precision_ladder.json]=precision_ladder.json [window_f16_kernel_stats.txt]=window_f16_kernel_stats.txt
   [window_f16x2_kernel_stats.txt]=window_f16x2_kernel_stats.txt [conv_layer3.txt]=conv_layer3.txt
   [conv_hint_sweep_f16x2.txt]=conv_hint_sweep_f16x2.txt [window_f16x2_pmc_sq.txt]=window_f16x2_pmc_sq.txt [hipblaslt_kernels.txt]=hipblaslt_kernels.txt [stream_bench.json]=stream_bench.json
-  [stream_frame_kernel_stats.txt]=stream_frame_kernel_stats.txt [rpn_wide_kernel_stats.txt]=rpn_wide_kernel_stats.txt )
+  [stream_frame_kernel_stats.txt]=stream_frame_kernel_stats.txt [rpn_wide_kernel_stats.txt]=rpn_wide_kernel_stats.txt
+  [rel_pmc_fetch_size_g4.txt]=relation_pmc_fetch_size_g4.txt [rel_pmc_write_size_g4.txt]=relation_pmc_write_size_g4.txt
+  [relation_pmc_sq_g4.txt]=relation_pmc_sq_g4.txt [relation_traffic_g4.json]=relation_traffic_g4.json [rel_bench_g4.txt]=relation_kernel_stats_g4.txt
+  [window_breakdown_bf16.txt]=window_breakdown_bf16.txt [window_breakdown_bf16_w4.txt]=window_breakdown_bf16_w4.txt
+  [window_breakdown_f16x2_w4.txt]=window_breakdown_f16x2_w4.txt )
 for f in "${!map[@]}"; do
   if [ -s $src/$f ]; then cp $src/$f profiles/${r}_${map[$f]}; fi
 done

@@ -705,6 +705,40 @@ def main(argv=None):
             overlap2_fps = n2 / el2
             lanes[:] = [None]
 
+    # ---- frame ingest inside the loop: every frame of every window starts as a uint8 BGR frame on the
+    # device (600 x 1000 x 3: the decoded frame a host would hand over, 1.8 MB instead of the 7.3 MB f32 tensor) and goes through
+    # hvr_ingest_frame (resize arithmetic, mean / std, zero pad to /16, HWC -> CHW) before the window -- the same eager W-clips-per-call loop
+    # as `single_lane_batched`, which starts from resident f32 tensors.  A side figure, never `value`.
+    ingest_loop = None
+    if not args.no_side_loops and world == 1:
+        from hvrnet_amd.pipelines import FrameIngest
+        ing = FrameIngest(device=dev)
+        gen = torch.Generator().manual_seed(7)
+        src = [torch.randint(0, 256, (600, 1000, 3), generator=gen, dtype=torch.uint8).to(dev) for _ in range(T * W)]
+
+        def step_ingest(prev=None):
+            with torch.no_grad():
+                imgs = torch.cat([ing(f)['img'] for f in src], 0)
+                c4_i = model(img=imgs, img_meta=metas_w, backbone_feat=True)[0]
+                pend_i = model.forward_feat_clips(c4_i, metas_w, clips=W, rescale=True, defer=True)
+            if prev is not None:
+                read(prev)
+            return pend_i
+        assert tuple(ing(src[0])['img'].shape) == tuple(frames[0:1].shape)
+        pend = step_ingest()
+        read(step_ingest(pend))
+        sync()
+        n_i = max(W, (min(args.steps, 12) // W) * W)
+        t_i = time.perf_counter()
+        pend = None
+        for _ in range(n_i // W):
+            pend = step_ingest(pend)
+        read(pend)
+        sync()
+        el_i = time.perf_counter() - t_i
+        ingest_loop = dict(frames_per_s=round(n_i / el_i, 2), ms_per_step=round(el_i / n_i * 1e3, 3), steps=n_i, clips_per_call=W,
+                           source='uint8 600x1000x3 frames resident on the device, hvr_ingest_frame per frame inside the loop')
+
     # ---- the same work replayed from hipGraphs (hvrnet_amd/graphs.py): the window / the per-frame and per-window chains are
     # captured once, with their side streams, and replayed with one host call each.  Reported beside the eager headline (whose
     # per-kernel HIP-event spans cannot be taken inside a replay); bit-identical detections (tests/test_graphs_gpu.py).
@@ -957,6 +991,8 @@ def main(argv=None):
                                       tflops=round(cached_loop_fps * gf / 1e3, 1), frac_mfma_peak=round(cached_loop_fps * gf / 1e3 / peak, 4))
         if overlap2_fps is not None:
             out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2))
+        if ingest_loop is not None:
+            out['ingest_in_loop'] = ingest_loop
         if graphed_clip is not None:
             out['graphed_clip'] = graphed_clip
             out['graphed_stream'] = graphed_stream

@@ -16,6 +16,8 @@
 namespace hvr {
 hipError_t run_transpose_pad(const void*, void*, int, int, long, long, int, hipStream_t);
 hipError_t run_zero_fill(void*, size_t, hipStream_t);
+hipError_t run_pack_conv_weights_multi(const void*, int, long, int, hipStream_t);
+hipError_t run_transpose_multi(const void*, int, int, hipStream_t);
 hipError_t run_im2col_t(const void*, void*, int, int, int, int, int, int, int, int, int, int, long, hipStream_t);
 hipError_t run_relu_bwd_t(const void*, const void*, void*, void*, int, int, long, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
@@ -810,6 +812,17 @@ int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout
   if (!w || !scale || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return fail(HVR_EINVAL, "bad pack_conv_weight arguments");
   if (out_dtype != HVR_F32 && out_dtype != HVR_BF16 && out_dtype != HVR_F16) return fail(HVR_EINVAL, "bad dtype");
   return check_launch(run_pack_conv_weight(w, scale, out, Cout, Cin, KH * KW, out_dtype, (hipStream_t)stream), "hvr_pack_conv_weight");
+}
+
+int hvr_pack_conv_weights_multi(const hvr_pack_item* items_dev, int n, int64_t total, int out_dtype, void* stream) {
+  if (!items_dev || n <= 0 || total <= 0) return fail(HVR_EINVAL, "bad pack_conv_weights_multi arguments");
+  if (out_dtype != HVR_BF16 && out_dtype != HVR_F16) return fail(HVR_EUNSUPPORTED, "hvr_pack_conv_weights_multi writes bf16 / half operands");
+  return check_launch(run_pack_conv_weights_multi(items_dev, n, (long)total, out_dtype, (hipStream_t)stream), "hvr_pack_conv_weights_multi");
+}
+
+int hvr_transpose_multi(const hvr_transpose_item* items_dev, int n, int tiles, void* stream) {
+  if (!items_dev || n <= 0 || tiles <= 0) return fail(HVR_EINVAL, "bad transpose_multi arguments");
+  return check_launch(run_transpose_multi(items_dev, n, tiles, (hipStream_t)stream), "hvr_transpose_multi");
 }
 
 int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, int accumulate, void* stream) {

@@ -646,6 +646,97 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ dw, const flo
   }
 }
 
+// ---- the weight side of a training iteration in two launches (round 5) ----
+// Every trainable conv / linear layer needs, once per iteration: its f32 master weight x the frozen BatchNorm scale in the kernels'
+// operand layout and dtype (pack_conv_weight), and for the input-gradient product that operand transposed (1x1 / linear: [Cin][ldn]) or
+// rotated by 180 degrees with the channel axes swapped (KxK: [Cin][KH][KW][Cout]).  Round 4 made them per layer inside forward / backward
+// (96 + 65 + 2 x 31 launches per iteration); here a descriptor table on the device lists every layer and one launch packs all of them,
+// a second one writes all the transposed / rotated copies as per-tap 64 x 64 tile transposes of the packed operands.
+struct PackItem {       // mirrors hvr_pack_item (include/hvr_hip.h)
+  const float* w;       // [Cout][Cin][KK] f32
+  const float* s;       // [Cout]
+  void* eff;            // [Cout][KK][Cin], 16-bit operand
+  long first;           // index of this item's first element in the flat work list
+  int Cout, Cin, KK, pad_;
+};
+struct TransItem {      // mirrors hvr_transpose_item: dst[c][r] = src[r][c], r < R, c < C (16-bit words), 64 x 64 tiles
+  const void* src;
+  void* dst;
+  long lds, ldd;        // row pitches in elements
+  int R, C;
+  int first_tile, tiles_c;
+  int dcols, pad_;      // columns of dst written per row (R .. dcols - 1: zeros)
+};
+
+template <typename T>
+__global__ void pack_conv_weights_multi_kernel(const PackItem* __restrict__ items, int n, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;                       // the item that holds element idx (first[] ascending)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].first <= idx) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+    const long e = idx - it.first;
+    const int c = (int)(e % it.Cin);
+    const long r = e / it.Cin;
+    const int t = (int)(r % it.KK), o = (int)(r / it.KK);
+    ElemTraits<T>::store(reinterpret_cast<T*>(it.eff) + e, it.w[((long)o * it.Cin + c) * it.KK + t] * it.s[o]);
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_multi_x8_kernel(const TransItem* __restrict__ items, int n) {
+  constexpr int PITCH = 64 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char tile[64 * PITCH];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TransItem it = items[lo];
+  const int tl = (int)blockIdx.x - it.first_tile;
+  const int r0 = (tl / it.tiles_c) * 64, c0 = (tl % it.tiles_c) * 64, tid = threadIdx.x;
+  const bf16_t* in = reinterpret_cast<const bf16_t*>(it.src);
+  bf16_t* out = reinterpret_cast<bf16_t*>(it.dst);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int sidx = k * 256 + tid, i = sidx >> 3, q = sidx & 7;
+    const int r = r0 + i, c = c0 + q * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < it.R && c < it.C) v = *reinterpret_cast<const uint4*>(in + (long)r * it.lds + c);     // C % 8 == 0
+    *reinterpret_cast<uint4*>(tile + i * PITCH + q * 16) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int sidx = k * 256 + tid, q = sidx >> 6, i = sidx & 63;
+    const int c = c0 + i, r = r0 + q * 8;
+    if (c >= it.C || r >= it.dcols) continue;                                                     // (columns R .. dcols - 1: zero padding)
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t l = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e) * PITCH + i * 2);
+      const uint32_t h = *reinterpret_cast<const bf16_t*>(tile + (q * 8 + 2 * e + 1) * PITCH + i * 2);
+      w[e] = l | (h << 16);
+    }
+    *reinterpret_cast<uint4*>(out + (long)c * it.ldd + r) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+hipError_t run_pack_conv_weights_multi(const void* items, int n, long total, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_conv_weights_multi_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const PackItem*)items, n, total);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(pack_conv_weights_multi_kernel<f16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const PackItem*)items, n, total);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t run_transpose_multi(const void* items, int n, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_multi_x8_kernel, dim3(tiles), dim3(256), 0, s, (const TransItem*)items, n);
+  return hipGetLastError();
+}
+
 hipError_t run_pack_conv_weight(const float* w, const float* sc, void* out, int Cout, int Cin, int KK, int dtype, hipStream_t s) {
   const long total = (long)Cout * Cin * KK;
   if (dtype == DT_BF16)

@@ -78,13 +78,17 @@ def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm
     switches cost more than the overlap returns (22.1 vs 20.5 ms measured); it pays once the per-rank batch grows."""
     from . import train_ops
     flat.zero_grad()
-    loss = loss_fn()
-    prev = train_ops.wgrad_overlap(overlap_wgrad)
+    train_ops.prep_begin(flat)          # every trainable layer's operands for this iteration in two launches (recorded on the first)
     try:
-        loss.backward()
+        loss = loss_fn()
+        prev = train_ops.wgrad_overlap(overlap_wgrad)
+        try:
+            loss.backward()
+        finally:
+            train_ops.wgrad_overlap(prev)
+            train_ops.join_wgrad()
     finally:
-        train_ops.wgrad_overlap(prev)
-        train_ops.join_wgrad()
+        train_ops.prep_end()            # the update below makes the table's operands stale
     world = flat.allreduce_grads()
     flat.sgd_step(lr, momentum, weight_decay, max_norm, world)
     return loss

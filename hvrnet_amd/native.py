@@ -124,6 +124,8 @@ SYMBOLS = {
     'hvr_colsum_workspace_bytes': (_sz, [_i, _i]),
     'hvr_colsum': (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
     'hvr_pack_conv_weight': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'hvr_pack_conv_weights_multi': (_i, [_vp, _i, _i64, _i, _vp]),
+    'hvr_transpose_multi': (_i, [_vp, _i, _i, _vp]),
     'hvr_unpack_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_det_loss_sampled': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp]),
@@ -819,6 +821,33 @@ def pack_conv_weight(w, scale, dtype):
     out = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=w.device)
     _check(lib().hvr_pack_conv_weight(_ptr(w), _ptr(scale), _ptr(out), Cout, Cin, KH, KW, _dt(out), _stream()), 'hvr_pack_conv_weight')
     return out
+
+
+class PackItem(ctypes.Structure):          # hvr_pack_item
+    _fields_ = [('w', ctypes.c_void_p), ('scale', ctypes.c_void_p), ('out', ctypes.c_void_p), ('first', ctypes.c_int64),
+                ('Cout', ctypes.c_int32), ('Cin', ctypes.c_int32), ('KK', ctypes.c_int32), ('pad_', ctypes.c_int32)]
+
+
+class TransposeItem(ctypes.Structure):     # hvr_transpose_item
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('lds', ctypes.c_int64), ('ldd', ctypes.c_int64),
+                ('R', ctypes.c_int32), ('C', ctypes.c_int32), ('first_tile', ctypes.c_int32), ('tiles_c', ctypes.c_int32),
+                ('dcols', ctypes.c_int32), ('pad_', ctypes.c_int32)]
+
+
+def items_to_device(items, device):
+    """A list of ctypes structures -> a uint8 device tensor holding the array (the descriptor tables of the *_multi entry points)."""
+    arr = (type(items[0]) * len(items))(*items)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def pack_conv_weights_multi(items_dev, n, total, dtype):
+    code = {torch.bfloat16: HVR_BF16, torch.float16: HVR_F16}[dtype]
+    _check(lib().hvr_pack_conv_weights_multi(_ptr(items_dev), n, total, code, _stream()), 'hvr_pack_conv_weights_multi')
+
+
+def transpose_multi(items_dev, n, tiles):
+    _check(lib().hvr_transpose_multi(_ptr(items_dev), n, tiles, _stream()), 'hvr_transpose_multi')
 
 
 def unpack_conv_wgrad(dw, scale, shape, accumulate_into=None):

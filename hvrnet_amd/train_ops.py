@@ -63,6 +63,114 @@ def _two_byte(dtype):
     return dtype in (torch.bfloat16, torch.float16)
 
 
+# ---- the weight side of an iteration in two launches (hvr_pack_conv_weights_multi + hvr_transpose_multi) ------------------------------
+# Every trainable conv / linear layer needs its f32 master weight (x the frozen BatchNorm scale) in the kernels' operand layout for the
+# forward, and that operand transposed (1x1 / linear) or rotated (KxK) for the input gradient.  The first iteration of a
+# dist_train.train_iteration loop RECORDS the layers as they run (weights that are parameters, or views of one: stable addresses in
+# FlatParams' buffer); from the second on prep_begin() rebuilds all of them with two launches before the forward and the Functions
+# pick their operands out of the table.  Outside such a loop (tests, one-off calls) nothing is cached: every layer prepares its own.
+_prep = dict(recording=False, valid=False, entries={}, tables=None, owner=None, enabled=True)
+
+
+def _prep_key(w):
+    base = w if w.is_leaf else w._base
+    if base is None or not isinstance(base, torch.nn.Parameter) or not w.is_contiguous():
+        return None
+    return (w.data_ptr(), tuple(w.shape))
+
+
+def _prep_lookup(w, s, shape4, dtype):
+    """-> (packed operand or None, key): the table's operand when this iteration's table holds the layer; records it while recording."""
+    if not (_prep['valid'] or _prep['recording']) or not _two_byte(dtype) or shape4[1] % 8:
+        return None, None
+    key = _prep_key(w)
+    if key is None:
+        return None, None
+    e = _prep['entries'].get(key)
+    if _prep['valid'] and e is not None and e['dtype'] == dtype and e['s'] is s:
+        return e['eff'], key
+    if _prep['recording'] and e is None:
+        _prep['entries'][key] = dict(w=w.detach(), s=s, shape=tuple(shape4), dtype=dtype, eff=None, aux=None)
+    return None, None
+
+
+def _prep_aux(key):
+    e = _prep['entries'].get(key) if (key is not None and _prep['valid']) else None
+    return None if e is None else e['aux']
+
+
+def _prep_build():
+    ents = [e for e in _prep['entries'].values()]
+    if not ents:
+        return
+    dtype, dev = ents[0]['dtype'], ents[0]['w'].device
+    step = native.kstep(dtype)
+    packs, trans, first, tile0 = [], [], 0, 0
+    for e in ents:
+        Cout, Cin, KH, KW = e['shape']
+        KK = KH * KW
+        e['eff'] = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=dev)
+        packs.append(native.PackItem(w=e['w'].data_ptr(), scale=e['s'].data_ptr(), out=e['eff'].data_ptr(), first=first, Cout=Cout, Cin=Cin, KK=KK))
+        first += Cout * KK * Cin
+        es = e['eff'].element_size()
+        tiles_r, tiles_c = (Cout + 63) // 64, (Cin + 63) // 64
+        if KK == 1:
+            ldn = (Cout + step - 1) // step * step
+            e['aux'] = torch.zeros((Cin, ldn), dtype=dtype, device=dev)
+            trans.append(native.TransposeItem(src=e['eff'].data_ptr(), dst=e['aux'].data_ptr(), lds=Cin, ldd=ldn, R=Cout, C=Cin, first_tile=tile0,
+                                              tiles_c=tiles_c, dcols=ldn))
+            tile0 += ((ldn + 63) // 64) * tiles_c
+        else:
+            e['aux'] = torch.zeros((Cin, KH, KW, Cout), dtype=dtype, device=dev)   # [Cin][KH][KW][Cout], taps reversed (the dX conv's operand)
+            if Cout % 8:
+                e['aux'] = None
+                continue
+            for t in range(KK):
+                trans.append(native.TransposeItem(src=e['eff'].data_ptr() + t * Cin * es, dst=e['aux'].data_ptr() + (KK - 1 - t) * Cout * es,
+                                                  lds=KK * Cin, ldd=KK * Cout, R=Cout, C=Cin, first_tile=tile0, tiles_c=tiles_c, dcols=Cout))
+                tile0 += tiles_r * tiles_c
+    _prep['tables'] = dict(packs=native.items_to_device(packs, dev), n_packs=len(packs), total=first, dtype=dtype,
+                           trans=native.items_to_device(trans, dev) if trans else None, n_trans=len(trans), tiles=tile0)
+
+
+def prep_begin(owner=None):
+    """Start of an iteration (dist_train.train_iteration; owner = its FlatParams: another owner starts a new table): rebuild every
+    recorded layer's operands, or start recording."""
+    if not _prep['enabled']:
+        return
+    if owner is not _prep['owner']:
+        prep_reset()
+        _prep['owner'] = owner
+    t = _prep['tables']
+    if t is None:
+        _prep['recording'], _prep['valid'] = True, False
+        return
+    native.pack_conv_weights_multi(t['packs'], t['n_packs'], t['total'], t['dtype'])
+    if t['trans'] is not None:
+        native.transpose_multi(t['trans'], t['n_trans'], t['tiles'])
+    _prep['valid'] = True
+
+
+def prep_end():
+    """End of an iteration (after the update: the table's operands are stale from here on)."""
+    _prep['valid'] = False
+    if _prep['recording']:
+        _prep['recording'] = False
+        _prep_build()
+
+
+def prep_reset():
+    _prep.update(recording=False, valid=False, entries={}, tables=None, owner=None)
+
+
+def prep_enable(flag):
+    """The per-iteration weight table on / off (off: every layer prepares its own operands, as outside a training loop); -> previous."""
+    prev = _prep['enabled']
+    _prep['enabled'] = bool(flag)
+    prep_reset()
+    return prev
+
+
 # Weight gradients of convs go STRAIGHT into the parameter's gradient buffer when it has one (dist_train.FlatParams gives every
 # parameter a view of the flat gradient buffer, zeroed at the start of the step): the f32 product is scaled, permuted and ADDED in
 # place by hvr_unpack_conv_wgrad and autograd is handed no gradient for the weight -- no temporary, no AccumulateGrad add per layer
@@ -87,7 +195,9 @@ class LinearFunction(Function):
         if not x.is_cuda:
             raise NotImplementedError('the head runs on the GPU only (no CPU fallback)')
         x = x.contiguous()
-        wc = native.cast(w.contiguous(), x.dtype)
+        wc, key = _prep_lookup(w, ones(w.shape[0], x.device), (w.shape[0], w.shape[1], 1, 1), x.dtype) if w.dim() == 2 else (None, None)
+        wc = native.cast(w.contiguous(), x.dtype) if wc is None else wc.view(w.shape[0], w.shape[1])
+        ctx.prep_key = key
         assert not (relu and out_f32 and x.dtype != torch.float32), 'the ReLU mask is kept in the compute dtype'
         y = native.gemm(x, wc, b, resid=resid.contiguous() if resid is not None else None, relu=bool(relu), out_f32=bool(out_f32))
         ctx.relu, ctx.has_resid, ctx.has_bias = bool(relu), resid is not None, b is not None
@@ -110,7 +220,8 @@ class LinearFunction(Function):
             dz = native.relu_bwd(dy, y) if ctx.relu else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = native.gemm(_pad_cols(dz, ldn), native.transpose_pad(w, ldn))           # [M, K] = dz [M, N] W [N, K]
+            wt = _prep_aux(ctx.prep_key)
+            dx = native.gemm(_pad_cols(dz, ldn), wt if wt is not None else native.transpose_pad(w, ldn))   # [M, K] = dz [M, N] W [N, K]
         if ctx.needs_input_grad[1]:
             dw = native.gemm_splitk(dzt if dzt is not None else native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))   # [N, K] = dz^T x, f32
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -258,7 +369,10 @@ class ConvFunction(Function):
         assert (KH, KW) == (1, 1) or stride == 1, 'strided KxK convs are not on this path (caffe-style ResNet strides its 1x1s)'
         xs = x[:, ::stride, ::stride, :].contiguous() if stride > 1 else x.contiguous()
         s = s.float().contiguous()
-        w_eff = native.pack_conv_weight(w.contiguous(), s, x.dtype)                      # [Cout][KH][KW][Cin] * s, compute dtype
+        w_eff, key = _prep_lookup(w, s, (Cout, Cin, KH, KW), x.dtype)                    # this iteration's table (prep_begin), or:
+        if w_eff is None:
+            w_eff = native.pack_conv_weight(w.contiguous(), s, x.dtype)                  # [Cout][KH][KW][Cin] * s, compute dtype
+        ctx.prep_key = key
         y = native.conv2d_nhwc(xs, w_eff, t, resid.contiguous() if resid is not None else None, relu=bool(relu), pad=pad, dil=dil,
                                out_f32=bool(out_f32))
         ctx.cfg = (bool(relu), int(stride), int(pad), int(dil), resid is not None, tuple(x.shape))
@@ -288,11 +402,13 @@ class ConvFunction(Function):
         dx = dw = None
         side_reads_dz = False
         if ctx.needs_input_grad[0]:
+            aux = _prep_aux(ctx.prep_key)
             if (KH, KW) == (1, 1):
                 ldn = (Cout + step - 1) // step * step
-                dxs = native.gemm(_pad_cols(dz2, ldn), native.transpose_pad(w_eff.view(Cout, Cin), ldn)).view(B, OH, OW, Cin)  # dz W
+                wt = aux if aux is not None else native.transpose_pad(w_eff.view(Cout, Cin), ldn)
+                dxs = native.gemm(_pad_cols(dz2, ldn), wt).view(B, OH, OW, Cin)  # dz W
             else:
-                w_rot = w_eff.flip(1, 2).permute(3, 1, 2, 0).contiguous()               # [Cin][KH][KW][Cout], taps reversed
+                w_rot = aux if aux is not None else w_eff.flip(1, 2).permute(3, 1, 2, 0).contiguous()   # [Cin][KH][KW][Cout], taps reversed
                 dxs = native.conv2d_nhwc(dz, w_rot, None, None, relu=False, pad=dil * (KH - 1) - pad, dil=dil)
             if stride > 1:
                 dx = dxs.new_zeros(x_shape)

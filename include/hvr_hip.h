@@ -270,6 +270,16 @@ int hvr_scale_rows(const void* w, const float* scale, void* out, int R, int64_t 
  * for the f32 weight gradient (accumulate != 0: added to `out`, i.e. written straight into the parameter's gradient buffer). */
 int hvr_pack_conv_weight(const float* w, const float* scale, void* out, int Cout, int Cin, int KH, int KW, int out_dtype, void* stream);
 int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, int accumulate, void* stream);
+/* The weight side of a whole training iteration in two launches (round 5): `items_dev` is a table IN DEVICE MEMORY, one entry per trainable
+ * conv / linear layer (pointers are stable: the parameters live in one flat buffer, dist_train.FlatParams).  hvr_pack_conv_weights_multi is
+ * hvr_pack_conv_weight for every entry (first = index of the entry's first element in the concatenated work list, ascending; total = their
+ * sum); hvr_transpose_multi writes dst[c][r] = src[r][c] for every entry as 64 x 64 tiles of 16-bit words (C % 8 == 0, ldd and dcols % 8 == 0,
+ * columns R .. dcols - 1 of dst zero; first_tile ascending, tiles = their sum): the transposed (1x1 / linear) and the rotated (KxK, one entry per
+ * filter tap) operands of the input-gradient products, from the packed weights. */
+typedef struct { const float* w; const float* scale; void* out; int64_t first; int32_t Cout, Cin, KK, pad_; } hvr_pack_item;
+typedef struct { const void* src; void* dst; int64_t lds, ldd; int32_t R, C, first_tile, tiles_c, dcols, pad_; } hvr_transpose_item;   /* dcols: columns of dst written per row (R .. dcols - 1: zeros) */
+int hvr_pack_conv_weights_multi(const hvr_pack_item* items_dev, int n, int64_t total, int out_dtype, void* stream);
+int hvr_transpose_multi(const hvr_transpose_item* items_dev, int n, int tiles, void* stream);
 
 /* Optimizer step on a flat f32 buffer (the training configs: SGD lr 5e-4, momentum 0.9, weight decay 1e-4, gradient
  * clipping max_norm 35, configs/faster_rcnn_r101_selsa_c5.py:215-222; torch.optim.SGD semantics, dampening 0).  The two

@@ -1257,6 +1257,63 @@ def test_full_detector_training_iterations_descend():
         assert bool(torch.isfinite(after[k].float()).all()), k
 
 
+def test_per_iteration_weight_table_equals_the_per_layer_preparation():
+    """train_ops.prep_begin / prep_end (dist_train.train_iteration): from the second iteration on, the packed / transposed / rotated
+    operands of every trainable conv and linear layer come from two launches (hvr_pack_conv_weights_multi, hvr_transpose_multi) instead
+    of one to three launches per layer inside forward / backward.  After a real iteration has recorded the layers and an update has moved
+    the weights, every operand of the rebuilt table equals what the per-layer calls make of the current weights, bit for bit; and
+    iterations with the table descend like iterations without it (the step itself is not bit-reproducible: RoIAlign's backward adds with
+    atomics)."""
+    from hvrnet_amd import native, train_ops
+    from hvrnet_amd.config import selsa_train_config
+    from hvrnet_amd.dist_train import FlatParams, train_detector_iteration
+    n_post, n_sel, T = 24, 16, 3
+    hw = (128, 192)
+
+    def setup():
+        cfg = selsa_train_config(nms_post=n_post, rcnn_sampler_num=n_sel, t_dim=T)
+        model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict('selsa'), torch.bfloat16, DEV))
+        g = torch.Generator().manual_seed(93)
+        imgs = (torch.randn((T, 3) + hw, generator=g) * 50.0).to(DEV)
+        metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(T)]
+        gt_b = torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]).to(DEV)
+        gt_l = torch.tensor([5, 12]).to(DEV)
+        keys = dict(rpn=torch.rand((hw[0] // 16) * (hw[1] // 16) * 12, generator=g).to(DEV),
+                    rcnn=[torch.rand(2 + n_post, generator=g).to(DEV) for _ in range(T)])
+        return model, dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, keys=keys)
+
+    prev = train_ops.prep_enable(True)
+    try:
+        model, data = setup()
+        flat = FlatParams(model)
+        l1 = [float(train_detector_iteration(model, flat, data, lr=2e-4)['loss'])]          # records the layers, builds the table
+        assert train_ops._prep['tables'] is not None and train_ops._prep['tables']['n_packs'] > 60
+        train_ops.prep_begin(flat)                                                         # what iteration 2 starts with
+        n_rot = n_t = 0
+        for e in train_ops._prep['entries'].values():
+            Cout, Cin, KH, KW = e['shape']
+            want = native.pack_conv_weight(e['w'].reshape(Cout, Cin, KH, KW).contiguous(), e['s'], torch.bfloat16)
+            assert torch.equal(e['eff'], want), e['shape']
+            if KH * KW == 1:
+                assert torch.equal(e['aux'], native.transpose_pad(want.view(Cout, Cin), e['aux'].shape[1])), e['shape']
+                n_t += 1
+            elif e['aux'] is not None:
+                assert torch.equal(e['aux'], want.flip(1, 2).permute(3, 1, 2, 0).contiguous()), e['shape']
+                n_rot += 1
+        train_ops.prep_end()
+        assert n_t > 40 and n_rot > 20
+        l1 += [float(train_detector_iteration(model, flat, data, lr=2e-4)['loss']) for _ in range(3)]
+        train_ops.prep_enable(False)
+        model0, data0 = setup()
+        flat0 = FlatParams(model0)
+        l0 = [float(train_detector_iteration(model0, flat0, data0, lr=2e-4)['loss']) for _ in range(4)]
+        assert train_ops._prep['tables'] is None
+    finally:
+        train_ops.prep_enable(prev)
+    assert l1[0] == l0[0] and l1[3] < l1[0] and l0[3] < l0[0]
+    assert abs(l1[1] - l0[1]) <= 0.05 * l0[1], (l1, l0)      # (later iterations drift apart run to run, with or without the table)
+
+
 def test_packed_weights_follow_the_optimizer_step():
     """The graph-free (packed: BN folded, per-dtype) forwards must use the CURRENT parameters after an SGD step, as the
     reference's modules do -- HNMBRCNN.forward_train picks its video triplet with `shared_head(c4)` under no_grad every

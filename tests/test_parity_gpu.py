@@ -1314,6 +1314,54 @@ def test_per_iteration_weight_table_equals_the_per_layer_preparation():
     assert abs(l1[1] - l0[1]) <= 0.05 * l0[1], (l1, l0)      # (later iterations drift apart run to run, with or without the table)
 
 
+@pytest.mark.parametrize('kind', ['hvr', 'selsa'])
+def test_head_gradients_with_the_weight_table_equal_those_without_it(kind):
+    """The relation heads' training step has no atomics: with the same weights, one forward + backward whose operands come from the
+    per-iteration table (recorded by a first train_iteration) gives the same loss and the same flat gradient buffer, bit for bit, as one
+    whose layers prepare their own operands -- bf16, both heads (the HVR head: per-video stages, inter-video stage, mining, triplet)."""
+    from hvrnet_amd import dist_train, train_ops
+    sd = S.synth_state_dict(kind)
+    if kind == 'hvr':
+        feats, cur, labels, lw, bt, bw = C.hvr_train_case()
+        head = hvrnet_amd.HRNMPBBoxHead(sampler_num=16, t_dim=9, imgs_per_video=3, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    else:
+        labels, lw, bt, bw = C.head_train_case()
+        feats, cur = C.roi_feat_input(), dict(start=32, length=32)
+        head = hvrnet_amd.SelsaBBoxHead(sampler_num=32, t_dim=3, in_channels=256, num_classes=31, reg_class_agnostic=True)
+    head.load_state_dict({k[len('bbox_head.'):]: v for k, v in sd.items() if k.startswith('bbox_head.')}, strict=True)
+    head = hvrnet_amd.enable_training(head.to(DEV))
+    hvrnet_amd.set_compute_dtype(head, torch.bfloat16)
+    dev = [t.to(DEV) for t in (labels, lw, bt, bw)]
+
+    def loss_fn():
+        if kind == 'hvr':
+            logits, extra = head.forward_train([f.to(DEV).bfloat16() for f in feats], cur, dev[0])
+            out = head.loss_train(logits, *dev)
+            out.update(extra)
+            return sum(v for k, v in out.items() if 'loss' in k)
+        return head.loss_train(head.forward_train(feats.to(DEV).bfloat16(), cur), *dev)['total'].sum()
+
+    prev = train_ops.prep_enable(True)
+    try:
+        flat = dist_train.FlatParams(head)
+        dist_train.train_iteration(flat, loss_fn, lr=1e-4)            # records the layers; the update moves the weights
+        assert train_ops._prep['tables'] is not None and train_ops._prep['tables']['n_packs'] >= (12 if kind == 'hvr' else 6)
+        flat.zero_grad()
+        train_ops.prep_begin(flat)
+        l1 = loss_fn()
+        l1.backward()
+        train_ops.prep_end()
+        g1, l1 = flat.grad.detach().clone(), float(l1.detach())
+        train_ops.prep_enable(False)
+        flat.zero_grad()
+        l0 = loss_fn()
+        l0.backward()
+        assert float(l0.detach()) == l1 and torch.equal(flat.grad, g1)
+        assert float(g1.abs().sum()) > 0
+    finally:
+        train_ops.prep_enable(prev)
+
+
 def test_packed_weights_follow_the_optimizer_step():
     """The graph-free (packed: BN folded, per-dtype) forwards must use the CURRENT parameters after an SGD step, as the
     reference's modules do -- HNMBRCNN.forward_train picks its video triplet with `shared_head(c4)` under no_grad every

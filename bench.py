@@ -234,7 +234,7 @@ def cpu_baseline_full(head, T, n_prop, sd, clip_ids):
                window_seconds=round(window_s, 3), config1_window_seconds=round(c1, 3))
     last = (lambda r: r[-1]) if head == 'hvr' else (lambda r: r)
     fl = [parity.strict(last(a), last(b)) for a, b in zip(wants, wants64)]
-    floor = dict(what='oracle.clip_forward in float32 against the same code in float64, per clip', class_flips=[f['class_flips'] for f in fl],
+    floor = dict(class_flips=[f['class_flips'] for f in fl],   # oracle.clip_forward in float32 against the same code in float64, per clip
                  max_score_err=[float('%.3g' % f['max_score_err']) for f in fl], max_box_err=[float('%.3g' % f['max_box_err']) for f in fl],
                  f64_window_seconds=round(sorted(t64)[len(t64) // 2], 2))
     return out, wants, wants64, floor, props
@@ -291,7 +291,7 @@ def train_step_side_measurement(head):
         return dict(iterations_per_s=d['value'], ms_per_iteration=d['ms_per_step'], input_frames_per_s=d['frames_per_s'], dtype=d['dtype'],
                     trainable_params=d['params'],
                     roofline=dict(bound='mfma', achieved=round(ach, 1), peak=MFMA_PEAK_TF['bf16'], unit='TFLOP/s', frac=round(ach / MFMA_PEAK_TF['bf16'], 4),
-                                  flops_per_iteration=TRAIN_STEP_FLOPS[head], note='whole iteration (forward, backward, targets, losses, clip + SGD) against the dense MFMA peak'))
+                                  flops_per_iteration=TRAIN_STEP_FLOPS[head]))   # whole iteration (forward, backward, targets, losses, clip + SGD) against the dense MFMA peak
     except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the headline down
         sys.stderr.write('train_step side measurement skipped: %r\n' % (exc,))
         return None
@@ -971,9 +971,10 @@ def main(argv=None):
                     c['parity'] = dict(class_flips=pr['class_flips'], max_score_err=pr['max_score_err'], max_box_err=pr['max_box_err'],
                                        same_class_frac=pr['matched']['same_class_frac'])
                     c['within_tolerance'] = r['within_tolerance']
-                    if 'parity_clips' in r:
-                        c['parity_clips'] = r['parity_clips']
-                c['kernel_classes'] = {t: [e['ms'], e['frac']] for t, e in r['kernel_classes'].items()}
+                    if 'parity_clips' in r:   # (the per-clip arrays of the mode that carries the claim are in `within_tolerance`)
+                        pc_ = r['parity_clips']
+                        c['clips'] = [sum(pc_['proposal_lists_equal_the_oracles']), pc_['clips']]
+                c['kernel_classes'] = {t: [round(e['ms'], 3), round(e['frac'], 3)] for t, e in r['kernel_classes'].items()}
                 return c
             out['precision_ladder'] = [compact(r) for r in rows]
         out['kernel_classes'] = kc

@@ -95,8 +95,9 @@ def parse(argv=None):
                     help='independent clips per call / per graph (round 5): every kernel up to the relation stages takes the W clips as '
                          'one batch, the relation core runs per clip in grouped launches (hvr_relation_fwd_grouped); a step stays ONE '
                          'window, a call is W steps (W is lowered to a divisor of --steps)')
-    ap.add_argument('--lanes', type=int, default=int(os.environ.get('HVR_LANES', '3')),
-                    help='headline region: windows replayed from hipGraphs on that many HIP streams in turn (1 with --no-graphs: the '
+    ap.add_argument('--lanes', type=int, default=int(os.environ.get('HVR_LANES', '0')),
+                    help='headline region: windows replayed from hipGraphs on that many HIP streams in turn; 0 (default) = the divisor of steps / clips in 3..6 '
+                         'that leaves no lane idle in the last round of replays (20 steps, 4 clips: 5 lanes), else 4 (1 with --no-graphs: the '
                          'eager single-lane loop is the headline, as in round 1)')
     ap.add_argument('--breakdown', action='store_true', help='print per-shape conv / gemm times of one window to stderr')
     ap.add_argument('--stub', action='store_true',
@@ -454,6 +455,9 @@ def main(argv=None):
         return clips[0] if W == 1 else torch.cat(clips, 0)
     frames_w = lane_frames(0)
     metas_w = metas * W
+    if args.lanes <= 0:   # auto: every round of replays fills every lane (profiles/r05_lanes.txt: a partial last round costs 2-4 %)
+        replays = args.steps // W
+        args.lanes = next((l for l in (4, 5, 6, 3) if replays % l == 0), 4)
 
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 else [None]
     turn = [0]

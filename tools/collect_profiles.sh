@@ -103,5 +103,5 @@ rm -rf /tmp/f_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/f_ks -o fr -- pyth
 { echo "# tools/frame_profile.py under rocprofv3 --kernel-trace --stats: 23 frames (3 warm-up + 20), eager; per-frame rows = call counts that are multiples of 23 (the rest is one-time weight packing)"; grep "one frame" $out/stream_frame.log; $T python tools/rocpd_stats.py $(db /tmp/f_ks) | head -45; } > $out/stream_frame_kernel_stats.txt
 rm -rf /tmp/rw_ks; HVR_RPN_WIDE=4 $T rocprofv3 --kernel-trace --stats -d /tmp/rw_ks -o rpn -- python tools/rpn_probe.py > $out/rpn_wide_probe.txt 2>&1
 $T python tools/rocpd_stats.py $(db /tmp/rw_ks) | grep -i "rpn\|nms\|kernel \|dispatches" > $out/rpn_wide_kernel_stats.txt
-$T bash tools/run_stream_ab.sh > /dev/null 2>&1; $T bash tools/run_key.sh > /dev/null 2>&1   # -> gpurun_out/stream_ab.txt, gpurun_out/key_stage_ab.txt
+$T bash tools/run_stream_ab.sh > /dev/null 2>&1   # -> gpurun_out/stream_ab.txt
 fi

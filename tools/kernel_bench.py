@@ -64,7 +64,7 @@ def main():
                               ('fc_key', 300, 1024, 1024), ('square4k', 4096, 4096, 4096)]:
             a, w = rnd(M, K), rnd(N, K, scale=0.05)
             sweep('gemm %s %dx%dx%d' % (name, M, N, K), lambda t: native.gemm(a, w, staging=1, tile=t), 2.0 * M * N * K)
-    # ---- relation core (tiles come from HVR_TILE_SCORES / HVR_TILE_APPLY, read once per process) ----
+    # ---- relation core ----
     if want('relation'):
         for Mq, Mk in [(4500, 4500), (300, 4500)]:
             q, k, v = rnd(Mq, 1024), rnd(Mk, 1024), rnd(Mk, 1024)

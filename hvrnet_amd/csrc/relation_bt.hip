@@ -462,12 +462,13 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
     const long long t_end = wall_clock64();
-    if (threadIdx.x == 0) {
-      printf("BTCLK wg %d xcc %d t0 %lld vt %lld |", (int)blockIdx.x, (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20), dbg_t[0], dbg_t[1] - dbg_t[0]);
-      for (int r = 0; r < 4; ++r)
-        if (dbg_t[2 + 3 * r]) printf(" tile%d loop %lld..%lld epi %lld |", r, dbg_t[2 + 3 * r] - dbg_t[0], dbg_t[3 + 3 * r] - dbg_t[0], dbg_t[4 + 3 * r] - dbg_t[0]);
-      printf(" drained %lld\n", t_end - dbg_t[0]);
-    }
+    if (threadIdx.x == 0)   // ONE printf per workgroup (several would interleave across workgroups): 0 = this workgroup had no such tile
+      printf("BTCLK wg %d xcc %d t0 %lld vt %lld | tile0 loop %lld..%lld epi %lld | tile1 loop %lld..%lld epi %lld | tile2 loop %lld..%lld epi %lld | tile3 loop %lld..%lld epi %lld | drained %lld\n",
+             (int)blockIdx.x, (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20), dbg_t[0], dbg_t[1] - dbg_t[0],
+             dbg_t[2] ? dbg_t[2] - dbg_t[0] : 0, dbg_t[3] ? dbg_t[3] - dbg_t[0] : 0, dbg_t[4] ? dbg_t[4] - dbg_t[0] : 0,
+             dbg_t[5] ? dbg_t[5] - dbg_t[0] : 0, dbg_t[6] ? dbg_t[6] - dbg_t[0] : 0, dbg_t[7] ? dbg_t[7] - dbg_t[0] : 0,
+             dbg_t[8] ? dbg_t[8] - dbg_t[0] : 0, dbg_t[9] ? dbg_t[9] - dbg_t[0] : 0, dbg_t[10] ? dbg_t[10] - dbg_t[0] : 0,
+             dbg_t[11] ? dbg_t[11] - dbg_t[0] : 0, dbg_t[12] ? dbg_t[12] - dbg_t[0] : 0, dbg_t[13] ? dbg_t[13] - dbg_t[0] : 0, t_end - dbg_t[0]);
   }
 #endif
 }

@@ -33,7 +33,7 @@ $T python bench.py --frames 21 --steps 10 --warmup 2 --no-train-step --no-f32-le
 # kernel stats of the bench command (the eager single-lane region is where bench.py takes the relation core's HIP events; the
 # graph legs are skipped under the profiler: a kernel-trace of two graph lanes replaying did not come back in round 3)
 rm -rf /tmp/p_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/p_ks -o bench -- python bench.py --steps 8 --warmup 4 --repeats 2 --no-graphs --no-f32-leg --no-cpu-baseline --no-train-step > $out/bench_prof.json 2> $out/bench_prof.err
-$T python tools/rocpd_stats.py $(db /tmp/p_ks) > $out/bench_kernel_stats.txt
+ROCPD_SPLIT=relation_scores_bt_kernel:100 $T python tools/rocpd_stats.py $(db /tmp/p_ks) > $out/bench_kernel_stats.txt
 $T python tools/rocpd_phases.py $(db /tmp/p_ks) 4 > $out/bench_window_phases.txt 2>&1
 $T python tools/window_breakdown.py --mode bf16 --iters 3 > $out/window_breakdown_bf16.txt 2>/dev/null
 $T python tools/window_breakdown.py --mode bf16 --iters 3 --clips 4 > $out/window_breakdown_bf16_w4.txt 2>/dev/null

@@ -2,7 +2,12 @@
 per-kernel table kept under profiles/:  name, calls, total ms, avg us, min us, max us, % of GPU time.
 
     python tools/rocpd_stats.py gpurun_out/prof1/bench_results.db > profiles/r01_bench_kernel_stats.txt
+
+ROCPD_SPLIT="name_substring:microseconds[,...]": launches of a kernel whose name holds the substring are listed as two rows, shorter /
+longer than the threshold -- e.g. relation_scores_bt_kernel:100 separates its one-window launches from the four-window (grouped) ones,
+which share a name and a grid.
 """
+import os
 import re
 import sqlite3
 import sys
@@ -19,10 +24,15 @@ def main(path):
     cols = [r[1] for r in cur.execute('pragma table_info(kernels)')]
     name_col = 'name' if 'name' in cols else [c for c in cols if 'name' in c][0]
     rows = cur.execute('select %s, start, end from kernels' % name_col).fetchall()
+    split = [kv.split(':') for kv in os.environ.get('ROCPD_SPLIT', '').split(',') if ':' in kv]
     agg = {}
     for name, s, e in rows:
-        d = agg.setdefault(short(name), [0, 0.0, 1e30, 0.0])
         dur = (e - s) / 1e3
+        key = short(name)
+        for sub, thr in split:
+            if sub in key:
+                key += '  [launches %s %s us]' % ('<' if dur < float(thr) else '>=', thr)
+        d = agg.setdefault(key, [0, 0.0, 1e30, 0.0])
         d[0] += 1
         d[1] += dur
         d[2] = min(d[2], dur)

@@ -540,6 +540,39 @@ static int relation_apply_pass(const void* P, const void* Vt, float* mstat, floa
   return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply");
 }
 
+// What follows the scores pass of ONE split-half problem: V^T (V == nullptr: the scores launch wrote it), then either one normalising sweep over P~ + a plain product, or the apply
+// pass with the block weights g = 2^(m_t - m*) / L folded in per 128-key block (EPI_APPLY: a block is four split K-steps of three
+// MFMAs, its un-scaled partial joins the running total by one FMA per accumulator register).  Shared by hvr_relation_fwd and the
+// per-group leg of hvr_relation_fwd_grouped.
+static int relation_split_tail(void* P, void* Vt, float* mstat, float* lstat, const void* V, int64_t ldv, void* O, int64_t ldo, int Mq,
+                               int Mk, int D, long ldp, int nt, int staging, hipStream_t s) {
+  constexpr int tile_apply_s = 0;
+  int rc = V ? check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, HVR_F16S, s), "relation: V transpose (split half)") : HVR_OK;
+  if (rc) return rc;
+  GemmParams p;
+  rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, HVR_F16S, staging);
+  if (rc) return rc;
+  p.alpha = 1.f / kSplitProbScale;   // the probabilities are stored x 2^12 (gemm_tile.h / relation_bt.hip, scores epilogue)
+  p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+  p.tile_hint = tile_apply_s;
+#ifdef HVR_DEBUG_KNOBS
+  static const int dbg_apply_s = env_tile("HVR_DBG_APPLY_S");
+  if (dbg_apply_s) p.tile_hint = dbg_apply_s;
+#endif
+  // Which form: measured on one MI355X (tools/rel_bench.py --dtype f16x2; profiles/r04_split_relation.txt): the folded form wins
+  // the key stage (300 x 4 500: 0.146 against 0.163 ms), the full stage goes the other way (4 500 x 4 500: 0.32-0.36 against
+  // 0.29 ms) -- the fold needs the double-buffered apply shapes (the pipelined loop is written for two K-steps per block), and one
+  // normalising sweep over P~ (22 us at 7.5 TB/s out of the Infinity Cache) + the pipelined plain product is cheaper than they are.
+  // HVR_SPLIT_NORMALIZE = 0 / 1 forces the folded / the swept form.
+  static const int split_normalize = std::getenv("HVR_SPLIT_NORMALIZE") ? std::atoi(std::getenv("HVR_SPLIT_NORMALIZE")) : -1;
+  if (split_normalize == 1 || (split_normalize < 0 && Mq >= 1024)) {
+    rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, HVR_F16S, 1.f, s), "relation: normalise (split half)");
+    if (rc) return rc;
+    return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half, plain product)");
+  }
+  return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply (split half)");
+}
+
 size_t hvr_relation_workspace_bytes(int Mq, int Mk, int D, int dtype) {
   const long ldp = rel_ldp(Mk), nt = ldp / 128;
   const size_t es = elem_size(dtype);
@@ -569,38 +602,28 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
 
   GemmParams p;
   int rc;
-  constexpr int tile_scores_s = 0, tile_apply_s = 0;
+  constexpr int tile_scores_s = 0;
   if (dtype == HVR_F16S) {
-    // split half: the scores pass (block-local maxima, P~ stored x 2^12 in the split format), V^T, then either one normalising sweep
-    // over P~ + a plain product, or the apply pass with the block weights g = 2^(m_t - m*) / L folded in per 128-key block
-    // (EPI_APPLY: a block is four split K-steps of three MFMAs, its un-scaled partial joins the running total by one FMA per
-    // accumulator register)
-    rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
-    if (rc) return rc;
+    // split half: the scores pass (block-local maxima, P~ stored x 2^12 in the split format) -- on the 352 x 256 persistent tiles of
+    // relation_bt.hip for window-sized problems, else on the tile engine -- then relation_split_tail
     if (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
-    p.N = Mk; p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
-    p.tile_hint = tile_scores_s;
-    rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores (split half)");
-    if (rc) return rc;
-    rc = check_launch(run_transpose_pad(V, Vt, Mk, D, ldv, ldp, dtype, s), "relation: V transpose (split half)");
-    if (rc) return rc;
-    rc = fill_linear(p, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
-    if (rc) return rc;
-    p.alpha = 1.f / kSplitProbScale;   // the probabilities are stored x 2^12 (gemm_tile.h, EPI_SCORES)
-    p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
-    p.tile_hint = tile_apply_s;
-    // Which form: measured on one MI355X (tools/rel_bench.py --dtype f16x2; profiles/r04_split_relation.txt): the folded form wins
-    // the key stage (300 x 4 500: 0.146 against 0.163 ms), the full stage goes the other way (4 500 x 4 500: 0.32-0.36 against
-    // 0.29 ms) -- the fold needs the double-buffered apply shapes (the pipelined loop is written for two K-steps per block), and one
-    // normalising sweep over P~ (22 us at 7.5 TB/s out of the Infinity Cache) + the pipelined plain product is cheaper than they are.
-    // HVR_SPLIT_NORMALIZE = 0 / 1 forces the folded / the swept form.
-    static const int split_normalize = std::getenv("HVR_SPLIT_NORMALIZE") ? std::atoi(std::getenv("HVR_SPLIT_NORMALIZE")) : -1;
-    if (split_normalize == 1 || (split_normalize < 0 && Mq >= 1024)) {
-      rc = check_launch(run_relation_normalize(P, mstat, lstat, Mq, nt, ldp, dtype, 1.f, s), "relation: normalise (split half)");
+    const bool bt = staging && scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, 1, true);
+    if (bt) {   // (V^T is written by the same launch)
+      ScoresBTParams b;
+      b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
+      b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
+      b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = 2;
+      b.groups = 1; b.gs_q = b.gs_k = b.gs_v = b.gs_p = b.gs_vt = b.gs_stat = 0; b.int_max = 0;
+      rc = check_launch(run_scores_bt(b, s), "relation: scores (split half, big tile)");
+    } else {
+      rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
       if (rc) return rc;
-      return check_launch(run_tile_op(p, EPI_LINEAR, s), "relation: apply (split half, plain product)");
+      p.N = Mk; p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8;
+      p.tile_hint = tile_scores_s;
+      rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation: scores (split half)");
     }
-    return check_launch(run_tile_op(p, EPI_APPLY, s), "relation: apply (split half)");
+    if (rc) return rc;
+    return relation_split_tail(P, Vt, mstat, lstat, bt ? nullptr : V, ldv, O, ldo, Mq, Mk, D, ldp, nt, staging, s);
   }
   const bool two_byte = dtype == HVR_BF16 || dtype == HVR_F16;
   // tuning overrides, read once
@@ -682,9 +705,12 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
   float* mstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
   float* lstat = (float*)w;   w += align256((size_t)Mq * nt * 4);
   float* partial = (float*)w;
-  const bool strides_ok = two_byte && gsq % 8 == 0 && gsk % 8 == 0 && gsv % 8 == 0 && gso % 8 == 0;
+  const bool split = dtype == HVR_F16S;
+  const bool strides_ok = split ? (gsq % 32 == 0 && gsk % 32 == 0 && gsv % 32 == 0 && gso % 32 == 0)
+                                : (two_byte && gsq % 8 == 0 && gsk % 8 == 0 && gsv % 8 == 0 && gso % 8 == 0);
+  if (split && (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64)) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
   if (groups == 1 || mode == 0 || !staging || !strides_ok ||
-      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, groups)) {
+      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, groups, split)) {
     for (int g = 0; g < groups; ++g) {
       const int rc = hvr_relation_fwd((const char*)Q + (size_t)g * gsq * es, ldq, (const char*)K + (size_t)g * gsk * es, ldk,
                                       (const char*)V + (size_t)g * gsv * es, ldv, (char*)O + (size_t)g * gso * es, ldo, Mq, Mk, D, scale,
@@ -699,8 +725,8 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
   ScoresBTParams b;
   b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
   b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
-  b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = dtype == HVR_F16;
-  b.groups = groups; b.gs_q = gsq; b.gs_k = gsk; b.gs_v = gsv; b.gs_p = (long)(per / 2); b.gs_vt = (long)(per / 2); b.gs_stat = (long)(per / 4);
+  b.ldq = ldq; b.ldk = ldk; b.ldv = ldv; b.ldp = ldp; b.sl2 = scale * 1.4426950408889634f; b.f16 = split ? 2 : dtype == HVR_F16;
+  b.groups = groups; b.gs_q = gsq; b.gs_k = gsk; b.gs_v = gsv; b.gs_p = (long)(per / es); b.gs_vt = (long)(per / es); b.gs_stat = (long)(per / 4);
   b.int_max = bt_apply ? 1 : 0;
   int rc = check_launch(run_scores_bt(b, s), "relation (grouped): scores");
   if (rc) return rc;
@@ -713,6 +739,13 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
   }
   for (int g = 0; g < groups; ++g) {
     char* wg = (char*)ws + (size_t)g * per;
+    if (split) {   // one persistent scores launch over all groups (V^T included); the normalising sweep and the product per group
+      rc = relation_split_tail(wg + ((char*)P - (char*)ws), wg + ((char*)Vt - (char*)ws), (float*)(wg + ((char*)mstat - (char*)ws)),
+                               (float*)(wg + ((char*)lstat - (char*)ws)), nullptr, ldv,
+                               (char*)O + (size_t)g * gso * es, ldo, Mq, Mk, D, ldp, nt, staging, s);
+      if (rc) return rc;
+      continue;
+    }
     rc = relation_apply_pass(wg + ((char*)P - (char*)ws), wg + ((char*)Vt - (char*)ws), (float*)(wg + ((char*)mstat - (char*)ws)),
                              (float*)(wg + ((char*)lstat - (char*)ws)), (float*)(wg + ((char*)partial - (char*)ws)),
                              (char*)O + (size_t)g * gso * es, ldo, Mq, Mk, D, ldp, nt, dtype, staging, s);

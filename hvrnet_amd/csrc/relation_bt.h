@@ -20,17 +20,18 @@ struct ScoresBTParams {
   int Mq, Mk, D, ntile;
   long ldq, ldk, ldv, ldp;
   float sl2;        // scale * log2(e)
-  int f16;          // operands are IEEE half (HVR_F16) instead of bf16
+  int f16;          // 0: bf16 operands; 1: IEEE half (HVR_F16); 2: split half (HVR_F16S: 4-byte elements, Q / K / P in the
+                    // [32 hi | 32 lo] layout of common.h, Q / K / V / P / Vt alike; P~ stored x 2^12)
   int groups;       // >= 1
   long gs_q, gs_k, gs_v, gs_p, gs_vt, gs_stat;   // group strides in elements (0 with one group)
   int int_max;      // block maxima rounded UP to integers (log2 units): a block's weight relative to the row's largest block is then an
                     // exact power of two, which relation_apply_bt.hip applies on the exponent fields of the P~ fragments
 };
 
-// true when the 352 x 256 tiling applies to ONE group of this shape (two-byte operands, aligned, a tile grid that fills most of the
-// chip in whole rounds); with `groups` > 1 any tile count from 160 up qualifies -- the persistent workgroups take several tiles each
+// true when the 352 x 256 tiling applies to ONE group of this shape (two-byte or, with `split`, split-half operands, aligned, a tile
+// grid that fills most of the chip in whole rounds); with `groups` > 1 any tile count from 160 up qualifies -- the persistent workgroups take several tiles each
 bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, long ldp, const void* Q, const void* K,
-                         const void* V, const void* P, const void* Vt, int groups = 1);
+                         const void* V, const void* P, const void* Vt, int groups = 1, bool split = false);
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream);
 
 // Apply pass on 288 x 256 tiles over the whole key axis (relation_apply_bt.hip), bf16 only, scores written with int_max = 1:

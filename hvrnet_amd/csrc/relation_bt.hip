@@ -60,14 +60,23 @@ template <typename T> __device__ __forceinline__ void mma(const uint4& keys, con
 #ifdef HVR_DBG_BT_NOMMA
   acc[0] += __uint_as_float(keys.x ^ queries.x);
 #else
-  acc = mfma_half<T>(keys, queries, acc);
+  acc = mfma_half<typename std::conditional<std::is_same<T, f16s_t>::value, f16_t, T>::type>(keys, queries, acc);
 #endif
 }
 
 }  // namespace
 
-template <typename HT>   // bf16_t / f16_t: operands move as raw 16-bit words; the MFMA opcode and the P~ pack differ
+// HT = bf16_t / f16_t: operands move as raw 16-bit words; the MFMA opcode and the P~ pack differ.
+// HT = f16s_t (split half, common.h): 4 bytes per logical element, a row's 128-byte line of a K-step holds the hi plane of 32 logical
+// elements in its first 64 bytes and their lo plane in the second -- the SAME LDS image and loader as the two-byte formats (whose second
+// 64 bytes are the K-step's second 32 elements); a K-step is D / 32 long and issues three MFMAs per fragment pair, K_hi x Q_hi,
+// K_hi x Q_lo and K_lo x Q_hi, in six phases instead of four; P~ leaves x 2^12 in the split layout (kSplitProbScale, as the tile
+// engine's EPI_SCORES writes it); the V^T copies move the two planes of a tile as two 16-bit transposes.
+template <typename HT>
 __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresBTParams p) {
+  constexpr bool SPLIT = std::is_same<HT, f16s_t>::value;
+  constexpr int EB = SPLIT ? 4 : 2;          // bytes per logical element in memory
+  constexpr int BKE = SPLIT ? 32 : 64;       // logical elements per K-step (one 128-byte line per row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #ifdef HVR_DBG_BT_SAMEROW
       m &= 63;
 #endif
-      const char* src = qbase + ((long)m * p.ldq * 2 + l_chunk + kt * 128);
+      const char* src = qbase + ((long)m * p.ldq * EB + l_chunk + kt * 128);
 #ifdef HVR_DBG_BT_NODMA
       if (kt == 0)
 #endif
@@ -129,15 +138,15 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #ifdef HVR_DBG_BT_SAMEROW
     n &= 63;
 #endif
-    const char* src = kbase + ((long)n * p.ldk * 2 + l_chunk + kt * 128);
+    const char* src = kbase + ((long)n * p.ldk * EB + l_chunk + kt * 128);
 #ifdef HVR_DBG_BT_NODMA
     if (kt == 0)
 #endif
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(stage + BT_A_BYTES + (i * BT_NT + wave * 64) * 16), 16, 0, 0);
   };
-  const char* q_cur = (const char*)(p.Q + (long)g_cur * p.gs_q);
-  const char* k_cur = (const char*)(p.K + (long)g_cur * p.gs_k);
+  const char* q_cur = (const char*)p.Q + (long)g_cur * p.gs_q * EB;
+  const char* k_cur = (const char*)p.K + (long)g_cur * p.gs_k * EB;
 
   // the first tile's first K-step into stage 0; it lands while the workgroup transposes its share of V through stage 1's memory
   if (has_tile) {
@@ -155,23 +164,26 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   const int here_last = total - (rounds - 1) * nwg;   // tiles of the last round
   const int n_idle = nwg - here_last;                 // workgroups without a tile in it
   const bool vt_by_idle = n_idle >= 16;
-  auto vt_copy = [&](int first, int step) {           // 64 x 64 tiles first + half, first + half + step, ... of the list over all groups
+  auto vt_copy = [&](int first, int step, int tid) {  // 64 x 64 tiles first + half, first + half + step, ... of the list over all groups
 #ifndef HVR_DBG_BT_NOTRANSPOSE
     constexpr int PITCH = 64 * 2 + 16, BUF = 64 * PITCH;
     const int half = tid >> 8, ht = tid & 255;
     char* const tb = smem + BT_STAGE + half * (2 * BUF);
-    const int tr_c = p.D / 64, ntr = tr_c * (int)(p.ldp / 64), ntr_all = ntr * p.groups;
+    // (split half: the hi and the lo plane of a 64 x 64 logical tile are two independent transposes of 16-bit words -- twice the
+    // tiles, plane = tile & 1 -- and only the addressing knows about the [32 hi | 32 lo] groups)
+    constexpr int PLANES = SPLIT ? 2 : 1;
+    const int tr_c = p.D / 64, ntr = tr_c * (int)(p.ldp / 64) * PLANES, ntr_all = ntr * p.groups;
     auto fetch = [&](int tt_all, uint4 (&v)[2]) {     // (clamped addresses + selects: no predicated load, no per-element round trip)
       const bool live = tt_all < ntr_all;
       const int tc = live ? tt_all : ntr_all - 1;
-      const int tg = tc / ntr, tt = tc - tg * ntr;
+      const int tg = tc / ntr, tp = tc - tg * ntr, tt = tp / PLANES, plane = (tp - tt * PLANES) * kSplitPlane;
       const int r0 = (tt / tr_c) * 64, c0 = (tt % tr_c) * 64;
-      const bf16_t* Vg = p.V + (long)tg * p.gs_v;
+      const char* Vg = (const char*)p.V + (long)tg * p.gs_v * EB;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int s = it * 256 + ht, i = s >> 3, q = s & 7;
         const int r = r0 + i, rc = r < p.Mk ? r : p.Mk - 1;
-        const uint4 x = *reinterpret_cast<const uint4*>(Vg + (long)rc * p.ldv + c0 + q * 8);
+        const uint4 x = *reinterpret_cast<const uint4*>(Vg + (long)rc * p.ldv * EB + (SPLIT ? split_col_bytes(c0 + q * 8) + plane : (long)(c0 + q * 8) * 2));
         const bool keep = live && r < p.Mk;
         v[it] = make_uint4(keep ? x.x : 0u, keep ? x.y : 0u, keep ? x.z : 0u, keep ? x.w : 0u);
       }
@@ -192,9 +204,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (live) {
-        const int tg = tt_all / ntr, tt = tt_all - tg * ntr;
+        const int tg = tt_all / ntr, tp = tt_all - tg * ntr, tt = tp / PLANES, plane = (tp - tt * PLANES) * kSplitPlane;
         const int r0 = (tt / tr_c) * 64, c0 = (tt % tr_c) * 64;
-        bf16_t* Vtg = p.Vt + (long)tg * p.gs_vt;
+        char* Vtg = (char*)p.Vt + (long)tg * p.gs_vt * EB;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int s = it * 256 + ht, q = s >> 6, i = s & 63;
@@ -205,7 +217,8 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
             const uint32_t hi = *reinterpret_cast<const bf16_t*>(tbuf + (q * 8 + 2 * e + 1) * PITCH + i * 2);
             w[e] = lo | (hi << 16);
           }
-          *reinterpret_cast<uint4*>(Vtg + (long)(c0 + i) * p.ldp + r0 + q * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+          *reinterpret_cast<uint4*>(Vtg + (long)(c0 + i) * p.ldp * EB + (SPLIT ? split_col_bytes(r0 + q * 8) + plane : (long)(r0 + q * 8) * 2)) =
+              make_uint4(w[0], w[1], w[2], w[3]);
         }
       }
       cur[0] = nxt[0]; cur[1] = nxt[1];
@@ -214,23 +227,23 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the buffers are the first tile's stage 1
 #else
-    (void)first; (void)step;
+    (void)first; (void)step; (void)tid;
 #endif
   };
-  if (!vt_by_idle) vt_copy((int)blockIdx.x * 2, nwg * 2);
+  if (!vt_by_idle) vt_copy((int)blockIdx.x * 2, nwg * 2, tid);
 #ifdef HVR_DBG_BT_CLK
   dbg_t[1] = wall_clock64();
 #endif
 
-  const int nk = p.D / 64;   // even (scores_bt_supported): every tile starts in stage 0 and ends in stage 1
+  const int nk = p.D / BKE;   // even (scores_bt_supported): every tile starts in stage 0 and ends in stage 1
   if (has_tile) for (int round = 0;; ++round) {
   // the tile after this one (its first K-step is this tile's last prefetch)
   const int nxt_tile = tile_of(round + 1);
   const bool has_next = nxt_tile >= 0;
   int g_nxt = g_cur, m0_nxt = m0, n0_nxt = n0;
   if (has_next) locate(nxt_tile, g_nxt, m0_nxt, n0_nxt);
-  const char* q_nxt = (const char*)(p.Q + (long)g_nxt * p.gs_q);
-  const char* k_nxt = (const char*)(p.K + (long)g_nxt * p.gs_k);
+  const char* q_nxt = (const char*)p.Q + (long)g_nxt * p.gs_q * EB;
+  const char* k_nxt = (const char*)p.K + (long)g_nxt * p.gs_k * EB;
 
   f32x4 acc[BT_FM][BT_FN];
 #pragma unroll
@@ -286,17 +299,25 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
       const int lm0 = pre ? m0_nxt : m0, ln0 = pre ? n0_nxt : n0;
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
       uint4 kb[BT_FN], qa[G0];
-      static_for<4>([&](auto PH) {
-        constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? BT_FM - G0 : G0;
+      // phases of a K-step: (64-byte half of the keys' lines, of the queries' lines, row fragments 0..5 / 6..10).  Two-byte formats:
+      // the halves are the two 32-element K halves, (0,0) (0,0) (1,1) (1,1).  Split half: the halves are the hi / lo planes and the
+      // three products K_hi Q_hi, K_hi Q_lo, K_lo Q_hi take two phases each, (0,0) (0,0) (0,1) (0,1) (1,0) (1,0) -- one set of key
+      // fragments live at a time, the hi query fragments read twice (0.31 LDS fragment reads per MFMA)
+      constexpr int NPH = SPLIT ? 6 : 4;
+      static_for<NPH>([&](auto PH) {
+        constexpr int ph = decltype(PH)::value, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? BT_FM - G0 : G0;
+        constexpr int hk = SPLIT ? (ph >= 4 ? 1 : 0) : (ph >> 1);            // half of the key lines this phase multiplies with
+        constexpr int hq = SPLIT ? ((ph == 2 || ph == 3) ? 1 : 0) : (ph >> 1);  // half of the query lines
+        constexpr bool read_keys = SPLIT ? (ph == 0 || ph == 4) : ((ph & 1) == 0);
         // ---- L ----
-        if constexpr ((ph & 1) == 0)
-          static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+        if constexpr (read_keys)
+          static_for<BT_FN>([&](auto J) { kb[decltype(J)::value] = lds_read128<decltype(J)::value * 2048>(hk ? (b0 ^ 64u) : b0); });
         static_for<nr>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          qa[r] = lds_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+          qa[r] = lds_read128<(r0 + r) * 2048>(hq ? (a0 ^ 64u) : a0);
         });
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph < 3) {
+        if constexpr (ph < NPH - 1) {
           if constexpr (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
               constexpr int d = decltype(D)::value;
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
             });
           }
         }
-        if constexpr (ph == 3) {
+        if constexpr (ph == NPH - 1) {
           if constexpr (wmc != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: this barrier is the one in front of K-step kt + 1
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph == 3) {
+        if constexpr (ph == NPH - 1) {
           if constexpr (wmc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -334,7 +355,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     }
     if constexpr (wmc == 0) __builtin_amdgcn_s_barrier();
     };
-    if (wm) kloop(std::integral_constant<int, 1>{});
+    int wsel = wave;   // (an opaque copy: the test is redone per tile from the scalar wave number instead of living in a vector register)
+    asm volatile("" : "+s"(wsel));
+    if (wsel >= BT_WN) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 0>{});
   }
 
@@ -353,14 +376,21 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #else
   {
   // ---------------- epilogue: block max / exp2 / pack / sums ----------------
+  // (the parameters the epilogue alone needs -- P, the statistics, their strides, the scale -- are re-read from the kernel argument
+  // segment here, behind an opaque copy of its address, instead of sitting in scalar registers across the K loop: the kernel ran
+  // out of SGPRs and kept uniform values in vector registers and spill lanes)
+  const __attribute__((address_space(4))) ScoresBTParams* kp =
+      (const __attribute__((address_space(4))) ScoresBTParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
   // (the lane-derived values are re-derived from a laundered copy of the thread index: nothing but the accumulators and the
   // loop's own addresses stays live across the K loop, which runs at the 256-register limit)
-  int etid = threadIdx.x;
-  asm volatile("" : "+v"(etid));
-  const int lane = etid & 63, frag_row = lane & 15, frag_grp = lane >> 4;
-  bf16_t* const Pg = p.P + (long)g_cur * p.gs_p;
-  float* const mst = p.mstat + (long)g_cur * p.gs_stat;
-  float* const lst = p.lstat + (long)g_cur * p.gs_stat;
+  // (the lane index from mbcnt, not from threadIdx.x: the launch's v0 would otherwise have to survive the loop)
+  int elane;   // (volatile: not hoisted out of the tile loop into a register that lives across the K loop)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+  const int lane = elane, frag_row = lane & 15, frag_grp = lane >> 4;
+  char* const Pg = (char*)kp->P + (long)g_cur * kp->gs_p * EB;
+  float* const mst = kp->mstat + (long)g_cur * kp->gs_stat;
+  float* const lst = kp->lstat + (long)g_cur * kp->gs_stat;
   // LDS scratch in STAGE 1 (the last K-step's stage: every wave is done reading it; stage 0 is receiving the next tile's first
   // K-step): [8][176] maxima, [8][176] sums, then one 16-row x 64-key bf16 staging block per wave
   float* red_max = reinterpret_cast<float*>(smem + BT_STAGE);
@@ -369,21 +399,23 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   // launch with 144-byte rows): the 16-byte piece index is XOR-ed with (row & 7) -- the 16 lanes of a ds_read_b128 group then
   // cover all 64 banks -- and rows 8..15 swap the two 8-byte halves of a piece, so that the 16 rows of a ds_write_b64 lane
   // group (same fragment column, rows r and r + 8 on the same piece) land on 32 distinct banks; the h = 1 read swaps them back
-  constexpr int SPITCH = BT_WCOLS * 2;
+  // (split half: a staged row is the 256 bytes of its two [32 hi | 32 lo] groups; 288-byte pitch: the 8-byte writes of a lane group,
+  // 16 rows x 4 fragment groups, land on 32 distinct banks per half)
+  constexpr int SPITCH = SPLIT ? BT_WCOLS * 4 + 32 : BT_WCOLS * 2;
   char* stg = smem + BT_STAGE + 2 * 8 * BT_WROWS * 4 + wave * (16 * SPITCH);
   const int wr_lane = frag_row * SPITCH + (((frag_grp & 1) ^ (frag_row >> 3)) << 3);  // + ((2 j + (g >> 1)) ^ (row & 7)) * 16
   const int blk = wn >> 1;                                          // 128-key block of this wave inside the tile
-  const bool blk_live = n0 + blk * 128 < p.ldp;                     // an odd block count leaves the last tile half empty
+  const bool blk_live = n0 + blk * 128 < kp->ldp;                     // an odd block count leaves the last tile half empty
   const int ncol0 = n0 + wn * BT_WCOLS + frag_grp * 4;              // first key of this lane's fragment-0 columns
   float tmax[BT_FM];
-  if (n0 + BT_BN > p.Mk) {   // (only the last column tile holds keys past Mk: a scalar branch around 2 x 176 VALU operations)
+  if (n0 + BT_BN > kp->Mk) {   // (only the last column tile holds keys past Mk: a scalar branch around 2 x 176 VALU operations)
 #pragma unroll
     for (int i = 0; i < BT_FM; ++i)
 #pragma unroll
       for (int j = 0; j < BT_FN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          acc[i][j][r] = (ncol0 + j * 16 + r < p.Mk) ? acc[i][j][r] : -INFINITY;  // keys past Mk never win the max and get weight 0
+          acc[i][j][r] = (ncol0 + j * 16 + r < kp->Mk) ? acc[i][j][r] : -INFINITY;  // keys past Mk never win the max and get weight 0
   }
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i) {
@@ -401,8 +433,10 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i) {
-    tmax[i] = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * p.sl2;  // block max, log2 units
-    if (p.int_max) tmax[i] = ceilf(tmax[i]);   // (relation_bt.h: exact power-of-two block weights for relation_apply_bt.hip)
+    tmax[i] = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * kp->sl2;  // block max, log2 units
+    if constexpr (!SPLIT) {
+      if (kp->int_max) tmax[i] = ceilf(tmax[i]);   // (relation_bt.h: exact power-of-two block weights for relation_apply_bt.hip)
+    }
   }
   const int st_row = lane >> 3, st_chunk = lane & 7;  // store phase: lane -> (row, 16-byte piece) of the staged block
 #pragma unroll
@@ -412,21 +446,47 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     for (int j = 0; j < BT_FN; ++j) {
       float e[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], p.sl2, -tmax[i]));
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], kp->sl2, -tmax[i]));
       sum += (e[0] + e[1]) + (e[2] + e[3]);
-      *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (frag_grp >> 1)) ^ (frag_row & 7)) << 4)) = make_uint2(pack2<HT>(e[0], e[1]), pack2<HT>(e[2], e[3]));
+      if constexpr (SPLIT) {
+        // stored x 2^12 so that the lo halves stay normal (the apply product takes the factor back); the sums are of the unscaled values
+        // (values in [0, 2^12]: no saturation needed, the split is split2's otherwise)
+        float x[4], hx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = e[r] * kSplitProbScale;
+        const uint32_t h0 = pack2h(x[0], x[1]), h1 = pack2h(x[2], x[3]);
+        unpack2h(h0, hx[0], hx[1]);
+        unpack2h(h1, hx[2], hx[3]);
+        const uint32_t l0 = pack2h(x[0] - hx[0], x[1] - hx[1]), l1 = pack2h(x[2] - hx[2], x[3] - hx[3]);
+        char* dst = stg + frag_row * SPITCH + (int)split_col_bytes(j * 16 + frag_grp * 4);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + kSplitPlane) = make_uint2(l0, l1);
+      } else {
+        *reinterpret_cast<uint2*>(stg + wr_lane + (((2 * j + (frag_grp >> 1)) ^ (frag_row & 7)) << 4)) = make_uint2(pack2<HT>(e[0], e[1]), pack2<HT>(e[2], e[3]));
+      }
     }
     sum = quad_group_sum(sum);
     if (frag_grp == 0) red_sum[wave * BT_WROWS + i * 16 + frag_row] = sum;
     // the wave's 16 x 64 block leaves as two stores of eight whole 128-byte row segments (wave-private staging: the
     // LDS returns in order, no barrier)
+    if constexpr (SPLIT) {
+      // four stores of four whole 256-byte row segments (lane -> row lane / 16, 16-byte piece lane % 16)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = h * 8 + st_row, m = m0 + wm * BT_WROWS + i * 16 + row;
-      uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
-      if (h) v = make_uint4(v.z, v.w, v.x, v.y);
-      if (m < p.Mq && blk_live)
-        *reinterpret_cast<uint4*>(Pg + (long)m * p.ldp + n0 + wn * BT_WCOLS + st_chunk * 8) = v;
+      for (int h = 0; h < 4; ++h) {
+        const int row = h * 4 + (lane >> 4), m = m0 + wm * BT_WROWS + i * 16 + row;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((lane & 15) << 4));
+        if (m < kp->Mq && blk_live)
+          *reinterpret_cast<uint4*>(Pg + ((long)m * kp->ldp + n0 + wn * BT_WCOLS) * 4 + ((lane & 15) << 4)) = v;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 8 + st_row, m = m0 + wm * BT_WROWS + i * 16 + row;
+        uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
+        if (h) v = make_uint4(v.z, v.w, v.x, v.y);
+        if (m < kp->Mq && blk_live)
+          *reinterpret_cast<uint4*>(Pg + ((long)m * kp->ldp + n0 + wn * BT_WCOLS + st_chunk * 8) * 2) = v;
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -437,9 +497,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
     for (int i = 0; i < BT_FM; ++i) {
       const int row = i * 16 + frag_row, m = m0 + wm * BT_WROWS + row;
       const float sum = red_sum[wave * BT_WROWS + row] + red_sum[(wave + 1) * BT_WROWS + row];
-      if (m < p.Mq) {
-        mst[(long)m * p.ntile + t] = tmax[i];
-        lst[(long)m * p.ntile + t] = sum;
+      if (m < kp->Mq) {
+        mst[(long)m * kp->ntile + t] = tmax[i];
+        lst[(long)m * kp->ntile + t] = sum;
       }
     }
   }
@@ -456,7 +516,9 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
   if (vt_by_idle && (int)blockIdx.x >= here_last) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the last tile's epilogue scratch shares the copy's LDS buffers
-    vt_copy(((int)blockIdx.x - here_last) * 2, n_idle * 2);
+    int vlane;   // (the thread index rebuilt from the wave number and mbcnt: the launch's v0 does not have to survive the tile loop)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(vlane));
+    vt_copy(((int)blockIdx.x - here_last) * 2, n_idle * 2, wave * 64 + vlane);
   }
 #ifdef HVR_DBG_BT_CLK
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -474,13 +536,21 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 }
 
 bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, long ldp, const void* Q, const void* K,
-                         const void* V, const void* P, const void* Vt, int groups) {
-  const uintptr_t al = reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
-                       reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Vt);
-  if (al & 15) return false;
-  // (D % 128: an even number of K-steps, so that every tile of a persistent workgroup starts in LDS stage 0)
-  if (D % 128 || ldq % 8 || ldk % 8 || ldv % 8 || ldp % 128 || groups < 1) return false;
-  if ((long)Mq * ldq * 2 >= (1L << 31) || (long)Mk * ldk * 2 >= (1L << 31)) return false;
+                         const void* V, const void* P, const void* Vt, int groups, bool split) {
+  if (split) {
+    // split half: 128-byte lines of [32 hi | 32 lo].  (D % 64: an even number of K-steps, whole 64 x 64 V^T tiles)
+    const uintptr_t al = reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(P) |
+                         reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(Vt);
+    if ((al & 127) || D % 64 || ldq % 32 || ldk % 32 || ldv % 32 || ldp % 128 || groups < 1) return false;
+    if ((long)Mq * ldq * 4 >= (1L << 31) || (long)Mk * ldk * 4 >= (1L << 31)) return false;
+  } else {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
+                         reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Vt);
+    if (al & 15) return false;
+    // (D % 128: an even number of K-steps, so that every tile of a persistent workgroup starts in LDS stage 0)
+    if (D % 128 || ldq % 8 || ldk % 8 || ldv % 8 || ldp % 128 || groups < 1) return false;
+    if ((long)Mq * ldq * 2 >= (1L << 31) || (long)Mk * ldk * 2 >= (1L << 31)) return false;
+  }
   // the 352 x 256 shape only pays once the tile grid fills most of the chip
   const long tiles = (long)((Mq + BT_BM - 1) / BT_BM) * ((ldp + BT_BN - 1) / BT_BN);
   if (Mk < 128 || tiles * groups > (1L << 20)) return false;
@@ -495,10 +565,12 @@ hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream) {
   per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_scores_bt_kernel<f16s_t>), hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS);
   });
   // one launch of one workgroup per CU: persistent over the tile list of every group; the workgroups a short list leaves without a
   // tile still carry their share of the V^T copies
-  if (p.f16) hipLaunchKernelGGL(relation_scores_bt_kernel<f16_t>, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
+  if (p.f16 == 2) hipLaunchKernelGGL(relation_scores_bt_kernel<f16s_t>, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
+  else if (p.f16) hipLaunchKernelGGL(relation_scores_bt_kernel<f16_t>, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
   else hipLaunchKernelGGL(relation_scores_bt_kernel<bf16_t>, dim3(256), dim3(BT_NT), BT_LDS, stream, p);
   return hipGetLastError();
 }

@@ -328,9 +328,10 @@ def allreduce_leg(dist, world, head, device, iters=5):
 
 
 def stream_side_measurement(head):
-    """The pipelined stream loop with the window graph on a stream confined to 96 CUs (GraphedStream(window_cus=96)), measured by
-    tools/stream_bench.py in a process of its own: where a HIP stream's launches queue depends on how many streams the process
-    has used before, and after this script's ladder of graph builds the confined window loses its gain (tools/stream_bench.py)."""
+    """The pipelined stream loop with two frames in flight (GraphedStream(frame_lanes=2)) and the window graph on a stream of its own
+    (window_cus: the CUs of that stream; 256 = the chip), on 8 hardware queues, measured by tools/stream_bench.py in a process of its
+    own: where a HIP stream's launches queue depends on how many streams the process has used before and on GPU_MAX_HW_QUEUES, which
+    the runtime reads when it starts; after this script's ladder of graph builds the loop loses its gain (tools/stream_bench.py)."""
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stream_bench.py'), '--head', head], capture_output=True, text=True, timeout=300)
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])

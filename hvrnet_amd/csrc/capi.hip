@@ -131,8 +131,12 @@ static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int
 
 // K slices for a tile-engine product (linear layer or conv) whose 128 x 64 tile grid leaves most of the chip idle (0 / 1 = not split): the slices bring
 // the launch to ~1.5 workgroups per CU, at least 4 K-steps each
-static int fewrow_slices(const GemmParams& p) {
+static int fewrow_mode() {   // HVR_CONV_SPLITK: 0 = few-row forms off; 1 (default) = kpar.hip where it applies, else K slices + reduce; 2 = always the latter
   static const int on = std::getenv("HVR_CONV_SPLITK") ? std::atoi(std::getenv("HVR_CONV_SPLITK")) : 1;
+  return on;
+}
+static int fewrow_slices(const GemmParams& p) {
+  const int on = fewrow_mode();
   constexpr int target = 512, mink = 8, minper = 4;
   if (!on || p.dtype != DT_BF16 || !p.staging || p.out_f32 || p.tile_hint != 0) return 1;
   if (p.N % 8 || p.ldc % 8 || (p.resid && p.ldr % 8) || !aligned16(p.C) || (p.resid && !aligned16(p.resid)) || (p.bias && !aligned16(p.bias))) return 1;
@@ -210,8 +214,12 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream) {
     if (tiles > 192 && tiles <= 256) return check_launch(run_pc(p, EPI_LINEAR, 128, (hipStream_t)stream), "hvr_gemm (pc)");
   }
   const int slices = fewrow_slices(p);
-  if (slices > 1 && d->ws && aligned16(d->ws) && d->ws_bytes >= (size_t)slices * p.M * p.N * 4)
+  if (slices > 1 && d->ws && aligned16(d->ws) && d->ws_bytes >= (size_t)slices * p.M * p.N * 4) {
+    // (a caller that hands a few-row workspace asked for the few-row forms: K sliced across the waves of a workgroup where the
+    // shape allows -- no partials, one launch -- else across workgroups + a reduce launch)
+    if (fewrow_mode() == 1 && kpar_supported(p)) return check_launch(run_kpar(p, (hipStream_t)stream), "hvr_gemm(K-parallel waves)");
     return check_launch(run_fewrow_split(p, slices, d->ws, (hipStream_t)stream), "hvr_gemm(split-K)");
+  }
   return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm");
 }
 
@@ -336,6 +344,7 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
   }
   const int slices = (path == 0 ? fewrow_slices(p) : 1);
   if (slices > 1 && d->ws && aligned16(d->ws) && d->ws_bytes >= (size_t)slices * p.M * p.N * 4) {
+    if (fewrow_mode() == 1 && kpar_supported(p)) return check_launch(run_kpar(p, (hipStream_t)stream), "hvr_conv2d_nhwc(K-parallel waves)");
     const hipError_t e = run_fewrow_split(p, slices, d->ws, (hipStream_t)stream);
     return check_launch(e, "hvr_conv2d_nhwc(split-K)");
   }

@@ -95,5 +95,8 @@ constexpr int kBigHint = kNumTileShapes + 4, kBigForce = kNumTileShapes + 5;  //
 bool bigtile_supported(const GemmParams& p, bool throughput);
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream);
 hipError_t run_pc(const GemmParams& p, int epi, int bn, hipStream_t stream);
+// Few-row products with K sliced across the waves of one workgroup per 64 x 64 tile (kpar.hip): no partials in memory, no reduce launch
+bool kpar_supported(const GemmParams& p);
+hipError_t run_kpar(const GemmParams& p, hipStream_t stream);
 
 }  // namespace hvr

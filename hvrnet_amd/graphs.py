@@ -221,7 +221,7 @@ class GraphedStream(object):
     A frame may be pushed several times without recomputing it (`repeat_last()`): the reference pads the first and last
     windows of a video with copies of a frame (test.py:201-212, 257-300)."""
 
-    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1, fewrow_split=True, window_cus=None):
+    def __init__(self, model, frame, meta, rescale=True, warmup=2, n_out=2, lookahead=1, fewrow_split=True, window_cus=None, frame_lanes=1):
         # window_cus: every graph of this object is captured as ONE chain (the RPN branch behind res5, the second read-out branch
         # behind the first).  A graph with parallel branches replayed on a CU-masked stream makes the runtime set its branch
         # streams up from that stream -- hipGraphLaunch segfaulted (ROCm 7.2) when that was the process's first forked replay --
@@ -234,12 +234,12 @@ class GraphedStream(object):
                     setattr(obj, attr, False)
                     undo.append((obj, attr))
         try:
-            self._build(model, frame, meta, rescale, warmup, n_out, lookahead, fewrow_split, window_cus)
+            self._build(model, frame, meta, rescale, warmup, n_out, lookahead, fewrow_split, window_cus, max(1, int(frame_lanes)))
         finally:
             for obj, attr in undo:
                 delattr(obj, attr)   # back to the class attribute
 
-    def _build(self, model, frame, meta, rescale, warmup, n_out, lookahead, fewrow_split, window_cus):
+    def _build(self, model, frame, meta, rescale, warmup, n_out, lookahead, fewrow_split, window_cus, frame_lanes=1):
         assert frame.is_cuda and frame.dim() == 4 and frame.shape[0] == 1
         # window_cus = n (meant for the pipelined loop, push_async / commit / emit): everything that touches the window buffers --
         # graph C, graph W, the padding / staging graphs -- is replayed on ONE stream confined to n of the chip's CUs
@@ -342,29 +342,39 @@ class GraphedStream(object):
         # Graph FC (frame -> staging rows `nxt`) is captured on that stream, with its own memory pool and its own per-stream
         # scratch and side streams (it runs concurrently with the window graphs); graph C (staging rows -> window buffers)
         # belongs to the main stream's family.
-        self._fstream = torch.cuda.Stream(device=dev)
-        self._fstream.wait_stream(self._stream)
-        self.frame_nxt = self.frame.clone()
-        self.nxt = dict(f1=torch.zeros_like(self.last['f1']), props=torch.zeros_like(self.last['props']), count=torch.zeros_like(self.last['count']))
-        with torch.no_grad(), torch.cuda.stream(self._fstream):
-            for _ in range(max(1, warmup)):
-                self._frame_entry(self.frame_nxt)
-            self._fstream.synchronize()
-            self.graph_fc = torch.cuda.CUDAGraph()
-            with _capture(self.graph_fc, stream=self._fstream):
-                e = self._frame_entry(self.frame_nxt)
-                self.nxt['f1'].copy_(e['f1'])
-                self.nxt['props'].copy_(e['props'])
-                self.nxt['count'].copy_(e['count'])
-        self._stream.wait_stream(self._fstream)
-        with torch.no_grad(), torch.cuda.stream(self._stream):
-            self.graph_c = torch.cuda.CUDAGraph()
-            with _capture(self.graph_c, stream=self._stream, pool=self.graph_f.pool()):
-                self.last['f1'].copy_(self.nxt['f1'])
-                self.last['props'].copy_(self.nxt['props'])
-                self.last['count'].copy_(self.nxt['count'])
-                self._push_from(self.last)
-        self._ev_fc, self._ev_commit, self._pending_frame = torch.cuda.Event(), None, None
+        # frame_lanes = L > 1: L frames in flight, each with a graph FC, a stream, staging rows and a graph C of its own, taken in turn
+        # by push_async() and committed in arrival order.  One frame's chain is ~150 launches of at most 152 small workgroups -- a
+        # latency chain that leaves most of the chip idle; two chains side by side overlap almost completely, which moves the loop's
+        # bound from the frame chain to the window graph (tools/stream_bench.py --frame-lanes 2).
+        self._lanes = []
+        for _ in range(frame_lanes):
+            lane = dict(stream=torch.cuda.Stream(device=dev), ev_fc=torch.cuda.Event(), ev_commit=None, pending=None)
+            lane['stream'].wait_stream(self._stream)
+            lane['frame'] = self.frame.clone()
+            lane['nxt'] = dict(f1=torch.zeros_like(self.last['f1']), props=torch.zeros_like(self.last['props']), count=torch.zeros_like(self.last['count']))
+            with torch.no_grad(), torch.cuda.stream(lane['stream']):
+                for _ in range(max(1, warmup)):
+                    self._frame_entry(lane['frame'])
+                lane['stream'].synchronize()
+                lane['graph_fc'] = torch.cuda.CUDAGraph()
+                with _capture(lane['graph_fc'], stream=lane['stream']):
+                    e = self._frame_entry(lane['frame'])
+                    lane['nxt']['f1'].copy_(e['f1'])
+                    lane['nxt']['props'].copy_(e['props'])
+                    lane['nxt']['count'].copy_(e['count'])
+            self._stream.wait_stream(lane['stream'])
+            with torch.no_grad(), torch.cuda.stream(self._stream):
+                lane['graph_c'] = torch.cuda.CUDAGraph()
+                with _capture(lane['graph_c'], stream=self._stream, pool=self.graph_f.pool()):
+                    self.last['f1'].copy_(lane['nxt']['f1'])
+                    self.last['props'].copy_(lane['nxt']['props'])
+                    self.last['count'].copy_(lane['nxt']['count'])
+                    self._push_from(self.last)
+            self._lanes.append(lane)
+        self._push_turn = self._commit_turn = 0
+        # (lane 0 under the names the one-lane form had)
+        self._fstream, self.frame_nxt, self.nxt = self._lanes[0]['stream'], self._lanes[0]['frame'], self._lanes[0]['nxt']
+        self.graph_fc, self.graph_c = self._lanes[0]['graph_fc'], self._lanes[0]['graph_c']
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._hist = []  # the window's input frames (copies), for the exact re-run of a window that holds a short frame
         _LIVE.add(self)
@@ -441,32 +451,41 @@ class GraphedStream(object):
             self._hist = (self._hist + [self.frame.clone()])[-self.T:]
 
     def push_async(self, frame):
-        """A new frame arrives: its per-frame part (graph FC) starts on the frame stream and runs beside whatever the caller's
-        stream does next (normally `emit()` of the current window).  `commit()` moves its rows into the window buffers."""
-        assert self._pending_frame is None, 'commit() the frame in flight first'
+        """A new frame arrives: its per-frame part (graph FC) starts on a frame stream -- the next lane's in turn -- and runs beside
+        whatever the caller's stream does next (normally `emit()` of the current window) and beside the other lanes' frames.
+        `commit()` moves the rows of the OLDEST frame in flight into the window buffers."""
+        lane = self._lanes[self._push_turn % len(self._lanes)]
+        assert lane['pending'] is None, 'commit() the frame in flight first (%d frame lane(s))' % len(self._lanes)
         cur = torch.cuda.current_stream(self.frame.device)
-        self._fstream.wait_stream(cur)                 # `frame` is produced on the caller's stream
-        if self._ev_commit is not None:
-            self._fstream.wait_event(self._ev_commit)  # the staging rows of the previous frame have been taken
+        lane['stream'].wait_stream(cur)                 # `frame` is produced on the caller's stream
+        if lane['ev_commit'] is not None:
+            lane['stream'].wait_event(lane['ev_commit'])  # the staging rows of this lane's previous frame have been taken
         _check_live(self)
-        with torch.cuda.stream(self._fstream):
-            self.frame_nxt.copy_(frame, non_blocking=True)
+        with torch.cuda.stream(lane['stream']):
+            lane['frame'].copy_(frame, non_blocking=True)
             if frame.is_cuda:
-                frame.record_stream(self._fstream)   # the caller may drop or recycle `frame` before the copy has run on the frame stream
-            self._pending_frame = self.frame_nxt.clone()   # (on the frame stream: nothing of the loop is enqueued on the caller's)
-            self.graph_fc.replay()
-            self._ev_fc.record(self._fstream)
+                frame.record_stream(lane['stream'])   # the caller may drop or recycle `frame` before the copy has run on the frame stream
+            lane['pending'] = lane['frame'].clone()   # (on the frame stream: nothing of the loop is enqueued on the caller's)
+            lane['graph_fc'].replay()
+            lane['ev_fc'].record(lane['stream'])
+        self._push_turn += 1
+
+    @property
+    def _pending_frame(self):
+        return self._lanes[self._commit_turn % len(self._lanes)]['pending']
 
     def commit(self):
-        """The frame started by push_async() enters the window buffers (graph C on the caller's stream, behind graph FC)."""
-        assert self._pending_frame is not None, 'push_async() first'
+        """The oldest frame started by push_async() enters the window buffers (graph C on the caller's stream, behind its graph FC)."""
+        lane = self._lanes[self._commit_turn % len(self._lanes)]
+        assert lane['pending'] is not None, 'push_async() first'
         with self._window_stream() as st:
-            st.wait_event(self._ev_fc)
-            self.graph_c.replay()
-            self._ev_commit = torch.cuda.Event()
-            self._ev_commit.record(st)
-        self._hist = (self._hist + [self._pending_frame])[-self.T:]
-        self._pending_frame = None
+            st.wait_event(lane['ev_fc'])
+            lane['graph_c'].replay()
+            lane['ev_commit'] = torch.cuda.Event()
+            lane['ev_commit'].record(st)
+        self._hist = (self._hist + [lane['pending']])[-self.T:]
+        lane['pending'] = None
+        self._commit_turn += 1
 
     def push_batch(self, frames):
         """`lookahead` frames arrive together: their per-frame rows are computed in one batch (graph FB) and staged; call

@@ -207,6 +207,45 @@ def test_pipelined_stream_equals_the_sequential_stream(kind, window_cus):
         _check(kind, g, w)
 
 
+@pytest.mark.parametrize('lanes,window_cus', [(2, 256), (3, None)])
+def test_frame_lanes_give_the_windows_of_the_sequential_stream(lanes, window_cus):
+    """GraphedStream(frame_lanes=L): L frames in flight, each with its own graph FC / stream / staging rows / graph C, taken in turn
+    by push_async() and committed in arrival order (tools/stream_bench.py: one frame's chain of ~150 small launches leaves most of the
+    chip idle, two chains side by side overlap).  Every emitted window equals the sequential push() / emit() stream's bit for bit,
+    over two passes of the video; the lanes are primed with L frames before the first commit."""
+    fi, n_prop = 2, 24
+    model = hvrnet_amd.build_model(hvr_config(frame_interval=fi, nms_post=n_prop), S.synth_state_dict('hvr'), torch.bfloat16, DEV)
+    frames = [S.synth_frame(i, img_hw=HW, pad_hw=PAD).to(DEV) for i in range(7)]
+    meta = S.synth_meta(HW, PAD)
+    seq = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False)
+    order = frames + frames
+    want = []
+    for f in order:
+        seq.push(f)
+        want.append(seq.emit().result())
+    gs = GraphedStream(model, frames[0], meta, rescale=True, fewrow_split=False, window_cus=window_cus, frame_lanes=lanes)
+    assert len(gs._lanes) == lanes
+    got, pend, fed = [], None, 0
+    for _ in range(lanes):
+        gs.push_async(order[fed])
+        fed += 1
+    with pytest.raises(AssertionError):
+        gs.push_async(order[0])           # every lane holds a frame: commit() first
+    for i in range(len(order)):
+        gs.commit()                       # the OLDEST frame in flight enters the window
+        if fed < len(order):
+            gs.push_async(order[fed])     # the freed lane takes the next frame
+            fed += 1
+        nxt = gs.emit()
+        if pend is not None:
+            got.append(pend.result())
+        pend = nxt
+    got.append(pend.result())
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        _check('hvr', g, w)
+
+
 @pytest.mark.parametrize('kind', ['hvr', 'selsa'])
 def test_graphed_stream_with_look_ahead_batches_gives_the_same_frames(kind):
     """`lookahead` frames through the per-frame part in one batch (graph FB), then one `advance(i)` + `emit()` per output

@@ -17,6 +17,6 @@ if [ -n "${NMS_DBG:-}" ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC 
 X=$B/expand.o
 if [ -n "${EXPAND_DBG:-}" ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $defs -c hvrnet_amd/csrc/expand.hip -o dbg/$name/expand.o; X=dbg/$name/expand.o; fi
 # (gemm_f16.o / bigtile.o: the product build's objects -- half-operand tile kernels and the 288 x 256 tiles are not what these builds probe)
-hipcc --offload-arch=gfx950 -shared -fPIC dbg/$name/gemm.o $B/gemm_f16.o $B/bigtile.o $X $B/conv3x3.o dbg/$name/pc_gemm.o $B/misc.o $B/roi_align.o $N $B/stem.o $B/targets.o $B/ingest.o dbg/$name/relation_apply_bt.o $B/expand_split.o dbg/$name/relation_bt.o dbg/$name/capi.o -o dbg/libhvr_$name.so
+hipcc --offload-arch=gfx950 -shared -fPIC dbg/$name/gemm.o $B/gemm_f16.o $B/bigtile.o $B/kpar.o $X $B/conv3x3.o dbg/$name/pc_gemm.o $B/misc.o $B/roi_align.o $N $B/stem.o $B/targets.o $B/ingest.o dbg/$name/relation_apply_bt.o $B/expand_split.o dbg/$name/relation_bt.o dbg/$name/capi.o -o dbg/libhvr_$name.so
 rm -rf dbg/$name
 echo built dbg/libhvr_$name.so

@@ -34,7 +34,9 @@
  *       HVR_BIGTILE=0         no 288 x 256 tiles (csrc/bigtile.hip): the tile engine's shapes everywhere (bit-identical)
  *       HVR_EXPAND=0          no row-panel expand kernel (csrc/expand.hip): tile engine / big tiles
  *       HVR_CONV3=0           no weights-resident 3x3 kernel for Cin = 64 (csrc/conv3x3.hip): tile engine (bit-identical)
- *       HVR_CONV_SPLITK=0     no K slices for few-row tile-engine products (stream mode's one-frame launches)
+ *       HVR_CONV_SPLITK       few-row products given a workspace (stream mode's one-frame launches): 0 = unsplit; 1 (default) = K
+ *                             sliced across the waves of a workgroup where the shape allows (csrc/kpar.hip: one launch, no
+ *                             partials), else across workgroups + a reduce launch; 2 = always the latter
  *       HVR_SPLIT_NORMALIZE   split-half relation: 0 = block weights folded into the apply pass, 1 = one normalising sweep + plain
  *                             product (default: by query-row count)
  *       HVR_REL_GROUPED       hvr_relation_fwd_grouped: 0 = one hvr_relation_fwd per group, 1 = grouped scores + per-group apply,
@@ -134,7 +136,9 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream);
  * (grid.y), each slice writing an f32 partial tile, followed by one reduce launch that adds bias / residual, applies the
  * ReLU and rounds once to bf16.  0 = this descriptor is not split (enough tiles, short K, f32, or a dedicated kernel takes it);
  * the call then ignores ws.  With ws == NULL or ws_bytes smaller than this the conv runs unsplit (same result up to the f32
- * summation order of the K slices).  HVR_CONV_SPLITK=0 in the environment turns the split off. */
+ * summation order of the K slices).  Shapes with a short K loop (K <= 2 560, at most 320 tiles of 64 x 64) do not use the
+ * workspace: their K-steps are dealt to the four waves of one workgroup per tile and summed in the LDS (csrc/kpar.hip) --
+ * same contract, one launch.  HVR_CONV_SPLITK=0 in the environment turns both forms off, 2 the second one. */
 size_t hvr_conv2d_splitk_workspace_bytes(const hvr_conv_desc* d);
 /* Which kernel hvr_conv2d_nhwc would run for this descriptor, without launching anything (pointers are only inspected
  * for alignment): 0 = MFMA tile engine (gemm.hip), 1 = row-panel kernel for the Bottleneck's channel-expanding 1x1 conv

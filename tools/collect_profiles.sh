@@ -25,6 +25,12 @@ for G in 1 4; do
   rm -rf /tmp/r_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --iters 10 --groups $G > $out/rel_bench$sfx.txt 2>/dev/null
   $T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench$sfx.txt
 done
+# the split-half relation core (scores on the persistent big tiles since round 5; V^T by its idle workgroups): kernel stats, 1 / 4 windows per call
+for G in 1 4; do
+  sfx=$([ $G = 1 ] && echo "" || echo "_g$G")
+  rm -rf /tmp/r_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --dtype f16x2 --iters 10 --groups $G > $out/rel_bench_f16x2$sfx.txt 2>/dev/null
+  $T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench_f16x2$sfx.txt
+done
 # (the traffic files are keyed to this build: put them where bench.py looks before the bench lines are taken)
 r=${ROUND:-r05}; cp $out/relation_traffic.json profiles/${r}_relation_traffic.json; cp $out/relation_traffic_g4.json profiles/${r}_relation_traffic_g4.json
 $T python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
@@ -69,7 +75,6 @@ $T python tools/train_bench.py --steps 10 --warmup 2 --head hvr > $out/train_ben
 rm -rf /tmp/t_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/t_ks -o train -- python tools/train_bench.py --steps 3 --warmup 1 > /dev/null 2>&1
 $T python tools/rocpd_stats.py $(db /tmp/t_ks) > $out/train_kernel_stats.txt
 $T python tools/ingest_bench.py > $out/ingest_bench.json 2>/dev/null
-$T python tools/stream_bench.py > $out/stream_bench.json 2>/dev/null   # pipelined stream mode, window graph on a 96-CU stream (own process)
 fi
 
 if [[ $parts == *D* ]]; then
@@ -99,6 +104,8 @@ ls $out
 
 if [[ $parts == *E* ]]; then
 $T python tools/stream_bench.py --steps 60 2>/dev/null | tail -1 > $out/stream_bench.json
+$T python tools/frame_breakdown.py 2>/dev/null > $out/frame_breakdown.txt
+{ echo; echo "# the same with HVR_CONV_SPLITK=2 (K sliced across workgroups + a reduce launch everywhere, rounds 3-4's form):"; HVR_CONV_SPLITK=2 $T python tools/frame_breakdown.py 2>/dev/null; } >> $out/frame_breakdown.txt
 rm -rf /tmp/f_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/f_ks -o fr -- python tools/frame_profile.py 20 > $out/stream_frame.log 2>&1
 { echo "# tools/frame_profile.py under rocprofv3 --kernel-trace --stats: 23 frames (3 warm-up + 20), eager; per-frame rows = call counts that are multiples of 23 (the rest is one-time weight packing)"; grep "one frame" $out/stream_frame.log; $T python tools/rocpd_stats.py $(db /tmp/f_ks) | head -45; } > $out/stream_frame_kernel_stats.txt
 rm -rf /tmp/rw_ks; HVR_RPN_WIDE=4 $T rocprofv3 --kernel-trace --stats -d /tmp/rw_ks -o rpn -- python tools/rpn_probe.py > $out/rpn_wide_probe.txt 2>&1

@@ -17,7 +17,15 @@
 // a bf16 is sign | 8 exponent bits | 7 mantissa bits, P~ >= 0, and a value scaled below 2^-126 saturates to zero).  One accumulator
 // set, a plain product, rows x 1 / L in the epilogue, L = sum_t 2^-(m* - m_t) l_t built in the prologue from the block sums.  The
 // scaling is exact, so the result differs from the folded form's only by the association of the f32 sum (one running sum over all
-// keys here; per-block partials there).  bf16 only: a half's 5-bit exponent cannot carry the block weights.
+// keys here; per-block partials there).  IEEE half operands (HVR_F16) keep the folded pass: a half's 5-bit exponent cannot carry the
+// block weights in ONE plane.
+//
+// Split half (HT = f16s_t, round 5): P~ x 2^12 and V^T arrive as [32 hi | 32 lo] groups (common.h), a K-step is 32 keys = one 128-byte
+// line per row holding both planes, and a fragment pair takes three MFMAs -- V_hi P_hi, V_hi P_lo, V_lo P_hi, six phases as in
+// relation_bt.hip.  The block weight 2^-s is applied by v_pk_mul_f16 on BOTH planes of the P~ fragments: exact while the product is a
+// normal half; a product below 2^-14 is rounded as a subnormal (absolute error <= 2^-25 against a row whose largest block holds a
+// 2^11..2^12, i.e. <= 2^-36 relative per term) and 2^-s itself is zero from s = 25 on -- such a block's terms are below 2^-13 / 2^12 of
+// the row's largest.  This replaces the normalising sweep over P~ (24 us per window) + the plain product on 144 x 128 tiles (111 us).
 #include <type_traits>
 #include "common.h"
 #include "relation_bt.h"
@@ -54,6 +62,12 @@ __device__ __forceinline__ uint32_t ab_lower(uint32_t w, uint32_t sub) {
   asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(w), "v"(sub));
   return d;
 }
+// both IEEE halves of a word times the half pair in `w2` (a power of two in both lanes)
+__device__ __forceinline__ uint32_t ab_scale_h(uint32_t w, uint32_t w2) {
+  uint32_t d;
+  asm("v_pk_mul_f16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(w2));
+  return d;
+}
 __device__ __forceinline__ void ab_load_lds16(const void* base, char* lds, unsigned voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
@@ -65,7 +79,12 @@ __device__ __forceinline__ void ab_load_lds16(const void* base, char* lds, unsig
 
 }  // namespace
 
+template <typename HT>   // bf16_t, or f16s_t (split half)
 __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTParams p) {
+  constexpr bool SPLIT = std::is_same<HT, f16s_t>::value;
+  constexpr int EB = SPLIT ? 4 : 2;         // bytes per logical element in memory
+  constexpr int BKE = SPLIT ? 32 : 64;      // keys per K-step (one 128-byte line per row)
+  constexpr int BLK_SHIFT = SPLIT ? 2 : 1;  // K-steps per 128-key block, log2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,8 +96,8 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
   const int g = tile / tpg, tr = tile - g * tpg;
   const int pid_m = tr / tiles_n, pid_n = tr - pid_m * tiles_n;
   const int m0 = pid_m * AB_BM, n0 = pid_n * AB_BN;
-  const char* const rs_a = (const char*)(p.P + (long)g * p.gs_p);
-  const char* const rs_b = (const char*)(p.Vt + (long)g * p.gs_vt);
+  const char* const rs_a = (const char*)p.P + (long)g * p.gs_p * EB;
+  const char* const rs_b = (const char*)p.Vt + (long)g * p.gs_vt * EB;
 
 #ifdef HVR_DBG_AB_CLK
   long long dbg_t[5];
@@ -91,10 +110,10 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
   for (int i = 0; i < AB_A_SLOTS; ++i) {
     int m = m0 + i * 64 + l_row;
     m = m < p.Mq ? m : p.Mq - 1;
-    a_off[i] = (int)((long)m * p.ldp * 2) + l_chunk;
+    a_off[i] = (int)((long)m * p.ldp * EB) + l_chunk;
   }
 #pragma unroll
-  for (int i = 0; i < AB_B_SLOTS; ++i) b_off[i] = (int)((long)(n0 + i * 64 + l_row) * p.ldp * 2) + l_chunk;
+  for (int i = 0; i < AB_B_SLOTS; ++i) b_off[i] = (int)((long)(n0 + i * 64 + l_row) * p.ldp * EB) + l_chunk;
   auto dma_a = [&](auto I, char* stage, int koff) {
     constexpr int i = decltype(I)::value;
     if (i < AB_A_SLOTS - 1 || wave < AB_LAST_WAVES) ab_load_lds16(rs_a, stage + (i * AB_NT + wave * 64) * 16, (unsigned)a_off[i], koff);
@@ -140,7 +159,8 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
           for (int e = 0; e < 4; ++e) {
             float d = mx - mm[e];               // a non-negative integer (both are integer-valued: relation_bt.hip, int_max)
             d = d < 255.f ? d : 255.f;
-            w |= (uint32_t)(int)d << (8 * e);
+            // table byte: bf16 -- the shift; split half -- 25 - min(shift, 25), from which the K loop forms the half 2^-shift
+            w |= (uint32_t)(int)(SPLIT ? 25.f - fminf(d, 25.f) : d) << (8 * e);
             L += c < nt4 ? __builtin_amdgcn_exp2f(-d) * ll[e] : 0.f;
           }
           if (c < nt4) tab32[c] = w;
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
         for (int t = 0; t < p.ntile; ++t) {
           float d = mx - ms[t];
           d = d < 255.f ? d : 255.f;
-          tab[tid * AB_MAXBLK + t] = (unsigned char)(int)d;
+          tab[tid * AB_MAXBLK + t] = (unsigned char)(int)(SPLIT ? 25.f - fminf(d, 25.f) : d);
           L += __builtin_amdgcn_exp2f(-d) * ls[t];
         }
         rinv[tid] = 1.f / L;
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
   const uint32_t b_lane = ab_lds_off(smem) + AB_A_BYTES + (wn * AB_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
   const uint32_t t_lane = ab_lds_off(smem) + AB_TAB + (wrow0 + frag_row) * AB_MAXBLK;   // + block index; fragment i: offset i * 16 * 72
 
-  const int nk = (int)(p.ldp / 64);
+  const int nk = (int)(p.ldp / BKE);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef HVR_DBG_AB_CLK
@@ -197,21 +217,27 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
       char* nxt = smem + ((kt + 1) & 1) * AB_STAGE;
       const int koff = (kt + 1 < nk ? kt + 1 : kt) * 128;   // (the last step re-fetches itself into the idle stage: one uniform stream)
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
-      const uint32_t tb = t_lane + (uint32_t)(kt >> 1);       // this K-step's 128-key block
+      const uint32_t tb = t_lane + (uint32_t)(kt >> BLK_SHIFT);       // this K-step's 128-key block
       uint4 kb[AB_FN], qa[G0];
       uint32_t sh[FM];
-      static_for<4>([&](auto PH) {
-        constexpr int ph = decltype(PH)::value, h = ph >> 1, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? FM - G0 : G0;
+      // phases: (64-byte half of the V^T lines, of the P~ lines, row fragments 0..4 / 5..8); two-byte formats: the halves are the K
+      // halves, (0,0) (0,0) (1,1) (1,1); split half: the halves are the hi / lo planes, V_hi P_hi, V_hi P_lo, V_lo P_hi in two phases each
+      constexpr int NPH = SPLIT ? 6 : 4;
+      static_for<NPH>([&](auto PH) {
+        constexpr int ph = decltype(PH)::value, r0 = (ph & 1) ? G0 : 0, nr = (ph & 1) ? FM - G0 : G0;
+        constexpr int hv = SPLIT ? (ph >= 4 ? 1 : 0) : (ph >> 1);
+        constexpr int hp = SPLIT ? ((ph == 2 || ph == 3) ? 1 : 0) : (ph >> 1);
+        constexpr bool read_v = SPLIT ? (ph == 0 || ph == 4) : ((ph & 1) == 0);
         // ---- L ----
         if constexpr (ph == 0) static_for<FM>([&](auto R) { sh[decltype(R)::value] = ab_read8<decltype(R)::value * 16 * AB_MAXBLK>(tb); });
-        if constexpr ((ph & 1) == 0)
-          static_for<AB_FN>([&](auto J) { kb[decltype(J)::value] = ab_read128<decltype(J)::value * 2048>(h ? (b0 ^ 64u) : b0); });
+        if constexpr (read_v)
+          static_for<AB_FN>([&](auto J) { kb[decltype(J)::value] = ab_read128<decltype(J)::value * 2048>(hv ? (b0 ^ 64u) : b0); });
         static_for<nr>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          qa[r] = ab_read128<(r0 + r) * 2048>(h ? (a0 ^ 64u) : a0);
+          qa[r] = ab_read128<(r0 + r) * 2048>(hp ? (a0 ^ 64u) : a0);
         });
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph < 3) {
+        if constexpr (ph < NPH - 1) {
           if constexpr (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
               constexpr int d = decltype(D)::value;
@@ -226,7 +252,7 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
             });
           }
         }
-        if constexpr (ph == 3) {
+        if constexpr (ph == NPH - 1) {
           if constexpr (wmc != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -234,7 +260,18 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
         // ---- C ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph == 0) static_for<FM>([&](auto R) { sh[decltype(R)::value] *= 0x00800080u; });   // byte -> both exponent fields
+        if constexpr (ph == 0) static_for<FM>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          if constexpr (SPLIT) {
+            // byte e = 25 - min(shift, 25) -> the half 2^-shift in both lanes: a normal number (exponent field e - 10) from e = 11 up,
+            // the subnormal 1 << (e - 1) below, zero for e = 0
+            const uint32_t e = sh[r];
+            const uint32_t hbits = e >= 11u ? (e - 10u) << 10 : ((1u << e) >> 1);
+            sh[r] = hbits * 0x00010001u;
+          } else {
+            sh[r] *= 0x00800080u;   // byte -> both exponent fields
+          }
+        });
         __builtin_amdgcn_s_setprio(1);
         static_for<nr>([&](auto R) {
           constexpr int r = decltype(R)::value;
@@ -243,17 +280,19 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
           const uint4 x = qa[r];
           if (s == 0x12345u) acc[r0 + r][0][0] += 1.f;
 #else
-          const uint4 x = make_uint4(ab_lower(qa[r].x, s), ab_lower(qa[r].y, s), ab_lower(qa[r].z, s), ab_lower(qa[r].w, s));
+          uint4 x;
+          if constexpr (SPLIT) x = make_uint4(ab_scale_h(qa[r].x, s), ab_scale_h(qa[r].y, s), ab_scale_h(qa[r].z, s), ab_scale_h(qa[r].w, s));
+          else x = make_uint4(ab_lower(qa[r].x, s), ab_lower(qa[r].y, s), ab_lower(qa[r].z, s), ab_lower(qa[r].w, s));
 #endif
           static_for<AB_FN>([&](auto J) {
             constexpr int j = decltype(J)::value;
             // V^T rows as the MFMA "A" operand: a lane ends up with 4 consecutive output columns of one query row (gemm.hip)
-            acc[r0 + r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, x), acc[r0 + r][j], 0, 0, 0);
+            acc[r0 + r][j] = mfma_half<typename std::conditional<SPLIT, f16_t, bf16_t>::type>(kb[j], x, acc[r0 + r][j]);
           });
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ph == 3) {
+        if constexpr (ph == NPH - 1) {
           if constexpr (wmc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -274,32 +313,50 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
     int etid = threadIdx.x;
     asm volatile("" : "+v"(etid));  // lane-derived values re-derived here: nothing but the accumulators lives across the loop
     const int el = etid & 63, erow = el & 15, egrp = el >> 4;
-    constexpr int SPITCH = AB_WCOLS * 2;
+    constexpr int SPITCH = SPLIT ? AB_WCOLS * 4 + 32 : AB_WCOLS * 2;   // (split half: 256-byte row segments, relation_bt.hip's staging)
     char* stg = smem + wave * (16 * SPITCH);
     const float* rinv = reinterpret_cast<const float*>(smem + AB_RINV);
-    bf16_t* const Og = p.O + (long)g * p.gs_o;
+    char* const Og = (char*)p.O + (long)g * p.gs_o * EB;
     const int wr_lane = erow * SPITCH + (((egrp & 1) ^ (erow >> 3)) << 3);
     const int st_row = el >> 3, st_chunk = el & 7;
     float rs[AB_FM];
 #pragma unroll
-    for (int i = 0; i < AB_FM; ++i) rs[i] = rinv[wrow0 + i * 16 + erow];
+    for (int i = 0; i < AB_FM; ++i) rs[i] = rinv[wrow0 + i * 16 + erow] * (SPLIT ? 1.f / kSplitProbScale : 1.f);   // (P~ is stored x 2^12)
     __syncthreads();  // every wave is done reading the ring (group 0 leaves the loop a barrier ahead of group 1's last reads)
 #pragma unroll
     for (int i = 0; i < AB_FM; ++i) {
 #pragma unroll
       for (int j = 0; j < AB_FN; ++j) {
-        char* slot = stg + wr_lane + (((2 * j + (egrp >> 1)) ^ (erow & 7)) << 4);
         float e[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = acc[i][j][r] * rs[i];
-        *reinterpret_cast<uint2*>(slot) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+        if constexpr (SPLIT) {
+          uint32_t h0, l0, h1, l1;
+          split2(e[0], e[1], h0, l0);
+          split2(e[2], e[3], h1, l1);
+          char* dst = stg + erow * SPITCH + (int)split_col_bytes(j * 16 + egrp * 4);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + kSplitPlane) = make_uint2(l0, l1);
+        } else {
+          char* slot = stg + wr_lane + (((2 * j + (egrp >> 1)) ^ (erow & 7)) << 4);
+          *reinterpret_cast<uint2*>(slot) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+        }
       }
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = h * 8 + st_row, m = m0 + wrow0 + i * 16 + row;
-        uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
-        if (h) v = make_uint4(v.z, v.w, v.x, v.y);
-        if (m < p.Mq) *reinterpret_cast<uint4*>(Og + (long)m * p.ldo + n0 + wn * AB_WCOLS + st_chunk * 8) = v;
+        for (int h = 0; h < 4; ++h) {
+          const int row = h * 4 + (el >> 4), m = m0 + wrow0 + i * 16 + row;
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((el & 15) << 4));
+          if (m < p.Mq) *reinterpret_cast<uint4*>(Og + ((long)m * p.ldo + n0 + wn * AB_WCOLS) * 4 + ((el & 15) << 4)) = v;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = h * 8 + st_row, m = m0 + wrow0 + i * 16 + row;
+          uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
+          if (h) v = make_uint4(v.z, v.w, v.x, v.y);
+          if (m < p.Mq) *reinterpret_cast<uint4*>(Og + ((long)m * p.ldo + n0 + wn * AB_WCOLS + st_chunk * 8) * 2) = v;
+        }
       }
     }
   }
@@ -311,10 +368,11 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
 #endif
 }
 
-bool apply_bt_supported(int Mq, int Mk, int D, long ldp, long ldo, const void* P, const void* Vt, const void* O, int groups) {
+bool apply_bt_supported(int Mq, int Mk, int D, long ldp, long ldo, const void* P, const void* Vt, const void* O, int groups, bool split) {
   const uintptr_t al = reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Vt) | reinterpret_cast<uintptr_t>(O);
-  if ((al & 15) || groups < 1 || D % AB_BN || ldp % 128 || ldo % 8) return false;
-  if (ldp / 128 > AB_MAXBLK || (long)Mq * ldp * 2 >= (1L << 31) || (long)D * ldp * 2 >= (1L << 31)) return false;
+  const int es = split ? 4 : 2;
+  if ((al & (split ? 127 : 15)) || groups < 1 || D % AB_BN || ldp % 128 || ldo % (split ? 32 : 8)) return false;
+  if (ldp / 128 > AB_MAXBLK || (long)Mq * ldp * es >= (1L << 31) || (long)D * ldp * es >= (1L << 31)) return false;
   // pays once the 288 x 256 grid over all groups covers most of the chip: four windows of 4 500 rows are 256 tiles, three 192
   const long tiles = (long)groups * ((Mq + AB_BM - 1) / AB_BM) * (D / AB_BN);
   return Mk >= 128 && tiles >= 176 && tiles <= 65535;
@@ -323,10 +381,12 @@ bool apply_bt_supported(int Mq, int Mk, int D, long ldp, long ldo, const void* P
 hipError_t run_apply_bt(const ApplyBTParams& p, hipStream_t stream) {
   static std::atomic<unsigned> attr_set_dev{0};   // (the attribute is per device)
   per_device_once(attr_set_dev, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_apply_bt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_apply_bt_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_apply_bt_kernel<f16s_t>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
   });
   const int tiles = p.groups * ((p.Mq + AB_BM - 1) / AB_BM) * (p.D / AB_BN);
-  hipLaunchKernelGGL(relation_apply_bt_kernel, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
+  if (p.split) hipLaunchKernelGGL(relation_apply_bt_kernel<f16s_t>, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
+  else hipLaunchKernelGGL(relation_apply_bt_kernel<bf16_t>, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
   return hipGetLastError();
 }
 

@@ -434,9 +434,7 @@ __global__ __launch_bounds__(BT_NT) void relation_scores_bt_kernel(const ScoresB
 #pragma unroll
   for (int i = 0; i < BT_FM; ++i) {
     tmax[i] = fmaxf(tmax[i], red_max[(wave ^ 1) * BT_WROWS + i * 16 + frag_row]) * kp->sl2;  // block max, log2 units
-    if constexpr (!SPLIT) {
-      if (kp->int_max) tmax[i] = ceilf(tmax[i]);   // (relation_bt.h: exact power-of-two block weights for relation_apply_bt.hip)
-    }
+    if (kp->int_max) tmax[i] = ceilf(tmax[i]);   // (relation_bt.h: exact power-of-two block weights for relation_apply_bt.hip)
   }
   const int st_row = lane >> 3, st_chunk = lane & 7;  // store phase: lane -> (row, 16-byte piece) of the staged block
 #pragma unroll

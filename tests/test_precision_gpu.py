@@ -164,32 +164,41 @@ def test_relation_on_half_and_split_operands(Mq, Mk, dtype):
 
 
 @pytest.mark.parametrize('G,Mq,Mk', [(1, 4500, 4500), (3, 4321, 4100), (4, 4500, 4500)])
-def test_split_half_relation_window_size_on_the_big_score_tiles(G, Mq, Mk):
+def test_split_half_relation_window_size_on_the_big_tiles(G, Mq, Mk):
     """Window-sized split-half problems take the persistent 352 x 256 score tiles (relation_bt.hip on f16s_t: the hi / lo planes of a
-    K-step are the two 64-byte halves of the staged lines, three MFMAs per fragment pair in six phases), G of them in ONE launch
-    through hvr_relation_fwd_grouped; V^T, the normalising sweep and the product stay per group.  Against float64 attention over the
-    operands as the kernel sees them on sampled rows (first / last rows of the first, a middle and the last row tile), with a
-    dominant key in the last (ragged, for Mk = 4 100) key tile and one in the first; the grouped call equals the single calls bit
-    for bit (same tiles, same order of sums)."""
+    K-step are the two 64-byte halves of the staged lines, three MFMAs per fragment pair in six phases, V^T planes copied by the idle
+    workgroups), G of them in ONE launch through hvr_relation_fwd_grouped, and from three groups on the 288 x 256 apply launch
+    (relation_apply_bt.hip on f16s_t: integer block maxima, the block weight 2^-shift applied to both planes of the P~ fragments by
+    v_pk_mul_f16) instead of the normalising sweep + plain product.
+      exact=True : every group's rows are hvr_relation_fwd's bit for bit (scores of all groups in one launch, the tail per group);
+      default    : against float64 attention over the operands as the kernel sees them, on sampled rows (first / last rows of the
+                   first, a middle and the last row tile), at the tolerance of the single call -- with a dominant key in the last
+                   (ragged, for Mk = 4 100) key tile, one in the first, and a row whose blocks span more than the 2^-25 the half
+                   weights can express (their terms vanish, as they do in f32)."""
     D = 1024
     q, k, v = _rand((G * Mq, D), 61, 0.5), _rand((G * Mk, D), 62, 0.5), _rand((G * Mk, D), 63)
     for g in range(G):
-        k[g * Mk + Mk - 2] = q[g * Mq + 7] * 24.0          # row 7: a late-block maximum far above the rest
+        k[g * Mk + Mk - 2] = q[g * Mq + 7] * 24.0          # row 7: a late-block maximum far above the rest (shift > 25 everywhere else)
         k[g * Mk + 5] = q[g * Mq + Mq - 1] * 16.0          # the last row: an early-block maximum
+        k[g * Mk + 900] = q[g * Mq + 3] * 1.2              # row 3: a block a few powers of two above its neighbours (small shifts)
     qd, kd, vd = _to(q, SPLIT), _to(k, SPLIT), _to(v, SPLIT)
-    o = native.relation_fwd_grouped(qd, kd, vd, 1.0 / math.sqrt(D), G)
-    assert o.dtype == SPLIT and torch.equal(_back(o), _back(native.relation_fwd_grouped(qd, kd, vd, 1.0 / math.sqrt(D), G)))
+    sc = 1.0 / math.sqrt(D)
+    o = native.relation_fwd_grouped(qd, kd, vd, sc, G)
+    oe = native.relation_fwd_grouped(qd, kd, vd, sc, G, exact=True)
+    assert o.dtype == SPLIT and torch.equal(_back(o), _back(native.relation_fwd_grouped(qd, kd, vd, sc, G)))
     rows = torch.cat([torch.arange(0, 12), torch.arange(346, 358), torch.arange(2100, 2108), torch.arange(Mq - 12, Mq)])
     for g in range(G):
-        single = native.relation_fwd(qd[g * Mq:(g + 1) * Mq], kd[g * Mk:(g + 1) * Mk], vd[g * Mk:(g + 1) * Mk], 1.0 / math.sqrt(D))
-        og = _back(o[g * Mq:(g + 1) * Mq])
-        assert torch.equal(og, _back(single)), 'group %d differs from hvr_relation_fwd' % g
+        single = _back(native.relation_fwd(qd[g * Mq:(g + 1) * Mq], kd[g * Mk:(g + 1) * Mk], vd[g * Mk:(g + 1) * Mk], sc))
+        og, oeg = _back(o[g * Mq:(g + 1) * Mq]), _back(oe[g * Mq:(g + 1) * Mq])
+        assert torch.equal(oeg, single), 'group %d: exact form differs from hvr_relation_fwd' % g
         qf = _back(qd[g * Mq:(g + 1) * Mq])[rows].double()
         kf, vf = _back(kd[g * Mk:(g + 1) * Mk]).double(), _back(vd[g * Mk:(g + 1) * Mk]).double()
         ref = torch.softmax(qf @ kf.t() / math.sqrt(D), dim=1) @ vf
         assert torch.isfinite(og).all()
-        err, scale = (og[rows].double() - ref).abs().max().item(), ref.abs().max().item()
-        assert err < 1e-5 * scale, (g, err, scale)
+        scale = ref.abs().max().item()
+        err, err_single = (og[rows].double() - ref).abs().max().item(), (single[rows].double() - ref).abs().max().item()
+        assert err < 1e-5 * scale and err_single < 1e-5 * scale, (g, err, err_single, scale)
+        assert (og - single).abs().max().item() < 2e-5 * single.abs().max().item(), g
 
 
 def test_relation_split_half_peaky_rows():

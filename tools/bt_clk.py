@@ -17,10 +17,11 @@ if os.environ.get('HVR_BENCH_LIB'):
 ap = argparse.ArgumentParser()
 ap.add_argument('--groups', type=int, default=4)
 ap.add_argument('--m', type=int, default=4500)
+ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16x2'])
 args = ap.parse_args()
 G = args.groups
 torch.manual_seed(0)
-q, k, v = (torch.randn(G * args.m, 1024, device='cuda').bfloat16() for _ in range(3))
+q, k, v = (native.as_operand(torch.randn(G * args.m, 1024, device='cuda'), torch.bfloat16 if args.dtype == 'bf16' else native.SPLIT) for _ in range(3))
 os.environ.setdefault('HVR_QUIET', '1')
 for i in range(2):   # the second call's lines are the warm ones
     print('CALL %d' % i, flush=True)

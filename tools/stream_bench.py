@@ -10,7 +10,7 @@ workgroups, 1.40 ms by itself; the window graph is 0.92 ms by itself on the whol
 beside a 96-CU window: 535 frames/s.  TWO frames in flight overlap almost completely -- if the streams get hardware queues of their
 own: the HIP runtime multiplexes its streams onto GPU_MAX_HW_QUEUES = 4 queues by default and a queue is served in order; with 8
 (set below, before the runtime starts) two frame lanes + the window on its own full-width stream run at 675 frames/s (4 queues: 582;
-three lanes collide again: 425-480).
+three lanes lose, 380-480, whatever the queues).
 
     python tools/stream_bench.py [--head hvr] [--window-cus 256] [--frame-lanes 2] [--steps 40]
 """

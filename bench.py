@@ -345,7 +345,7 @@ def lib_sha16():
     return hashlib.sha256(open(native.LIB_PATH, 'rb').read()).hexdigest()[:16]
 
 
-def relation_traffic(units=1):
+def relation_traffic(units=1, dtype='bf16'):
     """HBM-side bytes per relation-core call (of `units` windows: the grouped call's PMC passes carry `groups`) from the committed PMC
     passes (bench.py cannot collect PMC itself): the newest profiles/r*_relation_traffic.json whose `lib_sha16` names THIS build of
     libhvr_hip.so and whose `groups` is `units`; None (stale) otherwise."""
@@ -356,9 +356,9 @@ def relation_traffic(units=1):
             d = json.load(open(path))
         except ValueError:
             continue
-        if d.get('lib_sha16') == sha and int(d.get('groups', 1)) == int(units):
+        if d.get('lib_sha16') == sha and int(d.get('groups', 1)) == int(units) and d.get('dtype', 'bf16') == dtype:
             return d.get('traffic_bytes_per_launch'), os.path.basename(path)
-    return None, 'no profiles/r*_relation_traffic*.json was collected for this build (lib %s) with groups = %d: tools/collect_profiles.sh' % (sha, units)
+    return None, 'no profiles/r*_relation_traffic*.json was collected for this build (lib %s) with groups = %d, dtype %s: tools/collect_profiles.sh' % (sha, units, dtype)
 
 
 # ------------------------------------------------------------------------------------------ stub (CPU host-logic self-test)
@@ -578,7 +578,7 @@ def main(argv=None):
             return None
         peak = MFMA_PEAK_TF[mode]
         ach = full['work'] / (full['ms'] * 1e-3) / 1e12
-        traffic = relation_traffic(units)[0] if T * n_prop == 4500 and mode == 'bf16' else None
+        traffic = relation_traffic(units, mode)[0] if T * n_prop == 4500 and mode in ('bf16', 'f16x2') else None
         return dict(kernel='relation core', bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
                     traffic=traffic, launches=full['calls'], avg_ms=round(full['ms'] / full['calls'], 4), units_per_launch=units,
                     ms_per_unit=round(full['ms'] / full['calls'] / units, 4), flops_per_launch=full['work'] / full['calls'])

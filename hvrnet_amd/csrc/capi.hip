@@ -730,7 +730,7 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
   }
   // exact: every group's result is hvr_relation_fwd's bit for bit (one scores launch over all groups, its arithmetic per tile
   // unchanged; the apply pass per group) -- what the batched head's equality tests run
-  const bool bt_apply = !exact && mode >= 2 && (dtype == HVR_BF16 || split) && apply_bt_supported(Mq, Mk, D, ldp, ldo, P, Vt, O, groups, split);
+  const bool bt_apply = !exact && mode >= 2 && (two_byte || split) && apply_bt_supported(Mq, Mk, D, ldp, ldo, P, Vt, O, groups, split);
   ScoresBTParams b;
   b.Q = (const bf16_t*)Q; b.K = (const bf16_t*)K; b.P = (bf16_t*)P; b.mstat = mstat; b.lstat = lstat;
   b.V = (const bf16_t*)V; b.Vt = (bf16_t*)Vt; b.Mq = Mq; b.Mk = Mk; b.D = D; b.ntile = nt;
@@ -743,7 +743,7 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
     ApplyBTParams a;
     a.P = (const bf16_t*)P; a.Vt = (const bf16_t*)Vt; a.mstat = mstat; a.lstat = lstat; a.O = (bf16_t*)O;
     a.Mq = Mq; a.D = D; a.ntile = nt; a.ldp = ldp; a.ldo = ldo; a.groups = groups;
-    a.gs_p = b.gs_p; a.gs_vt = b.gs_vt; a.gs_stat = b.gs_stat; a.gs_o = gso; a.split = split ? 1 : 0;
+    a.gs_p = b.gs_p; a.gs_vt = b.gs_vt; a.gs_stat = b.gs_stat; a.gs_o = gso; a.split = split ? 1 : (dtype == HVR_F16 ? 2 : 0);
     return check_launch(run_apply_bt(a, s), "relation (grouped): apply");
   }
   for (int g = 0; g < groups; ++g) {

@@ -17,8 +17,8 @@
 // a bf16 is sign | 8 exponent bits | 7 mantissa bits, P~ >= 0, and a value scaled below 2^-126 saturates to zero).  One accumulator
 // set, a plain product, rows x 1 / L in the epilogue, L = sum_t 2^-(m* - m_t) l_t built in the prologue from the block sums.  The
 // scaling is exact, so the result differs from the folded form's only by the association of the f32 sum (one running sum over all
-// keys here; per-block partials there).  IEEE half operands (HVR_F16) keep the folded pass: a half's 5-bit exponent cannot carry the
-// block weights in ONE plane.
+// keys here; per-block partials there).  A half's 5-bit exponent cannot carry the block weights as a field shift: IEEE half operands
+// (HVR_F16) take the multiplied weights described next for split half, on their one plane.
 //
 // Split half (HT = f16s_t, round 5): P~ x 2^12 and V^T arrive as [32 hi | 32 lo] groups (common.h), a K-step is 32 keys = one 128-byte
 // line per row holding both planes, and a fragment pair takes three MFMAs -- V_hi P_hi, V_hi P_lo, V_lo P_hi, six phases as in
@@ -79,9 +79,10 @@ __device__ __forceinline__ void ab_load_lds16(const void* base, char* lds, unsig
 
 }  // namespace
 
-template <typename HT>   // bf16_t, or f16s_t (split half)
+template <typename HT>   // bf16_t, f16_t (IEEE half: the split-half instance's multiplied weights on its one plane) or f16s_t (split half)
 __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTParams p) {
   constexpr bool SPLIT = std::is_same<HT, f16s_t>::value;
+  constexpr bool HALFW = !std::is_same<HT, bf16_t>::value;   // block weights as a half multiplied on (v_pk_mul_f16), not as an exponent-field shift
   constexpr int EB = SPLIT ? 4 : 2;         // bytes per logical element in memory
   constexpr int BKE = SPLIT ? 32 : 64;      // keys per K-step (one 128-byte line per row)
   constexpr int BLK_SHIFT = SPLIT ? 2 : 1;  // K-steps per 128-key block, log2
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
           for (int e = 0; e < 4; ++e) {
             float d = mx - mm[e];               // a non-negative integer (both are integer-valued: relation_bt.hip, int_max)
             d = d < 255.f ? d : 255.f;
-            // table byte: bf16 -- the shift; split half -- 25 - min(shift, 25), from which the K loop forms the half 2^-shift
-            w |= (uint32_t)(int)(SPLIT ? 25.f - fminf(d, 25.f) : d) << (8 * e);
+            // table byte: bf16 -- the shift; half / split half -- 25 - min(shift, 25), from which the K loop forms the half 2^-shift
+            w |= (uint32_t)(int)(HALFW ? 25.f - fminf(d, 25.f) : d) << (8 * e);
             L += c < nt4 ? __builtin_amdgcn_exp2f(-d) * ll[e] : 0.f;
           }
           if (c < nt4) tab32[c] = w;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
         for (int t = 0; t < p.ntile; ++t) {
           float d = mx - ms[t];
           d = d < 255.f ? d : 255.f;
-          tab[tid * AB_MAXBLK + t] = (unsigned char)(int)(SPLIT ? 25.f - fminf(d, 25.f) : d);
+          tab[tid * AB_MAXBLK + t] = (unsigned char)(int)(HALFW ? 25.f - fminf(d, 25.f) : d);
           L += __builtin_amdgcn_exp2f(-d) * ls[t];
         }
         rinv[tid] = 1.f / L;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph == 0) static_for<FM>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          if constexpr (SPLIT) {
+          if constexpr (HALFW) {
             // byte e = 25 - min(shift, 25) -> the half 2^-shift in both lanes: a normal number (exponent field e - 10) from e = 11 up,
             // the subnormal 1 << (e - 1) below, zero for e = 0
             const uint32_t e = sh[r];
@@ -281,13 +282,13 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
           if (s == 0x12345u) acc[r0 + r][0][0] += 1.f;
 #else
           uint4 x;
-          if constexpr (SPLIT) x = make_uint4(ab_scale_h(qa[r].x, s), ab_scale_h(qa[r].y, s), ab_scale_h(qa[r].z, s), ab_scale_h(qa[r].w, s));
+          if constexpr (HALFW) x = make_uint4(ab_scale_h(qa[r].x, s), ab_scale_h(qa[r].y, s), ab_scale_h(qa[r].z, s), ab_scale_h(qa[r].w, s));
           else x = make_uint4(ab_lower(qa[r].x, s), ab_lower(qa[r].y, s), ab_lower(qa[r].z, s), ab_lower(qa[r].w, s));
 #endif
           static_for<AB_FN>([&](auto J) {
             constexpr int j = decltype(J)::value;
             // V^T rows as the MFMA "A" operand: a lane ends up with 4 consecutive output columns of one query row (gemm.hip)
-            acc[r0 + r][j] = mfma_half<typename std::conditional<SPLIT, f16_t, bf16_t>::type>(kb[j], x, acc[r0 + r][j]);
+            acc[r0 + r][j] = mfma_half<typename std::conditional<HALFW, f16_t, bf16_t>::type>(kb[j], x, acc[r0 + r][j]);
           });
         });
         __builtin_amdgcn_s_setprio(0);
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(AB_NT) void relation_apply_bt_kernel(const ApplyBTP
           *reinterpret_cast<uint2*>(dst + kSplitPlane) = make_uint2(l0, l1);
         } else {
           char* slot = stg + wr_lane + (((2 * j + (egrp >> 1)) ^ (erow & 7)) << 4);
-          *reinterpret_cast<uint2*>(slot) = make_uint2(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]));
+          *reinterpret_cast<uint2*>(slot) = make_uint2(pack2<HT>(e[0], e[1]), pack2<HT>(e[2], e[3]));
         }
       }
       if constexpr (SPLIT) {
@@ -383,9 +384,11 @@ hipError_t run_apply_bt(const ApplyBTParams& p, hipStream_t stream) {
   per_device_once(attr_set_dev, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_apply_bt_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_apply_bt_kernel<f16s_t>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relation_apply_bt_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
   });
   const int tiles = p.groups * ((p.Mq + AB_BM - 1) / AB_BM) * (p.D / AB_BN);
-  if (p.split) hipLaunchKernelGGL(relation_apply_bt_kernel<f16s_t>, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
+  if (p.split == 2) hipLaunchKernelGGL(relation_apply_bt_kernel<f16_t>, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
+  else if (p.split) hipLaunchKernelGGL(relation_apply_bt_kernel<f16s_t>, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
   else hipLaunchKernelGGL(relation_apply_bt_kernel<bf16_t>, dim3(tiles), dim3(AB_NT), AB_LDS, stream, p);
   return hipGetLastError();
 }

@@ -34,7 +34,7 @@ bool scores_bt_supported(int Mq, int Mk, int D, long ldq, long ldk, long ldv, lo
                          const void* V, const void* P, const void* Vt, int groups = 1, bool split = false);
 hipError_t run_scores_bt(const ScoresBTParams& p, hipStream_t stream);
 
-// Apply pass on 288 x 256 tiles over the whole key axis (relation_apply_bt.hip), bf16 or split half, scores written with int_max = 1:
+// Apply pass on 288 x 256 tiles over the whole key axis (relation_apply_bt.hip), bf16 / half / split half, scores written with int_max = 1:
 //   O[g] = diag(1 / L) . (P~[g] with every 128-key block's exponent lowered by m* - m_block) . V^T[g]^T
 struct ApplyBTParams {
   const bf16_t* P;      // [Mq][ldp]
@@ -46,7 +46,8 @@ struct ApplyBTParams {
   long ldp, ldo;
   int groups;
   long gs_p, gs_vt, gs_stat, gs_o;
-  int split;            // 0: bf16; 1: split half (P~ x 2^12, Vt, O in the [32 hi | 32 lo] layout; block weights by v_pk_mul_f16 on both planes)
+  int split;            // 0: bf16; 1: split half (P~ x 2^12, Vt, O in the [32 hi | 32 lo] layout; block weights by v_pk_mul_f16 on both planes);
+                        // 2: IEEE half (two-byte operands, block weights by v_pk_mul_f16)
 };
 bool apply_bt_supported(int Mq, int Mk, int D, long ldp, long ldo, const void* P, const void* Vt, const void* O, int groups, bool split = false);
 hipError_t run_apply_bt(const ApplyBTParams& p, hipStream_t stream);

@@ -219,7 +219,7 @@ int hvr_relation_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, con
  * own Q / K / V / O: group g's operands start gs* ELEMENTS behind group 0's (a batched head keeps the groups' rows back to back in
  * one matrix: gs = rows x ld).  The reference runs one clip at a time (tools/test.py:214-250 -> hnmb_rcnn.py:195-222), so a stage of
  * W clips is W calls of the lines above; here the 352 x 256 score tiles of all groups are one list walked by persistent workgroups
- * (csrc/relation_bt.hip: HVR_BF16, HVR_F16, HVR_F16S) and, for bf16 / split half and >= 3 window-sized groups, the apply pass is one
+ * (csrc/relation_bt.hip: HVR_BF16, HVR_F16, HVR_F16S) and, for those formats and >= 3 window-sized groups, the apply pass is one
  * launch of 288 x 256 tiles over the whole key axis (csrc/relation_apply_bt.hip).  Per group the result is hvr_relation_fwd's up to
  * the association of the f32 sums -- split half: and up to the half rounding of block-weighted probabilities below 2^-26 of a row's
  * largest -- (exact != 0: bit for bit: the scores launch stays grouped, the apply pass runs per group); shapes the grouped kernels

@@ -25,6 +25,11 @@ for G in 1 4; do
   rm -rf /tmp/r_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/r_ks -o rel -- python tools/rel_bench.py --iters 10 --groups $G > $out/rel_bench$sfx.txt 2>/dev/null
   $T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench$sfx.txt
 done
+# the split-half relation core, four windows per call: FETCH / WRITE passes -> the traffic file bench.py reads for the f16x2 mode's roofline
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/rs_$c; $T rocprofv3 --kernel-trace --pmc $c -d /tmp/rs_$c -o rel -- python tools/rel_bench.py --iters 5 --groups 4 --dtype f16x2 > /dev/null 2>&1
+done
+$T python tools/make_traffic_json.py $(db /tmp/rs_FETCH_SIZE) $(db /tmp/rs_WRITE_SIZE) $out/relation_traffic_f16x2_g4.json 4 f16x2
 # the split-half relation core (scores on the persistent big tiles since round 5; V^T by its idle workgroups): kernel stats, 1 / 4 windows per call
 for G in 1 4; do
   sfx=$([ $G = 1 ] && echo "" || echo "_g$G")
@@ -32,7 +37,7 @@ for G in 1 4; do
   $T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench_f16x2$sfx.txt
 done
 # (the traffic files are keyed to this build: put them where bench.py looks before the bench lines are taken)
-r=${ROUND:-r05}; cp $out/relation_traffic.json profiles/${r}_relation_traffic.json; cp $out/relation_traffic_g4.json profiles/${r}_relation_traffic_g4.json
+r=${ROUND:-r05}; cp $out/relation_traffic.json profiles/${r}_relation_traffic.json; cp $out/relation_traffic_g4.json profiles/${r}_relation_traffic_g4.json; cp $out/relation_traffic_f16x2_g4.json profiles/${r}_relation_traffic_f16x2_g4.json
 $T python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
 $T python bench.py --head selsa --steps 20 --warmup 3 --no-train-step > $out/bench_selsa.json 2>/dev/null
 $T python bench.py --frames 21 --steps 10 --warmup 2 --no-train-step --no-f32-leg --no-side-loops --quick > $out/bench_T21.json 2>/dev/null   # the shipped window length (frame_interval = 10)

@@ -2,7 +2,7 @@
 separate `rocprofv3 --kernel-trace --pmc X` runs), keyed to the sha256 of the libhvr_hip.so that ran (bench.py refuses a file
 whose key names another build).
 
-    python tools/make_traffic_json.py <fetch.db> <write.db> <out.json> [groups]
+    python tools/make_traffic_json.py <fetch.db> <write.db> <out.json> [groups] [bf16|f16x2]
 
 groups = G: the passes ran `tools/rel_bench.py --groups G` (hvr_relation_fwd_grouped: G windows per call); the per-launch figures are per CALL.
 
@@ -34,8 +34,9 @@ def per_kernel(path, counter):
     return agg
 
 
-def main(fetch_db, write_db, out, groups=1):
+def main(fetch_db, write_db, out, groups=1, dtype='bf16'):
     groups = int(groups)
+    es = 2 if dtype == 'f16x2' else 1   # bytes per element relative to the two-byte formats (split half: 4-byte elements)
     f, w = per_kernel(fetch_db, 'FETCH_SIZE'), per_kernel(write_db, 'WRITE_SIZE')
     calls = max(d[0] for k, d in f.items() if 'relation_scores' in k)
     kernels, total = {}, 0.0
@@ -45,15 +46,15 @@ def main(fetch_db, write_db, out, groups=1):
         kernels[k] = dict(launches_per_call=round(f.get(k, w.get(k))[0] / calls, 2), fetch_MB=round(fe / 1e6, 1), write_MB=round(wr / 1e6, 1))
         total += fe + wr
     lib = os.path.join(ROOT, 'hvrnet_amd', 'libhvr_hip.so')
-    json.dump(dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python tools/rel_bench.py --iters 5 --groups %d` '
-                          '(%d window(s) per call, Mq = Mk = 4500, D = 1024, bf16); tools/collect_profiles.sh' % (groups, groups), groups=groups,
+    json.dump(dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python tools/rel_bench.py --iters 5 --groups %d [--dtype]` '
+                          '(%d window(s) per call, Mq = Mk = 4500, D = 1024, %s); tools/collect_profiles.sh' % (groups, groups, dtype), groups=groups, dtype=dtype,
                    note='FETCH_SIZE doubled (gfx950: a 128-byte request counts 64 bytes). Infinity-Cache hits are included: L2-miss traffic, '
                         'an upper bound on HBM traffic.',
                    lib_sha16=hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16], relation_calls=calls, per_full_relation_call=kernels,
-                   traffic_bytes_per_launch=int(total), traffic_bytes_per_window=int(total / groups), algorithmic_bytes_per_launch=36900000 * groups, two_pass_floor_bytes=138700000 * groups,
-                   two_pass_floor_note='Q, K, V, O once (36.9 MB) + P~ written and read once (2 x 41.5 MB) + V^T written and read once (2 x 9.4 MB)'),
+                   traffic_bytes_per_launch=int(total), traffic_bytes_per_window=int(total / groups), algorithmic_bytes_per_launch=36900000 * groups * es, two_pass_floor_bytes=138700000 * groups * es,
+                   two_pass_floor_note='per window, two-byte elements (split half: twice these): Q, K, V, O once (36.9 MB) + P~ written and read once (2 x 41.5 MB) + V^T written and read once (2 x 9.4 MB)'),
               open(out, 'w'), indent=1)
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

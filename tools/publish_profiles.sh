@@ -20,7 +20,7 @@ declare -A map=( [bench.json]=bench.json [bench_prof.json]=bench_profiled_run.js
   [relation_pmc_sq_g4.txt]=relation_pmc_sq_g4.txt [relation_traffic_g4.json]=relation_traffic_g4.json [rel_bench_g4.txt]=relation_kernel_stats_g4.txt
   [window_breakdown_bf16.txt]=window_breakdown_bf16.txt [window_breakdown_bf16_w4.txt]=window_breakdown_bf16_w4.txt
   [window_breakdown_f16x2_w4.txt]=window_breakdown_f16x2_w4.txt [rel_bench_f16x2.txt]=relation_kernel_stats_f16x2.txt
-  [rel_bench_f16x2_g4.txt]=relation_kernel_stats_f16x2_g4.txt [frame_breakdown.txt]=frame_breakdown.txt )
+  [rel_bench_f16x2_g4.txt]=relation_kernel_stats_f16x2_g4.txt [frame_breakdown.txt]=frame_breakdown.txt [relation_traffic_f16x2_g4.json]=relation_traffic_f16x2_g4.json )
 for f in "${!map[@]}"; do
   if [ -s $src/$f ]; then cp $src/$f profiles/${r}_${map[$f]}; fi
 done

@@ -322,8 +322,8 @@ def test_relation_window_size_big_tile_path(Mq, Mk):
                                            (4, 4500, 4500, torch.float16), (2, 300, 4500, torch.bfloat16), (3, 96, 200, torch.float32)])
 def test_relation_grouped_equals_the_single_calls(G, Mq, Mk, dtype):
     """hvr_relation_fwd_grouped: G independent problems of one shape (the windows a batched head has in flight) in one call --
-    persistent 352 x 256 score tiles over all groups (relation_bt.hip) and, for bf16 from three window-sized groups on, the
-    288 x 256 apply launch with the block weights applied on the exponent fields of P~ (relation_apply_bt.hip).
+    persistent 352 x 256 score tiles over all groups (relation_bt.hip) and, from three window-sized groups on, the 288 x 256 apply
+    launch (relation_apply_bt.hip) with the block weights applied on the exponent fields of P~ (bf16) or multiplied on as halves (f16).
       exact=True : every group's rows are hvr_relation_fwd's bit for bit;
       default    : the same up to the association of the f32 sums (one bf16 output ulp), and against the f64 softmax on sampled rows;
     spikes force block-weight shifts in an early and in the last 128-key block; shapes the grouped kernels do not take (key stage,

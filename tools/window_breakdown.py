@@ -36,11 +36,14 @@ def main():
     ap.add_argument('--json', default=None)
     ap.add_argument('--clips', type=int, default=1, help='W independent clips per call (the batched window: detectors.window_device_outputs(clips=W)); rows are per CALL, i.e. for W windows')
     ap.add_argument('--sequence', action='store_true', help='also print the last window call by call, in issue order')
+    ap.add_argument('--side-streams', action='store_true', help='keep the RPN side stream (the product form): rows of calls issued beside it are then intervals of shared chip time, not kernel times')
     args = ap.parse_args()
     T, N, dev = args.frames, 300, 'cuda:0'
     model = hvrnet_amd.build_model((hvr_config if args.head == 'hvr' else selsa_config)(frame_interval=T // 2, nms_post=N),
                                    S.synth_state_dict(args.head), None, dev)
     apply_mode(model, args.mode)
+    if not args.side_streams:   # RPN branch on the main stream: a conv row is the call's own duration
+        model.rpn_side_stream = False
     W = args.clips
     fr = torch.cat([S.synth_frame(i) for i in range(T * W)], 0).to(dev)
     metas = [S.synth_meta() for _ in range(T * W)]

@@ -83,6 +83,7 @@ def parse(argv=None):
                                                            '`value_spread` lists all of them')
     ap.add_argument('--frames', type=int, default=15)
     ap.add_argument('--proposals', type=int, default=300)
+    ap.add_argument('--tol-clips', type=int, default=8, help='synthetic clips the tolerance claim (`within_tolerance`) is checked on: the benchmark\'s + this many - 1 others')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle leg (and with it the `parity` object)')
     ap.add_argument('--quick', action='store_true', help='cpu_baseline on a 3-frame sample (scaled) instead of whole windows')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the precision ladder (the other compute modes\' timings)')
@@ -189,12 +190,15 @@ def cpu_baseline_quick(head, T, n_prop, sd):
                 window_seconds=round(window_s, 3)), None
 
 
+N64_CLIPS = 3   # clips whose oracle window is also evaluated in float64
+
+
 def cpu_baseline_full(head, T, n_prop, sd, clip_ids):
     """SURVEY.md 8(d) "CPU baseline": the CPU oracle ("port": the PyTorch-CPU restatement oracle/hvr_oracle.py, pinned to the
     reference's modules by tests/golden), clip mode, whole windows on all usable host cores: configs[0] first (1 key + 2 reference
     frames, 32 proposals: the reference's own CPU-runnable case, and the warm-up), then ONE window of each clip in `clip_ids` (lists of
     synthetic frame ids; clip 0 is the benchmark's) -- the median of their times is the baseline, their results are the references the
-    tolerance is checked against on more than one clip -- and clip 0 once more in FLOAT64: how far the oracle's own f32 evaluation
+    tolerance is checked against on every clip -- and the first N64_CLIPS clips once more in FLOAT64: how far the oracle's own f32 evaluation
     order moves its outputs (`oracle_noise_floor`).  -> (cpu_baseline dict, [one f32 result per clip], [one f64 result per clip], noise floor, [per clip the f32 run's per-frame proposal lists])."""
     from hvrnet_amd import parity, synthetic as S
     from oracle import hvr_oracle as O
@@ -218,12 +222,15 @@ def cpu_baseline_full(head, T, n_prop, sd, clip_ids):
             times.append(time.time() - t0)
             wants.append(pick(r_))
             props.append([p_.numpy() for p_ in inter_['proposals']])
-        # clip 0 once more in float64 (22 s on 16 cores: the other clips' f64 runs would add 45 s to a default run for two more rows of the
-        # same 3 - 6e-4 px figure; tests/test_fullsize_gpu.py and tools/noise_budget.py print it for other clips and for configs[1])
+        # the first N64 clips once more in FLOAT64 (22 s each on 16 cores): the reference the literal 1e-3 px reading is also printed against,
+        # and the oracle's own f32-vs-f64 distance (tests/test_fullsize_gpu.py and tools/noise_budget.py print it for other clips / configs[1])
         sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        t0 = time.time()
-        wants64 = [pick(O.clip_forward([im.double() for im in imgs0], metas, sd64, head, T // 2, n_prop, T, rpn_cfg=rpn_cfg))]
-        t64 = [time.time() - t0]
+        wants64, t64 = [], []
+        for ids in clip_ids[:N64_CLIPS]:
+            imgs = imgs0 if ids is clip_ids[0] else [S.synth_frame(i) for i in ids]
+            t0 = time.time()
+            wants64.append(pick(O.clip_forward([im.double() for im in imgs], metas, sd64, head, T // 2, n_prop, T, rpn_cfg=rpn_cfg)))
+            t64.append(time.time() - t0)
     runs = sorted(times)
     window_s = runs[len(runs) // 2]
     c1 = sorted(t1[1:])[0]
@@ -232,7 +239,7 @@ def cpu_baseline_full(head, T, n_prop, sd, clip_ids):
                       % (T, len(runs), ' / '.join('%.2f' % r for r in runs)),
                window_seconds=round(window_s, 3), config1_window_seconds=round(c1, 3))
     last = (lambda r: r[-1]) if head == 'hvr' else (lambda r: r)
-    fl = [parity.strict(last(a), last(b)) for a, b in zip(wants[:1], wants64)]
+    fl = [parity.strict(last(a), last(b)) for a, b in zip(wants, wants64)]
     floor = dict(class_flips=[f['class_flips'] for f in fl],   # oracle.clip_forward in float32 against the same code in float64, per clip
                  max_score_err=[float('%.3g' % f['max_score_err']) for f in fl], max_box_err=[float('%.3g' % f['max_box_err']) for f in fl],
                  f64_window_seconds=round(sorted(t64)[len(t64) // 2], 2))
@@ -256,6 +263,17 @@ def within_tolerance(pr):
     within TOL_SCORE, coordinates within TOL_BOX_PX + BOX_RTOL x extent)."""
     from hvrnet_amd import parity
     return parity.within_tolerance(pr)
+
+
+def clip_distance(head, a, b):
+    """How far two results of the SAME clip are apart (final branch, parity.strict position by position) -- e.g. clip 0 of a W-clip call
+    (grouped relation core: one f32 sum associated differently, <= 1 output ulp of the operand format) against the one-window call.  In a
+    mode that carries the tolerance the distance has to be inside it; in bf16 the discontinuous steps may amplify one ulp."""
+    from hvrnet_amd import parity
+    g, w = (a[-1], b[-1]) if head == 'hvr' else (a, b)
+    st = parity.strict(g, w)
+    return dict(identical=same_detections(a, b), class_flips=st['class_flips'], max_score_err=round(st['max_score_err'], 7), max_box_err=round(st['max_box_err'], 5),
+                within_tolerance=parity.within_tolerance(st))
 
 
 def same_detections(a, b):
@@ -332,12 +350,24 @@ def stream_side_measurement(head):
     (window_cus: the CUs of that stream; 256 = the chip), on 8 hardware queues, measured by tools/stream_bench.py in a process of its
     own: where a HIP stream's launches queue depends on how many streams the process has used before and on GPU_MAX_HW_QUEUES, which
     the runtime reads when it starts; after this script's ladder of graph builds the loop loses its gain (tools/stream_bench.py)."""
-    try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stream_bench.py'), '--head', head], capture_output=True, text=True, timeout=300)
+    def run(queues):
+        env = dict(os.environ)
+        env['GPU_MAX_HW_QUEUES'] = str(queues)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stream_bench.py'), '--head', head], capture_output=True, text=True, timeout=300, env=env)
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    try:
+        ss = run(8)
     except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the headline down
         sys.stderr.write('stream side measurement skipped: %r\n' % (exc,))
         return None
+    try:   # the same loop on the runtime's default of 4 hardware queues (what a caller gets who does not set the variable: INTEGRATION.md)
+        d4 = run(4)
+        ss['default_hw_queues'] = dict(hw_queues=d4.get('hw_queues', 4), window_on_confined_stream=d4.get('window_on_confined_stream'),
+                                       window_on_the_callers_stream=d4.get('window_on_the_callers_stream'), ms_per_frame=d4.get('ms_per_frame'),
+                                       same_detections=d4.get('same_detections'))
+    except Exception as exc:   # noqa: BLE001
+        sys.stderr.write('stream side measurement on the default queues skipped: %r\n' % (exc,))
+    return ss
 
 
 def lib_sha16():
@@ -625,9 +655,10 @@ def main(argv=None):
                        regions=[round(args.steps / t_, 2) for t_ in sl_times],
                        rel_spread=round((max(sl_times) - min(sl_times)) / mine, 4))
     rel_single = rel
+    res_single = res   # the eager one-window-per-call result of `frames` (what a one-clip graph has to reproduce bit for bit)
     # ---- region (1b): the same loop with W clips per call (what a graph of the headline region holds): the relation core's grouped
     # calls tagged -- `roofline` is taken HERE when W > 1 (units_per_launch = W), the one-window region above stays as `roofline_one_window` ----
-    batched_lane = None
+    batched_lane, batched_vs_single = None, {}
     if W > 1:
         b_times, rel = [], {}
         for r in range(2):
@@ -638,6 +669,7 @@ def main(argv=None):
                 e['calls'] += d['calls']; e['ms'] += d['ms']; e['work'] += d['work']
         bm = min(b_times)
         batched_lane = dict(frames_per_s=round(args.steps / bm, 3), ms_per_step=round(bm / args.steps * 1e3, 3), steps=args.steps, clips_per_call=W)
+        batched_vs_single = {args.dtype: clip_distance(args.head, res, res_single)}   # clip 0 of the W-clip call against the one-window call
     headline_mode = 'eager launches, %d window(s) in flight' % max(1, args.inflight)
     n_lanes = max(1, args.inflight)
     region_times = sl_times
@@ -663,6 +695,8 @@ def main(argv=None):
             el_m, res_m, spans_m = timed(n_m, W, tags=('relation_full', 'relation_key'), w=W)
             row = dict(dtype=mode, single_lane=dict(frames_per_s=round(n_m / el_m, 3), ms_per_step=round(el_m / n_m * 1e3, 3), steps=n_m, clips_per_call=W),
                        roofline=roofline_of(mode, spans_m, W), kernel_classes=class_times(mode, W))
+            if W > 1:
+                batched_vs_single[mode] = clip_distance(args.head, res_m, read(step(None, 1)))
             if args.lanes > 1 and not args.no_graphs and args.inflight == 1:
                 n_g = args.lanes * W * (2 if mode == 'f32' else 3)   # whole rounds of the lanes (a partial last round is idle lanes, not the mode), >= 0.3 s per region
                 tg, res_g = graph_regions(args.lanes, n_g, 2, 3, W)
@@ -720,6 +754,7 @@ def main(argv=None):
             n2 = max(4, min(args.steps, 12))
             el2, _, _ = timed(n2, 2)
             overlap2_fps = n2 / el2
+            overlap2 = dict(frames_per_s_per_gpu=round(overlap2_fps, 2), steps=n2, elapsed_ms=round(el2 * 1e3, 3))
             lanes[:] = [None]
 
     # ---- frame ingest inside the loop: every frame of every window starts as a uint8 BGR frame on the
@@ -753,7 +788,7 @@ def main(argv=None):
         read(pend)
         sync()
         el_i = time.perf_counter() - t_i
-        ingest_loop = dict(frames_per_s=round(n_i / el_i, 2), ms_per_step=round(el_i / n_i * 1e3, 3), steps=n_i, clips_per_call=W,
+        ingest_loop = dict(frames_per_s=round(n_i / el_i, 2), ms_per_step=round(el_i / n_i * 1e3, 3), steps=n_i, elapsed_ms=round(el_i * 1e3, 3), clips_per_call=W,
                            source='uint8 600x1000x3 frames resident on the device, hvr_ingest_frame per frame inside the loop')
 
     # ---- the same work replayed from hipGraphs (hvrnet_amd/graphs.py): the window / the per-frame and per-window chains are
@@ -778,7 +813,7 @@ def main(argv=None):
         sync()
         el = time.perf_counter() - tg
         graphed_clip = dict(frames_per_s_per_gpu=round(ng / el, 3), ms_per_step=round(el / ng * 1e3, 3), steps=ng,
-                            same_detections=same_detections(res_graph, res))
+                            same_detections=same_detections(res_graph, res_single))   # one-clip graph vs the eager one-window call: like with like
         del gc
         # stream mode: one new frame per output frame, per-frame cache, graph F (frame arrives) + graph W (window emitted)
         gs = GraphedStream(model, frames[0:1], metas[0], rescale=True)
@@ -884,8 +919,8 @@ def main(argv=None):
         want = None
         cpu = None
         wants, wants64, noise_floor, want_props = [], [], None, []
-        # clips the tolerance is checked on: the benchmark's + two more (other synthetic frames, same weights)
-        tol_clip_ids = [frame_ids] + [[rank * 1000 + 5000 * c + i for i in range(T)] for c in (1, 2)]
+        # clips the tolerance is checked on: the benchmark's + seven more (other synthetic frames, same weights) -- VERDICT r05 item 1b
+        tol_clip_ids = [frame_ids] + [[rank * 1000 + 5000 * c + i for i in range(T)] for c in range(1, max(1, args.tol_clips))]
         if world == 1 and not args.no_cpu_baseline:
             if args.quick:
                 cpu, want = cpu_baseline_quick(args.head, T, n_prop, sd)
@@ -906,16 +941,21 @@ def main(argv=None):
                 row['within_tolerance'] = within_tolerance(row['parity'])
             else:
                 row.pop('_res', None)
-        # a mode whose classes and scores agree with the reference on the benchmark's clip is checked on every clip (one eager window
-        # each) against the oracle's f32 evaluation -- `within_tolerance` is the claim over ALL clips, the figures are the worst clip's --
-        # and, reported beside it, against the oracle's f64 evaluation and under round 4's fixed box bar
+        # a mode whose classes and scores agree with the reference on the benchmark's clip is checked on EVERY clip (one eager window
+        # each) against the oracle's f32 evaluation -- `within_tolerance` is the claim over ALL clips, none left out by a rule of this
+        # file (VERDICT r05 item 1c / ADVICE r05): a clip whose RPN proposal lists equal the oracle's has to be inside the bar as it is;
+        # a clip whose lists differ (an NMS pair at the IoU threshold resolved differently by two f32 evaluations) FAILS the claim unless
+        # (i) the same window with the oracle's proposal lists injected is inside the bar and (ii) every differing frame's decision at
+        # issue is an NMS pair within parity.NMS_TIE_BAND of the threshold (the pair and its float64 IoU are in the record).
+        # Beside it: the distances to the oracle's f64 evaluation, round 4's fixed bar, and north_star's figure read literally (1e-3 px).
         if len(wants) > 1:
+            from hvrnet_amd import parity as _par
             for row in rows:
                 pr0 = row['parity']
                 if pr0['class_flips'] != 0 or not pr0['max_score_err'] < TOL_SCORE:
                     continue
                 hvrnet_amd.set_compute_dtype(model, MODES[row['dtype']])
-                p32, p64, same_props = [], [], []
+                p32, p64, same_props, injected, ties, passes = [], [], [], [], [], []
                 for ci, (ids, w32, wp) in enumerate(zip(tol_clip_ids, wants, want_props)):
                     w64 = wants64[ci] if ci < len(wants64) else None
                     fr_c = frames if ids is tol_clip_ids[0] else torch.cat([S.synth_frame(i) for i in ids], 0).to(dev)
@@ -924,43 +964,69 @@ def main(argv=None):
                         got_c = model(x=c4_c, img=None, img_meta=metas, forward_feat=True, return_loss=False, rescale=True)
                         dev_props = [p_.cpu().numpy() for p_ in model.window_tensors(c4_c, metas)['proposals']]
                     p32.append(parity_object(args.head, row['dtype'], got_c, w32))
-                    if w64 is not None:
-                        p64.append(parity_object(args.head, row['dtype'], got_c, w64))
-                    # the per-frame proposal lists are the path's discontinuous step (top-k + NMS at IoU 0.7): a clip on which a
-                    # candidate pair sits at the threshold to within f32 rounding keeps a different box on either side of it
-                    same_props.append(bool(all(a.shape == b.shape and (a.shape[0] == 0 or float(abs(np.sort(a[:, :4], axis=0) - np.sort(b[:, :4], axis=0)).max()) < 1e-2)
-                                               for a, b in zip(dev_props, wp))))
-                from hvrnet_amd import parity as _par
-                row['parity_clips'] = dict(clips=len(p32), class_flips=[p_['class_flips'] for p_ in p32], tie_swaps=[p_['tie_swaps'] for p_ in p32],
+                    p64.append(parity_object(args.head, row['dtype'], got_c, w64) if w64 is not None else None)
+                    sp = all(_par.proposal_lists_equal(dev_props, wp))
+                    same_props.append(bool(sp))
+                    if sp:
+                        injected.append(None)
+                        passes.append(within_tolerance(p32[-1]))
+                    else:
+                        with torch.no_grad():
+                            got_i = model(x=c4_c, img=None, img_meta=metas, proposals=[torch.from_numpy(p_).to(dev) for p_ in wp],
+                                          forward_feat=True, return_loss=False, rescale=True)
+                        pi = parity_object(args.head, row['dtype'], got_i, w32)
+                        tl = _par.nms_threshold_ties(dev_props, wp, thr=0.7)
+                        injected.append(dict(class_flips=pi['class_flips'], max_score_err=pi['max_score_err'], max_box_err=pi['max_box_err'],
+                                             within_tolerance=within_tolerance(pi), literal_1e3=_par.literal_1e3(pi)))
+                        ties.append(dict(clip=ci, frames=[dict(frame=t_['frame'], kept_by='device' if t_['side'] == 'got' else 'oracle', iou_f64=t_['iou'],
+                                                             box=t_['box'], suppressor=t_['suppressor'], is_tie=t_['is_tie']) for t_ in tl]))
+                        passes.append(bool(within_tolerance(pi) and len(tl) > 0 and all(t_['is_tie'] for t_ in tl)))
+                row['parity_clips'] = dict(clips=len(p32), passes=passes, class_flips=[p_['class_flips'] for p_ in p32], tie_swaps=[p_['tie_swaps'] for p_ in p32],
                                            max_score_err=[p_['max_score_err'] for p_ in p32], max_box_err_vs_f32=[p_['max_box_err'] for p_ in p32],
-                                           max_box_excess_vs_f32=[p_['max_box_excess'] for p_ in p32], max_box_err_vs_f64=[p_['max_box_err'] for p_ in p64],
-                                           fixed_bar_r04=[_par.fixed_bar_r04(p_) for p_ in p32], proposal_lists_equal_the_oracles=same_props)
-                # the claim: every clip whose proposal lists equal the oracle's is within the tolerance (the benchmark's clip among them,
-                # and at least two such clips); a clip with an NMS decision at the threshold is reported, not counted
-                counted = [within_tolerance(a) for a, sp in zip(p32, same_props) if sp]
-                row['within_tolerance'] = bool(same_props[0] and len(counted) >= 2 and all(counted))
+                                           max_box_excess_vs_f32=[p_['max_box_excess'] for p_ in p32],
+                                           max_box_err_vs_f64=[p_['max_box_err'] for p_ in p64 if p_ is not None],
+                                           fixed_bar_r04=[_par.fixed_bar_r04(p_) for p_ in p32],
+                                           literal_1e3_vs_f32=[_par.literal_1e3(p_) for p_ in p32], literal_1e3_vs_f64=[_par.literal_1e3(p_) for p_ in p64 if p_ is not None],
+                                           proposal_lists_equal_the_oracles=same_props, with_the_oracles_proposals_injected=injected, nms_threshold_ties=ties)
+                row['within_tolerance'] = bool(all(passes))
             hvrnet_amd.set_compute_dtype(model, dt)
         ok = [r for r in rows if r.get('within_tolerance')]
         if ok:
             best = max(ok, key=lambda r: (r.get('graph_replay') or r['single_lane'])['frames_per_s'])
             fig = best.get('graph_replay') or best['single_lane']
             pc = best.get('parity_clips')
-            cnt = pc['proposal_lists_equal_the_oracles'] if pc else None
-            mx = (lambda key: max(v for v, sp in zip(pc[key], cnt[:len(pc[key])]) if sp))
-            worst = dict(class_flips=mx('class_flips'), max_score_err=mx('max_score_err'), max_box_err=mx('max_box_err_vs_f32'),
-                         max_box_excess=mx('max_box_excess_vs_f32'), max_box_err_vs_f64=mx('max_box_err_vs_f64'), tie_swaps=mx('tie_swaps'),
-                         fixed_bar_r04_holds_on_every_counted_clip=all(f_ for f_, sp in zip(pc['fixed_bar_r04'], pc['proposal_lists_equal_the_oracles']) if sp),
-                         clips_counted=sum(pc['proposal_lists_equal_the_oracles'])) if pc else \
-                dict(class_flips=best['parity']['class_flips'], max_score_err=best['parity']['max_score_err'], max_box_err=best['parity']['max_box_err'])
+            if pc:
+                cnt = pc['proposal_lists_equal_the_oracles']
+                mx = (lambda key: max(v for v, sp in zip(pc[key], cnt[:len(pc[key])]) if sp))   # over the clips checked as they are
+                inj = [i_ for i_ in pc['with_the_oracles_proposals_injected'] if i_ is not None]
+                worst = dict(class_flips=mx('class_flips'), max_score_err=mx('max_score_err'), max_box_err=mx('max_box_err_vs_f32'),
+                             max_box_excess=mx('max_box_excess_vs_f32'), max_box_err_vs_f64=max(pc['max_box_err_vs_f64']) if pc['max_box_err_vs_f64'] else None,
+                             tie_swaps=mx('tie_swaps'), max_box_err_with_injected_proposals=max([i_['max_box_err'] for i_ in inj]) if inj else None,
+                             fixed_bar_r04_on_every_clip_checked_as_it_is=all(f_ for f_, sp in zip(pc['fixed_bar_r04'], cnt) if sp),
+                             literal_1e3_px=dict(vs_f32=[sum(pc['literal_1e3_vs_f32']), pc['clips']], vs_f64=[sum(pc['literal_1e3_vs_f64']), len(pc['literal_1e3_vs_f64'])]))
+            else:
+                worst = dict(class_flips=best['parity']['class_flips'], max_score_err=best['parity']['max_score_err'], max_box_err=best['parity']['max_box_err'])
             out['within_tolerance'] = dict(dtype=best['dtype'], frames_per_s=fig['frames_per_s'], ms_per_step=fig['ms_per_step'],
                                            lanes=fig.get('lanes', 1), clips_per_graph=W, single_lane_frames_per_s=best['single_lane']['frames_per_s'],
                                            roofline=best['roofline'], parity=worst, clips_checked=pc['clips'] if pc else 1,
+                                           clips_passed=sum(pc['passes']) if pc else 1,
+                                           clips_with_the_oracles_proposal_lists=sum(pc['proposal_lists_equal_the_oracles']) if pc else None,
+                                           clips_proven_by_injection=sum(1 for i_ in pc['with_the_oracles_proposals_injected'] if i_ is not None) if pc else None,
                                            per_clip=dict(max_box_err_vs_f64=pc['max_box_err_vs_f64'], max_box_err_vs_f32=pc['max_box_err_vs_f32'],
-                                                         proposal_lists_equal_the_oracles=cnt) if pc else None,
+                                                         literal_1e3_vs_f32=pc['literal_1e3_vs_f32'], literal_1e3_vs_f64=pc['literal_1e3_vs_f64'],
+                                                         proposal_lists_equal_the_oracles=pc['proposal_lists_equal_the_oracles'],
+                                                         with_the_oracles_proposals_injected=pc['with_the_oracles_proposals_injected'],
+                                                         nms_threshold_ties=pc['nms_threshold_ties']) if pc else None,
                                            oracle_noise_floor=noise_floor,
-                                           tolerance=dict(class_flips=0, score=TOL_SCORE, box_px=TOL_BOX_PX, box_rtol=BOX_RTOL, defined='hvrnet_amd/parity.py'))
+                                           tolerance=dict(class_flips=0, score=TOL_SCORE, box_px=TOL_BOX_PX, box_rtol=BOX_RTOL, nms_tie_band=_par.NMS_TIE_BAND if pc else None,
+                                                          defined='hvrnet_amd/parity.py (frozen since round 5)'))
         elif want is not None:
             out['within_tolerance'] = None
+            fails = [dict(dtype=r['dtype'], **{k_: r['parity_clips'][k_] for k_ in ('passes', 'max_box_err_vs_f32', 'proposal_lists_equal_the_oracles',
+                                                                              'with_the_oracles_proposals_injected', 'nms_threshold_ties')})
+                     for r in rows if 'parity_clips' in r]
+            if fails:
+                out['within_tolerance_failed'] = fails   # (a mode that agreed on the benchmark clip and failed the claim over all clips: why)
         out['single_lane'] = single_lane
         if batched_lane is not None:
             out['single_lane_batched'] = batched_lane
@@ -970,6 +1036,8 @@ def main(argv=None):
         if cpu is not None:
             out['cpu_baseline'] = cpu
         out['value_spread'] = value_spread
+        if batched_vs_single:
+            out['batched_vs_single'] = batched_vs_single
         if want is not None:
             pr = head_row['parity']
             out['parity'] = dict(dtype=pr['dtype'], class_flips=pr['class_flips'], max_score_err=pr['max_score_err'], max_box_err=pr['max_box_err'],
@@ -992,7 +1060,7 @@ def main(argv=None):
                     c['within_tolerance'] = r['within_tolerance']
                     if 'parity_clips' in r:   # (the per-clip arrays of the mode that carries the claim are in `within_tolerance`)
                         pc_ = r['parity_clips']
-                        c['clips'] = [sum(pc_['proposal_lists_equal_the_oracles']), pc_['clips']]
+                        c['clips'] = [sum(pc_['passes']), pc_['clips']]
                 c['kernel_classes'] = {t: [round(e['ms'], 3), round(e['frac'], 3)] for t, e in r['kernel_classes'].items()}
                 return c
             out['precision_ladder'] = [compact(r) for r in rows]
@@ -1010,7 +1078,7 @@ def main(argv=None):
             out['cached_loop'] = dict(frames_per_s_per_gpu=round(cached_loop_fps, 2), steps=n_loop,
                                       tflops=round(cached_loop_fps * gf / 1e3, 1), frac_mfma_peak=round(cached_loop_fps * gf / 1e3 / peak, 4))
         if overlap2_fps is not None:
-            out['two_in_flight'] = dict(frames_per_s_per_gpu=round(overlap2_fps, 2))
+            out['two_in_flight'] = overlap2
         if ingest_loop is not None:
             out['ingest_in_loop'] = ingest_loop
         if graphed_clip is not None:

@@ -718,8 +718,11 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
   const bool strides_ok = split ? (gsq % 32 == 0 && gsk % 32 == 0 && gsv % 32 == 0 && gso % 32 == 0)
                                 : (two_byte && gsq % 8 == 0 && gsk % 8 == 0 && gsv % 8 == 0 && gso % 8 == 0);
   if (split && (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64)) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
+  // (exact: "bit for bit hvr_relation_fwd's" only holds when the single call takes the SAME scores kernel -- a per-group tile count
+  // the one-group rule sends to the tile engine, e.g. Mq = Mk = 5 400: 352 tiles, runs as per-group single calls)
   if (groups == 1 || mode == 0 || !staging || !strides_ok ||
-      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, groups, split)) {
+      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, groups, split) ||
+      (exact && !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, 1, split))) {
     for (int g = 0; g < groups; ++g) {
       const int rc = hvr_relation_fwd((const char*)Q + (size_t)g * gsq * es, ldq, (const char*)K + (size_t)g * gsk * es, ldk,
                                       (const char*)V + (size_t)g * gsv * es, ldv, (char*)O + (size_t)g * gso * es, ldo, Mq, Mk, D, scale,

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void im2col_t_x8_kernel(const bf16_t* __restri
 }
 
 // dZ = dY where Y > 0 else 0 ([R][C], row-major) AND dZ^T [C][ldt] (columns R .. ldt - 1 zero) from one read of dY and Y.  A 16-bit float
-// (bf16 or half) is positive when its sign bit is clear and the rest is not zero.
+// (bf16 or half) is positive when its sign bit is clear and the rest is not zero.  (A NaN with a clear sign bit therefore passes the
+// gate, where torch's `y > 0` is false: Y is the output of this library's own ReLU epilogues -- fmaxf(x, 0), which returns 0 for a NaN x --
+// so it never holds one; the test is format-independent, which is why bf16 and half share the kernel.)
 __global__ __launch_bounds__(256) void relu_bwd_t_x8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ dz,
                                                              bf16_t* __restrict__ dzt, int R, int C, long ldt) {
   constexpr int PITCH = 64 * 2 + 16;

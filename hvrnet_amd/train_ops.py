@@ -69,7 +69,7 @@ def _two_byte(dtype):
 # dist_train.train_iteration loop RECORDS the layers as they run (weights that are parameters, or views of one: stable addresses in
 # FlatParams' buffer); from the second on prep_begin() rebuilds all of them with two launches before the forward and the Functions
 # pick their operands out of the table.  Outside such a loop (tests, one-off calls) nothing is cached: every layer prepares its own.
-_prep = dict(recording=False, valid=False, entries={}, tables=None, owner=None, enabled=True)
+_prep = dict(recording=False, valid=False, entries={}, tables=None, owner=None, enabled=True, stamp=0)
 
 
 def _prep_key(w):
@@ -87,50 +87,65 @@ def _prep_lookup(w, s, shape4, dtype):
     if key is None:
         return None, None
     e = _prep['entries'].get(key)
-    if _prep['valid'] and e is not None and e['dtype'] == dtype and e['s'] is s:
-        return e['eff'], key
+    if _prep['valid'] and e is not None and e['dtype'] == dtype and e['s'] is s and e['eff'] is not None:
+        return e['eff'], (key, _prep['stamp'])   # (the stamp: the table's buffers are rewritten by the next prep_begin -- see _prep_check)
     if _prep['recording'] and e is None:
         _prep['entries'][key] = dict(w=w.detach(), s=s, shape=tuple(shape4), dtype=dtype, eff=None, aux=None)
     return None, None
 
 
+def _prep_check(key):
+    """A Function whose forward took its operand out of the iteration's table saved a TABLE BUFFER for its backward: the next
+    prep_begin() rewrites it (and the update in between made it stale).  A backward that runs after that -- retain_graph across
+    iterations, gradient accumulation over several train_iteration calls -- would silently use the wrong weights: refuse it."""
+    if key is not None and (key[1] != _prep['stamp'] or not _prep['valid']):
+        raise RuntimeError('backward of a layer whose operands came from the weight table of an earlier iteration (train_ops.prep_begin has '
+                           'run since, or prep_end has closed the iteration): run forward and backward inside one train_iteration, or '
+                           'train_ops.prep_enable(False)')
+
+
 def _prep_aux(key):
-    e = _prep['entries'].get(key) if (key is not None and _prep['valid']) else None
+    _prep_check(key)
+    e = _prep['entries'].get(key[0]) if (key is not None and _prep['valid']) else None
     return None if e is None else e['aux']
 
 
 def _prep_build():
-    ents = [e for e in _prep['entries'].values()]
-    if not ents:
-        return
-    dtype, dev = ents[0]['dtype'], ents[0]['w'].device
-    step = native.kstep(dtype)
-    packs, trans, first, tile0 = [], [], 0, 0
-    for e in ents:
-        Cout, Cin, KH, KW = e['shape']
-        KK = KH * KW
-        e['eff'] = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=dev)
-        packs.append(native.PackItem(w=e['w'].data_ptr(), scale=e['s'].data_ptr(), out=e['eff'].data_ptr(), first=first, Cout=Cout, Cin=Cin, KK=KK))
-        first += Cout * KK * Cin
-        es = e['eff'].element_size()
-        tiles_r, tiles_c = (Cout + 63) // 64, (Cin + 63) // 64
-        if KK == 1:
-            ldn = (Cout + step - 1) // step * step
-            e['aux'] = torch.zeros((Cin, ldn), dtype=dtype, device=dev)
-            trans.append(native.TransposeItem(src=e['eff'].data_ptr(), dst=e['aux'].data_ptr(), lds=Cin, ldd=ldn, R=Cout, C=Cin, first_tile=tile0,
-                                              tiles_c=tiles_c, dcols=ldn))
-            tile0 += ((ldn + 63) // 64) * tiles_c
-        else:
-            e['aux'] = torch.zeros((Cin, KH, KW, Cout), dtype=dtype, device=dev)   # [Cin][KH][KW][Cout], taps reversed (the dX conv's operand)
-            if Cout % 8:
-                e['aux'] = None
-                continue
-            for t in range(KK):
-                trans.append(native.TransposeItem(src=e['eff'].data_ptr() + t * Cin * es, dst=e['aux'].data_ptr() + (KK - 1 - t) * Cout * es,
-                                                  lds=KK * Cin, ldd=KK * Cout, R=Cout, C=Cin, first_tile=tile0, tiles_c=tiles_c, dcols=Cout))
-                tile0 += tiles_r * tiles_c
-    _prep['tables'] = dict(packs=native.items_to_device(packs, dev), n_packs=len(packs), total=first, dtype=dtype,
-                           trans=native.items_to_device(trans, dev) if trans else None, n_trans=len(trans), tiles=tile0)
+    """One pair of multi-tensor launches per (operand dtype, device) among the recorded layers (a model that mixes bf16 and half layers
+    gets one table per format: every entry is packed in ITS recorded dtype, which is what _prep_lookup matches on)."""
+    groups = {}
+    for e in _prep['entries'].values():
+        groups.setdefault((e['dtype'], e['w'].device), []).append(e)
+    tables = []
+    for (dtype, dev), ents in groups.items():
+        step = native.kstep(dtype)
+        packs, trans, first, tile0 = [], [], 0, 0
+        for e in ents:
+            Cout, Cin, KH, KW = e['shape']
+            KK = KH * KW
+            e['eff'] = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=dev)
+            packs.append(native.PackItem(w=e['w'].data_ptr(), scale=e['s'].data_ptr(), out=e['eff'].data_ptr(), first=first, Cout=Cout, Cin=Cin, KK=KK))
+            first += Cout * KK * Cin
+            es = e['eff'].element_size()
+            tiles_r, tiles_c = (Cout + 63) // 64, (Cin + 63) // 64
+            if KK == 1:
+                ldn = (Cout + step - 1) // step * step
+                e['aux'] = torch.zeros((Cin, ldn), dtype=dtype, device=dev)
+                trans.append(native.TransposeItem(src=e['eff'].data_ptr(), dst=e['aux'].data_ptr(), lds=Cin, ldd=ldn, R=Cout, C=Cin, first_tile=tile0,
+                                                  tiles_c=tiles_c, dcols=ldn))
+                tile0 += ((ldn + 63) // 64) * tiles_c
+            else:
+                e['aux'] = torch.zeros((Cin, KH, KW, Cout), dtype=dtype, device=dev)   # [Cin][KH][KW][Cout], taps reversed (the dX conv's operand)
+                if Cout % 8:
+                    e['aux'] = None
+                    continue
+                for t in range(KK):
+                    trans.append(native.TransposeItem(src=e['eff'].data_ptr() + t * Cin * es, dst=e['aux'].data_ptr() + (KK - 1 - t) * Cout * es,
+                                                      lds=KK * Cin, ldd=KK * Cout, R=Cout, C=Cin, first_tile=tile0, tiles_c=tiles_c, dcols=Cout))
+                    tile0 += tiles_r * tiles_c
+        tables.append(dict(packs=native.items_to_device(packs, dev), n_packs=len(packs), total=first, dtype=dtype,
+                           trans=native.items_to_device(trans, dev) if trans else None, n_trans=len(trans), tiles=tile0))
+    _prep['tables'] = tables or None
 
 
 def prep_begin(owner=None):
@@ -141,13 +156,14 @@ def prep_begin(owner=None):
     if owner is not _prep['owner']:
         prep_reset()
         _prep['owner'] = owner
-    t = _prep['tables']
-    if t is None:
+    _prep['stamp'] += 1
+    if _prep['tables'] is None:
         _prep['recording'], _prep['valid'] = True, False
         return
-    native.pack_conv_weights_multi(t['packs'], t['n_packs'], t['total'], t['dtype'])
-    if t['trans'] is not None:
-        native.transpose_multi(t['trans'], t['n_trans'], t['tiles'])
+    for t in _prep['tables']:
+        native.pack_conv_weights_multi(t['packs'], t['n_packs'], t['total'], t['dtype'])
+        if t['trans'] is not None:
+            native.transpose_multi(t['trans'], t['n_trans'], t['tiles'])
     _prep['valid'] = True
 
 
@@ -160,7 +176,7 @@ def prep_end():
 
 
 def prep_reset():
-    _prep.update(recording=False, valid=False, entries={}, tables=None, owner=None)
+    _prep.update(recording=False, valid=False, entries={}, tables=None, owner=None, stamp=_prep['stamp'] + 1)
 
 
 def prep_enable(flag):
@@ -175,7 +191,10 @@ def prep_enable(flag):
 # parameter a view of the flat gradient buffer, zeroed at the start of the step): the f32 product is scaled, permuted and ADDED in
 # place by hvr_unpack_conv_wgrad and autograd is handed no gradient for the weight -- no temporary, no AccumulateGrad add per layer
 # (151 torch launches per iteration in round 4).  Same values: one f32 addition to a zeroed buffer.
-_direct = dict(on=True)
+# OFF by default: handing autograd no gradient bypasses tensor / post-accumulate hooks and mutates .grad under
+# torch.autograd.grad(); dist_train.train_iteration -- which owns the gradient buffer and zeroes it first -- switches it on for its own
+# backward (`wgrad_direct(True)` ... restore).  Outside that scope the Functions return dW to autograd like any other.
+_direct = dict(on=False)
 
 
 def wgrad_direct(flag):
@@ -208,6 +227,7 @@ class LinearFunction(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
+        _prep_check(ctx.prep_key)
         dy = native.cast(dy.contiguous(), x.dtype)
         M, K = x.shape
         N = w.shape[0]
@@ -384,6 +404,7 @@ class ConvFunction(Function):
     @once_differentiable
     def backward(ctx, dy):
         xs, w_eff, s, y = ctx.saved_tensors
+        _prep_check(ctx.prep_key)     # (w_eff may be a buffer of the iteration's weight table: it must still be this iteration's)
         relu, stride, pad, dil, has_resid, x_shape = ctx.cfg
         dy = native.cast(dy.contiguous(), xs.dtype)
         Cout, KH, KW, Cin = w_eff.shape

@@ -279,3 +279,36 @@ def test_asm_wait_lint_passes_on_the_built_library():
         pytest.skip('no device assembly here (the library was built elsewhere)')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'hvrnet_amd', 'csrc', 'check_asm_waits.py')] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_the_tolerance_constants_are_frozen():
+    """hvrnet_amd/parity.py is frozen as the round-5 judge accepted it ("Next round" 1a): class indices exact, scores within
+    1e-3, boxes within 1e-3 px + 1.3e-6 x extent; round 4's fixed bar and north_star's literal 1e-3 px are reported beside it."""
+    from hvrnet_amd import parity
+    assert (parity.TOL_SCORE, parity.TOL_BOX_PX, parity.BOX_RTOL, parity.NMS_TIE_BAND) == (1e-3, 1e-3, 1.3e-6, 1e-4)
+    assert abs(parity.box_bar(1000.0) - 2.3e-3) < 1e-12
+    st = dict(class_flips=0, max_score_err=5e-4, max_box_err=1.04e-3, max_box_excess=1.04e-3 - 1.3e-3)
+    assert parity.within_tolerance(st) and parity.fixed_bar_r04(st) and not parity.literal_1e3(st)
+    assert parity.literal_1e3(dict(st, max_box_err=9.9e-4))
+    assert not parity.within_tolerance(dict(st, class_flips=1))
+
+
+def test_nms_threshold_ties_names_the_pair_at_issue():
+    """parity.nms_threshold_ties: two per-frame proposal lists that differ because one side kept a box the other suppressed -> the
+    (box, suppressor) pair whose IoU is nearest the threshold, per differing frame; only a pair inside the band is a tie."""
+    import numpy as np
+    from hvrnet_amd import parity
+    keep = np.array([[0, 0, 99, 99, 0.9], [200, 200, 300, 300, 0.7]], dtype=np.float64)
+    # a 100 x h box over a 100 x 100 box: IoU = 100 / h  ->  h = 100 / 0.7 puts the pair on the threshold
+    h_tie, h_far = 100.0 / 0.70000005, 100.0 / 0.705
+    tail = np.array([[400, 400, 500, 500, 0.6]], dtype=np.float64)
+    for h, is_tie in ((h_tie, True), (h_far, False)):
+        extra = np.array([[0, 0, 99, h - 1, 0.8]], dtype=np.float64)
+        got = np.concatenate([keep[:1], extra, keep[1:]], 0)       # this side kept the box ...
+        want = np.concatenate([keep, tail], 0)                     # ... the other suppressed it and its 300-th survivor moved up
+        assert parity.proposal_lists_equal([got, keep], [want, keep]) == [False, True]
+        ties = parity.nms_threshold_ties([got, keep], [want, keep], thr=0.7)
+        assert len(ties) == 1 and ties[0]['frame'] == 0 and ties[0]['side'] == 'got'
+        assert ties[0]['is_tie'] is is_tie and abs(ties[0]['iou'] - 100.0 / h) < 1e-9
+        assert ties[0]['suppressor'][:4] == [0, 0, 99, 99]
+    assert parity.nms_threshold_ties([keep], [keep]) == []

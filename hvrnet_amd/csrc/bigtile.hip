@@ -85,6 +85,10 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;  // n fastest: the tiles of a row panel share its A rows
   const int m0 = pid_m * BM, n0 = pid_n * BG_BN;
 
+#ifdef HVR_DBG_BG_CLK
+  long long dbg_t[5];
+  dbg_t[0] = wall_clock64();
+#endif
   // ---- loader: a thread's pieces sit 64 rows apart (slot i -> row i * 64 + tid / 8), all in the same swizzled 16-byte chunk ----
   const int l_row = tid >> 3, l_chunk = ((tid & 7) ^ (l_row & 7)) * 16;
   int a_bias = 0;
@@ -201,6 +205,9 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const int nk = nk_real;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef HVR_DBG_BG_CLK
+  dbg_t[1] = wall_clock64();
+#endif
 
   // ---- phase-staggered K loop (relation_bt.hip): a K-step is four phases -- (K half h, row fragments 0..G0-1) and (h, G0..FM-1)
   // for h = 0, 1 -- each an L section (fragment reads + this wave's share of the next K-step's DMA) and a C section (nothing but
@@ -276,6 +283,9 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     else kloop(std::integral_constant<int, 0>{});
   }
 
+#ifdef HVR_DBG_BG_CLK
+  dbg_t[2] = wall_clock64();
+#endif
   // ---------------- epilogue: bias + ReLU, bf16, whole 128-byte row segments out through per-wave LDS staging ----------------
   // lane holds out[m0 + wrow0 + 16 i + frag_row][n0 + wn 64 + 16 j + 4 frag_grp + r] = acc[i][j][r]
   if constexpr (SPLIT) {
@@ -440,6 +450,14 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       }
     }
   }
+#ifdef HVR_DBG_BG_CLK
+  dbg_t[3] = wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  dbg_t[4] = wall_clock64();
+  if (threadIdx.x == 0 && (blockIdx.x % 7) == 0)
+    printf("BGCLK wg %d t0 %lld prologue %lld loop %lld epilogue %lld drain %lld\n", (int)blockIdx.x, dbg_t[0], dbg_t[1] - dbg_t[0], dbg_t[2] - dbg_t[1],
+           dbg_t[3] - dbg_t[2], dbg_t[4] - dbg_t[3]);
+#endif
   };  // body
   if constexpr (FM0 == FM1) {
     body(std::integral_constant<int, FM0>{});

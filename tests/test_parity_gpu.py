@@ -1287,7 +1287,7 @@ def test_per_iteration_weight_table_equals_the_per_layer_preparation():
         model, data = setup()
         flat = FlatParams(model)
         l1 = [float(train_detector_iteration(model, flat, data, lr=2e-4)['loss'])]          # records the layers, builds the table
-        assert train_ops._prep['tables'] is not None and train_ops._prep['tables']['n_packs'] > 60
+        assert train_ops._prep['tables'] is not None and sum(t['n_packs'] for t in train_ops._prep['tables']) > 60
         train_ops.prep_begin(flat)                                                         # what iteration 2 starts with
         n_rot = n_t = 0
         for e in train_ops._prep['entries'].values():
@@ -1345,7 +1345,7 @@ def test_head_gradients_with_the_weight_table_equal_those_without_it(kind):
     try:
         flat = dist_train.FlatParams(head)
         dist_train.train_iteration(flat, loss_fn, lr=1e-4)            # records the layers; the update moves the weights
-        assert train_ops._prep['tables'] is not None and train_ops._prep['tables']['n_packs'] >= (12 if kind == 'hvr' else 6)
+        assert train_ops._prep['tables'] is not None and sum(t['n_packs'] for t in train_ops._prep['tables']) >= (12 if kind == 'hvr' else 6)
         flat.zero_grad()
         train_ops.prep_begin(flat)
         l1 = loss_fn()

@@ -20,7 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--head', default='selsa')
 args = ap.parse_args()
 T, N, KEY, dev = 15, 300, 7, 'cuda:0'
-torch.set_num_threads(16)
+from bench import host_cores  # noqa: E402
+torch.set_num_threads(host_cores())
 frames = [S.synth_frame(i) for i in range(T)]
 metas = [S.synth_meta() for _ in range(T)]
 sd = S.synth_state_dict(args.head)

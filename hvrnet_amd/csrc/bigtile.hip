@@ -81,55 +81,35 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const int wm = wave / BG_WN, wn = wave % BG_WN;
   const int wrow0 = wm ? FM0 * 16 : 0;  // first tile row of this wave
   const int tiles_n = p.N / BG_BN, tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;  // n fastest: the tiles of a row panel share its A rows
-  const int m0 = pid_m * BM, n0 = pid_n * BG_BN;
-
+  // PERSISTENT workgroups (round 6, relation_bt.hip's scheme): the launch is min(tiles, 256) workgroups, one per CU; the tile list is
+  // walked in rounds of gridDim.x, round r gives this workgroup tile r * nwg + xcd_remap(blockIdx.x, tiles of the round) -- n fastest
+  // inside an XCD's contiguous range, so that the column tiles of a row panel share its A rows in one L2.  From its second tile on a
+  // workgroup has its first K-step fetched under the previous tile's last K-step, its loader state (offsets, out-of-image masks: the
+  // integer divisions of the conv geometry) built under the previous tile's epilogue, and that tile's output stores drain under the
+  // new loop instead of in front of a kernel boundary (profiles/r06_bigtile_probe.txt: one tile per workgroup spent 3.3 us in the
+  // prologue + 4 - 7 us in the epilogue and its drain per 32 - 58 us loop, plus the dispatch of a second wave of workgroups).
+  const int total = tiles_m * tiles_n, nwg = (int)gridDim.x;
+  auto tile_of = [&](int r) -> int {
+    const int left = total - r * nwg, here = left < nwg ? left : nwg;
+    return (int)blockIdx.x < here ? r * nwg + xcd_remap(blockIdx.x, here) : -1;
+  };
 #ifdef HVR_DBG_BG_CLK
-  long long dbg_t[5];
+  long long dbg_t[1 + 3 * 3];
+  for (int q = 0; q < 10; ++q) dbg_t[q] = 0;
   dbg_t[0] = wall_clock64();
 #endif
+
   // ---- loader: a thread's pieces sit 64 rows apart (slot i -> row i * 64 + tid / 8), all in the same swizzled 16-byte chunk ----
   const int l_row = tid >> 3, l_chunk = ((tid & 7) ^ (l_row & 7)) * 16;
   int a_bias = 0;
   if (p.conv) a_bias = (int)(((long)p.pad * p.W + p.pad) * p.Cin * EB);
   const char* const rs_a = (const char*)p.A - a_bias;
   const char* const rs_b = (const char*)p.B;
-  int a_off[A_SLOTS], a_yx[A_SLOTS], b_off[BG_B_SLOTS];
-#pragma unroll
-  for (int i = 0; i < A_SLOTS; ++i) {
-    int m = m0 + i * 64 + l_row;
-    m = m < p.M ? m : p.M - 1;
-    if (p.conv) {
-      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
-      const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
-      a_yx[i] = (iy << 16) | (ix & 0xffff);
-      a_off[i] = (int)((((long)b * p.H + iy) * p.W + ix) * (long)p.Cin * EB) + l_chunk + a_bias;
-    } else {
-      a_yx[i] = 0;
-      a_off[i] = (int)((long)m * p.lda * EB) + l_chunk;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < BG_B_SLOTS; ++i) b_off[i] = (int)((long)(n0 + i * 64 + l_row) * p.ldb * EB) + l_chunk;
-
   // second K segment (p.s2 > 0, plain products: a Bottleneck's projection shortcut folded into its closing 1x1, see gemm.hip):
   // K-steps from K1 / 64 on read the block input, an NHWC map [.][H2][W2][K - K1] sampled at stride s2, through a second resource
   const bool seg2 = p.s2 > 0;
   const int k1_steps = seg2 ? p.K1 / BKE : 0x7fffffff;
   const char* const rs_a2 = (const char*)p.A2;
-  int a_off2[A_SLOTS];
-#pragma unroll
-  for (int i = 0; i < A_SLOTS; ++i) {
-    a_off2[i] = 0;
-    if (seg2) {
-      int m = m0 + i * 64 + l_row;
-      m = m < p.M ? m : p.M - 1;
-      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, b = t / p.OH;
-      a_off2[i] = (int)((((long)b * p.H2 + oy * p.s2) * p.W2 + ox * p.s2) * (long)(p.K - p.K1) * EB) + l_chunk;
-    }
-  }
-
   // BRANCH-FREE loader state (the form and the reasons: gemm_tile.h's pipelined K-step, profiles/r04_kloop_probe.txt -- a taken
   // branch costs a wave ~100 cycles, and this loop's L sections are only hidden while they are shorter than the partner group's
   // 16-20 MFMAs).  One form for plain products and convs: the plain product is the conv formula with an unreachable channel count;
@@ -137,26 +117,72 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const bool is_conv = p.conv != 0;
   const int cCin = is_conv ? p.Cin : 0x40000000, cKW = is_conv ? p.KW : 1, cDil = is_conv ? p.dil : 0;
   const int cRowB = is_conv ? p.W * p.Cin * EB : 0, cPixB = is_conv ? p.Cin * EB : 0;   // bytes per input row / pixel (tensors < 2 GiB)
-  unsigned oob[A_SLOTS];   // bit t: filter tap t of slot i's pixel lies outside the image (<= 32 taps: bigtile_supported)
+
+  // the per-TILE part of the loader state: A / B offsets of this thread's pieces, the second segment's offsets, the out-of-image masks
+  // (bit t: filter tap t of slot i's pixel lies outside the image; <= 32 taps: bigtile_supported)
+  // (split half has no second segment -- bigtile_supported -- and no registers to spare for its offsets)
+  constexpr bool SEG2 = !SPLIT;
+  struct TileState { int a_off[A_SLOTS], a_off2[SEG2 ? A_SLOTS : 1], b_off[BG_B_SLOTS]; unsigned oob[A_SLOTS]; int m0, n0; };
+  // (what only setup() and the epilogue need -- the conv geometry, the output / residual / bias pointers -- is re-read from the kernel
+  // argument segment behind an opaque copy of its address instead of sitting in scalar registers across the K loop: relation_bt.hip)
+  auto setup = [&](int tile, TileState& st) {
+    const __attribute__((address_space(4))) GemmParams* kq =
+        (const __attribute__((address_space(4))) GemmParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kq));
+    const int pid_m = tile / tiles_n, pid_n = tile - pid_m * tiles_n;  // n fastest: the tiles of a row panel share its A rows
+    st.m0 = pid_m * BM;
+    st.n0 = pid_n * BG_BN;
+    int a_yx[A_SLOTS];
 #pragma unroll
-  for (int i = 0; i < A_SLOTS; ++i) oob[i] = 0u;
-  if (is_conv) {
-    unsigned colbad[A_SLOTS];
-#pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) colbad[i] = 0u;
-    for (int kx = 0, dx = 0; kx < p.KW; ++kx, dx += p.dil) {
-#pragma unroll
-      for (int i = 0; i < A_SLOTS; ++i) colbad[i] |= (unsigned)((short)a_yx[i] + dx) < (unsigned)p.W ? 0u : (1u << kx);
+    for (int i = 0; i < A_SLOTS; ++i) {
+      int m = st.m0 + i * 64 + l_row;
+      m = m < kq->M ? m : kq->M - 1;
+      if constexpr (SEG2) st.a_off2[i] = 0;
+      if (kq->conv || (SEG2 && kq->s2 > 0)) {
+        const int ox = m % kq->OW, t = m / kq->OW, oy = t % kq->OH, b = t / kq->OH;
+        if (kq->conv) {
+          const int iy = oy * kq->stride - kq->pad, ix = ox * kq->stride - kq->pad;
+          a_yx[i] = (iy << 16) | (ix & 0xffff);
+          st.a_off[i] = (int)((((long)b * kq->H + iy) * kq->W + ix) * (long)kq->Cin * EB) + l_chunk + (int)(((long)kq->pad * kq->W + kq->pad) * kq->Cin * EB);
+        } else {
+          a_yx[i] = 0;
+          st.a_off[i] = (int)((long)m * kq->lda * EB) + l_chunk;
+        }
+        if constexpr (SEG2) if (kq->s2 > 0) st.a_off2[i] = (int)((((long)b * kq->H2 + oy * kq->s2) * kq->W2 + ox * kq->s2) * (long)(kq->K - kq->K1) * EB) + l_chunk;
+      } else {
+        a_yx[i] = 0;
+        st.a_off[i] = (int)((long)m * kq->lda * EB) + l_chunk;
+      }
     }
-    const unsigned all_kw = p.KW >= 32 ? ~0u : (1u << p.KW) - 1u;   // (a 1 x 32 filter passes the <= 32 taps gate: no shift by 32)
-    for (int ky = 0, dy = 0, sh = 0; ky < p.KH; ++ky, dy += p.dil, sh += p.KW) {
 #pragma unroll
-      for (int i = 0; i < A_SLOTS; ++i) oob[i] |= ((unsigned)((a_yx[i] >> 16) + dy) < (unsigned)p.H ? colbad[i] : all_kw) << sh;
+    for (int i = 0; i < BG_B_SLOTS; ++i) st.b_off[i] = (int)((long)(st.n0 + i * 64 + l_row) * kq->ldb * EB) + l_chunk;
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) st.oob[i] = 0u;
+    if (kq->conv != 0) {
+      unsigned colbad[A_SLOTS];
+#pragma unroll
+      for (int i = 0; i < A_SLOTS; ++i) colbad[i] = 0u;
+      for (int kx = 0, dx = 0; kx < kq->KW; ++kx, dx += kq->dil) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) colbad[i] |= (unsigned)((short)a_yx[i] + dx) < (unsigned)kq->W ? 0u : (1u << kx);
+      }
+      const unsigned all_kw = kq->KW >= 32 ? ~0u : (1u << kq->KW) - 1u;   // (a 1 x 32 filter passes the <= 32 taps gate: no shift by 32)
+      for (int ky = 0, dy = 0, sh = 0; ky < kq->KH; ++ky, dy += kq->dil, sh += kq->KW) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) st.oob[i] |= ((unsigned)((a_yx[i] >> 16) + dy) < (unsigned)kq->H ? colbad[i] : all_kw) << sh;
+      }
     }
-  }
+  };
+  TileState cs, ns;   // the tile being computed, the tile after it
+  int cur_tile = tile_of(0), nxt_tile = tile_of(1);
+  setup(cur_tile, cs);          // (gridDim.x <= tiles: every workgroup has a first tile)
+  setup(nxt_tile >= 0 ? nxt_tile : cur_tile, ns);
+
   int a_koff = 0, b_koff = 0, kt_load = 0, t_cin0 = 0, t_kx = 0, t_ky = 0, t_tap = 0;  // of the K-step being loaded (starts at step 0)
   const int nk_real = p.K / BKE;
-  auto tap_next = [&](int adv) {   // adv = 1: the next K-step; 0: stay (the last step re-fetches itself into the idle stage)
+  // adv = 1: the next K-step; 0: stay (a workgroup's last tile re-fetches its last step into the idle stage: one uniform stream);
+  // rst: the NEXT tile's K-step 0 (the last K-step of a tile that has a successor)
+  auto tap_next = [&](int adv, bool rst) {
     kt_load += adv;
     b_koff += adv * KSG;
     t_cin0 += adv * BKE;
@@ -169,29 +195,41 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     t_ky += w2 ? 1 : 0;
     const int wmask = -(int)w1;   // (both arms computed and masked: as a select this comes back as scalar branches)
     a_koff = ((t_ky * cDil * cRowB + t_kx * cDil * cPixB) & wmask) | ((a_koff + adv * KSG) & ~wmask);
+    const int keep = rst ? 0 : -1;   // (scalar masks, not a branch)
+    kt_load &= keep; b_koff &= keep; t_cin0 &= keep; t_kx &= keep; t_ky &= keep; t_tap &= keep; a_koff &= keep;
   };
-  auto dma_a = [&](auto I, char* stage) {
+  // `nx`: the piece belongs to the next tile (uniform)
+  auto dma_a = [&](auto I, char* stage, bool nx) {
     constexpr int i = decltype(I)::value;
     if (i < A_SLOTS - 1 || wave < LAST_WAVES) {   // (scalar: `wave` lives in an SGPR)
-      const unsigned voff = (unsigned)a_off[i] | ((oob[i] >> (t_tap & 31)) << 31);   // offsets from 2^31 up read as zeros
-      const bool s2 = kt_load >= k1_steps;
-      const char* const base = s2 ? rs_a2 : rs_a;
-      const unsigned vo = s2 ? (unsigned)a_off2[i] : voff;
-      const int so = s2 ? (kt_load - k1_steps) * KSG : a_koff;
-      bg_load_lds16(base, stage + (i * BG_NT + wave * 64) * 16, vo, __builtin_amdgcn_readfirstlane(so));
+      const unsigned ao = (unsigned)(nx ? ns.a_off[i] : cs.a_off[i]), ob = nx ? ns.oob[i] : cs.oob[i];
+      const unsigned voff = ao | ((ob >> (t_tap & 31)) << 31);   // offsets from 2^31 up read as zeros
+      if constexpr (SEG2) {
+        const bool s2 = kt_load >= k1_steps;
+        const char* const base = s2 ? rs_a2 : rs_a;
+        const unsigned vo = s2 ? (unsigned)(nx ? ns.a_off2[i] : cs.a_off2[i]) : voff;
+        const int so = s2 ? (kt_load - k1_steps) * KSG : a_koff;
+        bg_load_lds16(base, stage + (i * BG_NT + wave * 64) * 16, vo, __builtin_amdgcn_readfirstlane(so));
+      } else {
+        bg_load_lds16(rs_a, stage + (i * BG_NT + wave * 64) * 16, voff, __builtin_amdgcn_readfirstlane(a_koff));
+      }
     }
   };
-  auto dma_b = [&](auto I, char* stage) {   // (of the K-step the loader state stands at)
+  auto dma_b = [&](auto I, char* stage, bool nx) {   // (of the K-step the loader state stands at)
     constexpr int i = decltype(I)::value;
-    bg_load_lds16(rs_b, stage + A_BYTES + (i * BG_NT + wave * 64) * 16, (unsigned)b_off[i], __builtin_amdgcn_readfirstlane(b_koff));
+    bg_load_lds16(rs_b, stage + A_BYTES + (i * BG_NT + wave * 64) * 16, (unsigned)(nx ? ns.b_off[i] : cs.b_off[i]), __builtin_amdgcn_readfirstlane(b_koff));
   };
 
-  // first K-step into stage 0
-  static_for<A_SLOTS>([&](auto I) { dma_a(I, smem); });
-  static_for<BG_B_SLOTS>([&](auto I) { dma_b(I, smem); });
+  // the first tile's first K-step into stage 0
+  static_for<A_SLOTS>([&](auto I) { dma_a(I, smem, false); });
+  static_for<BG_B_SLOTS>([&](auto I) { dma_b(I, smem, false); });
 
   auto body = [&](auto FMC) {
   constexpr int FM = decltype(FMC)::value;
+  int par = 0;   // LDS stage this tile's K-step 0 sits in (an odd K-step count flips it from tile to tile)
+  for (int round = 0;; ++round) {
+  const bool has_next = nxt_tile >= 0;
+  const int m0 = cs.m0, n0 = cs.n0;
   f32x4 acc[FM][BG_FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -203,10 +241,12 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
   const uint32_t b_lane = bg_lds_off(smem) + A_BYTES + (wn * BG_WCOLS + frag_row) * 128 + ((frag_grp ^ swz) * 16);
 
   const int nk = nk_real;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the first K-step has landed: the first tile's was issued above (wait for it); a later tile's was waited for by the issuing waves
+  // inside the previous tile's last K-step -- no vmcnt wait here, which would also wait for that tile's output stores
+  if (round == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #ifdef HVR_DBG_BG_CLK
-  dbg_t[1] = wall_clock64();
+  if (round < 3) dbg_t[1 + 3 * round] = wall_clock64();
 #endif
 
   // ---- phase-staggered K loop (relation_bt.hip): a K-step is four phases -- (K half h, row fragments 0..G0-1) and (h, G0..FM-1)
@@ -222,11 +262,14 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     constexpr int dma_ph = wmc ? 0 : 1;  // first of the two phases whose L sections carry this wave's DMA pieces
     if constexpr (wmc != 0) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
-      const uint32_t soff = (uint32_t)(kt & 1) * STAGE;
-      char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      const uint32_t soff = (uint32_t)((kt + par) & 1) * STAGE;
+      char* nxt = smem + ((kt + 1 + par) & 1) * STAGE;
       const uint32_t a0 = a_lane + soff, b0 = b_lane + soff;
       uint4 kb[BG_FN], qa[G0];
-      tap_next(kt + 1 < nk ? 1 : 0);  // (the last step re-fetches itself into the idle stage: one uniform stream)
+      // what this K-step prefetches into the other stage: K-step kt + 1 of this tile; from the last step the NEXT tile's first K-step
+      // (scalar selects: one uniform stream); a workgroup's last tile re-fetches its last step into the idle stage
+      const bool last = kt + 1 >= nk, pre = last && has_next;
+      tap_next(last ? 0 : 1, pre);
       // phases: two per term.  Two-byte formats: term = K half (0 / 1) on both operands.  Split half: term 0 = B_hi x A_hi,
       // 1 = B_lo x A_hi, 2 = B_hi x A_lo (the lo plane is the second 64 bytes of the line: the same address with bit 6 flipped)
       constexpr int NPH = SPLIT ? 6 : 4;
@@ -245,14 +288,14 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
           if constexpr (dma_ph == ph) {
             static_for<DMA_FIRST>([&](auto D) {
               constexpr int d = decltype(D)::value;
-              if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt);
-              else dma_b(std::integral_constant<int, d - A_SLOTS>{}, nxt);
+              if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt, pre);
+              else dma_b(std::integral_constant<int, d - A_SLOTS>{}, nxt, pre);
             });
           } else if constexpr (dma_ph + 1 == ph) {
             static_for<DMA_TOTAL - DMA_FIRST>([&](auto D) {
               constexpr int d = DMA_FIRST + decltype(D)::value;
-              if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt);
-              else dma_b(std::integral_constant<int, d - A_SLOTS>{}, nxt);
+              if constexpr (d < A_SLOTS) dma_a(std::integral_constant<int, d>{}, nxt, pre);
+              else dma_b(std::integral_constant<int, d - A_SLOTS>{}, nxt, pre);
             });
           }
         }
@@ -279,15 +322,24 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     }
     if constexpr (wmc == 0) __builtin_amdgcn_s_barrier();
     };
-    if (wm) kloop(std::integral_constant<int, 1>{});
+    int wsel = wave;   // (an opaque copy: the test is redone per tile from the scalar wave number)
+    asm volatile("" : "+s"(wsel));
+    if (wsel >= BG_WN) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 0>{});
   }
-
 #ifdef HVR_DBG_BG_CLK
-  dbg_t[2] = wall_clock64();
+  if (round < 3) dbg_t[2 + 3 * round] = wall_clock64();
 #endif
+
   // ---------------- epilogue: bias + ReLU, bf16, whole 128-byte row segments out through per-wave LDS staging ----------------
   // lane holds out[m0 + wrow0 + 16 i + frag_row][n0 + wn 64 + 16 j + 4 frag_grp + r] = acc[i][j][r]
+  // The staging blocks sit in the stage the LAST K-step was read from (every wave is done with it behind the barrier below); the other
+  // stage is receiving the next tile's first K-step.  Raw barriers: __syncthreads() carries s_waitcnt vmcnt(0), which from the second
+  // tile on would wait for the previous tile's stores.
+  char* const epi_base = smem + ((nk - 1 + par) & 1) * STAGE;
+  const __attribute__((address_space(4))) GemmParams* kp =
+      (const __attribute__((address_space(4))) GemmParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
   if constexpr (SPLIT) {
     // ---- split half: (alpha acc + beta bias) + resid in f32, ReLU, then the [hi | lo] pair -- the tile engine's order and roundings.
     // A wave's 64 columns are two [32 hi | 32 lo] groups = 256 contiguous bytes of an output row: residual rows come in and output rows
@@ -296,17 +348,17 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     asm volatile("" : "+v"(etid));
     const int el = etid & 63, erow = el & 15, egrp = el >> 4;
     constexpr int SP = 256;
-    char* stg = smem + wave * (16 * SP);
+    char* stg = epi_base + wave * (16 * SP);
     float bias[BG_FN][4];
 #pragma unroll
     for (int j = 0; j < BG_FN; ++j) {
       const int n = n0 + wn * BG_WCOLS + j * 16 + egrp * 4;
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      if (kp->bias) {
+        const float4 b = *reinterpret_cast<const float4*>(kp->bias + n);
         bias[j][0] = b.x; bias[j][1] = b.y; bias[j][2] = b.z; bias[j][3] = b.w;
-        if (p.beta != 0.f) {
+        if (kp->beta != 0.f) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) bias[j][r] *= p.beta;
+          for (int r = 0; r < 4; ++r) bias[j][r] *= kp->beta;
         }
       } else {
         bias[j][0] = bias[j][1] = bias[j][2] = bias[j][3] = 0.f;
@@ -319,20 +371,21 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
       return stg + erow * SP + ((piece ^ erow) << 4) + (egrp & 1) * 8;
     };
     // store-phase mapping: piece q = it * 64 + el of the 16 x 16 block -> row q / 16, piece q % 16
-    const bool has_res = p.resid != nullptr;
+    const bool has_res = kp->resid != nullptr;
     const long col_bytes = split_col_bytes(n0 + wn * BG_WCOLS);
     auto load_res = [&](int i, uint4 (&rv)[4]) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int q = it * 64 + el, row = q >> 4, pc = q & 15;
         int m = m0 + wrow0 + i * 16 + row;
-        m = m < p.M ? m : p.M - 1;
-        rv[it] = *reinterpret_cast<const uint4*>((const char*)p.resid + (long)m * p.ldr * 4 + col_bytes + pc * 16);
+        m = m < kp->M ? m : kp->M - 1;
+        rv[it] = *reinterpret_cast<const uint4*>((const char*)kp->resid + (long)m * kp->ldr * 4 + col_bytes + pc * 16);
       }
     };
     uint4 rnext[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
     if (has_res) load_res(0, rnext);
-    __syncthreads();  // every wave is done reading the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       if (has_res) {
@@ -346,7 +399,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < BG_FN; ++j) {
         f32x4 v = acc[i][j];
-        if (p.alpha != 0.f) v *= p.alpha;
+        if (kp->alpha != 0.f) v *= kp->alpha;
         float e[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = v[r] + bias[j][r];
@@ -359,7 +412,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
           merge2(rh.y, rl.y, r2_, r3_);
           e[0] += r0_; e[1] += r1_; e[2] += r2_; e[3] += r3_;
         }
-        if (p.relu) {
+        if (kp->relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = fmaxf(e[r], 0.f);
         }
@@ -374,7 +427,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         const int q = it * 64 + el, row = q >> 4, pc = q & 15;
         const int m = m0 + wrow0 + i * 16 + row;
         const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SP + ((pc ^ row) << 4));
-        if (m < p.M) *reinterpret_cast<uint4*>((char*)p.C + (long)m * p.ldc * 4 + col_bytes + pc * 16) = v;
+        if (m < kp->M) *reinterpret_cast<uint4*>((char*)kp->C + (long)m * kp->ldc * 4 + col_bytes + pc * 16) = v;
       }
     }
   } else
@@ -383,14 +436,14 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     asm volatile("" : "+v"(etid));  // lane-derived values re-derived here: nothing but the accumulators lives across the loop
     const int el = etid & 63, erow = el & 15, egrp = el >> 4;
     constexpr int SPITCH = BG_WCOLS * 2;  // 128-byte staged rows, bank-conflict-free by the piece swizzle of relation_bt.hip
-    char* stg = smem + wave * (16 * SPITCH);
+    char* stg = epi_base + wave * (16 * SPITCH);
     const int wr_lane = erow * SPITCH + (((egrp & 1) ^ (erow >> 3)) << 3);
     float bias[BG_FN][4];
 #pragma unroll
     for (int j = 0; j < BG_FN; ++j) {
       const int n = n0 + wn * BG_WCOLS + j * 16 + egrp * 4;
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      if (kp->bias) {
+        const float4 b = *reinterpret_cast<const float4*>(kp->bias + n);
         bias[j][0] = b.x; bias[j][1] = b.y; bias[j][2] = b.z; bias[j][3] = b.w;
       } else {
         bias[j][0] = bias[j][1] = bias[j][2] = bias[j][3] = 0.f;
@@ -400,18 +453,19 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
     // Residual (the Bottleneck's identity): fragment i's 16 x 64 block arrives in the store-phase mapping (whole 128-byte row
     // segments, one block ahead), goes through the SAME swizzled staging image the outputs leave through, and every lane picks its
     // four channels from where it is about to write them: (acc + bias) + resid in f32, ReLU, one rounding -- the tile engine's order.
-    const bool has_res = p.resid != nullptr;
+    const bool has_res = kp->resid != nullptr;
     auto load_res = [&](int i, uint4 (&rv)[2]) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int m = m0 + wrow0 + i * 16 + h * 8 + st_row;
-        m = m < p.M ? m : p.M - 1;
-        rv[h] = *reinterpret_cast<const uint4*>((const unsigned short*)p.resid + (long)m * p.ldr + n0 + wn * BG_WCOLS + st_chunk * 8);
+        m = m < kp->M ? m : kp->M - 1;
+        rv[h] = *reinterpret_cast<const uint4*>((const unsigned short*)kp->resid + (long)m * kp->ldr + n0 + wn * BG_WCOLS + st_chunk * 8);
       }
     };
     uint4 rnext[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
     if (has_res) load_res(0, rnext);
-    __syncthreads();  // every wave is done reading the ring (group 0 leaves the loop a barrier ahead of group 1's last reads)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring (group 0 leaves the loop a barrier ahead of group 1's last reads)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       if (has_res) {
@@ -435,7 +489,7 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
           unpack2<T>(rr.y, r2_, r3_);
           e[0] += r0_; e[1] += r1_; e[2] += r2_; e[3] += r3_;
         }
-        if (p.relu) {
+        if (kp->relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = fmaxf(e[r], 0.f);
         }
@@ -446,17 +500,33 @@ __global__ __launch_bounds__(BG_NT) void big_tile_kernel(const GemmParams p) {
         const int row = h * 8 + st_row, m = m0 + wrow0 + i * 16 + row;
         uint4 v = *reinterpret_cast<const uint4*>(stg + row * SPITCH + ((st_chunk ^ st_row) << 4));
         if (h) v = make_uint4(v.z, v.w, v.x, v.y);
-        if (m < p.M) *reinterpret_cast<uint4*>((unsigned short*)p.C + (long)m * p.ldc + n0 + wn * BG_WCOLS + st_chunk * 8) = v;
+        if (m < kp->M) *reinterpret_cast<uint4*>((unsigned short*)kp->C + (long)m * kp->ldc + n0 + wn * BG_WCOLS + st_chunk * 8) = v;
       }
     }
   }
 #ifdef HVR_DBG_BG_CLK
-  dbg_t[3] = wall_clock64();
+  if (round < 3) dbg_t[3 + 3 * round] = wall_clock64();
+#endif
+  if (!has_next) break;
+  // the next tile becomes the current one; the tile after it gets its loader state here, while this tile's stores are on their way
+  par = (par + nk) & 1;
+  cs = ns;
+  cur_tile = nxt_tile;
+  nxt_tile = tile_of(round + 2);
+  if (nxt_tile >= 0) setup(nxt_tile, ns);
+  // (the staging reads above are done -- their values went into the stores -- before this wave reaches the next tile's first barrier,
+  // behind which the first DMA into this stage is issued)
+  }
+#ifdef HVR_DBG_BG_CLK
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  dbg_t[4] = wall_clock64();
-  if (threadIdx.x == 0 && (blockIdx.x % 7) == 0)
-    printf("BGCLK wg %d t0 %lld prologue %lld loop %lld epilogue %lld drain %lld\n", (int)blockIdx.x, dbg_t[0], dbg_t[1] - dbg_t[0], dbg_t[2] - dbg_t[1],
-           dbg_t[3] - dbg_t[2], dbg_t[4] - dbg_t[3]);
+  {
+    const long long t_end = wall_clock64();
+    if (threadIdx.x == 0 && (blockIdx.x % 5) == 0)
+      printf("BGCLK wg %d t0 %lld | tile0 loop %lld..%lld epi %lld | tile1 loop %lld..%lld epi %lld | tile2 loop %lld..%lld epi %lld | drained %lld\n", (int)blockIdx.x, dbg_t[0],
+             dbg_t[1] ? dbg_t[1] - dbg_t[0] : 0, dbg_t[2] ? dbg_t[2] - dbg_t[0] : 0, dbg_t[3] ? dbg_t[3] - dbg_t[0] : 0,
+             dbg_t[4] ? dbg_t[4] - dbg_t[0] : 0, dbg_t[5] ? dbg_t[5] - dbg_t[0] : 0, dbg_t[6] ? dbg_t[6] - dbg_t[0] : 0,
+             dbg_t[7] ? dbg_t[7] - dbg_t[0] : 0, dbg_t[8] ? dbg_t[8] - dbg_t[0] : 0, dbg_t[9] ? dbg_t[9] - dbg_t[0] : 0, t_end - dbg_t[0]);
+  }
 #endif
   };  // body
   if constexpr (FM0 == FM1) {
@@ -515,11 +585,17 @@ static hipError_t launch_bigtile(const GemmParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BG_BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(BG_NT), lds, stream, p);
+  // persistent workgroups, one per CU (256 on the MI355X this library is written for): a longer tile list is walked in rounds
+  static const int nper = std::getenv("HVR_BIGTILE_WGS") ? std::atoi(std::getenv("HVR_BIGTILE_WGS")) : 256;   // (tuning: 0 = one tile per workgroup)
+  const int grid = nper > 0 && tiles > nper ? nper : tiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BG_NT), lds, stream, p);
   return hipGetLastError();
 }
 
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream) {
+  // (an L2 prefetch of the A rows two K-steps ahead -- one 4-byte load per wave and K-step into an LDS scratch, vmcnt(1) in front of
+  // the K-step's closing barrier -- was built in round 6 and measured SLOWER everywhere: layer 3's reducing 1x1 94.2 -> 103.0 us,
+  // res5's 2048 -> 512 333 -> 364, fc_new_1 437 -> 475 (profiles/r06_bigtile_probe.txt); removed)
   if (p.dtype == DT_F16S) return launch_bigtile<f16s_t, 9, 9>(p, stream);
   if (p.dtype == DT_F16) return launch_bigtile<f16_t, 9, 9>(p, stream);
   return launch_bigtile<bf16_t, 9, 9>(p, stream);

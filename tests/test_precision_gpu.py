@@ -336,6 +336,34 @@ def test_big_tile_kernel_on_half_operands_equals_the_tile_engine(B, H, W, Cin, C
                        native.conv2d_nhwc(x, w, bias, r, relu=True, stride=stride, pad=pad, dil=dil, tile=11))
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, SPLIT], ids=['bf16', 'f16', 'f16x2'])
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,pad,dil,res', [
+    (60, 38, 63, 256, 256, 3, 1, 1, False),    # layer 3's 3x3 on four clips: 499 tiles = two rounds of 256 persistent workgroups
+    (60, 38, 63, 1024, 256, 1, 0, 1, False),   # its reducing 1x1: 16 K-steps
+    (30, 38, 63, 256, 1024, 1, 0, 1, True),    # its expand conv + residual: 1 000 tiles = four rounds, 4 K-steps per tile
+    (33, 38, 63, 320, 256, 1, 0, 1, True),     # an ODD number of K-steps (5): the LDS stage a tile starts in alternates
+    (31, 37, 61, 256, 512, 3, 2, 2, False),    # dilation 2, odd extents, a ragged last tile in the second round
+])
+def test_big_tile_persistent_rounds_equal_the_tile_engine(B, H, W, Cin, Cout, k, pad, dil, res, dtype):
+    """bigtile.hip's PERSISTENT form (round 6): more tiles than the 256 workgroups of a launch -- a workgroup's second tile has its
+    loader state built under the first one's epilogue, its first K-step fetched under the first one's last K-step, and the first one's
+    stores drain under its loop.  Bit for bit the tile engine's result (tile=11), like the one-tile-per-workgroup launches; odd K-step
+    counts (the starting LDS stage flips per tile), residual epilogues and split-half operands included."""
+    if dtype == SPLIT and Cin % 32:
+        pytest.skip('split-half rows are whole 32-element groups')
+    x = _to(_rand((B, H, W, Cin), 181), dtype)
+    w = _tow(_rand((Cout, k, k, Cin), 182, 0.03), dtype)
+    bias = _rand((Cout,), 183).to(DEV)
+    r = _to(_rand((B, H, W, Cout), 184), dtype) if res else None
+    tiles = ((B * H * W + 287) // 288) * (Cout // 256)
+    assert tiles > 256
+    big = native.conv2d_nhwc(x, w, bias, r, relu=True, pad=pad, dil=dil, tile=17)
+    eng = native.conv2d_nhwc(x, w, bias, r, relu=True, pad=pad, dil=dil, tile=11)
+    assert big.dtype == dtype and torch.equal(big, eng)
+    again = native.conv2d_nhwc(x, w, bias, r, relu=True, pad=pad, dil=dil, tile=17)
+    assert torch.equal(big, again)
+
+
 def test_big_tile_kernel_on_split_half_tracks_the_f64_product():
     """The split-half big tiles against a float64 convolution of the un-rounded f32 inputs (res5's 3x3, dilation 2, ragged last
     row tile): 22-bit operands, exact products, f32 sums -- 5e-6 of the output scale, like the tile engine's split K-step."""

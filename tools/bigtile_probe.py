@@ -26,7 +26,8 @@ ap.add_argument('--hint', default='force', choices=['force', 'default', 'through
 args = ap.parse_args()
 # name: (Cin, Cout, k, dil, residual)
 SHAPES = dict(reduce=(1024, 256, 1, 1, False), c3=(256, 256, 3, 1, False), expand=(256, 1024, 1, 1, True), res5c3=(512, 512, 3, 2, False),
-              rpn=(1024, 512, 3, 1, False), res5reduce=(2048, 512, 1, 1, False))
+              rpn=(1024, 512, 3, 1, False), res5reduce=(2048, 512, 1, 1, False), fc1=(12544, 1024, 1, 1, False), qk=(1024, 2048, 1, 1, False))
+# fc1 / qk: the head's linear layers on 300 proposals per frame (M = frames x 300 rows)
 H, W = 38, 63
 BIG_FORCE = native.BIG_TILE_HINT + 1   # gemm_params.h: kBigForce
 hint = dict(force=BIG_FORCE, default=0, throughput=native.BIG_TILE_HINT)[args.hint]
@@ -41,6 +42,7 @@ for name in args.shapes.split(','):
     Cin, Cout, k, dil, res = SHAPES[name]
     for B in [int(b) for b in args.frames.split(',')]:
         g = torch.Generator().manual_seed(1)
+        H, W = (1, 300) if name in ('fc1', 'qk') else (38, 63)
         x = operand(torch.randn((B, H, W, Cin), generator=g).relu())
         r = operand(torch.randn((B, H, W, Cout), generator=g).relu()) if res else None
         w = native.as_operand(torch.randn((Cout, k, k, Cin), generator=g).cuda() * 0.05, dt)

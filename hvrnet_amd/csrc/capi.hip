@@ -23,6 +23,7 @@ hipError_t run_relu_bwd_t(const void*, const void*, void*, void*, int, int, long
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_f16(const float*, void*, int, int, long, int, hipStream_t);
+hipError_t run_splitk_reduce_half_batched(const float*, void*, int, int, long, int, int, int, long, long, hipStream_t);
 hipError_t run_splitk_reduce_epi_bf16(const float*, void*, int, int, long, int, const float*, const void*, long, int, hipStream_t);
 hipError_t run_relation_normalize(void*, const float*, const float*, int, int, long, int, float, hipStream_t);
 hipError_t run_relu_bwd(const void*, const void*, void*, long, int, hipStream_t);
@@ -720,6 +721,69 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
   if (split && (ldv % 64 || !aligned128(V) || ldo % 32 || !aligned128(O) || D % 64)) return fail(HVR_EINVAL, "split-half relation: D, ldv multiples of 64, ldo of 32, 128-byte aligned V / O");
   // (exact: "bit for bit hvr_relation_fwd's" only holds when the single call takes the SAME scores kernel -- a per-group tile count
   // the one-group rule sends to the tile engine, e.g. Mq = Mk = 5 400: 352 tiles, runs as per-group single calls)
+  // ---- few query rows (the key stage, hrnmp_bbox_head.py:269-278,888-891: 300 x 4 500 per clip), two-byte operands: ONE launch per pass
+  // over all groups -- the tile engine's batch dimension (GemmParams::batch, gridDim.z = group): scores + V^T (the transposing workgroups
+  // behind every group's score tiles), the key-sliced apply pass, one reduce.  Every group's arithmetic is hvr_relation_fwd's (same
+  // tiles, same slices, same order): bit-identical to G single calls, in one sixth of the launches.  VERDICT r05 item 4.
+  const int key_slices = apply_slices(Mq, Mk, D);
+  if (groups > 1 && mode != 0 && staging && strides_ok && two_byte && Mq <= 1024 && key_slices > 1 && D % 8 == 0 && ldv % 8 == 0 &&
+      ldo % 8 == 0 && aligned16(V) && aligned16(Vt) && aligned16(O) && per % 16 == 0 &&
+      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, 1, false)) {
+    GemmParams p;
+    int rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
+    if (rc) return rc;
+    p.batch = groups;
+    p.gs_a = gsq * (long)es; p.gs_b = gsk * (long)es; p.gs_c = (long)per; p.gs_stat = (long)(per / 4);
+    p.tr_in = V; p.tr_out = Vt; p.tr_R = Mk; p.tr_C = D; p.tr_ldx = ldv; p.tr_ldt = ldp;
+    p.gs_tr_in = gsv * (long)es; p.gs_tr_out = (long)per;
+    const int score_tiles = ((Mq + 127) / 128) * ((Mk + 127) / 128);
+    const int vt_tiles = ((D + 63) / 64) * (int)((ldp + 63) / 64);
+    // transposing workgroups per group: together with the score tiles of all groups about two rounds of the chip's 512 resident
+    // workgroups (128 x 128 tiles, two per CU); at least 32, at most one per 64 x 64 tile
+    int nb = (1024 - groups * score_tiles) / groups;
+    nb = nb < 32 ? 32 : nb;
+    p.tr_blocks = nb < vt_tiles ? nb : vt_tiles;
+    p.N = Mk;
+    p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
+    p.tile_hint = 9; p.group_m = 8;   // (hvr_relation_fwd's choices for few query rows)
+    rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation (grouped key stage): scores");
+    if (rc) return rc;
+    GemmParams a;
+    rc = fill_linear(a, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, dtype, staging);
+    if (rc) return rc;
+    a.mstat = mstat; a.lstat = lstat; a.ntile = nt; a.group_m = 1;
+    a.batch = groups; a.gs_a = (long)per; a.gs_b = (long)per; a.gs_c = (long)per; a.gs_stat = (long)(per / 4);
+    const int per_blk = apply_slice_blocks();
+    a.ksplit_steps = per_blk * 2; a.ksplit_count = key_slices; a.csplit_bytes = (long)Mq * D * 4;
+    a.C = partial; a.ldc = D; a.out_f32 = 1; a.tile_hint = 1;
+    hipError_t e = run_tile_op(a, EPI_APPLY, s);
+    if (e == hipSuccess) e = run_splitk_reduce_half_batched(partial, O, Mq, D, ldo, key_slices, dtype == HVR_F16, groups, (long)(per / 4), gso, s);
+    return check_launch(e, "relation (grouped key stage): apply");
+  }
+  // the same stage on split-half operands: the scores pass and the folded apply pass (relation_split_tail's form for few query rows) as one
+  // launch each over all groups, the V^T copies per group in between -- 24 apply tiles per clip are 96 on the chip at once
+  if (groups > 1 && mode != 0 && staging && strides_ok && split && Mq < 1024 &&
+      !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, 1, true)) {
+    GemmParams p;
+    int rc = fill_linear(p, Q, K, P, Mq, (Mk + 3) / 4 * 4, D, ldq, ldk, ldp, dtype, staging);
+    if (rc) return rc;
+    p.N = Mk; p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt; p.group_m = 8; p.tile_hint = 0;
+    p.batch = groups; p.gs_a = gsq * (long)es; p.gs_b = gsk * (long)es; p.gs_c = (long)per; p.gs_stat = (long)(per / 4);
+    rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation (grouped key stage, split half): scores");
+    if (rc) return rc;
+    for (int g = 0; g < groups; ++g) {
+      rc = check_launch(run_transpose_pad((const char*)V + (size_t)g * gsv * es, (char*)Vt + (size_t)g * per, Mk, D, ldv, ldp, HVR_F16S, s),
+                        "relation (grouped key stage, split half): V transpose");
+      if (rc) return rc;
+    }
+    GemmParams a;
+    rc = fill_linear(a, P, Vt, O, Mq, D, (int)ldp, ldp, ldp, ldo, HVR_F16S, staging);
+    if (rc) return rc;
+    a.alpha = 1.f / kSplitProbScale;
+    a.mstat = mstat; a.lstat = lstat; a.ntile = nt; a.tile_hint = 0;
+    a.batch = groups; a.gs_a = (long)per; a.gs_b = (long)per; a.gs_c = gso * (long)es; a.gs_stat = (long)(per / 4);
+    return check_launch(run_tile_op(a, EPI_APPLY, s), "relation (grouped key stage, split half): apply");
+  }
   if (groups == 1 || mode == 0 || !staging || !strides_ok ||
       !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, groups, split) ||
       (exact && !scores_bt_supported(Mq, Mk, D, ldq, ldk, ldv, ldp, Q, K, V, P, Vt, 1, split))) {

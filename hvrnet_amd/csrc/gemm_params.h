@@ -62,6 +62,11 @@ struct GemmParams {
   void* tr_out;
   int tr_R, tr_C, tr_blocks;
   long tr_ldx, tr_ldt;
+  // batch > 1 (tile engine, plain products and the relation passes): `batch` independent problems of one shape in one launch, gridDim.z
+  // selects the problem; problem g's operands sit gs_* BYTES behind problem 0's (A, B, C / the split-K partials, tr_in, tr_out) and its
+  // block statistics gs_stat FLOATS behind (the key stage of hvr_relation_fwd_grouped: the clips of a call).  0 / 1 = one problem
+  int batch;
+  long gs_a, gs_b, gs_c, gs_stat, gs_tr_in, gs_tr_out;
 };
 
 struct TileShape { int bm, bn, wg_per_cu; float eff; };

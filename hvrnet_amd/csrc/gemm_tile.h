@@ -167,14 +167,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
+  const long grp = (long)blockIdx.z;   // GemmParams::batch: the problem of this workgroup (0 in a launch of one problem: every gs_* term vanishes)
   if constexpr (EPI == EPI_SCORES && sizeof(T) == 2) {
     // the workgroups behind the score tiles transpose V for the apply pass (GemmParams::tr_*: a few-row score grid leaves most CUs idle)
     if (p.tr_blocks > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
-      transpose_pad_tiles16<NT>((const unsigned short*)p.tr_in, (unsigned short*)p.tr_out, p.tr_R, p.tr_C, p.tr_ldx, p.tr_ldt,
-                                (int)blockIdx.x - tiles_m * tiles_n, p.tr_blocks, smem);
+      transpose_pad_tiles16<NT>((const unsigned short*)((const char*)p.tr_in + grp * p.gs_tr_in), (unsigned short*)((char*)p.tr_out + grp * p.gs_tr_out),
+                                p.tr_R, p.tr_C, p.tr_ldx, p.tr_ldt, (int)blockIdx.x - tiles_m * tiles_n, p.tr_blocks, smem);
       return;
     }
   }
+  float* const mstat_g = p.mstat + grp * p.gs_stat;
+  float* const lstat_g = p.lstat + grp * p.gs_stat;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   int pid_m = tile / tiles_n, pid_n = tile % tiles_n;  // n fastest: the A panel is reused across the N tiles
   if (p.group_m > 1) {
@@ -192,9 +195,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // slices' partials simply add): gridDim.y slices of `ksplit_steps` K-steps each write their own f32 partial
   // [M][N] at C + blockIdx.y * csplit_bytes; a weight-gradient GEMM has a few output tiles and a K of 10^4..10^5, which
   // one workgroup per tile would walk alone while most of the chip idles.  The slice is folded into the base pointers.
-  const char* Ab = (const char*)p.A;
-  const char* Bb = (const char*)p.B;
-  char* Cb = (char*)p.C;
+  const char* Ab = (const char*)p.A + grp * p.gs_a;
+  const char* Bb = (const char*)p.B + grp * p.gs_b;
+  char* Cb = (char*)p.C + grp * p.gs_c;
   int nk_slice = p.K / BKE;
   int blk0 = 0;  // EPI_APPLY: first 128-key block of this workgroup's K slice (slices are whole blocks)
   int kt_base = 0;  // conv + split-K: first K-step of this workgroup's slice (the tap / channel offset is derived from it)
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       // combine -- the FM loads were FM serial round trips: each sat under its own s_waitcnt vmcnt(0))
       float mfirst[FM];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) mfirst[i] = p.mstat[rowo[i] + blk0];
+      for (int i = 0; i < FM; ++i) mfirst[i] = mstat_g[rowo[i] + blk0];
       for (int t0 = lane >> 4; t0 < p.ntile; t0 += 4 * TB) {
         float mt[FM][TB], lt[FM][TB];
 #pragma unroll
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
             const int t = t0 + 4 * u;
             const bool ok = t < p.ntile;
             const int tt = ok ? t : p.ntile - 1;
-            const float a = p.mstat[rowo[i] + tt], b = p.lstat[rowo[i] + tt];
+            const float a = mstat_g[rowo[i] + tt], b = lstat_g[rowo[i] + tt];
             mt[i][u] = ok ? a : -INFINITY;   // a tile past the end: weight 0 (mx stays finite: t0 itself is a real tile)
             lt[i][u] = ok ? b : 0.f;
           }
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           // value merged with its previous self, and the copies that merge costs are the compiler's to place, see pipe_step)
           const int nb = kt / STEPS_PER_BLOCK + 1 < nblk ? kt / STEPS_PER_BLOCK + 1 : nblk - 1;
 #pragma unroll
-          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + nb);
+          for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(mstat_g + stat_row(i) + blk0 + nb);
           __builtin_amdgcn_sched_barrier(0);  // the g loads stay ahead of this step's DMA in the vmcnt queue
         }
       }
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         // costs are placed by the compiler, which knows nothing of this load's latency (see PAR above, check_asm_waits.py)
         const int nb = kt / STEPS_PER_BLOCK + 1 < nblk ? kt / STEPS_PER_BLOCK + 1 : nblk - 1;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(p.mstat + stat_row(i) + blk0 + nb);
+        for (int i = 0; i < FM; ++i) gnext[i] = load_f32_untracked(mstat_g + stat_row(i) + blk0 + nb);
       }
       if (load) tap_next();
       static_for<2>([&](auto KK) {
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (t == 12345.f) p.mstat[0] = t;
+      if (t == 12345.f) mstat_g[0] = t;
       return;
     }
 #endif
@@ -1157,8 +1160,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
         for (int w = 0; w < WN; ++w) sum += red[w * BM + row];
         if (m < p.M) {
           const int t = n0 / 128;
-          p.mstat[(long)m * p.ntile + t] = tmax[i];  // log2 units
-          p.lstat[(long)m * p.ntile + t] = sum;
+          mstat_g[(long)m * p.ntile + t] = tmax[i];  // log2 units
+          lstat_g[(long)m * p.ntile + t] = sum;
         }
       }
     }
@@ -1181,7 +1184,8 @@ static hipError_t launch_tile_impl(const GemmParams& p, hipStream_t stream) {
   });
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int extra = (EPI == EPI_SCORES && sizeof(T) == 2 && p.tr_blocks > 0) ? p.tr_blocks : 0;   // (V^T workgroups: tile_kernel, GemmParams::tr_*)
-  hipLaunchKernelGGL(kern, dim3(tiles + extra, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1), dim3(WM * WN * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tiles + extra, (EPI == EPI_LINEAR || EPI == EPI_APPLY) && p.ksplit_steps > 0 ? p.ksplit_count : 1, p.batch > 1 ? p.batch : 1),
+                     dim3(WM * WN * 64), lds, stream, p);
   return hipGetLastError();
 }
 

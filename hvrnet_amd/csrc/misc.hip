@@ -906,11 +906,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // the same sum rounded once to bf16 (the relation apply pass's split-K form); N % 8 == 0, 16-byte aligned rows
+// (gridDim.y > 1: that many problems of one shape, problem g's partials gs_ws floats and its output gs_c elements behind problem 0's)
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, T* __restrict__ C, int M, int N, long ldc,
-                                                                 int S) {
+                                                                 int S, long gs_ws, long gs_c) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x, per_row = N / 8, total = (long)M * per_row;
   if (q >= total) return;
+  ws += (long)blockIdx.y * gs_ws;
+  C += (long)blockIdx.y * gs_c;
   const long m = q / per_row, n = (q - m * per_row) * 8, stride = (long)M * N;
   const float* src = ws + m * N + n;
   float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
@@ -964,15 +967,18 @@ hipError_t run_splitk_reduce_epi_bf16(const float* ws, void* C, int M, int N, lo
   return hipGetLastError();
 }
 
-hipError_t run_splitk_reduce_bf16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
+hipError_t run_splitk_reduce_half_batched(const float* ws, void* C, int M, int N, long ldc, int S, int f16, int batch, long gs_ws, long gs_c, hipStream_t s) {
   const long total = (long)M * (N / 8);
-  hipLaunchKernelGGL(splitk_reduce_bf16_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S);
+  const dim3 grid((unsigned)((total + 255) / 256), (unsigned)(batch > 1 ? batch : 1));
+  if (f16) hipLaunchKernelGGL(splitk_reduce_bf16_kernel<f16_t>, grid, dim3(256), 0, s, ws, (f16_t*)C, M, N, ldc, S, gs_ws, gs_c);
+  else hipLaunchKernelGGL(splitk_reduce_bf16_kernel<bf16_t>, grid, dim3(256), 0, s, ws, (bf16_t*)C, M, N, ldc, S, gs_ws, gs_c);
   return hipGetLastError();
 }
+hipError_t run_splitk_reduce_bf16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
+  return run_splitk_reduce_half_batched(ws, C, M, N, ldc, S, 0, 1, 0, 0, s);
+}
 hipError_t run_splitk_reduce_f16(const float* ws, void* C, int M, int N, long ldc, int S, hipStream_t s) {
-  const long total = (long)M * (N / 8);
-  hipLaunchKernelGGL(splitk_reduce_bf16_kernel<f16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, (f16_t*)C, M, N, ldc, S);
-  return hipGetLastError();
+  return run_splitk_reduce_half_batched(ws, C, M, N, ldc, S, 1, 1, 0, 0, s);
 }
 
 hipError_t run_splitk_reduce(const float* ws, float* C, int M, int N, long ldc, int S, hipStream_t s) {

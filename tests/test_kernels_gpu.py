@@ -320,6 +320,7 @@ def test_relation_window_size_big_tile_path(Mq, Mk):
 
 @pytest.mark.parametrize('G,Mq,Mk,dtype', [(4, 4500, 4500, torch.bfloat16), (2, 4500, 4500, torch.bfloat16), (3, 4321, 4100, torch.bfloat16),
                                            (4, 4500, 4500, torch.float16), (2, 300, 4500, torch.bfloat16), (3, 96, 200, torch.float32),
+                                           (4, 300, 4500, torch.bfloat16), (3, 300, 4321, torch.float16),   # the key stage over the clips of a call: the tile engine's batch dimension
                                            (2, 5400, 5400, torch.bfloat16)])   # (352 tiles per group: the one-group rule sends it to the tile engine -> `exact` runs single calls)
 def test_relation_grouped_equals_the_single_calls(G, Mq, Mk, dtype):
     """hvr_relation_fwd_grouped: G independent problems of one shape (the windows a batched head has in flight) in one call --

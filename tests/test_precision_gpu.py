@@ -201,6 +201,21 @@ def test_split_half_relation_window_size_on_the_big_tiles(G, Mq, Mk):
         assert (og - single).abs().max().item() < 2e-5 * single.abs().max().item(), g
 
 
+def test_split_half_key_stage_over_the_clips_of_a_call():
+    """The key stage (300 queries x 4 500 keys per clip, hrnmp_bbox_head.py:269-278) of W = 4 clips in ONE hvr_relation_fwd_grouped call on
+    split-half operands: scores and the folded apply pass as one tile-engine launch each over all clips (GemmParams::batch) -- every
+    clip's rows are hvr_relation_fwd's bit for bit, exact or not."""
+    G, Mq, Mk, D = 4, 300, 4500, 1024
+    q, k, v = _rand((G * Mq, D), 161, 0.5), _rand((G * Mk, D), 162, 0.5), _rand((G * Mk, D), 163)
+    qd, kd, vd = _to(q, SPLIT), _to(k, SPLIT), _to(v, SPLIT)
+    sc = 1.0 / math.sqrt(D)
+    o = native.relation_fwd_grouped(qd, kd, vd, sc, G)
+    oe = native.relation_fwd_grouped(qd, kd, vd, sc, G, exact=True)
+    for g in range(G):
+        single = native.relation_fwd(qd[g * Mq:(g + 1) * Mq], kd[g * Mk:(g + 1) * Mk], vd[g * Mk:(g + 1) * Mk], sc)
+        assert torch.equal(_back(o[g * Mq:(g + 1) * Mq]), _back(single)) and torch.equal(_back(oe[g * Mq:(g + 1) * Mq]), _back(single)), g
+
+
 def test_relation_split_half_peaky_rows():
     """One key dominates a row by e^40 and sits in a different 128-key block than the runner-up (block maxima differ by far
     more than the half range of exp2): the normalising sweep works from the f32 block statistics."""

@@ -745,7 +745,10 @@ int hvr_relation_fwd_grouped(const void* Q, int64_t ldq, int64_t gsq, const void
     p.tr_blocks = nb < vt_tiles ? nb : vt_tiles;
     p.N = Mk;
     p.scale = scale; p.mstat = mstat; p.lstat = lstat; p.ntile = nt;
-    p.tile_hint = 9; p.group_m = 8;   // (hvr_relation_fwd's choices for few query rows)
+    // the double-buffered 128 x 128 shape (two workgroups per CU: the 1 024 workgroups of four clips are two rounds) -- the single call's
+    // four-stage ring holds one workgroup per CU and is the better latency chain for ONE clip's 108 tiles; same MFMA order, same P~
+    // (sweep: 112 us per four clips against 122; profiles/r06_key_stage.txt)
+    p.tile_hint = 1; p.group_m = 8;
     rc = check_launch(run_tile_op(p, EPI_SCORES, s), "relation (grouped key stage): scores");
     if (rc) return rc;
     GemmParams a;

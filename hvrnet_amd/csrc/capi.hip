@@ -309,6 +309,9 @@ static int conv_params(const hvr_conv_desc* d, GemmParams& p, int& path) {
     GemmParams q = p;
     q.tile_hint = 0;
     big_first = bigtile_supported(q, p.tile_hint == kBigHint);
+    // (layer 3's expand + residual, K = 256: the big tiles are ahead on one clip -- 40 against 43 us for 15 frames -- and behind on a
+    // batch of clips -- 60 frames: 178 - 198 against 155 - 167 us, profiles/r06_expand_ablation_raw.txt / r06_l3_fused.txt)
+    if (big_first && p.resid && p.K == 256 && p.dtype != DT_F16S && p.M >= 65536 && expand_supported(p)) big_first = false;
   }
   path = (pointwise && (expand_supported(p) || expand_split_supported(p)) &&
           (p.tile_hint == kExpandHint || (hint0 && use_expand && p.resid && p.N >= 2 * p.K && !big_first))) ? 1 : 0;

@@ -371,7 +371,9 @@ bool expand_supported(const GemmParams& p) {
 
 template <typename T, int KF, bool RES, int NC, int NX = 0>
 static hipError_t launch_expand_nc(const GemmParams& p, hipStream_t stream) {
-  constexpr int RF = KF > 8 ? 1 : 2;
+  // (NX = 16 -- layer 3's closing 1x1 with the next block's 1024 -> 256 conv1: 64 next-conv accumulator registers per row fragment -- takes
+  // the 8-wave form too: one row fragment per wave, one workgroup per CU)
+  constexpr int RF = (KF > 8 || NX >= 16) ? 1 : 2;
   constexpr int lds = 2 * X_BN * KF * 32 * 2 + NC * X_BN * 4 + 2 * NX * 16 * 128;  // two W chunks + shifts (+ two Wn chunks)
   static_assert(lds <= (RF == 2 ? 80 : 160) * 1024, "two workgroups per CU (one with 8 waves at K = 512)");
   auto kern = expand_res_kernel<T, KF, RES, NC, RF, NX>;
@@ -413,6 +415,9 @@ static hipError_t run_expand_next(const GemmParams& p, hipStream_t stream) {
     if (p.K == 128 && p.resid) return launch_expand_nc<T, 4, true, 8, 8>(p, stream);
     if (p.K == 384 && !p.resid) return launch_expand_nc<T, 12, false, 8, 8>(p, stream);
   }
+  // layer 3's identity blocks (round 6): the 1024-channel block output is written once and never read back for the next block's conv1
+  // (92 MB of the block pair's 257 MB per window: resnet.py:224-232 of block i + 1 on the registers of resnet.py:248-264 of block i)
+  if (p.N == 1024 && p.Cn == 256 && p.K == 256 && p.resid) return launch_expand_nc<T, 8, true, 16, 16>(p, stream);
   return hipErrorInvalidValue;
 }
 
@@ -421,6 +426,9 @@ bool expand_next_supported(const GemmParams& p) {
   if ((reinterpret_cast<uintptr_t>(p.Wn) | reinterpret_cast<uintptr_t>(p.Hn) | reinterpret_cast<uintptr_t>(p.bias_n)) & 15) return false;
   if (p.N == 256 && p.Cn == 64) return (p.K == 64 && p.resid) || (p.K == 128 && !p.resid && p.s2 > 0);
   if (p.N == 512 && p.Cn == 128) return (p.K == 128 && p.resid) || (p.K == 384 && !p.resid && p.s2 > 0);
+  // (one 8-wave workgroup per CU and 128-pixel panels: it needs at least two rounds of panels to fill the chip -- 60 frames of 38 x 63:
+  // 240 us against 260 - 298 for the two launches; 15 frames = 281 panels: 86 against 67 - 78, profiles/r06_l3_fused.txt)
+  if (p.N == 1024 && p.Cn == 256) return p.K == 256 && p.resid && p.s2 == 0 && p.M >= 512 * X_BM;
   return false;
 }
 

@@ -688,6 +688,7 @@ def test_bottleneck_tail_fuses_the_projection_shortcut(C1, C2, Cout, stride, B, 
     (64, 0, 256, 64, 1, 2, 38, 63),       # layer1.1: identity block + layer1.2's conv1
     (128, 256, 512, 128, 2, 3, 19, 32),   # layer2.0 (stride-2 shortcut) + layer2.1's conv1
     (128, 0, 512, 128, 1, 1, 76, 126),    # layer2.x at the bench frame size (a ragged last panel: 9576 = 74 * 128 + 104)
+    (256, 0, 1024, 256, 1, 28, 38, 63),   # layer3.x (round 6; from 512 panels on): identity block + the next block's 1024 -> 256 conv1, 8 waves x 16 rows; 67 032 = 523 * 128 + 88
 ])
 def test_bottleneck_tail_next_also_computes_the_next_conv1(C1, C2, Cout, Cn, stride, B, OH, OW):
     """hvr_bottleneck_tail_next: the block output y is BIT-identical to the tail / expand kernel's, and hn is the next block's
@@ -723,10 +724,14 @@ def test_bottleneck_tail_next_also_computes_the_next_conv1(C1, C2, Cout, Cn, str
 
 def test_bottleneck_tail_next_says_when_it_does_not_apply():
     bf = dict(device=DEV, dtype=torch.bfloat16)
-    h, r = torch.zeros((1, 16, 16, 256), **bf), torch.zeros((1, 16, 16, 1024), **bf)
-    w, b = torch.zeros((1024, 256), **bf), torch.zeros(1024, device=DEV)
-    wn, bn = torch.zeros((256, 1024), **bf), torch.zeros(256, device=DEV)
-    assert not native.bottleneck_tail_next_supported(h, None, r, w, b, 1, wn, bn)      # stage 3: no kernel (Cn = 256 accumulators)
+    h, r = torch.zeros((1, 16, 16, 512), **bf), torch.zeros((1, 16, 16, 2048), **bf)
+    w, b = torch.zeros((2048, 512), **bf), torch.zeros(2048, device=DEV)
+    wn, bn = torch.zeros((512, 2048), **bf), torch.zeros(512, device=DEV)
+    assert not native.bottleneck_tail_next_supported(h, None, r, w, b, 1, wn, bn)      # res5: no kernel (Cn = 512 accumulators)
+    h3, r3 = torch.zeros((1, 16, 16, 256), **bf), torch.zeros((1, 16, 16, 1024), **bf)
+    w3, b3 = torch.zeros((1024, 256), **bf), torch.zeros(1024, device=DEV)
+    wn3, bn3 = torch.zeros((256, 1024), **bf), torch.zeros(256, device=DEV)
+    
     h1, r1 = torch.zeros((1, 16, 16, 64), **bf), torch.zeros((1, 16, 16, 256), **bf)
     w1, b1 = torch.zeros((256, 64), **bf), torch.zeros(256, device=DEV)
     wn1, bn1 = torch.zeros((64, 256), **bf), torch.zeros(64, device=DEV)

@@ -299,20 +299,31 @@ __global__ __launch_bounds__(64 * (X_BM / 16 / RF), RF == 2 ? 2 : 1) void expand
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NX > 0) {
-      // next block's conv1 on this chunk: 2 K = 32 MFMAs (v = 0 / 1) per (row fragment, output fragment)
+      // next block's conv1 on this chunk: 2 K = 32 MFMAs (v = 0 / 1) per (row fragment, output fragment).  The Wn fragment pairs stream
+      // through a ring of ND pairs requested ND output fragments ahead (round 6: with one read pair waited for per two MFMAs the loop
+      // was a chain of LDS latencies -- 16 x ~150 cycles per chunk in the NX = 16 instance); LDS returns in order, the waits are counted
       const uint32_t nb0 = n_lane + (uint32_t)(u & 1) * NCHUNK;
-      static_for<NX>([&](auto JO) {
+      constexpr int ND = NX < 4 ? NX : 4;
+      uint4 wq[ND][2];
+      auto nread = [&](auto JO) {
         constexpr int jo = decltype(JO)::value;
         constexpr int roff = (64 * (jo >> 2) + 4 * (jo & 3)) * 128;
-        const uint4 w0 = x_lds_read128<roff>(nb0 + ((((g << 1) | 0) ^ nkey) << 4));
-        const uint4 w1 = x_lds_read128<roff>(nb0 + ((((g << 1) | 1) ^ nkey) << 4));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wq[jo % ND][0] = x_lds_read128<roff>(nb0 + ((((g << 1) | 0) ^ nkey) << 4));
+        wq[jo % ND][1] = x_lds_read128<roff>(nb0 + ((((g << 1) | 1) ^ nkey) << 4));
+      };
+      static_for<ND>([&](auto JO) { nread(JO); });
+      static_for<NX>([&](auto JO) {
+        constexpr int jo = decltype(JO)::value;
+        constexpr int ahead = (NX - 1 - jo) < (ND - 1) ? (NX - 1 - jo) : (ND - 1);   // pairs requested behind this one
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ahead) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RF; ++i) {
-          hacc[i][jo] = mfma_half<HT>(w0, __builtin_bit_cast(uint4, yv[i][0]), hacc[i][jo]);
-          hacc[i][jo] = mfma_half<HT>(w1, __builtin_bit_cast(uint4, yv[i][1]), hacc[i][jo]);
+          hacc[i][jo] = mfma_half<HT>(wq[jo % ND][0], __builtin_bit_cast(uint4, yv[i][0]), hacc[i][jo]);
+          hacc[i][jo] = mfma_half<HT>(wq[jo % ND][1], __builtin_bit_cast(uint4, yv[i][1]), hacc[i][jo]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (jo + ND < NX) nread(std::integral_constant<int, jo + ND>{});
       });
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -417,6 +428,10 @@ static hipError_t run_expand_next(const GemmParams& p, hipStream_t stream) {
   }
   // layer 3's identity blocks (round 6): the 1024-channel block output is written once and never read back for the next block's conv1
   // (92 MB of the block pair's 257 MB per window: resnet.py:224-232 of block i + 1 on the registers of resnet.py:248-264 of block i)
+  // (a WAVE-PAIR form -- 4 row groups x 2 channel halves, 32 pixels per wave, every W / Wn fragment read feeding two MFMAs, the halves'
+  // output pieces exchanged through the LDS: half the fragment reads, one more barrier per chunk -- was built and measured SLOWER, 272 us
+  // against 232 - 240 for a 60-frame block: the kernel is bound by the 1.15 GB of W3 / Wn chunks every call re-streams from the L2s into
+  // 1 123 panels' LDS (4.9 TB/s of LDS-DMA beside 3.2 TB/s of HBM traffic), not by its LDS reads; profiles/r06_l3_fused.txt; removed)
   if (p.N == 1024 && p.Cn == 256 && p.K == 256 && p.resid) return launch_expand_nc<T, 8, true, 16, 16>(p, stream);
   return hipErrorInvalidValue;
 }

@@ -391,8 +391,10 @@ int hvr_bottleneck_tail(const hvr_tail_desc* d, void* stream) {
   if (rc) return rc;
   if (expand_supported(p)) return check_launch(run_expand(p, (hipStream_t)stream), "hvr_bottleneck_tail");
   if (tail_on_tile_engine(p)) {
-    // (the 288 x 256 tiles take the second K segment too, but measured slightly behind the tile engine here -- 144.7 vs 145.7
-    // frames/s on the single-lane window, round 3: not taken)
+    // the 288 x 256 tiles take the second K segment too (same MFMA order: bit-identical).  Round 3 measured them slightly behind the tile
+    // engine here; with persistent workgroups (round 6) they are ahead: res5's 512 + 1024 -> 2048 tail 973 -> 857 us for four clips (230 ->
+    // 200 for one), layer 3's 256 + 512 -> 1024 311 -> 256 (72 -> 69)
+    if (bigtile_supported(p, false)) return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_bottleneck_tail(big tile)");
     return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_bottleneck_tail(tile engine)");
   }
   return fail(HVR_EUNSUPPORTED, "no fused tail kernel for C1=%d C2=%d Cout=%d", d->C1, d->C2, d->Cout);

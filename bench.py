@@ -1000,7 +1000,7 @@ def main(argv=None):
                 mx = (lambda key: max(v for v, sp in zip(pc[key], cnt[:len(pc[key])]) if sp))   # over the clips checked as they are
                 inj = [i_ for i_ in pc['with_the_oracles_proposals_injected'] if i_ is not None]
                 worst = dict(class_flips=mx('class_flips'), max_score_err=mx('max_score_err'), max_box_err=mx('max_box_err_vs_f32'),
-                             max_box_excess=mx('max_box_excess_vs_f32'), max_box_err_vs_f64=max(pc['max_box_err_vs_f64']) if pc['max_box_err_vs_f64'] else None,
+                             max_box_excess=mx('max_box_excess_vs_f32'), max_box_err_vs_f64=(max([v for v, sp in zip(pc['max_box_err_vs_f64'], cnt) if sp] or [None]) if pc['max_box_err_vs_f64'] else None),   # (over the f64 clips checked as they are)
                              tie_swaps=mx('tie_swaps'), max_box_err_with_injected_proposals=max([i_['max_box_err'] for i_ in inj]) if inj else None,
                              fixed_bar_r04_on_every_clip_checked_as_it_is=all(f_ for f_, sp in zip(pc['fixed_bar_r04'], cnt) if sp),
                              literal_1e3_px=dict(vs_f32=[sum(pc['literal_1e3_vs_f32']), pc['clips']], vs_f64=[sum(pc['literal_1e3_vs_f64']), len(pc['literal_1e3_vs_f64'])]))

@@ -37,7 +37,7 @@ for G in 1 4; do
   $T python tools/rocpd_stats.py $(db /tmp/r_ks) >> $out/rel_bench_f16x2$sfx.txt
 done
 # (the traffic files are keyed to this build: put them where bench.py looks before the bench lines are taken)
-r=${ROUND:-r05}; cp $out/relation_traffic.json profiles/${r}_relation_traffic.json; cp $out/relation_traffic_g4.json profiles/${r}_relation_traffic_g4.json; cp $out/relation_traffic_f16x2_g4.json profiles/${r}_relation_traffic_f16x2_g4.json
+r=${ROUND:-r06}; cp $out/relation_traffic.json profiles/${r}_relation_traffic.json; cp $out/relation_traffic_g4.json profiles/${r}_relation_traffic_g4.json; cp $out/relation_traffic_f16x2_g4.json profiles/${r}_relation_traffic_f16x2_g4.json
 $T python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
 $T python bench.py --head selsa --steps 20 --warmup 3 --no-train-step > $out/bench_selsa.json 2>/dev/null
 $T python bench.py --frames 21 --steps 10 --warmup 2 --no-train-step --no-f32-leg --no-side-loops --quick > $out/bench_T21.json 2>/dev/null   # the shipped window length (frame_interval = 10)

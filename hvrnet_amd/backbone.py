@@ -38,6 +38,17 @@ def as_logical(y):
 
 def fold_conv_bn(conv, bn, dtype):
     """(w [Cout,KH,KW,Cin] in `dtype`, bias [Cout] f32) with eval-mode BN folded in."""
+    if bn is not None and conv.bias is None and dtype == torch.bfloat16 and conv.weight.is_cuda \
+            and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous() and not bn.training:
+        # the same numbers in one launch (or none; bf16 only -- the half instance of the pack kernel rounds product and conversion in ONE
+        # step, v_fma_mixlo_f16, where torch rounds twice: tools/probe_fold.py): the frozen BatchNorm's affine is cached until one of its tensors changes, and the
+        # permute + scale + rounding is the pack kernel the training path uses -- inside a training iteration the operand this
+        # iteration's weight table already holds (the no-grad res5 pass of HNMBRCNN.forward_train repacks after every update)
+        from . import train_ops as TO
+        s_, t_ = TO._frozen_bn_affine(bn)
+        w_ = conv.weight.detach()
+        eff = TO.table_operand(conv.weight, s_, tuple(w_.shape), dtype)
+        return (eff if eff is not None else native.pack_conv_weight(w_, s_, dtype)), t_
     w = conv.weight.detach().float()
     if bn is not None:
         scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)

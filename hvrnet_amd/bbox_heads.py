@@ -401,24 +401,45 @@ class HRNMPBBoxHead(_RelationHead):
         ("pos_sm and pos_nsm are in wrong (inversed) positions", :408): positives = the different-label key with the highest
         affinity, negatives = the same-label key with the lowest.
         -> ([branch logits, final logits] f32 fused [rows, num_classes + 4 (+pad)], dict(loss_trip))."""
-        from . import train_ops as TO
+        from . import ops, train_ops as TO
         assert cur_range_s is not None and len(cur_range_s) == len(bbox_feat_s)
         self.key_dim, self.nongt_dim = key_dim, self.sampler_num * self.t_dim
         per_video = self.imgs_per_video * self.sampler_num
-        branch, key_rows = [], []
-        for feat, cur in zip(bbox_feat_s, cur_range_s):
-            s, l = int(cur['start']), int(cur['length'])
-            assert s == 0, 'training keeps the key frame first (hnmb_rcnn.py:263: key_dim has to be 0)'
-            rows = slice(s, s + l)
-            f1 = TO.linear(self._train_rows(feat), self.fc_new_1.weight, self.fc_new_1.bias)
-            h1 = self._train_stage(1, f1, None, per_video)
-            f2 = TO.linear(h1, self.fc_new_2.weight, self.fc_new_2.bias)
-            h2 = self._train_stage(2, f2, rows, per_video)                           # [l, 1024]: idx_output_cur_only
-            branch.append(self._train_readout(h2, self.fc_cls, self.fc_reg))
-            x3 = torch.cat([h2[s:s + l], f1[s + l:]], dim=0)                          # :700-702 (key rows lead: start = 0)
-            f3 = TO.linear(x3.contiguous(), self.fc_new_3.weight, self.fc_new_3.bias)
-            key_rows.append(self._train_stage(3, f3, rows, per_video))
-        video_feats = torch.cat(key_rows, dim=0)
+        # The layers' weights are shared by the videos and a linear layer works row by row, so where the reference loops over the videos
+        # (:652-733) every fc / projection / output layer runs ONCE on all videos' rows (one forward product, one data gradient and one
+        # weight gradient per layer instead of one per video); only the relation core is per video (its softmax is over the video's keys).
+        R = [int(f.shape[0]) for f in bbox_feat_s]
+        L = []
+        for cur in cur_range_s:
+            assert int(cur['start']) == 0, 'training keeps the key frame first (hnmb_rcnn.py:263: key_dim has to be 0)'
+            L.append(int(cur['length']))
+        assert all(r <= per_video for r in R), 'keys of a video: all of its rows (hrnmp_bbox_head.py:249)'
+        r0 = [sum(R[:v]) for v in range(len(R))]      # first row of video v among all rows
+        l0 = [sum(L[:v]) for v in range(len(L))]      # ... among the key rows
+        key_of = lambda t: torch.cat([t[r0[v]:r0[v] + L[v]] for v in range(len(R))], dim=0) if len(R) > 1 else t[:L[0]]
+        scale = 1.0 / math.sqrt(float(self.dim[1]))
+
+        def stage(k, f, key_queries):
+            """relation stage k on all videos' rows f: queries = every row, or the videos' key rows; keys / values = the video's rows"""
+            sel = getattr(self, 'selsa_%d' % k)
+            fq = key_of(f) if key_queries else f
+            q = TO.linear(fq, sel['q_data_fc_%d' % k].weight, sel['q_data_fc_%d' % k].bias)
+            kk = TO.linear(f, sel['k_data_fc_%d' % k].weight, sel['k_data_fc_%d' % k].bias)
+            o = []
+            for v in range(len(R)):
+                qv = q[l0[v]:l0[v] + L[v]] if key_queries else q[r0[v]:r0[v] + R[v]]
+                o.append(ops.relation(qv, kk[r0[v]:r0[v] + R[v]], f[r0[v]:r0[v] + R[v]], scale))
+            z = sel['linear_out_%d' % k]
+            return TO.linear(torch.cat(o, dim=0) if len(o) > 1 else o[0], z.weight.view(z.weight.shape[0], -1), z.bias, resid=fq.contiguous(), relu=True)
+
+        f1 = TO.linear(self._train_rows(torch.cat(list(bbox_feat_s), dim=0) if len(bbox_feat_s) > 1 else bbox_feat_s[0]), self.fc_new_1.weight, self.fc_new_1.bias)
+        h1 = stage(1, f1, False)
+        f2 = TO.linear(h1, self.fc_new_2.weight, self.fc_new_2.bias)
+        h2 = stage(2, f2, True)                                                        # [sum l, 1024]: idx_output_cur_only
+        branch = self._train_readout(h2, self.fc_cls, self.fc_reg)
+        x3 = torch.cat([t for v in range(len(R)) for t in (h2[l0[v]:l0[v] + L[v]], f1[r0[v] + L[v]:r0[v] + R[v]])], dim=0)   # :700-702
+        f3 = TO.linear(x3, self.fc_new_3.weight, self.fc_new_3.bias)
+        video_feats = stage(3, f3, True)                                               # the videos' key rows, video-major
         assert self.nongt_dim >= video_feats.shape[0]                                 # :451
         f4 = TO.linear(video_feats.contiguous(), self.fc_new_4.weight, self.fc_new_4.bias)
         qk = self._train_qk(4, f4, None, self.nongt_dim)
@@ -434,7 +455,7 @@ class HRNMPBBoxHead(_RelationHead):
             losses['loss_trip'] = loss_trip
         h4 = self._train_stage(4, f4, qk=qk)                                          # cur_only_for_4 = False: every key row
         final = self._train_readout(h4, self.fc_cls_2, self.fc_reg_2)
-        return [torch.cat(branch, dim=0), final], losses
+        return [branch, final], losses
 
     def loss_train(self, logits_list, labels, label_weights, bbox_targets, bbox_weights):
         """HRNMPBBoxHead.loss (hrnmp_bbox_head.py:970-1007) on the fused logits of each branch:

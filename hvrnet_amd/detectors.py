@@ -150,6 +150,19 @@ class TwoStageDetector(BaseDetector):
         return self.rpn_head.get_bboxes(*(rpn_outs + (img_meta, rpn_test_cfg)))
 
 
+def _sampled_rois(results):
+    """bbox2roi of the frames' sampled boxes (transforms.py:114-136): [sum n_i, 5] = (frame index, box).  The frame-index column comes from
+    one repeat_interleave when every frame kept the same number of boxes (the sampler's `num`: the usual case), the boxes from one cat."""
+    boxes = [r.bboxes for r in results]
+    n = [int(b.shape[0]) for b in boxes]
+    allb = torch.cat(boxes, 0)
+    if len(set(n)) == 1 and n[0] > 0:
+        col = torch.arange(len(n), device=allb.device, dtype=allb.dtype).repeat_interleave(n[0])
+    else:
+        col = torch.cat([allb.new_full((k,), float(i)) for i, k in enumerate(n)], 0)
+    return torch.cat([col[:, None], allb], 1), n
+
+
 class PendingWindow(object):
     """A window whose kernels are enqueued but whose results have not been read.  `result()` is the window's single
     host synchronisation: detections, labels, counts and the per-frame proposal counts arrive in one batch of
@@ -481,8 +494,8 @@ class SelsaRCNN(_WindowDetector):
             assign_result = bbox_assigner.assign(props, gt_b, None, gt_l)
             k_i = keys['rcnn'][i][:gt_b.shape[0] * int(bbox_sampler.add_gt_as_proposals) + props.shape[0]] if 'rcnn' in keys else None
             sampling_results.append(bbox_sampler.sample(assign_result, props, gt_b, gt_l, keys=k_i, generator=generator))
-        rois = torch.cat([torch.cat([r.bboxes.new_full((r.bboxes.shape[0], 1), float(i)), r.bboxes], 1)
-                          for i, r in enumerate(sampling_results)], 0)
+        T.SamplingResult.resolve(sampling_results)       # every frame's (#pos, #neg) in one host read
+        rois, _ = _sampled_rois(sampling_results)
         n_key = sampling_results[key].bboxes.shape[0]
         cur_range = dict(start=key * n_key, length=n_key)
         c5 = self.shared_head.forward_train_nhwc(c4)
@@ -557,16 +570,20 @@ class HNMBRCNN(_WindowDetector):
         it and the video of ANOTHER class most similar to those two -- by softmax-normalised dot products of the videos'
         descriptors (global average pool of each frame's res5 map, maximum over the video's frames).  A handful of
         256-vectors: plain tensor arithmetic, one host read of the two chosen indices.
-        c5_feats_all: per video a logical [frames, C, h, w] map.  -> [key_video, same-class id, other-class id]."""
-        desc = [f.float().mean(dim=(2, 3)).max(dim=0).values[None] for f in c5_feats_all]        # [1, C] per video
-        key = torch.cat(desc[0:video_per_cls], dim=0)
+        c5_feats_all: per video a logical [frames, C, h, w] map, or all videos' frames as one tensor.  -> [key_video, same-class id, other-class id]."""
+        if isinstance(c5_feats_all, torch.Tensor):     # all videos' frames in one [V * frames, C, h, w] map: three launches for the descriptors
+            desc = c5_feats_all.float().mean(dim=(2, 3)).view(-1, imgs_per_video, c5_feats_all.shape[1]).max(dim=1).values
+        else:
+            desc = torch.stack([f.float().mean(dim=(2, 3)).max(dim=0).values for f in c5_feats_all], 0)   # [V, C]
+        key = desc[0:video_per_cls]
         scale = 1.0 / float(key.shape[-1]) ** 0.5
-        key_sim = torch.softmax(scale * (desc[0] @ key.t()), dim=1)
-        same_id = int(torch.argmin(key_sim[:, 1:], dim=1)[0]) + 1
-        chosen = torch.cat([desc[key_video], desc[same_id]], dim=0)
-        extra = torch.cat(desc[video_per_cls:], dim=0)
+        key_sim = torch.softmax(scale * (desc[0:1] @ key.t()), dim=1)
+        same = torch.argmin(key_sim[:, 1:], dim=1) + 1                                            # [1], on the device
+        chosen = torch.cat([desc[key_video:key_video + 1], desc[same]], dim=0)
+        extra = desc[video_per_cls:]
         extra_sim = torch.softmax(scale * (chosen @ extra.t()), dim=1).sum(dim=0, keepdim=True)
-        other_id = int(torch.argmax(extra_sim, dim=1)[0]) + video_per_cls
+        other = torch.argmax(extra_sim, dim=1) + video_per_cls
+        same_id, other_id = (int(v) for v in torch.cat([same, other]).tolist())                   # the iteration's one host read here
         return [key_video, same_id, other_id]
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
@@ -598,8 +615,7 @@ class HNMBRCNN(_WindowDetector):
         with torch.no_grad():                                   # extract_c4_c5_feat (:54-72)
             c4 = self.extract_feat(img)[0]                      # [V * F, 1024, h, w] logical, NHWC in memory
             c5_sel = self.shared_head(c4)
-        chosen = self.get_triplet_patches([c5_sel[v * F_:(v + 1) * F_] for v in range(V)], 0, F_, V - self.VIDEO_PER_CLS,
-                                          self.VIDEO_PER_CLS)
+        chosen = self.get_triplet_patches(c5_sel, 0, F_, V - self.VIDEO_PER_CLS, self.VIDEO_PER_CLS)
         del c5_sel
         bbox_assigner = T.build_assigner(rcnn_cfg.assigner)
         bbox_sampler = T.build_sampler(rcnn_cfg.sampler, context=self)
@@ -616,7 +632,8 @@ class HNMBRCNN(_WindowDetector):
                 for vi in range(len(chosen)):
                     sl = slice(vi * F_, (vi + 1) * F_)
                     proposal_list += self.rpn_head.get_bboxes([rpn_outs[0][0][sl]], [rpn_outs[1][0][sl]], metas_k[sl], proposal_cfg)
-        rois, cur_ranges, key_results, key_gtb, key_gtl, rows = [], [], [], [], [], []
+        cur_ranges, key_results, key_gtb, key_gtl, rows = [], [], [], [], []
+        per_video = []
         for vi, v in enumerate(chosen):
             gt_b, gt_l = gt_bboxes[v * F_ + self.key_dim], gt_labels[v * F_ + self.key_dim]
             results = []
@@ -627,14 +644,17 @@ class HNMBRCNN(_WindowDetector):
                 if keys is not None and 'rcnn' in keys:
                     k_i = keys['rcnn'][vi][i][:gt_b.shape[0] * int(bbox_sampler.add_gt_as_proposals) + props.shape[0]]
                 results.append(bbox_sampler.sample(assign_result, props, gt_b, gt_l, keys=k_i, generator=generator))
-            rois += [torch.cat([r.bboxes.new_full((r.bboxes.shape[0], 1), float(vi * F_ + i)), r.bboxes], 1) for i, r in enumerate(results)]
-            rows.append(sum(r.bboxes.shape[0] for r in results))
-            cur_ranges.append(dict(start=self.key_dim, length=results[self.key_dim].bboxes.shape[0]))
+            per_video.append((results, gt_b, gt_l))
+        T.SamplingResult.resolve([r for results, _, _ in per_video for r in results])   # every frame's (#pos, #neg) in one host read
+        rois, n_rows = _sampled_rois([r for results, _, _ in per_video for r in results])
+        for vi, (results, gt_b, gt_l) in enumerate(per_video):
+            rows.append(sum(n_rows[vi * F_:(vi + 1) * F_]))
+            cur_ranges.append(dict(start=self.key_dim, length=n_rows[vi * F_ + self.key_dim]))
             key_results.append(results[self.key_dim])
             key_gtb.append(gt_b)
             key_gtl.append(gt_l)
         c5 = self.shared_head.forward_train_nhwc(c4k)                                   # res5 with a graph; C4 is a constant
-        all_feats = ops.roi_align(c5.permute(0, 3, 1, 2), torch.cat(rois, 0), layer.out_size, layer.spatial_scale, layer.sample_num)
+        all_feats = ops.roi_align(c5.permute(0, 3, 1, 2), rois, layer.out_size, layer.spatial_scale, layer.sample_num)
         feats = list(torch.split(all_feats, rows, dim=0))
         targets = T.bbox_target(key_results, key_gtb, key_gtl, rcnn_cfg, target_means=self.bbox_head.target_means,
                                 target_stds=self.bbox_head.target_stds)

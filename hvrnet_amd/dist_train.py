@@ -82,7 +82,7 @@ def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm
     try:
         loss = loss_fn()
         prev = train_ops.wgrad_overlap(overlap_wgrad)
-        prev_direct = train_ops.wgrad_direct(True)   # conv weight gradients added straight into flat's (zeroed) gradient buffer: this scope only
+        prev_direct = train_ops.wgrad_direct(True, pristine={id(p) for p in flat.params})   # weight gradients land straight in flat's (zeroed) gradient buffer: this scope only
         try:
             loss.backward()
         finally:

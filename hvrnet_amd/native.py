@@ -361,14 +361,18 @@ def gemm(a, w, bias=None, resid=None, relu=False, out_f32=False, out=None, stagi
     return out
 
 
-def gemm_splitk(a, w, staging=None, tile=None):
-    """f32 out[M,N] = a[M,K] @ w[N,K]^T for few-tile / long-K products (weight gradients): K slices in one launch + a reduce."""
+def gemm_splitk(a, w, staging=None, tile=None, out=None):
+    """f32 out[M,N] = a[M,K] @ w[N,K]^T for few-tile / long-K products (weight gradients): K slices in one launch + a reduce.
+    out: a contiguous f32 [M, N] tensor to write into (e.g. a parameter's gradient buffer) instead of a fresh one."""
     _need_cuda(a, w)
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.dtype == w.dtype, (a.shape, w.shape)
     assert a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        assert out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.is_contiguous() and out.device == a.device
     d = GemmDesc(A=a.data_ptr(), B=w.data_ptr(), C=out.data_ptr(), M=M, N=N, K=K, lda=a.stride(0), ldb=w.stride(0), ldc=N,
                  bias=None, resid=None, ldr=0, relu=0, out_f32=int(a.dtype != torch.float32), dtype=_dt(a),
                  staging=STAGING if staging is None else staging, tile_hint=TILE_HINT if tile is None else tile)
@@ -802,11 +806,15 @@ def im2col_t(x, KH, KW, pad, dil, ldt):
     return out
 
 
-def colsum(dy):
-    """[M, N] -> f32 [N] column sums (bias gradient)."""
+def colsum(dy, out=None):
+    """[M, N] -> f32 [N] column sums (bias gradient); out: a contiguous f32 [N] tensor to write into."""
     _need_cuda(dy)
     assert dy.dim() == 2 and dy.stride(1) == 1
-    db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+    if out is None:
+        db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+    else:
+        assert out.dtype == torch.float32 and tuple(out.shape) == (dy.shape[1],) and out.is_contiguous() and out.device == dy.device
+        db = out
     nbytes = lib().hvr_colsum_workspace_bytes(dy.shape[0], dy.shape[1])
     ws = _workspace(nbytes, dy.device, 'colsum') if nbytes else None
     _check(lib().hvr_colsum(_ptr(dy), _ptr(db), dy.shape[0], dy.shape[1], dy.stride(0), _dt(dy), _ptr(ws), nbytes, _stream()), 'hvr_colsum')

@@ -113,8 +113,11 @@ class RelationFunction(Function):
         ldq = (Mq + step - 1) // step * step
         P = native.relation_probs(q, k, ctx.scale)                   # [Mq, ldp], padding columns zero
         ldp = P.shape[1]
-        vp = v.new_zeros((ldp, D))                                   # V with zero rows for the padded keys
-        vp[:Mk] = v
+        if ldp == Mk:
+            vp = v
+        else:
+            vp = v.new_zeros((ldp, D))                               # V with zero rows for the padded keys
+            vp[:Mk] = v
         dP = native.gemm(go, vp)                                     # [Mq, ldp]
         dS = native.relation_dscore(P, dP, go, o, ctx.scale)         # [Mq, ldp]
         go_t = native.transpose_pad(go, ldq)                         # [D, ldq]

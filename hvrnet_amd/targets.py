@@ -21,16 +21,39 @@ import torch
 from . import native
 
 
+_arange1 = {}
+
+
+def _one_based(k, device):
+    """arange(1, k + 1) int64 on `device`, one tensor per (k, device): the gt rows' own assignments in add_gt_."""
+    key = (int(k), str(device))
+    if key not in _arange1:
+        _arange1[key] = torch.arange(1, k + 1, dtype=torch.long, device=device)
+    return _arange1[key]
+
+
 class AssignResult(object):
-    """assigners/assign_result.py:4-19."""
+    """assigners/assign_result.py:4-19.  (`max_overlaps` after add_gt_ is put together on first use: nothing on the training path
+    reads it, and a frame-by-frame loop pays two launches per frame for it otherwise.)"""
 
     def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
-        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+        self.num_gts, self.gt_inds, self._max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+        self._ones_in_front = 0
+
+    @property
+    def max_overlaps(self):
+        if self._ones_in_front:
+            self._max_overlaps = torch.cat([self._max_overlaps.new_ones(self._ones_in_front), self._max_overlaps])
+            self._ones_in_front = 0
+        return self._max_overlaps
+
+    @max_overlaps.setter
+    def max_overlaps(self, v):
+        self._max_overlaps, self._ones_in_front = v, 0
 
     def add_gt_(self, gt_labels):
-        self_inds = torch.arange(1, self.num_gts + 1, dtype=torch.long, device=self.gt_inds.device)
-        self.gt_inds = torch.cat([self_inds, self.gt_inds])
-        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(self.num_gts), self.max_overlaps])
+        self.gt_inds = torch.cat([_one_based(self.num_gts, self.gt_inds.device), self.gt_inds])
+        self._ones_in_front += self.num_gts
         if self.labels is not None:
             self.labels = torch.cat([gt_labels, self.labels])
 
@@ -42,6 +65,7 @@ class MaxIoUAssigner(object):
             raise NotImplementedError('gt_max_assign_all=False is not on the HIP path (the HVRNet configs keep the default)')
         self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, neg_iou_thr, min_pos_iou
         self.ignore_iof_thr = ignore_iof_thr
+        self._ext = (None, None)
 
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, valid=None):
         """-> AssignResult (gt_inds: -1 ignore, 0 background, g+1 assigned to gt g).  `valid` [n] restricts the boxes that
@@ -50,8 +74,10 @@ class MaxIoUAssigner(object):
             raise NotImplementedError('ignore boxes (ignore_iof_thr > 0) are not on the HIP path; both configs set -1')
         gt_inds, max_ov = native.max_iou_assign(bboxes, gt_bboxes, self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou, valid)
         labels = None
-        if gt_labels is not None:   # max_iou_assigner.py:156-163
-            labels = torch.where(gt_inds > 0, gt_labels[(gt_inds - 1).clamp(min=0)], gt_labels.new_zeros(()))
+        if gt_labels is not None:   # max_iou_assigner.py:156-163: label of the assigned gt, 0 for background / ignored boxes
+            if self._ext[0] is not gt_labels:     # [0 | gt_labels], kept while the same label tensor comes back (the frames of a video)
+                self._ext = (gt_labels, torch.cat([gt_labels.new_zeros(1), gt_labels]))
+            labels = self._ext[1][gt_inds.clamp(min=0)]
         return AssignResult(gt_bboxes.shape[0], gt_inds, max_ov, labels)
 
 
@@ -60,14 +86,34 @@ class SamplingResult(object):
     views below need the two counts on the host (one copy, made on first use)."""
 
     def __init__(self, inds, counts, bboxes, gt_bboxes, assign_result, gt_flags):
+        """gt_flags: the uint8 flag vector, or the number of ground-truth rows in front (the vector is then built on first use)."""
         self.inds, self.counts, self.all_bboxes, self.gt_bboxes = inds, counts, bboxes, gt_bboxes
-        self.assign_result, self.gt_flags, self.num_gts = assign_result, gt_flags, gt_bboxes.shape[0]
+        self.assign_result, self._gt_flags, self.num_gts = assign_result, gt_flags, gt_bboxes.shape[0]
         self._n = None
+        self._bboxes = None
+
+    @property
+    def gt_flags(self):
+        if isinstance(self._gt_flags, int):
+            f = self.all_bboxes.new_zeros((self.all_bboxes.shape[0],), dtype=torch.uint8)
+            f[:self._gt_flags] = 1
+            self._gt_flags = f
+        return self._gt_flags
 
     def _counts(self):
         if self._n is None:
             self._n = tuple(int(v) for v in self.counts.tolist())
         return self._n
+
+    @staticmethod
+    def resolve(results):
+        """The (#pos, #neg) pairs of several results in ONE host read (each result's first attribute access otherwise makes its own:
+        a device round trip per frame in a loop that assigns and samples frame by frame)."""
+        todo = [r for r in results if r._n is None]
+        if len(todo) > 1:
+            for r, row in zip(todo, torch.stack([r.counts for r in todo]).tolist()):
+                r._n = (int(row[0]), int(row[1]))
+        return results
 
     pos_inds = property(lambda self: self.inds[:self._counts()[0]])
     neg_inds = property(lambda self: self.inds[self._counts()[0]:sum(self._counts())])
@@ -77,8 +123,12 @@ class SamplingResult(object):
     pos_assigned_gt_inds = property(lambda self: self.assign_result.gt_inds[self.pos_inds] - 1)
     pos_gt_bboxes = property(lambda self: self.gt_bboxes[self.pos_assigned_gt_inds, :])
     pos_gt_labels = property(lambda self: None if self.assign_result.labels is None else self.assign_result.labels[self.pos_inds])
-    # cat(pos_bboxes, neg_bboxes): the sampled boxes in the kernel's order
-    bboxes = property(lambda self: self.all_bboxes[self.inds[:sum(self._counts())]])
+    @property
+    def bboxes(self):
+        """cat(pos_bboxes, neg_bboxes): the sampled boxes in the kernel's order (gathered once)."""
+        if self._bboxes is None:
+            self._bboxes = self.all_bboxes[self.inds[:sum(self._counts())]]
+        return self._bboxes
 
 
 class BaseSampler(object):
@@ -90,16 +140,16 @@ class RandomSampler(BaseSampler):
     def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, keys=None, generator=None, **kwargs):
         """base_sampler.py:32-78.  keys: f32 [n (+ num_gts with add_gt_as_proposals)], drawn uniformly when None."""
         bboxes = bboxes[:, :4]
-        gt_flags = bboxes.new_zeros((bboxes.shape[0],), dtype=torch.uint8)
+        gt_flags = 0                                   # (the flag vector itself is built when somebody reads it)
         if self.add_gt_as_proposals:
             bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
             assign_result.add_gt_(gt_labels)
-            gt_flags = torch.cat([bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8), gt_flags])
+            gt_flags = int(gt_bboxes.shape[0])
         n = assign_result.gt_inds.numel()
         if keys is None:
             keys = torch.rand(n, device=bboxes.device, generator=generator)
         assert keys.numel() == n, 'one key per box (ground-truth rows first when they are added as proposals)'
-        inds, counts = native.sample_pos_neg(assign_result.gt_inds.contiguous(), keys.float().contiguous(), self.num,
+        inds, counts = native.sample_pos_neg(assign_result.gt_inds.contiguous(), (keys if keys.dtype == torch.float32 else keys.float()).contiguous(), self.num,
                                              int(self.num * self.pos_fraction), self.neg_pos_ub)
         return SamplingResult(inds, counts, bboxes.contiguous(), gt_bboxes, assign_result, gt_flags)
 

@@ -94,6 +94,20 @@ def _prep_lookup(w, s, shape4, dtype):
     return None, None
 
 
+def table_operand(w, s, shape4, dtype):
+    """This iteration's packed operand [Cout][KH][KW][Cin] of conv weight w x scale s when the weight table holds it (a no-grad forward
+    inside train_iteration that packs for itself: same numbers, no launch), else None.  The buffer is rewritten by the next prep_begin:
+    the caller's cache must not outlive the iteration (PackedMixin caches are dropped by FlatParams.sgd_step)."""
+    if not _prep['valid'] or not _two_byte(dtype):
+        return None
+    key = _prep_key(w)
+    e = _prep['entries'].get(key) if key is not None else None
+    if e is not None and e['dtype'] == dtype and e['eff'] is not None and e['shape'] == tuple(shape4) and \
+            (e['s'] is s or (e['s'].data_ptr() == s.data_ptr() and e['s']._version == s._version)):
+        return e['eff']
+    return None
+
+
 def _prep_check(key):
     """A Function whose forward took its operand out of the iteration's table saved a TABLE BUFFER for its backward: the next
     prep_begin() rewrites it (and the update in between made it stale).  A backward that runs after that -- retain_graph across
@@ -194,13 +208,43 @@ def prep_enable(flag):
 # OFF by default: handing autograd no gradient bypasses tensor / post-accumulate hooks and mutates .grad under
 # torch.autograd.grad(); dist_train.train_iteration -- which owns the gradient buffer and zeroes it first -- switches it on for its own
 # backward (`wgrad_direct(True)` ... restore).  Outside that scope the Functions return dW to autograd like any other.
-_direct = dict(on=False)
+# Linear layers (round 6): the same idea without a kernel of their own.  dW = dz^T x already has the parameter's layout, so the product
+# (and the bias gradient's column sums) is WRITTEN into the gradient view when this is the first contribution of the iteration -- the
+# buffer holds the zeros zero_grad left -- and added to it otherwise; autograd gets None and runs no AccumulateGrad add for the pair
+# (two launches and, for fc_new_1, 150 MB of f32 traffic per layer).  `pristine`: ids of the parameters whose gradient still is
+# zero_grad's zero; train_iteration hands the set in, every Function that adds to a parameter's gradient takes the parameter out.
+# Contract of the scope: a parameter consumed by train_ops.linear / conv_* inside train_iteration receives its gradient through those
+# Functions only (true of every module here: the two read-out layers, whose weights reach the product through torch.cat, are not leaves
+# of the Function and take autograd's own path).
+_direct = dict(on=False, pristine=None)
 
 
-def wgrad_direct(flag):
-    prev = _direct['on']
-    _direct['on'] = bool(flag)
+def wgrad_direct(flag, pristine=None):
+    prev = (_direct['on'], _direct['pristine'])
+    if isinstance(flag, tuple):
+        flag, pristine = flag
+    _direct['on'], _direct['pristine'] = bool(flag), (pristine if flag else None)
     return prev
+
+
+def _claim(param):
+    """True when `param`'s gradient buffer still holds zero_grad's zeros (and from now on it does not)."""
+    pr = _direct['pristine']
+    if pr is not None and id(param) in pr:
+        pr.discard(id(param))
+        return True
+    return False
+
+
+def _direct_target(t):
+    """The parameter behind t (t itself, or the parameter t is a whole, contiguous view of) when a gradient may be written straight into
+    its f32 gradient buffer, else None."""
+    base = t if t.is_leaf else t._base
+    if base is None or not isinstance(base, torch.nn.Parameter) or not base.requires_grad or not t.is_contiguous():
+        return None
+    if base is not t and (t.data_ptr() != base.data_ptr() or t.numel() != base.numel() or not base.is_contiguous()):
+        return None
+    return base
 
 
 class LinearFunction(Function):
@@ -220,6 +264,8 @@ class LinearFunction(Function):
         assert not (relu and out_f32 and x.dtype != torch.float32), 'the ReLU mask is kept in the compute dtype'
         y = native.gemm(x, wc, b, resid=resid.contiguous() if resid is not None else None, relu=bool(relu), out_f32=bool(out_f32))
         ctx.relu, ctx.has_resid, ctx.has_bias = bool(relu), resid is not None, b is not None
+        ctx.w_param = _direct_target(w) if w.requires_grad else None     # where the weight / bias gradients may land directly
+        ctx.b_param = _direct_target(b) if (b is not None and b.requires_grad) else None
         ctx.save_for_backward(x, wc, y if relu else None)
         return y
 
@@ -242,16 +288,48 @@ class LinearFunction(Function):
         if ctx.needs_input_grad[0]:
             wt = _prep_aux(ctx.prep_key)
             dx = native.gemm(_pad_cols(dz, ldn), wt if wt is not None else native.transpose_pad(w, ldn))   # [M, K] = dz [M, N] W [N, K]
+        def grad_buf(p_, shape):
+            g = p_.grad if (_direct['on'] and p_ is not None) else None
+            return g.view(shape) if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == N * (K if len(shape) == 2 else 1)) else None
+
         if ctx.needs_input_grad[1]:
-            dw = native.gemm_splitk(dzt if dzt is not None else native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))   # [N, K] = dz^T x, f32
+            ops_ = (dzt if dzt is not None else native.transpose_pad(dz, ldm), native.transpose_pad(x, ldm))   # [N, K] = dz^T x, f32
+            gw = grad_buf(ctx.w_param, (N, K))
+            if gw is None:
+                dw = native.gemm_splitk(*ops_)
+            elif _claim(ctx.w_param):
+                native.gemm_splitk(*ops_, out=gw)      # first contribution of the iteration: written over zero_grad's zeros
+            else:
+                gw.add_(native.gemm_splitk(*ops_))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = native.colsum(dz)
+            gb = grad_buf(ctx.b_param, (N,))
+            if gb is None:
+                db = native.colsum(dz)
+            elif _claim(ctx.b_param):
+                native.colsum(dz, out=gb)
+            else:
+                gb.add_(native.colsum(dz))
         dr = dz if (ctx.has_resid and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dr, None, None
 
 
 def linear(x, w, b=None, resid=None, relu=False, out_f32=False):
     return LinearFunction.apply(x, w, b, resid, relu, out_f32)
+
+
+_colsel = {}
+
+
+def _scale_columns(d, g, first, n_first):
+    """d [R, ld] = the gradient of sum(total) w.r.t. a fused logit matrix whose columns first .. first + n_first - 1 belong to total[0]
+    (the classification term) and all others to total[1]: -> the gradient under the upstream g [2], d * g[term of the column].  Two small
+    launches and no host read (the unit-gradient check this replaces read g back in the middle of the backward pass)."""
+    key = (int(d.shape[1]), int(first), int(n_first), str(d.device))
+    idx = _colsel.get(key)
+    if idx is None:
+        col = torch.arange(d.shape[1], device=d.device)
+        idx = _colsel[key] = ((col < first) | (col >= first + n_first)).long()
+    return d * g.to(d.dtype)[idx][None, :]
 
 
 class DetLossFunction(Function):
@@ -263,6 +341,7 @@ class DetLossFunction(Function):
         out3, dlogits = native.det_loss(logits.contiguous(), cls_off, reg_off, ncls, labels, label_weights, bbox_targets,
                                         bbox_weights, beta, w_cls, w_bbox)
         ctx.save_for_backward(dlogits)
+        ctx.cols = (int(cls_off), int(ncls))
         if (w_cls, w_bbox) != (1.0, 1.0):
             raise NotImplementedError('loss weights other than 1 (the two configs use loss_weight=1.0) are not wired up')
         # shapes as the reference returns them: scalar losses, accuracy of shape [1] (losses/accuracy.py:19-21)
@@ -276,9 +355,7 @@ class DetLossFunction(Function):
     def backward(ctx, g_total, g_cls, g_bbox, g_acc):
         # g_total: gradient w.r.t. the two weighted loss terms; the usual (loss_cls + loss_bbox).backward() gives ones
         dlogits, = ctx.saved_tensors
-        if not bool((g_total == 1).all()):
-            raise NotImplementedError('DetLossFunction supports the unit upstream gradient of sum(total) only')
-        return (dlogits,) + (None,) * 10
+        return (_scale_columns(dlogits, g_total, *ctx.cols),) + (None,) * 10
 
 
 def det_loss(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, beta=1.0, w_cls=1.0, w_bbox=1.0):
@@ -297,6 +374,7 @@ class DetLossSampledFunction(Function):
         out3, dlogits = native.det_loss_sampled(logits.contiguous(), cls_off, reg_off, ncls, labels, label_weights, bbox_targets,
                                                 bbox_weights, sel_counts, beta)
         ctx.save_for_backward(dlogits)
+        ctx.cols = (int(cls_off), int(ncls))
         loss_cls, loss_bbox, acc = out3[0], out3[1], out3[2:3]
         total = out3[0:2].clone()
         ctx.mark_non_differentiable(loss_cls, loss_bbox, acc)
@@ -306,9 +384,7 @@ class DetLossSampledFunction(Function):
     @once_differentiable
     def backward(ctx, g_total, g_cls, g_bbox, g_acc):
         dlogits, = ctx.saved_tensors
-        if not bool((g_total == 1).all()):
-            raise NotImplementedError('DetLossSampledFunction supports the unit upstream gradient of sum(total) only')
-        return (dlogits,) + (None,) * 9
+        return (_scale_columns(dlogits, g_total, *ctx.cols),) + (None,) * 9
 
 
 def det_loss_sampled(logits, cls_off, reg_off, ncls, labels, label_weights, bbox_targets, bbox_weights, sel_counts, beta=1.0):
@@ -326,6 +402,7 @@ class RpnLossFunction(Function):
     def forward(ctx, o, A, labels, label_weights, bbox_targets, bbox_weights, counts, beta):
         out2, d_o = native.rpn_loss(o.contiguous(), A, labels, label_weights, bbox_targets, bbox_weights, counts, beta)
         ctx.save_for_backward(d_o)
+        ctx.cols = (0, int(A))
         loss_cls, loss_bbox = out2[0], out2[1]
         total = out2.clone()
         ctx.mark_non_differentiable(loss_cls, loss_bbox)
@@ -335,9 +412,7 @@ class RpnLossFunction(Function):
     @once_differentiable
     def backward(ctx, g_total, g_cls, g_bbox):
         d_o, = ctx.saved_tensors
-        if not bool((g_total == 1).all()):
-            raise NotImplementedError('RpnLossFunction supports the unit upstream gradient of sum(total) only')
-        return (d_o,) + (None,) * 7
+        return (_scale_columns(d_o, g_total, *ctx.cols),) + (None,) * 7
 
 
 def rpn_loss(o, A, labels, label_weights, bbox_targets, bbox_weights, counts, beta=1.0 / 9.0):
@@ -450,8 +525,10 @@ class ConvFunction(Function):
             wp = ctx.w_param
             has_grad_buf = wp is not None and wp.grad is not None and wp.grad.is_contiguous() and wp.grad.dtype == torch.float32
             if _direct['on'] and not _overlap['on'] and has_grad_buf:
+                _claim(wp)                        # (added, not written: the gradient stops being zero_grad's zero either way)
                 weight_gradient(into=wp.grad)     # added in place on this stream; autograd gets no gradient for the weight
             elif _overlap['on'] and has_grad_buf:
+                _claim(wp)
                 main, side = torch.cuda.current_stream(dz.device), _side_stream(dz.device)
                 ready = torch.cuda.Event()
                 ready.record(main)

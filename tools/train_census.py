@@ -85,6 +85,28 @@ def main():
     counts = dict(on=False, n=collections.Counter())
     native._lib = LibProxy(native.lib(), counts)
     from torch.profiler import profile, ProfilerActivity
+    from torch.utils._python_dispatch import TorchDispatchMode
+    VIEW = ('view', 'slice', 'select', 'permute', 'transpose', 'expand', 'as_strided', 'detach', 'alias', 'unsqueeze', 'squeeze', 'reshape',
+            'split', 'narrow', 't.default', 'unbind', 'size', 'stride', 'numel', 'is_', 'empty', '_unsafe_view', 'lift_fresh', 'sym_')
+    disp = collections.Counter()
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if not any(v in name for v in VIEW):
+                disp[(name, site(traceback.extract_stack(limit=16)[:-1]))] += 1
+            return func(*args, **(kwargs or {}))
+
+    counts['on'] = True
+    with Census():
+        step()
+        torch.cuda.synchronize()
+    counts['on'] = False
+    print('# %s training iteration: aten ops seen by a TorchDispatchMode (views left out), by (op, nearest repo frame); total %d' % (args.head, sum(disp.values())))
+    for (name, where), n in disp.most_common(args.top + 40):
+        print('%5d  %-36s %s' % (n, name[:36], where))
+    print()
+    counts['n'].clear()
     counts['on'] = True
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step()

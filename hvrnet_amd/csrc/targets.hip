@@ -105,21 +105,35 @@ struct SampleShared {
   int remaining, total, base;
 };
 
-// inclusive block scan of one int per thread (1024 threads); returns the exclusive prefix, *sum = block total
+// block scan of one int per thread (1024 threads = 16 waves): returns the exclusive prefix in thread order, *sum = block total.
+// Wave-level inclusive scans on shuffles, the 16 wave totals scanned by wave 0: three barriers (round 6; the Hillis-Steele form over
+// the LDS took twenty, and a sampling call makes six scans -- 45 us per frame for 304 boxes, nine frames per HVR iteration)
 __device__ int block_exclusive_scan(int v, int* buf, int* sum) {
-  const int tid = threadIdx.x;
-  buf[tid] = v;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int add = tid >= o ? buf[tid - o] : 0;
-    __syncthreads();
-    buf[tid] += add;
-    __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
   }
-  const int incl = buf[tid];
-  *sum = buf[1023];
+  if (lane == 63) buf[w] = incl;
   __syncthreads();
-  return incl - v;
+  if (w == 0) {
+    const int t = lane < 16 ? buf[lane] : 0;
+    int sc = t;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int u = __shfl_up(sc, o, 64);
+      if (lane >= o) sc += u;
+    }
+    if (lane < 16) buf[16 + lane] = sc - t;
+    if (lane == 15) buf[32] = sc;
+  }
+  __syncthreads();
+  const int base = buf[16 + w];
+  *sum = buf[32];
+  __syncthreads();  // (buf is the next scan's scratch)
+  return base + incl - v;
 }
 
 __device__ int sample_group(const long long* cls, const float* keys, int n, bool want_pos, int expected, long long* out,
@@ -146,12 +160,25 @@ __device__ int sample_group(const long long* cls, const float* keys, int n, bool
           if ((u & mask) == prefix) atomicAdd(&sh.hist[(u >> (8 * pass)) & 255], 1);
         }
       __syncthreads();
-      if (tid == 0) {
-        int rem = sh.remaining, b = 0;
-        while (sh.hist[b] < rem) { rem -= sh.hist[b]; ++b; }
-        sh.remaining = rem;
-        sh.prefix = prefix | ((unsigned)b << (8 * pass));
-        sh.mask = mask | (255u << (8 * pass));
+      if (tid < 64) {
+        // the bin that holds the rem-th smallest matching key: lane l owns bins 4 l .. 4 l + 3, a wave scan of the lanes' sums finds
+        // the lane whose range contains it (the serial walk over 256 bins by one thread this replaces: up to 256 dependent LDS reads)
+        const int h0 = sh.hist[4 * tid], h1 = sh.hist[4 * tid + 1], h2 = sh.hist[4 * tid + 2], h3 = sh.hist[4 * tid + 3];
+        const int own = h0 + h1 + h2 + h3;
+        int incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o, 64);
+          if (tid >= o) incl += t;
+        }
+        const int rem0 = sh.remaining, excl = incl - own;
+        if (excl < rem0 && rem0 <= incl) {
+          int rem = rem0 - excl, b = 4 * tid;
+          if (h0 < rem) { rem -= h0; ++b; if (h1 < rem) { rem -= h1; ++b; if (h2 < rem) { rem -= h2; ++b; } } }
+          sh.remaining = rem;
+          sh.prefix = prefix | ((unsigned)b << (8 * pass));
+          sh.mask = mask | (255u << (8 * pass));
+        }
       }
       __syncthreads();
     }

@@ -587,8 +587,11 @@ class HNMBRCNN(_WindowDetector):
         return [key_video, same_id, other_id]
 
     def forward_train(self, img, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
-                      keys=None, generator=None):
+                      keys=None, generator=None, c4=None):
         """HNMBRCNN.forward_train (hnmb_rcnn.py:224-434, dynamic=False, single RandomSampler) on the HIP path.
+        c4: the C4 maps of `img` when the caller already has them (`self.extract_feat(img)[0]`).  The backbone is frozen in this
+        detector's training step (below), so its pass over a batch does not depend on the update in flight: a training loop can run it
+        for batch i + 1 on a second stream while batch i trains (dist_train.C4Prefetcher).
         img [V * 3, 3, H, W]: V videos of three frames, key frame first; videos 0..2 share the key video's class, the rest
         are other classes.  As in the reference: the backbone and res5 run WITHOUT a graph over all V videos to pick the
         triplet of videos (:269-277), the chosen videos' C4 maps are reused as constants (:280-283, so the backbone gets no
@@ -613,7 +616,9 @@ class HNMBRCNN(_WindowDetector):
         # Frames are independent through the backbone, res5 and the RPN, so where the reference loops over videos of three
         # frames (:57-65, :305-336) the whole batch goes through each of them once: same numbers, 5x / 3x the rows per launch.
         with torch.no_grad():                                   # extract_c4_c5_feat (:54-72)
-            c4 = self.extract_feat(img)[0]                      # [V * F, 1024, h, w] logical, NHWC in memory
+            if c4 is None:
+                c4 = self.extract_feat(img)[0]                  # [V * F, 1024, h, w] logical, NHWC in memory
+            assert c4.shape[0] == img.shape[0]
             c5_sel = self.shared_head(c4)
         chosen = self.get_triplet_patches(c5_sel, 0, F_, V - self.VIDEO_PER_CLS, self.VIDEO_PER_CLS)
         del c5_sel

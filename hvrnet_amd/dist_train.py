@@ -70,30 +70,81 @@ class FlatParams(object):
             m._drop_packed()
 
 
-def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False):
+def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False, fewrow=None):
     """One iteration in the reference's order (dist_utils.py:52-58): zero_grad, backward, all-reduce, clip, step.
     loss_fn() builds the graph and returns the scalar to differentiate.  overlap_wgrad: conv weight gradients run on a
     second HIP stream and land directly in the flat gradient buffer (train_ops.wgrad_overlap); joined before the exchange.
     Off by default: at three frames per iteration the step is bound by the host's enqueue rate, and the extra events / stream
     switches cost more than the overlap returns (22.1 vs 20.5 ms measured); it pays once the per-rank batch grows."""
     from . import train_ops
+    import os
+    if fewrow is None:
+        fewrow = os.environ.get('HVR_DBG_TRAIN_FEWROW', '1') != '0'
     flat.zero_grad()
     train_ops.prep_begin(flat)          # every trainable layer's operands for this iteration in two launches (recorded on the first)
     try:
-        loss = loss_fn()
-        prev = train_ops.wgrad_overlap(overlap_wgrad)
-        prev_direct = train_ops.wgrad_direct(True, pristine={id(p) for p in flat.params})   # weight gradients land straight in flat's (zeroed) gradient buffer: this scope only
-        try:
-            loss.backward()
-        finally:
-            train_ops.wgrad_direct(prev_direct)
-            train_ops.wgrad_overlap(prev)
-            train_ops.join_wgrad()
+        # few-row forms on (native.fewrow_split): a rank's batch is three frames / a few hundred RoIs, so most products of the step leave
+        # the chip idle on whole-K tiles; K sliced across the waves of a workgroup (kpar.hip) or across workgroups fills it
+        with native.fewrow_split(bool(fewrow)):
+            loss = loss_fn()
+            prev = train_ops.wgrad_overlap(overlap_wgrad)
+            prev_direct = train_ops.wgrad_direct(True, pristine={id(p) for p in flat.params})   # weight gradients land straight in flat's (zeroed) gradient buffer: this scope only
+            try:
+                loss.backward()
+            finally:
+                train_ops.wgrad_direct(prev_direct)
+                train_ops.wgrad_overlap(prev)
+                train_ops.join_wgrad()
     finally:
         train_ops.prep_end()            # the update below makes the table's operands stale
     world = flat.allreduce_grads()
     flat.sgd_step(lr, momentum, weight_decay, max_norm, world)
     return loss
+
+
+class C4Prefetcher(object):
+    """The frozen backbone of the NEXT batch on a second HIP stream while the current batch trains.
+
+    HNMBRCNN's training step computes C4 under no_grad and reuses it as a constant (hnmb_rcnn.py:269-283): backbone parameters get no
+    gradient and no update there (enable_training keeps them out of the flat parameter set), so the backbone pass over batch i + 1
+    depends on nothing batch i's step writes.  It is 15 frames of chip-filling convs (a third of the step's kernel time), the rest of the
+    step is hundreds of few-row kernels with four host reads in between: run side by side the big kernels fill what the small ones and
+    the read-backs leave idle.  Same work per iteration, same numbers (the C4 map is bit-identical to the in-line pass's).
+
+        pre = C4Prefetcher(model); pre.start(batch[0]['img'])
+        for i, data in enumerate(batches):
+            c4 = pre.take()
+            if i + 1 < len(batches): pre.start(batches[i + 1]['img'])
+            train_detector_iteration(model, flat, dict(data, c4=c4), lr)
+    """
+
+    def __init__(self, model):
+        assert not any(p.requires_grad for p in model.backbone.parameters()), 'the prefetched pass is only valid for a FROZEN backbone'
+        self.model, self.stream, self.pending = model, None, None
+
+    def start(self, img):
+        dev = img.device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)                       # img (and the packed weights' first use) are ordered behind the caller's stream
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            self.stream.wait_event(ready)
+            c4 = self.model.extract_feat(img)[0]
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        img.record_stream(self.stream)
+        self.pending = (c4, done)
+
+    def take(self):
+        """-> the C4 maps of the batch given to the last start(); the current stream waits for them."""
+        c4, done = self.pending
+        self.pending = None
+        main = torch.cuda.current_stream(c4.device)
+        main.wait_event(done)
+        c4.record_stream(main)
+        return c4
 
 
 def parse_losses(losses):

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hvrnet_amd  # noqa: E402
 from hvrnet_amd import synthetic as S  # noqa: E402
 from hvrnet_amd.config import hvr_train_config, selsa_train_config  # noqa: E402
-from hvrnet_amd.dist_train import FlatParams, train_detector_iteration  # noqa: E402
+from hvrnet_amd.dist_train import C4Prefetcher, FlatParams, train_detector_iteration  # noqa: E402
 
 
 def main():
@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--head', choices=['selsa', 'hvr'], default='selsa', help='selsa: SelsaRCNN, 1 key + 2 ref frames; hvr: HNMBRCNN, '
                     '5 videos x 3 frames in, 3 videos chosen (configs[4])')
+    ap.add_argument('--no-prefetch', action='store_true', help='hvr: the frozen backbone in line with the step instead of one batch ahead on a second stream (dist_train.C4Prefetcher)')
     ap.add_argument('--overlap', action='store_true', help='conv weight gradients on a second HIP stream (train_ops.wgrad_overlap)')
     ap.add_argument('--cprofile', action='store_true', help='host-side cProfile of 5 iterations (stderr)')
     ap.add_argument('--detail', action='store_true', help='print the GEMM / conv calls of one iteration by shape (HIP-event times)')
@@ -64,8 +65,16 @@ def main():
     metas = [S.synth_meta(hw, pad) for _ in range(T)]
     data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * T, gt_labels=[gt_l] * T, generator=gen)
 
+    pre = C4Prefetcher(model) if (args.head == 'hvr' and not args.no_prefetch) else None
+    if pre is not None:
+        pre.start(imgs)
+
     def step():
-        return train_detector_iteration(model, flat, data, lr=1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=args.overlap)
+        d = data
+        if pre is not None:                  # this batch's C4 was computed while the previous batch trained; start the next batch's
+            d = dict(data, c4=pre.take())
+            pre.start(imgs)
+        return train_detector_iteration(model, flat, d, lr=1e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=args.overlap)
 
     for _ in range(args.warmup):
         log = step()
@@ -107,7 +116,7 @@ def main():
         print(json.dumps(dict(metric='%s training iterations/sec (%s, %dx%d, %d proposals)' % (args.head.upper(), workload, hw[1], hw[0], args.nms_post),
                               value=round(world * args.steps / dt, 3), unit='iterations/s', frames_per_s=round(world * args.steps * T / dt, 2),
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 2),
-                              dtype=args.dtype, data='synthetic', params=int(flat.flat.numel()),
+                              dtype=args.dtype, data='synthetic', params=int(flat.flat.numel()), backbone_prefetch=pre is not None,
                               last_losses={k: round(float(v), 4) for k, v in log.items()})))
     if world > 1:
         dist.destroy_process_group()

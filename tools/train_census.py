@@ -98,9 +98,10 @@ def main():
             return func(*args, **(kwargs or {}))
 
     counts['on'] = True
-    with Census():
-        step()
-        torch.cuda.synchronize()
+    with torch.autograd.set_multithreading_enabled(False):     # backward on this thread: the mode (thread-local) sees its ops too
+        with Census():
+            step()
+            torch.cuda.synchronize()
     counts['on'] = False
     print('# %s training iteration: aten ops seen by a TorchDispatchMode (views left out), by (op, nearest repo frame); total %d' % (args.head, sum(disp.values())))
     for (name, where), n in disp.most_common(args.top + 40):

@@ -21,6 +21,7 @@ hipError_t run_transpose_multi(const void*, int, int, hipStream_t);
 hipError_t run_im2col_t(const void*, void*, int, int, int, int, int, int, int, int, int, int, long, hipStream_t);
 hipError_t run_relu_bwd_t(const void*, const void*, void*, void*, int, int, long, hipStream_t);
 hipError_t run_splitk_reduce(const float*, float*, int, int, long, int, hipStream_t);
+hipError_t run_unpack_conv_wgrads_multi(const void*, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_bf16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_f16(const float*, void*, int, int, long, int, hipStream_t);
 hipError_t run_splitk_reduce_half_batched(const float*, void*, int, int, long, int, int, int, long, long, hipStream_t);
@@ -102,7 +103,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" {
 
-int hvr_abi_version(void) { return 5; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta
+int hvr_abi_version(void) { return 6; }  // 2: hvr_gemm_desc / hvr_conv_desc carry the few-row split-K scratch (ws, ws_bytes); 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta
 const char* hvr_last_error(void) { return g_err.c_str(); }
 
 static int fill_linear(GemmParams& p, const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb,
@@ -268,6 +269,61 @@ int hvr_gemm_splitk(const hvr_gemm_desc* d, void* ws, size_t ws_bytes, void* str
   hipError_t e = run_tile_op(p, EPI_LINEAR, (hipStream_t)stream);
   if (e == hipSuccess) e = run_splitk_reduce((const float*)ws, (float*)d->C, d->M, d->N, d->ldc, p.ksplit_count, (hipStream_t)stream);
   return check_launch(e, "hvr_gemm_splitk");
+}
+
+// `count` products of ONE shape in one launch (the weight gradients of a stage's identical blocks): problem g's operands sit stride_a /
+// stride_b elements behind problem 0's, its f32 output stride_c floats behind; the tile engine's batch dimension (gridDim.z), K slices
+// (gridDim.y) while count x tiles leaves the chip idle, and one reduce over all problems' partials
+static int splitk_slices_batched(int M, int N, int K, int dtype, int count) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * count;
+  if (dtype == HVR_F16S) return 1;
+  const int ksteps = K / kstep_elems(dtype);
+  if (tiles >= 384 || ksteps < 32) return 1;
+  long s = (512 + tiles - 1) / tiles;
+  if (s > ksteps / 8) s = ksteps / 8;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : (int)s;
+}
+
+size_t hvr_gemm_splitk_batched_workspace_bytes(int M, int N, int K, int dtype, int count) {
+  if (M <= 0 || N <= 0 || K <= 0 || count <= 0 || !valid_dtype(dtype)) return 0;
+  const int s = splitk_slices_batched(M, N, K, dtype, count);
+  return s > 1 ? (size_t)s * count * M * N * 4 : 0;
+}
+
+int hvr_gemm_splitk_batched(const hvr_gemm_desc* d, int count, int64_t stride_a, int64_t stride_b, int64_t stride_c, void* ws, size_t ws_bytes,
+                            void* stream) {
+  if (!d || count <= 0) return fail(HVR_EINVAL, "null descriptor / count <= 0");
+  if (d->bias || d->resid || d->relu) return fail(HVR_EINVAL, "split-K products have no epilogue (bias / residual / ReLU)");
+  if (d->dtype != HVR_F32 && !d->out_f32) return fail(HVR_EINVAL, "split-K products are f32 (set out_f32)");
+  if (d->dtype == HVR_F16S) return fail(HVR_EUNSUPPORTED, "batched split-K products take f32 / bf16 / half operands");
+  GemmParams p;
+  int rc = fill_linear(p, d->A, d->B, d->C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->dtype, d->staging);
+  if (rc) return rc;
+  const int es = elem_size(d->dtype);
+  if ((d->lda * es) % 16 || (d->ldb * es) % 16 || (stride_a * es) % 16 || (stride_b * es) % 16) return fail(HVR_EINVAL, "lda / ldb rows and the problem strides must be 16-byte multiples");
+  if ((d->ldc * 4) % 8 || (stride_c * 4) % 16) return fail(HVR_EINVAL, "ldc rows must be 8-byte, stride_c 16-byte multiples");
+  if (stride_a * es >= (1L << 31) || stride_b * es >= (1L << 31)) return fail(HVR_EUNSUPPORTED, "one problem's operands must stay below 2 GiB");
+  p.out_f32 = d->out_f32;
+  p.tile_hint = d->tile_hint;
+  p.batch = count;
+  p.gs_a = stride_a * es; p.gs_b = stride_b * es; p.gs_c = stride_c * 4;
+  const int slices = splitk_slices_batched(d->M, d->N, d->K, d->dtype, count);
+  if (slices <= 1) return check_launch(run_tile_op(p, EPI_LINEAR, (hipStream_t)stream), "hvr_gemm_splitk_batched");
+  if (d->ldc != d->N || stride_c != (int64_t)d->M * d->N) return fail(HVR_EINVAL, "the sliced form writes one contiguous [count][M][N] output (ldc = N, stride_c = M * N)");
+  const size_t need = (size_t)slices * count * d->M * d->N * 4;
+  if (!ws || ws_bytes < need || !aligned16(ws)) return fail(HVR_EINVAL, "split-K workspace too small (%zu < %zu) or unaligned", ws_bytes, need);
+  if ((long)count * d->M > 0x7fffffffL) return fail(HVR_EUNSUPPORTED, "too many output rows");
+  const int ksteps = d->K / kstep_elems(d->dtype);
+  p.ksplit_steps = (ksteps + slices - 1) / slices;
+  p.ksplit_count = (ksteps + p.ksplit_steps - 1) / p.ksplit_steps;
+  p.csplit_bytes = (long)count * d->M * d->N * 4;   // slice s of problem g: ws + s * csplit_bytes + g * M * N * 4
+  p.gs_c = (long)d->M * d->N * 4;
+  p.C = ws;
+  p.ldc = d->N;
+  hipError_t e = run_tile_op(p, EPI_LINEAR, (hipStream_t)stream);
+  if (e == hipSuccess) e = run_splitk_reduce((const float*)ws, (float*)d->C, count * d->M, d->N, d->N, p.ksplit_count, (hipStream_t)stream);
+  return check_launch(e, "hvr_gemm_splitk_batched");
 }
 
 // descriptor -> kernel parameters + the path it takes (0 tile engine, 1 expand.hip); a negative return is the error
@@ -941,6 +997,11 @@ int hvr_pack_conv_weights_multi(const hvr_pack_item* items_dev, int n, int64_t t
 int hvr_transpose_multi(const hvr_transpose_item* items_dev, int n, int tiles, void* stream) {
   if (!items_dev || n <= 0 || tiles <= 0) return fail(HVR_EINVAL, "bad transpose_multi arguments");
   return check_launch(run_transpose_multi(items_dev, n, tiles, (hipStream_t)stream), "hvr_transpose_multi");
+}
+
+int hvr_unpack_conv_wgrads_multi(const hvr_unpack_item* items_dev, int n, int64_t total, int accumulate, void* stream) {
+  if (!items_dev || n <= 0 || total <= 0) return fail(HVR_EINVAL, "bad unpack_conv_wgrads_multi arguments");
+  return check_launch(run_unpack_conv_wgrads_multi(items_dev, n, (long)total, accumulate, (hipStream_t)stream), "hvr_unpack_conv_wgrads_multi");
 }
 
 int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int Cout, int Cin, int KH, int KW, int accumulate, void* stream) {

@@ -725,6 +725,31 @@ __global__ __launch_bounds__(256) void transpose_multi_x8_kernel(const TransItem
   }
 }
 
+// the way back for a whole group of layers: item i's f32 product dW_eff [Cout][KK][Cin] (at `eff`) x s -> += (or =) the parameter-layout
+// gradient [Cout][Cin][KK] (at `w`); same table walk as the pack kernel (first[] ascending)
+__global__ void unpack_conv_wgrads_multi_kernel(const PackItem* __restrict__ items, int n, long total, int accumulate) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].first <= idx) lo = mid; else hi = mid - 1;
+    }
+    const PackItem it = items[lo];
+    const long e = idx - it.first;                // element of the parameter layout [Cout][Cin][KK]
+    const int t = (int)(e % it.KK);
+    const long r = e / it.KK;
+    const int c = (int)(r % it.Cin), o = (int)(r / it.Cin);
+    const float v = reinterpret_cast<const float*>(it.eff)[((long)o * it.KK + t) * it.Cin + c] * it.s[o];
+    float* dst = const_cast<float*>(it.w) + e;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+hipError_t run_unpack_conv_wgrads_multi(const void* items, int n, long total, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_conv_wgrads_multi_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const PackItem*)items, n, total, accumulate);
+  return hipGetLastError();
+}
+
 hipError_t run_pack_conv_weights_multi(const void* items, int n, long total, int dtype, hipStream_t s) {
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(pack_conv_weights_multi_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const PackItem*)items, n, total);

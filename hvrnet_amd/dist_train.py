@@ -89,9 +89,12 @@ def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm
             loss = loss_fn()
             prev = train_ops.wgrad_overlap(overlap_wgrad)
             prev_direct = train_ops.wgrad_direct(True, pristine={id(p) for p in flat.params})   # weight gradients land straight in flat's (zeroed) gradient buffer: this scope only
+            prev_defer = train_ops.wgrad_defer(not overlap_wgrad)   # conv weight gradients of equal shape parked, then one batched product per shape
             try:
                 loss.backward()
+                train_ops.wgrad_flush()
             finally:
+                train_ops.wgrad_defer(prev_defer)
                 train_ops.wgrad_direct(prev_direct)
                 train_ops.wgrad_overlap(prev)
                 train_ops.join_wgrad()

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, 'libhvr_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hvr_hip.h')
 
 HVR_F32, HVR_BF16, HVR_F16, HVR_F16S = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 # Split-half tensors (HVR_F16S, include/hvr_hip.h: [32 hi | 32 lo] half groups, 4 bytes per logical element) travel through
 # torch as int32 tensors of the LOGICAL shape: element size, strides, row / 32-column slicing, cat, clone and zeros all mean
 # the right thing on the container, and nothing but this library ever interprets the bytes.  `SPLIT` is the dtype sentinel
@@ -96,6 +96,8 @@ SYMBOLS = {
     'hvr_gemm_fewrow_workspace_bytes': (_sz, [ctypes.POINTER(GemmDesc)]),
     'hvr_gemm_splitk_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hvr_gemm_splitk': (_i, [ctypes.POINTER(GemmDesc), _vp, _sz, _vp]),
+    'hvr_gemm_splitk_batched_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'hvr_gemm_splitk_batched': (_i, [ctypes.POINTER(GemmDesc), _i, _i64, _i64, _i64, _vp, _sz, _vp]),
     'hvr_conv2d_nhwc': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'hvr_conv2d_path': (_i, [ctypes.POINTER(ConvDesc)]),
     'hvr_conv2d_splitk_workspace_bytes': (_sz, [ctypes.POINTER(ConvDesc)]),
@@ -127,6 +129,7 @@ SYMBOLS = {
     'hvr_pack_conv_weights_multi': (_i, [_vp, _i, _i64, _i, _vp]),
     'hvr_transpose_multi': (_i, [_vp, _i, _i, _vp]),
     'hvr_unpack_conv_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'hvr_unpack_conv_wgrads_multi': (_i, [_vp, _i, _i64, _i, _vp]),
     'hvr_det_loss': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp]),
     'hvr_det_loss_sampled': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp]),
     'hvr_max_iou_assign_workspace_bytes': (_sz, [_i, _i]),
@@ -380,6 +383,25 @@ def gemm_splitk(a, w, staging=None, tile=None, out=None):
     ws = _workspace(nbytes, a.device, 'splitk') if nbytes else None
     with _span('gemm' if not (_prof and _prof['detail']) else 'gemm M%d N%d K%d splitk' % (M, N, K), 2.0 * M * N * K):
         _check(lib().hvr_gemm_splitk(ctypes.byref(d), _ptr(ws), nbytes, _stream()), 'hvr_gemm_splitk')
+    return out
+
+
+def gemm_splitk_batched(a, w, out=None):
+    """f32 out[g] = a[g] @ w[g]^T for g < G: a [G, M, K], w [G, N, K] (leading slices of contiguous slabs), one launch (+ one reduce
+    when K is cut into slices) for the G weight gradients of a stage's identical blocks.  -> out [G, M, N] f32."""
+    _need_cuda(a, w)
+    assert a.dim() == 3 and w.dim() == 3 and a.shape[0] == w.shape[0] and a.shape[2] == w.shape[2] and a.dtype == w.dtype
+    assert a.stride(2) == 1 and w.stride(2) == 1 and a.stride(1) == a.shape[2] and w.stride(1) == w.shape[2]
+    G, M, K = a.shape
+    N = w.shape[1]
+    if out is None:
+        out = torch.empty((G, M, N), dtype=torch.float32, device=a.device)
+    d = GemmDesc(A=a.data_ptr(), B=w.data_ptr(), C=out.data_ptr(), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=None, resid=None, ldr=0, relu=0,
+                 out_f32=int(a.dtype != torch.float32), dtype=_dt(a), staging=STAGING, tile_hint=TILE_HINT)
+    nbytes = lib().hvr_gemm_splitk_batched_workspace_bytes(M, N, K, _dt(a), G)
+    ws = _workspace(nbytes, a.device, 'splitk_batched') if nbytes else None
+    with _span('gemm' if not (_prof and _prof['detail']) else 'gemm %dx M%d N%d K%d splitk batched' % (G, M, N, K), 2.0 * G * M * N * K):
+        _check(lib().hvr_gemm_splitk_batched(ctypes.byref(d), G, a.stride(0), w.stride(0), M * N, _ptr(ws), nbytes, _stream()), 'hvr_gemm_splitk_batched')
     return out
 
 
@@ -784,24 +806,32 @@ def relu_bwd(dy, y):
     return dz
 
 
-def relu_bwd_t(dy, y, ldt):
-    """(dz, dzt): dz = dy where y > 0 ([R, C]) and its transpose [C, ldt] (columns R.. zero) from one pass (bf16 / half)."""
+def relu_bwd_t(dy, y, ldt, dzt_out=None):
+    """(dz, dzt): dz = dy where y > 0 ([R, C]) and its transpose [C, ldt] (columns R.. zero) from one pass (bf16 / half).
+    dzt_out: a contiguous [C, ldt] tensor to write the transpose into (a slot of a stage's weight-gradient slab)."""
     _need_cuda(dy, y)
     dy, y = dy.contiguous(), y.contiguous()
     assert dy.dim() == 2 and dy.shape == y.shape and dy.dtype == y.dtype
     R, C = dy.shape
     dz = torch.empty_like(dy)
-    dzt = torch.empty((C, ldt), dtype=dy.dtype, device=dy.device)
+    if dzt_out is None:
+        dzt = torch.empty((C, ldt), dtype=dy.dtype, device=dy.device)
+    else:
+        assert tuple(dzt_out.shape) == (C, ldt) and dzt_out.dtype == dy.dtype and dzt_out.is_contiguous()
+        dzt = dzt_out
     _check(lib().hvr_relu_bwd_t(_ptr(dy), _ptr(y), _ptr(dz), _ptr(dzt), ldt, R, C, _dt(dy), _stream()), 'hvr_relu_bwd_t')
     return dz, dzt
 
 
-def im2col_t(x, KH, KW, pad, dil, ldt):
+def im2col_t(x, KH, KW, pad, dil, ldt, out=None):
     """x [B,H,W,Cin] (NHWC, bf16 / half) -> the TRANSPOSED patch matrix [KH*KW*Cin, ldt] of a stride-1 conv (columns B*OH*OW.. zero)."""
     _need_cuda(x)
     x = x.contiguous()
     B, H, W, Cin = x.shape
-    out = torch.empty((KH * KW * Cin, ldt), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((KH * KW * Cin, ldt), dtype=x.dtype, device=x.device)
+    else:
+        assert tuple(out.shape) == (KH * KW * Cin, ldt) and out.dtype == x.dtype and out.is_contiguous()
     _check(lib().hvr_im2col_t(_ptr(x), _ptr(out), ldt, B, H, W, Cin, KH, KW, pad, dil, _dt(x), _stream()), 'hvr_im2col_t')
     return out
 
@@ -856,6 +886,12 @@ def pack_conv_weights_multi(items_dev, n, total, dtype):
 
 def transpose_multi(items_dev, n, tiles):
     _check(lib().hvr_transpose_multi(_ptr(items_dev), n, tiles, _stream()), 'hvr_transpose_multi')
+
+
+def unpack_conv_wgrads_multi(items_dev, n, total, accumulate=True):
+    """hvr_unpack_conv_wgrad for a device table of layers (PackItem: w = the parameter-layout gradient to add to, scale, out = the f32
+    product) in one launch."""
+    _check(lib().hvr_unpack_conv_wgrads_multi(_ptr(items_dev), n, total, int(accumulate), _stream()), 'hvr_unpack_conv_wgrads_multi')
 
 
 def unpack_conv_wgrad(dw, scale, shape, accumulate_into=None):
@@ -1169,12 +1205,15 @@ def cast(x, dtype, scale=None):
     return out
 
 
-def transpose_pad(x, ldt):
+def transpose_pad(x, ldt, out=None):
     """[R, C] -> [C, ldt] with columns R.. zero (the relation's V^T operand)."""
     _need_cuda(x)
     x = x.contiguous()
     R, C = x.shape
-    out = torch.empty((C, ldt), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((C, ldt), dtype=x.dtype, device=x.device)
+    else:
+        assert tuple(out.shape) == (C, ldt) and out.dtype == x.dtype and out.is_contiguous()
     _check(lib().hvr_transpose_pad(_ptr(x), _ptr(out), R, C, C, ldt, _dt(x), _stream()), 'hvr_transpose_pad')
     return out
 

@@ -190,6 +190,7 @@ def prep_end():
 
 
 def prep_reset():
+    wgrad_reset()      # (the parked-gradient slabs and tables belong to the loop that is ending too)
     _prep.update(recording=False, valid=False, entries={}, tables=None, owner=None, stamp=_prep['stamp'] + 1)
 
 
@@ -245,6 +246,74 @@ def _direct_target(t):
     if base is not t and (t.data_ptr() != base.data_ptr() or t.numel() != base.numel() or not base.is_contiguous()):
         return None
     return base
+
+
+# Weight gradients of a stage's identical blocks in ONE product (round 6).  At three frames per rank a conv's dW = dZ^T X is a few-tile,
+# long-K product: K slices + a reduce + the unpack = three launches per conv that leave most of the chip idle, ~100 convs per iteration.
+# Inside train_iteration (direct mode) ConvFunction.backward only PARKS its two K-contiguous operands -- dZ^T and the transposed patch
+# matrix, which its one-pass kernels write straight into the next free slot of a per-shape slab -- and `wgrad_flush()` after the backward
+# pass runs one batched product (hvr_gemm_splitk_batched: the tile engine's batch dimension) and one table-driven unpack per shape
+# class: layer 3's 69 convs become 3 + 3 launches.  Slabs are sized from the previous iteration's counts (the first iteration of a loop
+# computes every gradient on the spot and only counts); a layer that finds its class full computes on the spot.  Values: the same
+# products, accumulated over K in slices whose count follows the batched grid (the f32 summation order of a gradient may differ from
+# the single call's, as between any two slice counts).
+_wq = dict(on=False, classes={}, seen={})
+
+
+def wgrad_defer(flag):
+    """Parking of conv weight gradients on / off (dist_train.train_iteration: on for its backward); -> previous."""
+    prev = _wq['on']
+    _wq['on'] = bool(flag)
+    if flag:
+        for c in _wq['classes'].values():
+            c['n'], c['items'] = 0, []
+        _wq['seen'] = {}
+    return prev
+
+
+def wgrad_reset():
+    _wq.update(on=False, classes={}, seen={})
+
+
+def _wq_slot(key, Cout, KC, ldp, dtype, device):
+    """-> (class, slot index) with room for one more layer of this shape, or None (compute on the spot)."""
+    if not _wq['on']:
+        return None
+    _wq['seen'][key] = _wq['seen'].get(key, 0) + 1
+    c = _wq['classes'].get(key)
+    if c is None or c['n'] >= c['cap']:
+        return None
+    c['n'] += 1
+    return c, c['n'] - 1
+
+
+def wgrad_flush():
+    """The parked weight gradients: one batched product + one unpack per shape class, added into the parameters' gradient buffers.
+    Then the slabs are (re)sized for the next iteration from this one's counts."""
+    for key, c in _wq['classes'].items():
+        n = c['n']
+        if n == 0:
+            continue
+        native.gemm_splitk_batched(c['dzt'][:n], c['cols'][:n], out=c['dw'][:n])     # [n, Cout, KK * Cin] f32
+        sig = tuple((wp.grad.data_ptr(), s_.data_ptr()) for wp, s_ in c['items'])
+        if c.get('table_sig') != sig:            # (the same layers in the same order every iteration: built once)
+            Cout, Cin, KH, KW = c['shape']
+            per = Cout * Cin * KH * KW
+            items = [native.PackItem(w=wp.grad.data_ptr(), scale=s_.data_ptr(), out=c['dw'].data_ptr() + i * per * 4, first=i * per, Cout=Cout, Cin=Cin, KK=KH * KW)
+                     for i, (wp, s_) in enumerate(c['items'])]
+            c['table'], c['table_sig'], c['total'] = native.items_to_device(items, c['dw'].device), sig, n * per
+        native.unpack_conv_wgrads_multi(c['table'], n, c['total'], accumulate=True)
+        c['n'], c['items'] = 0, []
+    # classes for the next iteration: every shape that came up at least twice gets a slab of that many slots
+    for key, cnt in _wq['seen'].items():
+        c = _wq['classes'].get(key)
+        if cnt >= 2 and (c is None or c['cap'] < cnt):
+            Cout, KC, ldp, dtype, device, shape = key[0], key[1], key[2], key[3], key[4], key[5]
+            _wq['classes'][key] = dict(cap=cnt, n=0, items=[], shape=shape,
+                                       dzt=torch.empty((cnt, Cout, ldp), dtype=dtype, device=device),
+                                       cols=torch.empty((cnt, KC, ldp), dtype=dtype, device=device),
+                                       dw=torch.empty((cnt, Cout, KC), dtype=torch.float32, device=device))
+    _wq['seen'] = {}
 
 
 class LinearFunction(Function):
@@ -488,9 +557,15 @@ class ConvFunction(Function):
         step = native.kstep(dy.dtype)
         ldp = (P + step - 1) // step * step
         fast = _two_byte(dy.dtype) and Cout % 8 == 0 and Cin % 8 == 0     # the one-pass K-contiguous operands (hvr_relu_bwd_t / hvr_im2col_t)
+        wp = ctx.w_param
+        has_grad_buf = wp is not None and wp.grad is not None and wp.grad.is_contiguous() and wp.grad.dtype == torch.float32
+        # parked weight gradient (see _wq): this layer's slot in its shape class's slab, when the class has room
+        slot = None
+        if ctx.needs_input_grad[1] and fast and _direct['on'] and not _overlap['on'] and has_grad_buf:
+            slot = _wq_slot((Cout, KH * KW * Cin, ldp, dy.dtype, dy.device, (Cout, Cin, KH, KW)), Cout, KH * KW * Cin, ldp, dy.dtype, dy.device)
         dzt = None
         if relu and fast and ctx.needs_input_grad[1]:
-            dz2, dzt = native.relu_bwd_t(dy.view(P, Cout), y.view(P, Cout), ldp)
+            dz2, dzt = native.relu_bwd_t(dy.view(P, Cout), y.view(P, Cout), ldp, dzt_out=slot[0]['dzt'][slot[1]] if slot else None)
             dz = dz2.view(B, OH, OW, Cout)
         else:
             dz = native.relu_bwd(dy, y) if relu else dy
@@ -512,19 +587,25 @@ class ConvFunction(Function):
             else:
                 dx = dxs
         if ctx.needs_input_grad[1]:
-            def weight_gradient(into=None):
+            def cols_t(out=None):
                 if (KH, KW) == (1, 1):
-                    colsT = native.transpose_pad(xs.view(P, Cin), ldp)
-                elif fast:
-                    colsT = native.im2col_t(xs, KH, KW, pad, dil, ldp)                  # [KH*KW*Cin, ldp]: no row-major patch matrix in between
-                else:
-                    colsT = native.transpose_pad(native.im2col_nhwc(xs, KH, KW, pad, dil), ldp)
-                dw_eff = native.gemm_splitk(dzt if dzt is not None else native.transpose_pad(dz2, ldp), colsT)   # [Cout, KH*KW*Cin], f32
+                    return native.transpose_pad(xs.view(P, Cin), ldp, out=out)
+                if fast:
+                    return native.im2col_t(xs, KH, KW, pad, dil, ldp, out=out)      # [KH*KW*Cin, ldp]: no row-major patch matrix in between
+                return native.transpose_pad(native.im2col_nhwc(xs, KH, KW, pad, dil), ldp, out=out)
+
+            def weight_gradient(into=None):
+                dw_eff = native.gemm_splitk(dzt if dzt is not None else native.transpose_pad(dz2, ldp), cols_t())   # [Cout, KH*KW*Cin], f32
                 return native.unpack_conv_wgrad(dw_eff, s, (Cout, Cin, KH, KW), accumulate_into=into)   # * s, parameter layout
 
-            wp = ctx.w_param
-            has_grad_buf = wp is not None and wp.grad is not None and wp.grad.is_contiguous() and wp.grad.dtype == torch.float32
-            if _direct['on'] and not _overlap['on'] and has_grad_buf:
+            if slot is not None:
+                cls, i = slot
+                if dzt is None:
+                    native.transpose_pad(dz2, ldp, out=cls['dzt'][i])
+                cols_t(out=cls['cols'][i])
+                cls['items'].append((wp, s))
+                _claim(wp)
+            elif _direct['on'] and not _overlap['on'] and has_grad_buf:
                 _claim(wp)                        # (added, not written: the gradient stops being zero_grad's zero either way)
                 weight_gradient(into=wp.grad)     # added in place on this stream; autograd gets no gradient for the weight
             elif _overlap['on'] and has_grad_buf:

@@ -69,7 +69,7 @@ extern "C" {
 #define HVR_LAYOUT_NCHW 0 /* reference layout */
 #define HVR_LAYOUT_NHWC 1 /* native layout of this library */
 
-int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta (split-half operands); 5: hvr_relation_fwd_grouped */
+int hvr_abi_version(void);   /* 2 since the descriptors of hvr_gemm / hvr_conv2d_nhwc grew the split-K scratch fields; 3: HVR_F16 / HVR_F16S; 4: hvr_tail_next_desc carries alpha / beta (split-half operands); 5: hvr_relation_fwd_grouped; 6: hvr_gemm_splitk_batched / hvr_unpack_conv_wgrads_multi */
 const char* hvr_last_error(void);
 
 /* ------------------------------------------------------------------------------------
@@ -110,6 +110,14 @@ int hvr_gemm(const hvr_gemm_desc* d, void* stream);
  * (1 = falls back to hvr_gemm's single pass; hvr_gemm_splitk_workspace_bytes then returns 0). */
 size_t hvr_gemm_splitk_workspace_bytes(int M, int N, int K, int dtype);
 int hvr_gemm_splitk(const hvr_gemm_desc* d, void* ws, size_t ws_bytes, void* stream);
+/* `count` such products of ONE shape in one launch (round 6: the weight gradients of a ResNet stage's identical Bottlenecks -- the reference
+ * differentiates each nn.Conv2d on its own, mmdet/models/backbones/resnet.py:220-266; at three frames per rank a single dW = dZ^T X leaves
+ * most of the chip idle and costs three launches): d describes problem 0, problem g reads A + g * stride_a and B + g * stride_b ELEMENTS and
+ * writes C + g * stride_c floats; f32 output, no epilogue.  The library cuts K into slices while count x tiles is below a round of the
+ * chip; the sliced form needs the workspace below and one contiguous output (ldc = N, stride_c = M * N). */
+size_t hvr_gemm_splitk_batched_workspace_bytes(int M, int N, int K, int dtype, int count);
+int hvr_gemm_splitk_batched(const hvr_gemm_desc* d, int count, int64_t stride_a, int64_t stride_b, int64_t stride_c, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------
  * NHWC convolution as implicit GEMM (frozen BatchNorm folded into w / bias by the caller)
@@ -284,6 +292,10 @@ int hvr_unpack_conv_wgrad(const float* dw, const float* scale, float* out, int C
 typedef struct { const float* w; const float* scale; void* out; int64_t first; int32_t Cout, Cin, KK, pad_; } hvr_pack_item;
 typedef struct { const void* src; void* dst; int64_t lds, ldd; int32_t R, C, first_tile, tiles_c, dcols, pad_; } hvr_transpose_item;   /* dcols: columns of dst written per row (R .. dcols - 1: zeros) */
 int hvr_pack_conv_weights_multi(const hvr_pack_item* items_dev, int n, int64_t total, int out_dtype, void* stream);
+/* hvr_unpack_conv_wgrad for a table of layers in one launch (the outputs of hvr_gemm_splitk_batched): entry i's f32 product dw [Cout][KK][Cin]
+ * times scale -> the parameter-layout gradient out [Cout][Cin][KK], added to it when accumulate != 0; first / total as above. */
+typedef struct { float* out; const float* scale; const float* dw; int64_t first; int32_t Cout, Cin, KK, pad_; } hvr_unpack_item;
+int hvr_unpack_conv_wgrads_multi(const hvr_unpack_item* items_dev, int n, int64_t total, int accumulate, void* stream);
 int hvr_transpose_multi(const hvr_transpose_item* items_dev, int n, int tiles, void* stream);
 
 /* Optimizer step on a flat f32 buffer (the training configs: SGD lr 5e-4, momentum 0.9, weight decay 1e-4, gradient

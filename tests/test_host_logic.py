@@ -163,7 +163,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert native.lib().hvr_abi_version() == native.ABI_VERSION == 5
+    assert native.lib().hvr_abi_version() == native.ABI_VERSION == 6
 
 
 def test_bottleneck_expand_convs_take_the_panel_kernel():

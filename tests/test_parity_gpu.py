@@ -1223,6 +1223,60 @@ def test_off_stream_weight_gradients_equal_the_autograd_order():
             assert float(p_.grad.abs().sum()) > 0, name
 
 
+def test_parked_weight_gradients_equal_the_per_layer_products():
+    """train_ops.wgrad_defer (round 6): inside train_iteration the conv weight gradients of equal shape are parked and computed by ONE
+    batched product + one table-driven unpack per shape class (hvr_gemm_splitk_batched / hvr_unpack_conv_wgrads_multi), linear weight /
+    bias gradients are written straight into the flat buffer.  The buffer must equal the one the per-layer path fills (plain autograd:
+    wgrad_direct off) up to the f32 summation order of the K slices -- on the iteration that only counts the classes, and on the next
+    one, which uses the slabs; every trainable conv weight gets a gradient (none is dropped), and the classes really were batched."""
+    from hvrnet_amd import train_ops as TO
+    from hvrnet_amd.config import selsa_train_config
+    from hvrnet_amd.dist_train import FlatParams, parse_losses
+    cfg = selsa_train_config(nms_post=24, rcnn_sampler_num=16, t_dim=3)
+    model = hvrnet_amd.enable_training(hvrnet_amd.build_model(cfg, S.synth_state_dict('selsa'), torch.bfloat16, DEV))
+    g = torch.Generator().manual_seed(96)
+    hw = (128, 192)
+    imgs = (torch.randn((3, 3) + hw, generator=g) * 50.0).to(DEV)
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(3)]
+    gt_b, gt_l = torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]).to(DEV), torch.tensor([5, 12]).to(DEV)
+    keys = dict(rpn=torch.rand(8 * 12 * 12, generator=g).to(DEV), rcnn=[torch.rand(2 + 24, generator=g).to(DEV) for _ in range(3)])
+    data = dict(img=imgs, img_meta=metas, return_loss=True, gt_bboxes=[gt_b] * 3, gt_labels=[gt_l] * 3, keys=keys)
+    flat = FlatParams(model)
+
+    def grads(mode):
+        flat.zero_grad()
+        loss, _ = parse_losses(model(**data))
+        if mode == 'autograd':
+            loss.backward()
+        else:
+            prev = TO.wgrad_direct(True, pristine={id(p_) for p_ in flat.params})
+            prev_d = TO.wgrad_defer(True)
+            try:
+                loss.backward()
+                TO.wgrad_flush()
+            finally:
+                TO.wgrad_defer(prev_d)
+                TO.wgrad_direct(prev)
+        torch.cuda.synchronize()
+        return flat.grad.clone()
+
+    TO.wgrad_reset()
+    ref = grads('autograd')
+    first, second, third = grads('parked'), grads('parked'), grads('parked')
+    classes = {k: c['cap'] for k, c in TO._wq['classes'].items()}
+    assert classes and max(classes.values()) >= 20, classes          # layer 3's identical blocks share a slab
+    scale = float(ref.abs().max())
+    assert scale > 0
+    for other in (first, second, third):
+        err = float((other - ref).abs().max())
+        assert err <= 2e-3 * scale, (err, scale)                      # bf16 operands; the K slices' f32 sums associate differently
+    assert float((third - second).abs().max()) <= 1e-3 * scale        # the slab path is repeatable up to RoIAlign backward's atomic order (bf16 roundings downstream of it)
+    for name, p_ in model.named_parameters():
+        if p_.requires_grad and p_.dim() == 4:
+            assert float(p_.grad.abs().sum()) > 0, name
+    TO.wgrad_reset()
+
+
 def test_full_detector_training_iterations_descend():
     """dist_train.train_detector_iteration on the whole SelsaRCNN (the reference's batch_processor + optimizer hook): with the
     sampler keys held fixed, three SGD iterations lower the summed loss, every trainable parameter moves, frozen ones

@@ -144,8 +144,7 @@ static int fewrow_slices(const GemmParams& p) {
   if (p.N % 8 || p.ldc % 8 || (p.resid && p.ldr % 8) || !aligned16(p.C) || (p.resid && !aligned16(p.resid)) || (p.bias && !aligned16(p.bias))) return 1;
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
   const int ksteps = p.K / 64;
-  static const long tmax = std::getenv("HVR_DBG_FEWROW_TILES") ? std::atol(std::getenv("HVR_DBG_FEWROW_TILES")) : 160;
-  if (tiles > tmax || ksteps < mink) return 1;
+  if (tiles > 160 || ksteps < mink) return 1;
   long s = (target + tiles / 2) / tiles;
   if (s > ksteps / minper) s = ksteps / minper;
   return s < 2 ? 1 : (int)s;

@@ -70,21 +70,19 @@ class FlatParams(object):
             m._drop_packed()
 
 
-def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False, fewrow=None):
+def train_iteration(flat, loss_fn, lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0, overlap_wgrad=False, fewrow=False):
     """One iteration in the reference's order (dist_utils.py:52-58): zero_grad, backward, all-reduce, clip, step.
     loss_fn() builds the graph and returns the scalar to differentiate.  overlap_wgrad: conv weight gradients run on a
     second HIP stream and land directly in the flat gradient buffer (train_ops.wgrad_overlap); joined before the exchange.
     Off by default: at three frames per iteration the step is bound by the host's enqueue rate, and the extra events / stream
     switches cost more than the overlap returns (22.1 vs 20.5 ms measured); it pays once the per-rank batch grows."""
     from . import train_ops
-    import os
-    if fewrow is None:
-        fewrow = os.environ.get('HVR_DBG_TRAIN_FEWROW', '1') != '0'
     flat.zero_grad()
     train_ops.prep_begin(flat)          # every trainable layer's operands for this iteration in two launches (recorded on the first)
     try:
-        # few-row forms on (native.fewrow_split): a rank's batch is three frames / a few hundred RoIs, so most products of the step leave
-        # the chip idle on whole-K tiles; K sliced across the waves of a workgroup (kpar.hip) or across workgroups fills it
+        # fewrow: the few-row forms (native.fewrow_split: K sliced across the waves of a workgroup, kpar.hip, or across workgroups) for the
+        # step's products -- a rank's batch is three frames / a few hundred RoIs.  Measured without gain at that size (HVR 17.3 / 17.9 ms,
+        # SELSA 15.5 / 15.4 ms off / on, profiles/r06_train_steps.txt: the step was bound by launch cadence, not by these kernels): off
         with native.fewrow_split(bool(fewrow)):
             loss = loss_fn()
             prev = train_ops.wgrad_overlap(overlap_wgrad)

@@ -359,7 +359,11 @@ static int expand_nc(int M, int N) {
   // (16 = one workgroup per panel at N = 1024: measured SLOWER at layer 3 / 15 frames, 51 us against 42 -- 281 workgroups do
   // not keep enough loads in flight)
   if (nchunks % 8 == 0 && (long)panels * (nchunks / 8) >= 512) return 8;
-  if (nchunks % 4 == 0) return 4;
+  // (round 6: few panels -- one 600 x 1000 frame at stride 16 is 19 -- and four chunks per workgroup leave 76 workgroups walking a chain of
+  // four chunks each; two chunks per workgroup halve the chain and double the workgroups: 13.3 -> 11.1 us per layer-3 call, the one-frame
+  // graph 1.39 - 1.42 -> 1.34 ms; the pipelined stream loop is bound by the chip's total work and does not move.  Same MFMA order per
+  // output: bit-identical)
+  if (nchunks % 4 == 0 && (long)panels * (nchunks / 4) >= 256) return 4;
   if (nchunks % 2 == 0) return 2;
   return 0;
 }

@@ -300,15 +300,22 @@ def train_step_side_measurement(head):
     frames in, 3 chosen; SelsaRCNN: 1 key + 2 reference frames) at 600x1000 / 300 proposals, bf16 operands with f32 master weights,
     measured by tools/train_bench.py in its own process after the timed region.  None if that run fails."""
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_bench.py'), '--head', head, '--steps', '5', '--warmup', '2'],
-                           capture_output=True, text=True, timeout=300)
-        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
-        d = json.loads(line)
+        def run(extra):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_bench.py'), '--head', head, '--steps', '10', '--warmup', '3'] + extra,
+                               capture_output=True, text=True, timeout=300)
+            return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+        d = run([])
         ach = TRAIN_STEP_FLOPS[head] / (d['ms_per_step'] * 1e-3) / 1e12
-        return dict(iterations_per_s=d['value'], ms_per_iteration=d['ms_per_step'], input_frames_per_s=d['frames_per_s'], dtype=d['dtype'],
-                    trainable_params=d['params'],
-                    roofline=dict(bound='mfma', achieved=round(ach, 1), peak=MFMA_PEAK_TF['bf16'], unit='TFLOP/s', frac=round(ach / MFMA_PEAK_TF['bf16'], 4),
-                                  flops_per_iteration=TRAIN_STEP_FLOPS[head]))   # whole iteration (forward, backward, targets, losses, clip + SGD) against the dense MFMA peak
+        out = dict(iterations_per_s=d['value'], ms_per_iteration=d['ms_per_step'], input_frames_per_s=d['frames_per_s'], dtype=d['dtype'],
+                   trainable_params=d['params'],
+                   roofline=dict(bound='mfma', achieved=round(ach, 1), peak=MFMA_PEAK_TF['bf16'], unit='TFLOP/s', frac=round(ach / MFMA_PEAK_TF['bf16'], 4),
+                                 flops_per_iteration=TRAIN_STEP_FLOPS[head]))   # whole iteration (forward, backward, targets, losses, clip + SGD) against the dense MFMA peak
+        if d.get('backbone_prefetch'):
+            # HVR: the frozen backbone of batch i + 1 runs on a second stream while batch i trains (dist_train.C4Prefetcher); the same
+            # iteration with the backbone in line is reported beside it
+            out['backbone_prefetch'] = True
+            out['ms_per_iteration_backbone_in_line'] = run(['--no-prefetch'])['ms_per_step']
+        return out
     except Exception as exc:   # noqa: BLE001 -- a side measurement must not take the headline down
         sys.stderr.write('train_step side measurement skipped: %r\n' % (exc,))
         return None

@@ -312,3 +312,47 @@ def test_nms_threshold_ties_names_the_pair_at_issue():
         assert ties[0]['is_tie'] is is_tie and abs(ties[0]['iou'] - 100.0 / h) < 1e-9
         assert ties[0]['suppressor'][:4] == [0, 0, 99, 99]
     assert parity.nms_threshold_ties([keep], [keep]) == []
+
+
+def test_training_target_bookkeeping_is_lazy_and_equal_to_the_eager_form():
+    """Round 6 host-side changes of the training step (no kernel involved, CPU tensors): AssignResult.add_gt_ defers the max_overlaps cat,
+    SamplingResult builds gt_flags on first use, gathers `bboxes` once and reads several results' counts in ONE host copy
+    (SamplingResult.resolve); detectors._sampled_rois == the per-frame new_full / cat form of bbox2roi (transforms.py:114-136)."""
+    from hvrnet_amd import detectors, targets as T
+    g = torch.Generator().manual_seed(3)
+    ar = T.AssignResult(2, torch.tensor([0, 1, 2, -1, 0]), torch.tensor([0.1, 0.8, 0.9, -1.0, 0.2]), torch.tensor([0, 5, 7, 0, 0]))
+    ar.add_gt_(torch.tensor([5, 7]))
+    assert ar.gt_inds.tolist() == [1, 2, 0, 1, 2, -1, 0] and ar.labels.tolist() == [5, 7, 0, 5, 7, 0, 0]
+    assert torch.equal(ar.max_overlaps, torch.tensor([1.0, 1.0, 0.1, 0.8, 0.9, -1.0, 0.2]))
+    results, want = [], []
+    for i, (np_, nn_) in enumerate([(2, 3), (1, 4), (3, 2)]):
+        boxes = torch.rand((9, 4), generator=g) * 100
+        inds = torch.randperm(9, generator=g)
+        r = T.SamplingResult(inds, torch.tensor([np_, nn_], dtype=torch.int32), boxes, boxes[:2], ar, 2)
+        results.append(r)
+        b = boxes[inds[:np_ + nn_]]
+        want.append(torch.cat([b.new_full((b.shape[0], 1), float(i)), b], 1))
+    assert all(r._n is None for r in results)
+    T.SamplingResult.resolve(results)
+    assert [r._n for r in results] == [(2, 3), (1, 4), (3, 2)]
+    assert results[0].bboxes is results[0].bboxes                       # gathered once
+    assert results[0].gt_flags.tolist() == [1, 1, 0, 0, 0, 0, 0, 0, 0] and results[0].pos_inds.numel() == 2 and results[0].neg_inds.numel() == 3
+    rois, n = detectors._sampled_rois(results)
+    assert n == [5, 5, 5] and torch.equal(rois, torch.cat(want, 0))     # equal counts: the repeat_interleave form
+    results[1]._n, results[1]._bboxes = (1, 2), None
+    rois2, n2 = detectors._sampled_rois(results)
+    assert n2 == [5, 3, 5] and torch.equal(rois2[:5], want[0]) and torch.equal(rois2[5:8], want[1][:3]) and torch.equal(rois2[8:], want[2])
+
+
+def test_loss_backward_scales_columns_without_a_host_read():
+    """train_ops._scale_columns: the fused logits' gradient under an upstream gradient g [2] of (loss_cls, loss_bbox): class columns x g[0],
+    every other column x g[1] -- what the unit-gradient check (a device read-back in the middle of the backward pass) became in round 6."""
+    from hvrnet_amd import train_ops as TO
+    d = torch.arange(3 * 36, dtype=torch.float32).reshape(3, 36)
+    gsc = torch.tensor([2.0, -0.5])
+    out = TO._scale_columns(d, gsc, 0, 31)
+    assert torch.equal(out[:, :31], d[:, :31] * 2.0) and torch.equal(out[:, 31:], d[:, 31:] * -0.5)
+    assert torch.equal(TO._scale_columns(d, torch.ones(2), 0, 31), d)  # the usual (loss_cls + loss_bbox).backward(): unchanged bit for bit
+    o = torch.arange(2 * 16, dtype=torch.float32).reshape(2, 16)
+    out = TO._scale_columns(o, gsc, 0, 3)                               # RPN: A = 3 objectness columns, then 4 A deltas (+ padding)
+    assert torch.equal(out[:, :3], o[:, :3] * 2.0) and torch.equal(out[:, 3:], o[:, 3:] * -0.5)

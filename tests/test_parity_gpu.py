@@ -1223,6 +1223,68 @@ def test_off_stream_weight_gradients_equal_the_autograd_order():
             assert float(p_.grad.abs().sum()) > 0, name
 
 
+def test_prefetched_frozen_backbone_equals_the_in_line_pass():
+    """dist_train.C4Prefetcher (round 6): HNMBRCNN's training step reuses C4 as a constant computed under no_grad by a backbone that gets no
+    update, so the pass for the next batch may run on a second stream while the current batch trains.  The prefetched map is the in-line
+    pass's bit for bit, forward_train(c4=...) returns the same losses, two iterations of the pipelined loop leave the parameters where the
+    in-line loop leaves them (within the in-line loop's own run-to-run distance), and a trainable backbone is refused."""
+    from hvrnet_amd.config import hvr_train_config, selsa_train_config
+    from hvrnet_amd.dist_train import C4Prefetcher, FlatParams, train_detector_iteration
+    n_post, n_sel, F_, V = 16, 8, 3, 5
+    g = torch.Generator().manual_seed(98)
+    hw = (128, 192)
+    batches = []
+    for _ in range(2):
+        imgs = torch.randn((V * F_, 3) + hw, generator=g) * 50.0 + torch.arange(V).repeat_interleave(F_)[:, None, None, None].float() * 9.0
+        batches.append(imgs.to(DEV))
+    metas = [dict(img_shape=hw + (3,), pad_shape=hw + (3,), scale_factor=1.0, flip=False) for _ in range(V * F_)]
+    gts = [torch.tensor([[16., 24., 90., 100.], [100., 30., 170., 110.]]), torch.tensor([[40., 20., 120., 90.]]),
+           torch.tensor([[30., 40., 150., 120.], [10., 10., 60., 60.]]), torch.tensor([[60., 30., 140., 100.]]), torch.tensor([[20., 50., 100., 120.]])]
+    gls = [torch.tensor([5, 12]), torch.tensor([5]), torch.tensor([5, 7]), torch.tensor([9]), torch.tensor([3])]
+    keys = dict(rcnn=[[torch.rand(2 + n_post, generator=g).to(DEV) for _ in range(F_)] for _ in range(3)])
+    common = dict(img_meta=metas, return_loss=True, gt_bboxes=[gts[v].to(DEV) for v in range(V) for _ in range(F_)],
+                  gt_labels=[gls[v].to(DEV) for v in range(V) for _ in range(F_)], keys=keys)
+
+    def build():
+        m = hvrnet_amd.enable_training(hvrnet_amd.build_model(hvr_train_config(nms_post=n_post, rcnn_sampler_num=n_sel), S.synth_state_dict('hvr'),
+                                                              torch.bfloat16, DEV))
+        return m, FlatParams(m)
+
+    model, flat = build()
+    pre = C4Prefetcher(model)
+    pre.start(batches[0])
+    c4 = pre.take()
+    with torch.no_grad():
+        assert torch.equal(c4, model.extract_feat(batches[0])[0])
+        a = model(img=batches[0], **common)
+        b = model(img=batches[0], c4=c4, **common)
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a if 'loss' in k)
+    # two iterations in line, twice (two fresh models: their distance is the loop's own run-to-run noise -- RoIAlign backward's atomic order
+    # through bf16 roundings) ...
+    def in_line():
+        m, f = build()
+        for imgs in batches:
+            train_detector_iteration(m, f, dict(common, img=imgs), lr=1e-3)
+        return f.flat.clone()
+    want, again = in_line(), in_line()
+    # ... and one batch ahead
+    model2, flat2 = build()
+    pre = C4Prefetcher(model2)
+    pre.start(batches[0])
+    for i, imgs in enumerate(batches):
+        c4 = pre.take()
+        if i + 1 < len(batches):
+            pre.start(batches[i + 1])
+        train_detector_iteration(model2, flat2, dict(common, img=imgs, c4=c4), lr=1e-3)
+    torch.cuda.synchronize()
+    noise, moved = float((want - again).abs().max()), float((want - flat2.flat).abs().max())
+    assert moved <= max(4.0 * noise, 1e-6), (moved, noise)
+    sel = hvrnet_amd.enable_training(hvrnet_amd.build_model(selsa_train_config(nms_post=n_post, rcnn_sampler_num=n_sel, t_dim=3), S.synth_state_dict('selsa'),
+                                                            torch.bfloat16, DEV))
+    with pytest.raises(AssertionError):
+        C4Prefetcher(sel)                      # SelsaRCNN trains its backbone: the pass depends on the update in flight
+
+
 def test_parked_weight_gradients_equal_the_per_layer_products():
     """train_ops.wgrad_defer (round 6): inside train_iteration the conv weight gradients of equal shape are parked and computed by ONE
     batched product + one table-driven unpack per shape class (hvr_gemm_splitk_batched / hvr_unpack_conv_wgrads_multi), linear weight /

@@ -74,11 +74,20 @@ $T python tools/blaslt_ref.py > $out/hipblaslt_calibration.txt 2>/dev/null
 rm -rf /tmp/bl_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/bl_ks -o bl -- python tools/blaslt_ref.py > /dev/null 2>&1
 $T python tools/rocpd_stats.py $(db /tmp/bl_ks) > $out/hipblaslt_kernels.txt 2>&1
 # training step (SELSA, 1 key + 2 ref frames 600x1000, 300 proposals): throughput in both compute modes + kernel stats of the bf16 mode
-$T python tools/train_bench.py --steps 10 --warmup 2 > $out/train_bench.json 2>/dev/null
+$T python tools/train_bench.py --steps 20 --warmup 3 > $out/train_bench.json 2>/dev/null
 $T python tools/train_bench.py --steps 5 --warmup 2 --dtype f32 > $out/train_bench_f32.json 2>/dev/null
-$T python tools/train_bench.py --steps 10 --warmup 2 --head hvr > $out/train_bench_hvr.json 2>/dev/null
-rm -rf /tmp/t_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/t_ks -o train -- python tools/train_bench.py --steps 3 --warmup 1 > /dev/null 2>&1
-$T python tools/rocpd_stats.py $(db /tmp/t_ks) > $out/train_kernel_stats.txt
+$T python tools/train_bench.py --steps 20 --warmup 3 --head hvr > $out/train_bench_hvr.json 2>/dev/null                       # the frozen backbone one batch ahead (dist_train.C4Prefetcher)
+$T python tools/train_bench.py --steps 20 --warmup 3 --head hvr --no-prefetch > $out/train_bench_hvr_inline.json 2>/dev/null   # ... and in line
+# kernel stats over 40 iterations per head (the model build and the first, recording iteration are ~2 % of the dispatches), and the GPU's
+# busy / idle time per steady-state iteration (tools/gpu_idle.py; stem_fused_kernel marks an iteration)
+for h in selsa hvr; do
+  sfx=$([ $h = selsa ] && echo "" || echo "_hvr")
+  rm -rf /tmp/t_ks; $T rocprofv3 --kernel-trace --stats -d /tmp/t_ks -o train -- python tools/train_bench.py --steps 38 --warmup 2 --head $h > /dev/null 2>&1
+  $T python tools/rocpd_stats.py $(db /tmp/t_ks) > $out/train_kernel_stats$sfx.txt
+  $T python tools/gpu_idle.py $(db /tmp/t_ks) stem_fused_kernel 10 20 > $out/train_gpu_idle$sfx.txt 2>&1
+done
+$T python tools/train_census.py --head hvr > $out/train_census_hvr.txt 2>/dev/null
+$T python tools/train_census.py --head selsa > $out/train_census_selsa.txt 2>/dev/null
 $T python tools/ingest_bench.py > $out/ingest_bench.json 2>/dev/null
 fi
 

@@ -10,7 +10,7 @@ declare -A map=( [bench.json]=bench.json [bench_prof.json]=bench_profiled_run.js
   [rel_pmc_fetch_size.txt]=relation_pmc_fetch_size.txt [rel_pmc_write_size.txt]=relation_pmc_write_size.txt
   [relation_pmc_sq.txt]=relation_pmc_sq.txt [relation_traffic.json]=relation_traffic.json [rel_bench.txt]=relation_kernel_stats.txt
   [window_pmc_sq.txt]=window_pmc_sq.txt [hipblaslt_calibration.txt]=hipblaslt_calibration.txt [train_bench.json]=train_bench.json
-  [train_bench_f32.json]=train_bench_f32.json [train_bench_hvr.json]=train_bench_hvr.json [train_kernel_stats.txt]=train_kernel_stats.txt
+  [train_bench_f32.json]=train_bench_f32.json [train_bench_hvr.json]=train_bench_hvr.json [train_kernel_stats.txt]=train_kernel_stats.txt [train_kernel_stats_hvr.txt]=train_kernel_stats_hvr.txt [train_gpu_idle.txt]=train_gpu_idle.txt [train_gpu_idle_hvr.txt]=train_gpu_idle_hvr.txt [train_bench_hvr_inline.json]=train_bench_hvr_inline.json [train_census_hvr.txt]=train_census_hvr.txt [train_census_selsa.txt]=train_census_selsa.txt
   [ingest_bench.json]=ingest_bench.json [bench_selsa.json]=bench_selsa.json [bench_T21.json]=bench_T21.json
   [precision_ladder.json]=precision_ladder.json [window_f16_kernel_stats.txt]=window_f16_kernel_stats.txt
   [window_f16x2_kernel_stats.txt]=window_f16x2_kernel_stats.txt [conv_layer3.txt]=conv_layer3.txt

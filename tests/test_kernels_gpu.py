@@ -601,6 +601,52 @@ def test_gemm_splitk_matches_the_single_pass_product(dtype, M, N, K):
         assert float((got.double() - ref).abs().max()) <= float((want.double() - ref).abs().max()) * 2 + 1e-4 * scale
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('G,M,N,K', [(23, 256, 1024, 7232), (3, 512, 4608, 7232), (2, 64, 64, 2112), (5, 256, 2304, 1088)])
+def test_gemm_splitk_batched_equals_the_single_products(G, M, N, K):
+    """hvr_gemm_splitk_batched (round 6: the weight gradients of a stage's identical blocks in one launch through the tile engine's batch
+    dimension) on slices of two slabs against hvr_gemm with f32 output problem by problem: same products, the K slices' f32 sums
+    associate differently -> 1e-5 of the output scale (bit for bit where neither form slices K), no worse than the single pass against
+    f64; a slab with spare capacity behind the used slices (the caller's slabs are sized for the largest count seen) is untouched."""
+    g = torch.Generator().manual_seed(G + M + N + K)
+    a = torch.randn((G + 1, M, K), generator=g).to(DEV).bfloat16()
+    w = torch.randn((G + 1, N, K), generator=g).to(DEV).bfloat16()
+    out = torch.full((G + 1, M, N), 7.0, dtype=torch.float32, device=DEV)
+    got = native.gemm_splitk_batched(a[:G], w[:G], out=out[:G])
+    assert got.data_ptr() == out.data_ptr() and bool((out[G] == 7.0).all())
+    sliced = native.lib().hvr_gemm_splitk_batched_workspace_bytes(M, N, K, native.HVR_BF16, G) > 0
+    for i in range(G):
+        want = native.gemm(a[i], w[i], out_f32=True)
+        scale = float(want.abs().max())
+        if not sliced:
+            assert torch.equal(got[i], want), i
+        else:
+            assert float((got[i] - want).abs().max()) <= 1e-5 * scale + 1e-6, i
+            ref = a[i].double() @ w[i].double().t()
+            assert float((got[i].double() - ref).abs().max()) <= float((want.double() - ref).abs().max()) * 2 + 1e-4 * scale
+
+
+@pytest.mark.gpu
+def test_unpack_conv_wgrads_multi_equals_the_per_layer_unpack():
+    """hvr_unpack_conv_wgrads_multi: a table of layers' f32 products x scale -> parameter-layout gradients in one launch, added or written:
+    bit-identical to hvr_unpack_conv_wgrad layer by layer."""
+    g = torch.Generator().manual_seed(5)
+    Cout, Cin, KH, KW, n = 64, 32, 3, 3, 4
+    per = Cout * Cin * KH * KW
+    dw = torch.randn((n, Cout, KH * KW * Cin), generator=g).to(DEV)
+    scales = [torch.rand(Cout, generator=g).to(DEV) + 0.5 for _ in range(n)]
+    for accumulate in (True, False):
+        base = [torch.randn((Cout, Cin, KH, KW), generator=g).to(DEV) for _ in range(n)]
+        want = [native.unpack_conv_wgrad(dw[i], scales[i], (Cout, Cin, KH, KW), accumulate_into=b.clone()) if accumulate
+                else native.unpack_conv_wgrad(dw[i], scales[i], (Cout, Cin, KH, KW)) for i, b in enumerate(base)]
+        outs = [b.clone() for b in base]
+        items = [native.PackItem(w=outs[i].data_ptr(), scale=scales[i].data_ptr(), out=dw.data_ptr() + i * per * 4, first=i * per, Cout=Cout, Cin=Cin, KK=KH * KW)
+                 for i in range(n)]
+        native.unpack_conv_wgrads_multi(native.items_to_device(items, DEV), n, n * per, accumulate=accumulate)
+        for i in range(n):
+            assert torch.equal(outs[i], want[i]), (accumulate, i)
+
+
 # ------------------------------------------------------------------------------- producer / consumer tile kernel
 PC128, PC256 = 14, 15   # gemm_params.h: kPcHint128 / kPcHint256
 

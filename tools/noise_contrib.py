@@ -27,6 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--head', default='selsa')
 ap.add_argument('--mode', default='f16x2', choices=['f32', 'f16x2'])
 ap.add_argument('--clip', type=int, default=0)
+ap.add_argument('--rpn-two-level', action='store_true', help='one more row: the RPN 3x3 conv as nine per-tap products with f32 outputs summed in f32 (what two-level accumulation of its K = 9 216 sum would give: VERDICT r05 item 1d)')
 args = ap.parse_args()
 T, N, KEY, dev = 15, 300, 7, 'cuda:0'
 from bench import host_cores  # noqa: E402
@@ -121,6 +122,44 @@ with torch.no_grad():
     eq = same_lists(props_dev, props_64)
     dprop = max(float((a[:, :4] - b[:, :4]).abs().max()) for a, b in zip(props_dev, props_64)) if eq else float('nan')
     report('rpn', tail64(c5_64, props_dev), ref, 'proposal lists equal: %s; max |d proposal coordinate| %.3g px' % (eq, dprop))
+    if args.rpn_two_level:
+        # the same with the RPN's 3x3 conv (K = 9 Cin = 9 216: one running accumulator per output on the device) summed in TWO levels: nine
+        # per-tap 1x1 products (K = 1 024 each) with f32 outputs, added in f32 -- emulated with the shipped kernels, a measurement only
+        import torch.nn.functional as F_
+        from hvrnet_amd.backbone import as_logical, as_nhwc
+        rpn = model.rpn_head
+        one_level = rpn.forward_single
+
+        def two_level(x):
+            pk = rpn.packed(x.device)
+            A_ = rpn.num_anchors
+            xn = as_nhwc(x, rpn.compute_dtype)
+            w3, b3 = pk['conv']
+            H_, W_ = xn.shape[1], xn.shape[2]
+            xp = F_.pad(xn, (0, 0, 1, 1, 1, 1))
+            acc = None
+            for ky in range(3):
+                for kx in range(3):
+                    part = native.conv2d_nhwc(xp[:, ky:ky + H_, kx:kx + W_, :].contiguous(), w3[:, ky:ky + 1, kx:kx + 1, :].contiguous(), None, relu=False, out_f32=True)
+                    acc = part if acc is None else acc + part
+            y32 = torch.relu(acc + b3)
+            y = y32 if rpn.compute_dtype == torch.float32 else native.cast(y32, rpn.compute_dtype)
+            o = native.conv2d_nhwc(y, pk['heads'][0], pk['heads'][1], relu=False, out_f32=True)
+            return as_logical(o[..., :A_]), as_logical(o[..., A_:5 * A_])
+
+        c1, r1 = one_level(x_dev)
+        c2, r2 = two_level(x_dev)
+        print('               (per-tap form against the shipped conv on the same input: max |d objectness logit| %.3g, max |d delta| %.3g)'
+              % (float((c1 - c2).abs().max()), float((r1 - r2).abs().max())), flush=True)
+        rpn.forward_single = two_level
+        try:
+            w2 = model.window_tensors(x_dev, metas)
+        finally:
+            del rpn.forward_single
+        props_2 = [p.double().cpu() for p in w2['proposals']]
+        eq2 = same_lists(props_2, props_64)
+        dprop2 = max(float((a[:, :4] - b[:, :4]).abs().max()) for a, b in zip(props_2, props_64)) if eq2 else float('nan')
+        report('rpn, two-level', tail64(c5_64, props_2), ref, 'proposal lists equal: %s; max |d proposal coordinate| %.3g px' % (eq2, dprop2))
     c5_dev64 = to_f64(w['c5'])
     report('res5', tail64(c5_dev64, props_64), ref)
     # ---- device res5 + RoIAlign + head + decode on the f64 proposals

@@ -1029,11 +1029,14 @@ def main(argv=None):
                                                           defined='hvrnet_amd/parity.py (frozen since round 5)'))
         elif want is not None:
             out['within_tolerance'] = None
+        if want is not None:
+            # every mode that agreed with the reference on the benchmark clip and FAILED the claim over all clips, with the reason -- also when a
+            # slower mode carries the claim (a faster mode's failure is not to disappear behind it)
             fails = [dict(dtype=r['dtype'], **{k_: r['parity_clips'][k_] for k_ in ('passes', 'max_box_err_vs_f32', 'proposal_lists_equal_the_oracles',
                                                                               'with_the_oracles_proposals_injected', 'nms_threshold_ties')})
-                     for r in rows if 'parity_clips' in r]
+                     for r in rows if 'parity_clips' in r and not r.get('within_tolerance')]
             if fails:
-                out['within_tolerance_failed'] = fails   # (a mode that agreed on the benchmark clip and failed the claim over all clips: why)
+                out['within_tolerance_failed'] = fails
         out['single_lane'] = single_lane
         if batched_lane is not None:
             out['single_lane_batched'] = batched_lane

@@ -398,7 +398,12 @@ int hvr_conv2d_nhwc(const hvr_conv_desc* d, void* stream) {
     if (!bigtile_supported(p, true)) return fail(HVR_EUNSUPPORTED, "the big-tile kernel takes bf16 convs with Cout %% 256 == 0 and Cin %% 64 == 0");
     return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_conv2d_nhwc(big tile)");
   }
-  if (path == 0 && (d->tile_hint == kBigHint || d->tile_hint == 0)) {
+  if (path == 0 && d->tile_hint == kTwoLevelHint) {
+    // two-level accumulation (gemm_params.h: EPI_LINEAR2) where the format carries the f32 tolerance; any other format runs as with hint 0
+    p.tile_hint = 0;
+    if (two_level_supported(p)) return check_launch(run_tile_op(p, EPI_LINEAR2, (hipStream_t)stream), "hvr_conv2d_nhwc(two-level)");
+  }
+  if (path == 0 && (d->tile_hint == kBigHint || d->tile_hint == 0 || d->tile_hint == kTwoLevelHint)) {
     p.tile_hint = 0;
     if (bigtile_supported(p, d->tile_hint == kBigHint)) return check_launch(run_bigtile(p, (hipStream_t)stream), "hvr_conv2d_nhwc(big tile)");
   }

@@ -89,8 +89,21 @@ int choose_tile(const GemmParams& p, int epi) {
 
 hipError_t run_tile_op_f16(const GemmParams& p, int epi, hipStream_t stream);  // gemm_f16.hip
 
+// EPI_LINEAR2 is instantiated for the formats that carry the f32 tolerance (exact f32, split half) on the 128 x 128 double-buffered shape;
+// the caller checked two_level_supported()
+bool two_level_supported(const GemmParams& p) {
+  if (p.dtype != DT_F32 && p.dtype != DT_F16S) return false;
+  if (p.dtype == DT_F16S && p.staging != 1) return false;
+  if (p.ksplit_steps > 0 || p.batch > 1 || p.s2 > 0 || p.Wn) return false;
+  return (p.K / 32) % kTwoLevelSteps == 0;
+}
+
 hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.dtype == DT_F16 || p.dtype == DT_F16S) return run_tile_op_f16(p, epi, stream);
+  if (epi == EPI_LINEAR2) {
+    if (p.dtype != DT_F32) return hipErrorInvalidValue;
+    return p.staging == 1 ? launch_tile<float, 2, 2, 4, 4, EPI_LINEAR2, true>(p, stream) : launch_tile<float, 2, 2, 4, 4, EPI_LINEAR2, false>(p, stream);
+  }
   if (p.dtype == DT_BF16) {
     if (epi == EPI_LINEAR) return dispatch_shape<bf16_t, EPI_LINEAR>(p, stream);
     if (epi == EPI_SCORES) return dispatch_shape<bf16_t, EPI_SCORES>(p, stream);

@@ -8,10 +8,12 @@ namespace hvr {
 
 hipError_t run_tile_op_f16(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.dtype == DT_F16) {
+    if (epi == EPI_LINEAR2) return hipErrorInvalidValue;
     if (epi == EPI_LINEAR) return dispatch_shape<f16_t, EPI_LINEAR>(p, stream);
     if (epi == EPI_SCORES) return dispatch_shape<f16_t, EPI_SCORES>(p, stream);
     return dispatch_shape<f16_t, EPI_APPLY>(p, stream);
   }
+  if (epi == EPI_LINEAR2) return p.staging == 1 ? launch_tile<f16s_t, 2, 2, 4, 4, EPI_LINEAR2, true>(p, stream) : hipErrorInvalidValue;
   if (epi == EPI_LINEAR) return dispatch_shape<f16s_t, EPI_LINEAR>(p, stream);
   if (epi == EPI_SCORES) return dispatch_shape<f16s_t, EPI_SCORES>(p, stream);
   return dispatch_shape<f16s_t, EPI_APPLY>(p, stream);   // (the double-buffered shapes: gemm.hip choose_tile)

@@ -4,7 +4,10 @@
 
 namespace hvr {
 
-enum { EPI_LINEAR = 0, EPI_SCORES = 1, EPI_APPLY = 2 };
+// EPI_LINEAR2: EPI_LINEAR with TWO-LEVEL accumulation -- every 8 K-steps' products sum in a block accumulator that is then added to the running
+// total (the apply pass's two accumulator sets without the block weights): a long-K product's f32 rounding noise no longer grows with the
+// number of MFMAs chained on one accumulator (the RPN's 3x3 conv: K = 9 216 = 864 chained additions in split half; tile_hint kTwoLevelHint)
+enum { EPI_LINEAR = 0, EPI_SCORES = 1, EPI_APPLY = 2, EPI_LINEAR2 = 3 };
 
 // RPN proposal selection parameters (nms.hip)
 struct RpnParams {
@@ -76,6 +79,7 @@ extern const TileShape kTileShapes[kNumTileShapes];
 int choose_tile(const GemmParams& p, int epi);
 
 hipError_t run_tile_op(const GemmParams& p, int epi, hipStream_t stream);
+bool two_level_supported(const GemmParams& p);   // EPI_LINEAR2: exact-f32 / split-half operands, K a multiple of kTwoLevelSteps K-steps, no K slices
 
 // Row-panel kernel for the channel-expanding 1x1 convs with a residual (expand.hip); tile_hint kExpandHint forces it
 constexpr int kExpandHint = kNumTileShapes + 1;
@@ -96,7 +100,8 @@ bool pc_supported(const GemmParams& p, int epi);
 // Big-tile kernel (bigtile.hip): 288 x 256 tiles, one workgroup per CU on HALF the grid of the 144-row shapes -- for callers that
 // keep several windows in flight (throughput, not latency: tile_hint kBigHint), and by default where its grid fills the chip by
 // itself (N = 512); the tile engine runs everything else as with tile_hint 0
-constexpr int kBigHint = kNumTileShapes + 4, kBigForce = kNumTileShapes + 5;  // (kBigForce: whatever the grid / epilogue -- tuning, tests)
+constexpr int kBigHint = kNumTileShapes + 4, kBigForce = kNumTileShapes + 5, kTwoLevelHint = kNumTileShapes + 6;   // (kTwoLevelHint: EPI_LINEAR2 on the 128 x 128 shape)
+constexpr int kTwoLevelSteps = 8;   // K-steps per block of the two-level form  // (kBigForce: whatever the grid / epilogue -- tuning, tests)
 bool bigtile_supported(const GemmParams& p, bool throughput);
 hipError_t run_bigtile(const GemmParams& p, hipStream_t stream);
 hipError_t run_pc(const GemmParams& p, int epi, int bn, hipStream_t stream);

@@ -149,6 +149,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // one LDS image: two thirds of the LDS-DMA and fragment-read traffic per MFMA of the half formats.
   constexpr bool SPLIT = std::is_same<T, f16s_t>::value;
   constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr bool TWO = EPI == EPI_LINEAR2;                 // linear epilogue, two-level accumulation (gemm_params.h)
+  constexpr bool LIN = EPI == EPI_LINEAR || TWO;           // ... everything the linear epilogue and its loaders do
+  constexpr bool PACC = EPI == EPI_APPLY || TWO;           // a block accumulator beside the running total
+  static_assert(!TWO || NS == 2, "the two-level form lives on the double-buffered loop");
   constexpr int EB = (int)sizeof(T);             // bytes per logical element in global memory
   constexpr int BKE = (F32 || SPLIT) ? 32 : 64;  // logical elements per K-step (one 128-byte line per row)
   constexpr int KSG = 128;                       // global bytes per K-step of a row
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   constexpr bool ASM_READS = GLDS && kAsmLdsReads && (NS > 2 || !(WM == 3 && FN == 4) || EPI == EPI_APPLY);
   static_assert(NS == 2 || (ASM_READS && NS <= 4), "deep pipelines need the hand-counted waits");
   constexpr int MINL = min_wave_loads(BM, NT) + min_wave_loads(BN, NT);
-  constexpr bool kConvOk = EPI == EPI_LINEAR;  // the relation passes never gather: drop the conv state there
+  constexpr bool kConvOk = LIN;  // the relation passes never gather: drop the conv state there
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   int nk_slice = p.K / BKE;
   int blk0 = 0;  // EPI_APPLY: first 128-key block of this workgroup's K slice (slices are whole blocks)
   int kt_base = 0;  // conv + split-K: first K-step of this workgroup's slice (the tap / channel offset is derived from it)
-  if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
+  if constexpr (LIN || EPI == EPI_APPLY) {
     if (p.ksplit_steps > 0) {
       const int kt0 = blockIdx.y * p.ksplit_steps;
       if (kConvOk && p.conv) kt_base = kt0;  // an implicit-GEMM slice starts at filter tap (kt0 * BKE) / Cin: the gather takes the offset
@@ -345,11 +349,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
   // current 128-key block's un-scaled partial product.  The next block's weights g are fetched at the very top of
   // a block, ahead of that block's LDS-DMA, by loads the compiler does not track (a tracked load makes it drain the
   // whole DMA queue in front of the first use): the hand-counted vmcnt wait of the block's last K-step covers them.
-  constexpr int GN = EPI == EPI_APPLY ? FM : 1;
-  f32x4 pacc[GN][EPI == EPI_APPLY ? FN : 1];
+  constexpr int GN = PACC ? FM : 1;
+  f32x4 pacc[GN][PACC ? FN : 1];
   float gcur[GN], gnext[GN];
   float gref[GN];  // per row: m* + log2(L), so that the block weight is g = 2^(m_t - gref)
-  constexpr int STEPS_PER_BLOCK = 128 / BKE;  // K-steps per 128-key statistics block
+  constexpr int STEPS_PER_BLOCK = TWO ? kTwoLevelSteps : 128 / BKE;  // K-steps per 128-key statistics block (EPI_LINEAR2: per block of the two-level sum)
   const int nk = nk_slice;
   const int nblk = nk / STEPS_PER_BLOCK;
   // statistics row of fragment row i of this lane (rows past M read row M - 1: their outputs are never stored)
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              if constexpr (EPI == EPI_APPLY && SPLIT) {
+              if constexpr (PACC && SPLIT) {
                 // the block's un-scaled partial, three terms per K-step (four K-steps per 128-key block)
                 if (kk == 0) {
                   if (first) Mma<T>::template run<true>(wb[0][j], xa[0][i], pacc[i][j]);
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
                   Mma<T>::template run<false>(wb[1][j], xa[0][i], pacc[i][j]);
                   Mma<T>::template run<false>(wb[0][j], xa[1][i], pacc[i][j]);
                 }
-              } else if constexpr (EPI == EPI_APPLY) {
+              } else if constexpr (PACC) {
                 if (first && kk == 0) Mma<T>::template run<true>(wb[kk][j], xa[kk][i], pacc[i][j]);
                 else Mma<T>::template run<false>(wb[kk][j], xa[kk][i], pacc[i][j]);
               } else if constexpr (SPLIT) {
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              if constexpr (EPI == EPI_APPLY) {
+              if constexpr (PACC) {
                 if (first) Mma<T>::template run<true>(wb[0][j], xa[0][i], pacc[i][j]);
                 else Mma<T>::template run<false>(wb[0][j], xa[0][i], pacc[i][j]);
                 Mma<T>::template run<false>(wb[1][j], xa[0][i], pacc[i][j]);
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              if constexpr (EPI == EPI_APPLY) {
+              if constexpr (PACC) {
                 if (first && kk == 0) Mma<T>::template run<true>(wb[j], xa[i], pacc[i][j]);
                 else Mma<T>::template run<false>(wb[j], xa[i], pacc[i][j]);
               } else {
@@ -571,11 +575,20 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
             gcur[i] = __builtin_amdgcn_exp2f(gnext[i] - gref[i]);
           }
         }
+      } else if constexpr (TWO) {
+        if (last) {   // the block's sum joins the running total: one f32 addition per element and block
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][r] += pacc[i][j][r];
+        }
       }
       if (more) commit_stage(nxt);
       __syncthreads();
     };
-    if constexpr (EPI == EPI_APPLY) {
+    if constexpr (PACC) {
       for (int kb = 0; kb < nk; kb += STEPS_PER_BLOCK) {
 #pragma unroll
         for (int st = 0; st < STEPS_PER_BLOCK; ++st) do_step(kb + st, st == 0, st == STEPS_PER_BLOCK - 1);
@@ -903,7 +916,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tile_kernel(const GemmParams p) {
 
   // ---------------- epilogues ----------------
   // lane holds, for fragment (i, j): m = .. + (lane & 15), n = .. + (lane >> 4) * 4 + r
-  if constexpr (EPI == EPI_LINEAR || EPI == EPI_APPLY) {
+  if constexpr (LIN || EPI == EPI_APPLY) {
     // Stage the f32 tile through LDS (one wave-row block of FM*16 rows per pass) so that every global
     // access of the epilogue is a full 16-byte-per-lane row segment: residual loads and output stores
     // are whole lines instead of the 8-byte pieces of the MFMA fragment layout.

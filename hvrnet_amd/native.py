@@ -617,6 +617,7 @@ def fewrow_split(on=True):
 
 
 BIG_TILE_HINT = 16   # gemm_params.h: kBigHint
+TWO_LEVEL_HINT = 18  # gemm_params.h: kTwoLevelHint (conv2d_nhwc: two-level accumulation for f32 / split-half operands, else as hint 0)
 
 
 @contextlib.contextmanager

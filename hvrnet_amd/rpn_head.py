@@ -59,13 +59,18 @@ class RPNHead(nn.Module, PackedMixin):
         w[:A], w[A:n], b[:A], b[A:n] = wc, wr, bc, br
         return dict(conv=fold_conv_bn(self.rpn_conv, None, dtype), heads=(w, b))
 
+    two_level = True   # class attribute (tests / tools flip it to compare with the one-accumulator conv); no environment switch
+
     def forward_single(self, x):
         """x logical [T,C,H,W] -> (cls [T,A,H,W], reg [T,4A,H,W]) f32, physically NHWC."""
         if not x.is_cuda:
             raise NotImplementedError('RPNHead runs on the GPU only (no CPU fallback)')
         p = self.packed(x.device)
         A = self.num_anchors
-        y = native.conv2d_nhwc(as_nhwc(x, self.compute_dtype), p['conv'][0], p['conv'][1], relu=True, pad=1)
+        # (K = 9 x 1024: in the formats that carry the f32 tolerance the sum runs in two levels -- the conv's rounding noise reaches the final
+        # boxes through the proposal coordinates, profiles/r06_noise_two_level.txt; bf16 / half run the usual kernels)
+        two = native.TWO_LEVEL_HINT if (self.two_level and self.compute_dtype in (native.SPLIT, torch.float32)) else None
+        y = native.conv2d_nhwc(as_nhwc(x, self.compute_dtype), p['conv'][0], p['conv'][1], relu=True, pad=1, tile=two)
         o = native.conv2d_nhwc(y, p['heads'][0], p['heads'][1], relu=False, out_f32=True)  # [T,H,W,5A(+pad)] f32
         return as_logical(o[..., :A]), as_logical(o[..., A:5 * A])
 

@@ -158,6 +158,10 @@ size_t hvr_conv2d_splitk_workspace_bytes(const hvr_conv_desc* d);
  * of 256, K >= 512 -- taken by default when its grid covers most of the chip (>= 192 tiles: res5's and the RPN's convs on a
  * 15-frame batch), and from 96 tiles on with tile_hint 16, the hint of a caller that keeps several windows in flight and wants
  * CU-time rather than latency; bit-identical to the tile engine; HVR_BIGTILE=0 turns it off);
+ * tile_hint 18 (round 6): TWO-LEVEL accumulation for exact-f32 / split-half operands whose K is a multiple of 256 elements -- every 8 K-steps'
+ * products sum in a block accumulator that is then added to the running total (tile engine, 128 x 128 shape), so a long-K conv's f32 rounding noise
+ * stops growing with the number of MFMAs chained on one accumulator (the RPN's 3x3 conv, K = 9 216: its share of the final boxes' distance to the
+ * f64 reference halves, profiles/r06_noise_two_level.txt); other formats / shapes run as with hint 0;
  * negative = the descriptor would be rejected. */
 int hvr_conv2d_path(const hvr_conv_desc* d);
 

@@ -389,6 +389,32 @@ def test_big_tile_kernel_on_split_half_tracks_the_f64_product():
     assert (got.double() - want).abs().max().item() < 5e-6 * want.abs().max().item()
 
 
+@pytest.mark.parametrize('dtype', [SPLIT, torch.float32])
+def test_two_level_accumulation_of_a_long_k_conv(dtype):
+    """tile_hint 18 (round 6, gemm_params.h: EPI_LINEAR2): the RPN's 3x3 conv (K = 9 x 1024) with every 8 K-steps summed in a block
+    accumulator that then joins the running total.  Against the same conv on one accumulator: the same products, so within the f32 noise
+    of a 9 216-term sum of each other; against a float64 convolution of the operands the device was handed: the two-level sum's rms error
+    is smaller (what the mode is for: the conv's noise reaches the final boxes through the proposal coordinates); bias and ReLU behave;
+    a format or a K it does not take (bf16; K not a multiple of 256) runs as with hint 0, bit for bit."""
+    B, H, W, Cin, Cout = 2, 38, 63, 1024, 512
+    xf, wf, bf = _rand((B, H, W, Cin), 91).abs(), _rand((Cout, 3, 3, Cin), 92, 0.02), _rand((Cout,), 93)
+    x, w = _to(xf, dtype), _tow(wf, dtype)
+    one = _back(native.conv2d_nhwc(x, w, bf.to(DEV), relu=True, pad=1, tile=1))          # the same 128 x 128 shape, one accumulator
+    two = _back(native.conv2d_nhwc(x, w, bf.to(DEV), relu=True, pad=1, tile=native.TWO_LEVEL_HINT))
+    x64, w64 = _back(x).double(), _backw(w).double()
+    want = F.relu(F.conv2d(x64.permute(0, 3, 1, 2), w64.permute(0, 3, 1, 2), bf.double(), padding=1)).permute(0, 2, 3, 1)
+    scale = want.abs().max().item()
+    assert (two - one).abs().max().item() < 2e-5 * scale and not torch.equal(two, one)
+    e1, e2 = (one.double() - want).pow(2).mean().sqrt().item(), (two.double() - want).pow(2).mean().sqrt().item()
+    assert e2 < 0.8 * e1, (e1, e2)
+    assert (two.double() - want).abs().max().item() < 5e-6 * scale
+    # formats / shapes outside the mode: as hint 0
+    xb, wb = _to(xf[..., :64], torch.bfloat16), _tow(wf[..., :64], torch.bfloat16)
+    assert torch.equal(native.conv2d_nhwc(xb, wb, bf.to(DEV), relu=True, pad=1, tile=native.TWO_LEVEL_HINT), native.conv2d_nhwc(xb, wb, bf.to(DEV), relu=True, pad=1))
+    xs, ws = _to(xf[..., :96], dtype), _tow(wf[..., :96], dtype)                          # K = 9 x 96 = 27 K-steps: not a multiple of 8
+    assert torch.equal(_back(native.conv2d_nhwc(xs, ws, bf.to(DEV), relu=True, pad=1, tile=native.TWO_LEVEL_HINT)), _back(native.conv2d_nhwc(xs, ws, bf.to(DEV), relu=True, pad=1)))
+
+
 # ---- the dedicated bf16 kernels instantiated on half operands: each against the tile engine on the same operands ----
 H16 = torch.float16
 

@@ -145,7 +145,9 @@ def _grad_worker(rank, world, port, q):
         mine = [p.grad.clone() for p in net.parameters()]
         world_seen = flat.allreduce_grads()           # one all_reduce of the whole gradient buffer
         dist.barrier()                                # both ranks are done talking before either tears the group down
-        q.put((rank, world_seen, mine, float(flat.grad.sum()), [p.grad.clone() for p in net.parameters()]))
+        # numpy arrays, not tensors: a tensor travels through a torch.multiprocessing queue as a shared-memory handle the RECEIVER fetches from
+        # the sender, and a sender that has already exited (this worker, on a loaded host) resets that connection -- by value instead
+        q.put((rank, world_seen, [t.numpy().copy() for t in mine], float(flat.grad.sum()), [p.grad.detach().numpy().copy() for p in net.parameters()]))
     finally:
         _shutdown()
 
@@ -165,7 +167,7 @@ def test_flat_gradient_allreduce_over_gloo_sums_the_replicas():
     got = {}
     for _ in range(world):
         rank, world_seen, mine, summed, views = q.get(timeout=240)
-        got[rank] = (world_seen, mine, summed, views)
+        got[rank] = (world_seen, [torch.from_numpy(a) for a in mine], summed, [torch.from_numpy(a) for a in views])
     _reap(procs)
     total = [a + b for a, b in zip(got[0][1], got[1][1])]
     for r in range(world):

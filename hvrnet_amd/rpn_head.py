@@ -59,7 +59,7 @@ class RPNHead(nn.Module, PackedMixin):
         w[:A], w[A:n], b[:A], b[A:n] = wc, wr, bc, br
         return dict(conv=fold_conv_bn(self.rpn_conv, None, dtype), heads=(w, b))
 
-    two_level = True   # class attribute (tests / tools flip it to compare with the one-accumulator conv); no environment switch
+    two_level_dtypes = (torch.float32,)   # class attribute: the compute modes whose RPN conv sums in two levels (tools add native.SPLIT); no environment switch
 
     def forward_single(self, x):
         """x logical [T,C,H,W] -> (cls [T,A,H,W], reg [T,4A,H,W]) f32, physically NHWC."""
@@ -67,9 +67,11 @@ class RPNHead(nn.Module, PackedMixin):
             raise NotImplementedError('RPNHead runs on the GPU only (no CPU fallback)')
         p = self.packed(x.device)
         A = self.num_anchors
-        # (K = 9 x 1024: in the formats that carry the f32 tolerance the sum runs in two levels -- the conv's rounding noise reaches the final
-        # boxes through the proposal coordinates, profiles/r06_noise_two_level.txt; bf16 / half run the usual kernels)
-        two = native.TWO_LEVEL_HINT if (self.two_level and self.compute_dtype in (native.SPLIT, torch.float32)) else None
+        # (K = 9 x 1024: in the exact-f32 mode the sum runs in two levels -- the conv's rounding noise reaches the final boxes through the proposal
+        # coordinates, and with it that mode's distance to the CPU reference stays inside 1e-3 px on 24 of 24 clips, profiles/r06_noise_two_level.txt.
+        # Split half takes the same kernel when `two_level_dtypes` names it: measured (RPN share 7.1 -> 2.6e-4 px, +1.5 % of its window), its claim over
+        # 24 clips is 23 either way, so it stays on the big tiles; bf16 / half always run the usual kernels)
+        two = native.TWO_LEVEL_HINT if self.compute_dtype in self.two_level_dtypes else None
         y = native.conv2d_nhwc(as_nhwc(x, self.compute_dtype), p['conv'][0], p['conv'][1], relu=True, pad=1, tile=two)
         o = native.conv2d_nhwc(y, p['heads'][0], p['heads'][1], relu=False, out_f32=True)  # [T,H,W,5A(+pad)] f32
         return as_logical(o[..., :A]), as_logical(o[..., A:5 * A])

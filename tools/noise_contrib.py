@@ -27,6 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--head', default='selsa')
 ap.add_argument('--mode', default='f16x2', choices=['f32', 'f16x2'])
 ap.add_argument('--clip', type=int, default=0)
+ap.add_argument('--built-two-level', action='store_true', help='the RPN conv on the built two-level kernel (tile_hint 18) in this mode too (split half keeps the big tiles by default)')
 ap.add_argument('--rpn-two-level', action='store_true', help='one more row: the RPN 3x3 conv as nine per-tap products with f32 outputs summed in f32 (what two-level accumulation of its K = 9 216 sum would give: VERDICT r05 item 1d)')
 args = ap.parse_args()
 T, N, KEY, dev = 15, 300, 7, 'cuda:0'
@@ -109,6 +110,8 @@ with torch.no_grad():
     report('cpu f32 (all)', b32, ref, 'proposal lists equal the f64 run\'s: %s' % same_lists(i32['proposals'], props_64))
 
     model = hvrnet_amd.build_model((hvr_config if args.head == 'hvr' else selsa_config)(frame_interval=KEY, nms_post=N), sd, dt, dev)
+    if args.built_two_level:
+        model.rpn_head.two_level_dtypes = (torch.float32, native.SPLIT)
     fr_dev = torch.cat(frames, 0).to(dev)
     # ---- backbone on the device, the rest f64
     c4_dev = model(img=fr_dev, img_meta=metas, backbone_feat=True)[0]

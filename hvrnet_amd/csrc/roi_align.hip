@@ -37,6 +37,20 @@ __device__ __forceinline__ BilinearTap make_tap(int height, int width, float y, 
   return t;
 }
 
+// one axis of make_tap: the two cells a coordinate falls between and their weights (ok = false: outside (-1, size), no contribution)
+struct AxisTap { int lo, hi; float wl, wh; bool ok; };
+__device__ __forceinline__ AxisTap axis_tap(int size, float v) {
+  AxisTap t;
+  t.ok = !(v < -1.0f || v > (float)size);
+  if (v <= 0.f) v = 0.f;
+  int lo = (int)v, hi;
+  if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+  if (!t.ok) { lo = hi = 0; v = 0.f; }
+  const float l = v - lo;
+  t.lo = lo; t.hi = hi; t.wl = 1.f - l; t.wh = l;
+  return t;
+}
+
 struct RoiGeom {
   int batch;
   float start_w, start_h, bin_w, bin_h;
@@ -202,6 +216,37 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ gout, const float
     const RoiGeom g = roi_geom(rois + (long)n * 5, spatial_scale, sample_num, PH, PW);
     const float go = gout[index];
     const float count = (float)(g.sn_h * g.sn_w);
+    if (nhwc && g.sn_h == 2 && g.sn_w == 2) {
+      // 2 x 2 samples per bin (both configs), NHWC: the bilinear weights are separable, and the two sample rows (columns) of a bin mostly
+      // fall into the same or adjacent feature rows -- their taps are merged per axis first, so a bin costs rows x cols = 4 .. 9 atomics
+      // instead of 16 (round 6: the scatter is 0.6 - 0.9 ms of a training iteration).  Same sums, associated per axis.
+      int ry[4], rx[4];
+      float wy[4], wx[4];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const AxisTap ty = axis_tap(H, g.start_h + ph * g.bin_h + (s + .5f) * g.bin_h * .5f);
+        const AxisTap tx = axis_tap(W, g.start_w + pw * g.bin_w + (s + .5f) * g.bin_w * .5f);
+        ry[2 * s] = ty.lo; ry[2 * s + 1] = ty.hi; wy[2 * s] = ty.ok ? ty.wl : 0.f; wy[2 * s + 1] = ty.ok ? ty.wh : 0.f;
+        rx[2 * s] = tx.lo; rx[2 * s + 1] = tx.hi; wx[2 * s] = tx.ok ? tx.wl : 0.f; wx[2 * s + 1] = tx.ok ? tx.wh : 0.f;
+      }
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i) {
+          if (ry[j] == ry[i] && wy[j] != 0.f) { wy[i] += wy[j]; wy[j] = 0.f; }
+          if (rx[j] == rx[i] && wx[j] != 0.f) { wx[i] += wx[j]; wx[j] = 0.f; }
+        }
+      float* base = gin + (long)g.batch * H * W * C + c;
+      const float gs = go / count;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (wy[a] == 0.f) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (wx[b] != 0.f) atomicAdd(base + ((long)ry[a] * W + rx[b]) * C, gs * wy[a] * wx[b]);
+      }
+      continue;
+    }
     for (int iy = 0; iy < g.sn_h; ++iy) {
       const float y = g.start_h + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.sn_h;
       for (int ix = 0; ix < g.sn_w; ++ix) {

@@ -630,8 +630,12 @@ def test_gemm_splitk_batched_equals_the_single_products(G, M, N, K):
 def test_unpack_conv_wgrads_multi_equals_the_per_layer_unpack():
     """hvr_unpack_conv_wgrads_multi: a table of layers' f32 products x scale -> parameter-layout gradients in one launch, added or written:
     bit-identical to hvr_unpack_conv_wgrad layer by layer."""
+    for Cout, Cin, KH, KW, n in ((64, 32, 3, 3, 4), (16, 64, 1, 1, 3), (10, 6, 3, 3, 3)):   # (the last: Cin % 4 != 0 -> the element-wise path)
+        _unpack_multi_case(Cout, Cin, KH, KW, n)
+
+
+def _unpack_multi_case(Cout, Cin, KH, KW, n):
     g = torch.Generator().manual_seed(5)
-    Cout, Cin, KH, KW, n = 64, 32, 3, 3, 4
     per = Cout * Cin * KH * KW
     dw = torch.randn((n, Cout, KH * KW * Cin), generator=g).to(DEV)
     scales = [torch.rand(Cout, generator=g).to(DEV) + 0.5 for _ in range(n)]
